@@ -1,0 +1,255 @@
+/* libsgx_hip.so - flat C ABI of the MI355X (gfx950) train-step hot path.
+ *
+ * The reference (Deci-AI/super-gradients 3.7.1) owns NO native code and has NO FFI: every FLOP of
+ * its train step is an ATen / torchvision call issued from Python.  This
+ * header is therefore the boundary a maintainer would bind (ctypes stub in INTEGRATION.md) to replace
+ * those call sites; each entry point cites the reference call site(s) it replaces.  Paths are
+ * relative to /root/reference/src/super_gradients/.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  All tensors are fp32 unless noted.
+ *   - Activations are NHWC in HBM with explicit element strides: element (n,h,w,c) of a tensor lives
+ *     at  base + n*ld_img + (h*W + w)*ld_pix + c   (ld_pix >= C lets a producer write straight into a
+ *     channel slice of a concat buffer - the reference's torch.cat copies disappear).
+ *     Channel counts, ld_pix and channel offsets must be multiples of 4 floats (16-byte vector access).
+ *   - Convolution weights are OHWI: w[k][r][s][c]  (the GEMM-K axis, c, is contiguous).
+ *   - Every call is asynchronous on the given hipStream_t (passed as void*), never allocates, never
+ *     synchronises, keeps no pointer after return.  Scratch comes from the caller (workspace queries).
+ *   - Return value: 0 = OK, negative = error (see codes); sgx_last_error() gives a thread-local message.
+ *   - Re-entrant: safe from the Python main thread and the autograd engine thread concurrently.
+ */
+#ifndef SGX_HIP_H
+#define SGX_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGX_OK 0
+#define SGX_ERR_BAD_ARG (-1)
+#define SGX_ERR_UNSUPPORTED (-2)
+#define SGX_ERR_HIP (-3)
+#define SGX_ERR_WORKSPACE (-4)
+
+#define SGX_ACT_NONE 0
+#define SGX_ACT_RELU 1
+#define SGX_ACT_SILU 2
+
+int32_t sgx_version(void);
+const char* sgx_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution (implicit GEMM on fp32 MFMA, v_mfma_f32_32x32x2_f32).
+ * Replaces torch.nn.functional.conv2d fwd/bwd issued by nn.Conv2d inside
+ *   modules/qarepvgg_block.py:105-128,197-198   (branch_3x3 / branch_1x1)
+ *   modules/conv_bn_act_block.py:88,93          (Conv)      modules/conv_bn_relu_block.py:8-60
+ *   training/models/detection_models/yolo_nas/dfl_heads.py:57-66 (stem / cls / reg / pred convs)
+ *   training/models/classification_models/resnet.py:29-31,57-61,162 (ResNet convs)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sgx_conv_desc {
+    int32_t N, H, W, C;       /* input: images, height, width, channels (C % 4 == 0)            */
+    int32_t K;                /* output channels                                                */
+    int32_t R, S;             /* filter height / width                                          */
+    int32_t stride, pad;      /* same in both spatial dims; groups = 1, dilation = 1            */
+    int32_t Ho, Wo;           /* output spatial = (H + 2*pad - R)/stride + 1                    */
+    int64_t x_ld_pix, x_ld_img; /* input strides (elements)                                     */
+    int64_t y_ld_pix, y_ld_img; /* output strides (elements)                                    */
+} sgx_conv_desc;
+
+/* y = act(conv(x, w) + bias [+ addend]);  bias/addend may be NULL; addend has y's strides.
+ * If stat_partials != NULL the epilogue also emits per-CTA-row-block per-channel partial sums of the
+ * PRE-activation output: stat_partials[2][n_row_blocks][K] (sum, sum of squares), where
+ * n_row_blocks = sgx_conv2d_fwd_stat_blocks(d).  (BatchNorm statistics without re-reading y.)  */
+int32_t sgx_conv2d_fwd(const sgx_conv_desc* d, const float* x, const float* w, const float* bias,
+                       const float* addend, float* y, int32_t act, float* stat_partials, void* stream);
+int32_t sgx_conv2d_fwd_stat_blocks(const sgx_conv_desc* d);
+
+/* dx = conv_transpose(dy, w) [+ addend] [+ dx if accumulate].  d describes the FORWARD conv; dy uses
+ * the y strides, dx/addend the x strides.  ws: sgx_conv2d_bwd_data_workspace(d) bytes.            */
+int64_t sgx_conv2d_bwd_data_workspace(const sgx_conv_desc* d);
+int32_t sgx_conv2d_bwd_data(const sgx_conv_desc* d, const float* dy, const float* w, const float* addend,
+                            float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream);
+
+/* dw[k][r][s][c] += sum_pixels dy * x   (accumulates into dw: callers zero the gradient arena once per
+ * optimizer step).  dbias[k] += sum dy if dbias != NULL.  ws: sgx_conv2d_bwd_weight_workspace(d).  */
+int64_t sgx_conv2d_bwd_weight_workspace(const sgx_conv_desc* d);
+int32_t sgx_conv2d_bwd_weight(const sgx_conv_desc* d, const float* x, const float* dy, float* dw,
+                              float* dbias, void* ws, int64_t ws_bytes, void* stream);
+
+/* ConvTranspose2d kernel 2, stride 2 (+bias): modules/sampling.py:72-73 via yolo_stages.py:292-294.
+ * x [N,H,W,C] -> y [N,2H,2W,K].  It is the adjoint of a 2x2 stride-2 convolution, so it runs on the same
+ * kernels: forward = data-gradient kernel of that conv, backward-data = its forward, backward-weight =
+ * its weight-gradient.  Weight layout wt[c][r][s][k] (OHWI of the adjoint conv; nn.ConvTranspose2d's
+ * logical [C][K][2][2] permuted - the host mirror keeps the logical shape as a strided view).        */
+int64_t sgx_convT2x2_workspace(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K);
+int32_t sgx_convT2x2_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const float* x, int64_t x_ld_pix,
+                         int64_t x_ld_img, const float* wt, const float* bias, float* y, int64_t y_ld_pix,
+                         int64_t y_ld_img, void* ws, int64_t ws_bytes, void* stream);
+int32_t sgx_convT2x2_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const float* dy, int64_t dy_ld_pix,
+                              int64_t dy_ld_img, const float* wt, float* dx, int64_t dx_ld_pix, int64_t dx_ld_img,
+                              void* stream);
+int32_t sgx_convT2x2_bwd_weight(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const float* x, int64_t x_ld_pix,
+                                int64_t x_ld_img, const float* dy, int64_t dy_ld_pix, int64_t dy_ld_img, float* dwt,
+                                float* dbias, void* ws, int64_t ws_bytes, void* stream);
+
+/* Layout changes at the model boundary (reference keeps NCHW end to end).
+ * nchw_to_nhwc pads channels with zeros up to Cpad (Cpad % 4 == 0).                               */
+int32_t sgx_nchw_to_nhwc(int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cpad, const float* x, float* y, void* stream);
+int32_t sgx_nhwc_to_nchw(int32_t N, int32_t C, int32_t H, int32_t W, const float* x, int64_t x_ld_pix, int64_t x_ld_img,
+                         float* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm (training mode) and the fused elementwise stages around it.
+ * Replaces F.batch_norm + ReLU/SiLU + the branch adds at
+ *   modules/qarepvgg_block.py:118,162,184-204   modules/conv_bn_act_block.py:89-93
+ *   yolo_nas/yolo_stages.py:61-63 (alpha*x + y)   classification_models/resnet.py:43-50,72-84
+ * A "row" is one pixel (M = N*H*W rows), channels are columns.
+ * ------------------------------------------------------------------------------------------- */
+/* Two-stage deterministic per-channel reduction.  partials: [2][nblk][C], nblk = sgx_stats_blocks(M). */
+int32_t sgx_stats_blocks(int64_t M);
+int32_t sgx_channel_stats_partial(const float* x, int64_t M, int32_t C, int64_t ld, float* partials, void* stream);
+/* From partial sums: batch mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale;
+ * saves mean & invstd; updates running stats in place (momentum, unbiased var) like nn.BatchNorm2d.  */
+int32_t sgx_bn_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                        float* save_mean, float* save_invstd, float* scale, float* shift, void* stream);
+/* eval-mode BatchNorm folded to an affine map from the running statistics.                          */
+int32_t sgx_bn_eval_scale_shift(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                                const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* y = act(scale[c]*x + shift[c] + a1*r1 + a2*r2); scale/shift/r1/r2 may be NULL (identity / absent).
+ * a1_dev (device scalar, e.g. the learnable bottleneck alpha) overrides a1 when not NULL.
+ * If partials != NULL also emits per-channel partial stats of the PRE-activation value.            */
+int32_t sgx_affine_act_fwd(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* r1,
+                           int64_t r1_ld, float a1, const float* a1_dev, const float* r2, int64_t r2_ld, float a2,
+                           float* y, int64_t y_ld, int64_t M, int32_t C, int32_t act, float* partials, void* stream);
+/* BN backward, stage 1: g = dy * act'(scale*x+shift) ; partial sums of g and g*x per channel
+ * (partials [2][nblk][C]).  act mask is recomputed from x, scale, shift (nothing else is stored).  */
+int32_t sgx_bn_bwd_reduce(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale,
+                          const float* shift, int64_t M, int32_t C, int32_t act, float* partials, void* stream);
+/* stage 2 (tiny): dgamma += sum g*xhat, dbeta += sum g; coefficients for stage 3:
+ * dx = c1[c]*g + c2[c]*x + c3[c].  coef: [3][C].                                                    */
+int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma,
+                            const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                            float* coef, void* stream);
+/* stage 3: dx = c1*g + c2*x + c3 with g recomputed as in stage 1.  Optionally also writes g itself
+ * (g_out != NULL) for consumers that need the masked upstream gradient.                            */
+int32_t sgx_bn_bwd_apply(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale,
+                         const float* shift, const float* coef, float* dx, int64_t dx_ld, float* g_out, int64_t g_ld,
+                         int64_t M, int32_t C, int32_t act, void* stream);
+/* z = a*x + y with a device-resident scalar a (yolo_stages.py:61-63) and its backward pieces:
+ * sgx_dot_partial gives sum(x*dz) partials [nblk] for d a; finalize with sgx_sum_partials.          */
+int32_t sgx_dot_partial(const float* a, int64_t a_ld, const float* b, int64_t b_ld, int64_t M, int32_t C,
+                        float* partials, void* stream);
+int32_t sgx_sum_partials(const float* partials, int32_t n, float scale, float* out, int32_t accumulate, void* stream);
+/* y = a*x (+ y if accumulate) elementwise over [M,C] with strides; a_dev overrides a if not NULL.   */
+int32_t sgx_axpy(const float* x, int64_t x_ld, float a, const float* a_dev, float* y, int64_t y_ld, int64_t M,
+                 int32_t C, int32_t accumulate, void* stream);
+/* per-channel column sum: out[c] (+)= sum_rows x[row][c]  (conv bias gradients).                     */
+/* rows_per_img/ld_img: rows are grouped in images of rows_per_img rows, image i starts at x + i*ld_img
+ * (pass rows_per_img = M, ld_img = 0 for a plain [M,C] matrix).  ws: sgx_stats_blocks(M)*C floats.  */
+int32_t sgx_colsum(const float* x, int64_t ld, int64_t M, int32_t C, int64_t rows_per_img, int64_t ld_img, float* out,
+                   int32_t accumulate, float* ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pooling.  SPP max-pool k in {5,9,13} stride 1 (detection_models/csp_darknet53.py:146-150),
+ * ResNet stem max-pool 3x3 s2 p1 and global average pool (classification_models/resnet.py:164,205).
+ * ------------------------------------------------------------------------------------------- */
+/* argmax (optional, int32 [N,Ho,Wo,C] contiguous) = flat input pixel index h*W+w of the first maximum in
+ * row-major window order (ATen's tie rule); it is what the backward consumes.                        */
+int32_t sgx_maxpool_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad,
+                        const float* x, int64_t x_ld_pix, int64_t x_ld_img, float* y, int64_t y_ld_pix,
+                        int64_t y_ld_img, int32_t* argmax, void* stream);
+/* dx (+)= sum of dy over the windows whose arg-max is this pixel (gather form: deterministic, no atomics). */
+int32_t sgx_maxpool_bwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad,
+                        const int32_t* argmax, const float* dy, int64_t dy_ld_pix, int64_t dy_ld_img, float* dx,
+                        int64_t dx_ld_pix, int64_t dx_ld_img, int32_t accumulate, void* stream);
+int32_t sgx_avgpool_fwd(int32_t N, int32_t HW, int32_t C, const float* x, int64_t x_ld_pix, int64_t x_ld_img,
+                        float* y, void* stream);
+int32_t sgx_avgpool_bwd(int32_t N, int32_t HW, int32_t C, const float* dy, float* dx, int64_t dx_ld_pix,
+                        int64_t dx_ld_img, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Detection head decode, PPYoloELoss (assigner + VFL/GIoU/DFL with hand-written backward), NMS.
+ * ------------------------------------------------------------------------------------------- */
+/* dfl_heads.py:207-235 + bbox_utils.py:9-29: boxes[B,L,4] = dist2bbox(softmax(distri)·[0..R]) * stride,
+ * scores = sigmoid(logits).  points are in grid units (anchor_points / stride).                    */
+int32_t sgx_dfl_decode(int32_t B, int32_t L, int32_t C, int32_t reg_max, const float* logits, const float* distri,
+                       const float* points_grid, const float* strides, float* boxes, float* scores, void* stream);
+
+/* training/losses/ppyolo_loss.py:726-775: flat targets [T,6] -> padded per-image lists.
+ * gt_count[B] (int32), gt_index[B][nmax] (row index into targets or -1).  Built on device, no host sync;
+ * nmax is chosen by the caller (>= max boxes per image; rows beyond it are dropped and counted in
+ * overflow[0]).                                                                                    */
+int32_t sgx_targets_index(const float* targets, int32_t T, int32_t B, int32_t nmax, int32_t* gt_count,
+                          int32_t* gt_index, int32_t* overflow, void* stream);
+
+typedef struct sgx_loss_desc {
+    int32_t B, L, C, reg_max;   /* batch, anchors, classes, DFL bins-1 (16)                      */
+    int32_t nmax;               /* padded GT slots per image                                      */
+    int32_t use_static_assigner;/* 1 = ATSS (ppyolo_loss.py:258-434), 0 = TAL (:437-561)         */
+    int32_t use_varifocal;      /* 1 = varifocal (:1079-1084), 0 = focal (:1069-1077)            */
+    int32_t num_levels;         /* ATSS: pyramid levels                                           */
+    int32_t level_count[8];     /* ATSS: anchors per level                                        */
+    float w_cls, w_iou, w_dfl;  /* 1.0, 2.5, 0.5                                                  */
+} sgx_loss_desc;
+
+int64_t sgx_ppyoloe_loss_workspace(const sgx_loss_desc* d);
+/* Forward: assignment (no grad) + the four sums.  Outputs:
+ *   sums[4]      = cls_sum, iou_sum, dfl_sum, assigned_scores_sum          (ppyolo_loss.py:834-852)
+ *   assigned_label[B,L] int32 (bg = C), assigned_box[B,L,4] (pixels), assigned_score[B,L]
+ *   g_logits[B,L,C], g_distri[B,L,4*(R+1)]: d(w_cls*cls_sum)/dlogits and d(w_iou*iou_sum+w_dfl*dfl_sum)/ddistri
+ * The caller finishes  loss_k = w_k*sum_k / max(score_sum_allreduced,1)  and scales the stored
+ * gradients by upstream/max(...) in sgx_scale_by_device_scalar (no host sync anywhere).            */
+int32_t sgx_ppyoloe_loss_fwd(const sgx_loss_desc* d, const float* logits, const float* distri, const float* anchors,
+                             const float* points, const float* strides, const float* targets, const int32_t* gt_count,
+                             const int32_t* gt_index, float* sums, int32_t* assigned_label, float* assigned_box,
+                             float* assigned_score, float* g_logits, float* g_distri, void* ws, int64_t ws_bytes,
+                             void* stream);
+/* items[4] = (w_cls*cls, w_iou*iou, w_dfl*dfl)/max(score_sum,1) and their sum; inv_norm[0] = 1/max(..). */
+int32_t sgx_ppyoloe_loss_finalize(const float* sums, float w_cls, float w_iou, float w_dfl, float score_div,
+                                  float* items, float* inv_norm, void* stream);
+/* y[i] = x[i] * s[0] * t[0]  (t may be NULL)                                                       */
+int32_t sgx_scale_by_device_scalar(const float* x, const float* s, const float* t, float* y, int64_t n, void* stream);
+
+/* pp_yolo_e/post_prediction_callback.py:42-123 + torchvision.ops.nms/batched_nms (requirements.txt:12).
+ * Per image: score filter -> top-k (score desc, candidate index asc) -> greedy NMS (IoU > thr suppresses)
+ * -> at most max_predictions rows [x1,y1,x2,y2,score,class].  out [B][max_predictions][6], out_count[B],
+ * out_index[B][max_predictions] = candidate index (anchor*C + class for multi-label, anchor otherwise).
+ * class_mode: 0 = class-agnostic (nms), 1 = per-class via coordinate offsets (batched_nms, numel<=4000),
+ *             2 = per-class exact (batched_nms vanilla loop).                                       */
+typedef struct sgx_nms_desc {
+    int32_t B, L, C;
+    int32_t multi_label, class_mode;
+    int32_t nms_top_k, max_predictions;
+    float score_threshold, iou_threshold;
+} sgx_nms_desc;
+int64_t sgx_nms_workspace(const sgx_nms_desc* d);
+int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const float* scores, float* out, int32_t* out_count,
+                int32_t* out_index, int32_t* num_candidates, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Classification loss (training/losses/label_smoothing_cross_entropy_loss.py:86-111, mean reduction).
+ * ------------------------------------------------------------------------------------------- */
+/* loss: B+1 floats (loss[0] = mean loss, loss[1..B] = per-row losses); dlogits = d loss[0] / d logits.   */
+int32_t sgx_softmax_ce_fwd_bwd(int32_t B, int32_t K, const float* logits, const int64_t* labels, float smoothing,
+                               float* loss, float* dlogits, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer / EMA over flat fp32 arenas (one launch per arena instead of ~500 tiny ATen kernels):
+ * sg_trainer.py:639-644, training/utils/ema.py:126-141, optimizer_utils.py:32-59.
+ * seg_end[nseg] (int64, ascending, device) splits the arena into segments with per-segment weight
+ * decay seg_wd[nseg] (zero-WD groups for BN/bias).                                                  */
+int32_t sgx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, int32_t step, const int64_t* seg_end, const float* seg_wd, int32_t nseg,
+                       const float* grad_scale, void* stream);
+int32_t sgx_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, float momentum, float dampening,
+                     int32_t nesterov, int32_t first_step, const int64_t* seg_end, const float* seg_wd, int32_t nseg,
+                     void* stream);
+int32_t sgx_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream);
+int32_t sgx_fill(float* p, int64_t n, float v, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,159 @@
+"""ctypes binding of libsgx_hip.so (include/sgx_hip.h).
+
+The product has exactly one compute library: the hipcc-built gfx950 shared object in
+`super_gradients_amd/csrc/libsgx_hip.so`.  There is no CPU fallback: if the library is missing, or a
+tensor that is not on a HIP device reaches a kernel wrapper, we raise.
+
+Two HIP runtimes in one process would make torch's streams/pointers foreign to our kernels.  The wheel's
+`torch/lib/libamdhip64.so` and ROCm's `/opt/rocm/lib/libamdhip64.so.7` share the SONAME `libamdhip64.so.7`,
+so loading our library AFTER `import torch` makes the dynamic loader bind it to the runtime torch already
+loaded; `_check_single_runtime()` verifies that.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_void_p
+
+import torch  # noqa: F401  (must be imported before the library is loaded - see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsgx_hip.so")
+
+_LIB = None
+# Set ONLY by tests/emu (kernel-logic tests on host memory against tests/emu/_build/libsgx_emu.so).
+# Nothing in the package, bench.py or __graft_entry__ ever sets it.
+_TEST_HOST_MODE = False
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "Ho", "Wo")] + [
+        (n, c_int64) for n in ("x_ld_pix", "x_ld_img", "y_ld_pix", "y_ld_img")
+    ]
+
+
+class LossDesc(ctypes.Structure):
+    _fields_ = [
+        ("B", c_int32), ("L", c_int32), ("C", c_int32), ("reg_max", c_int32), ("nmax", c_int32),
+        ("use_static_assigner", c_int32), ("use_varifocal", c_int32), ("num_levels", c_int32),
+        ("level_count", c_int32 * 8), ("w_cls", c_float), ("w_iou", c_float), ("w_dfl", c_float),
+    ]
+
+
+class NmsDesc(ctypes.Structure):
+    _fields_ = [
+        ("B", c_int32), ("L", c_int32), ("C", c_int32), ("multi_label", c_int32), ("class_mode", c_int32),
+        ("nms_top_k", c_int32), ("max_predictions", c_int32), ("score_threshold", c_float), ("iou_threshold", c_float),
+    ]
+
+
+_P = c_void_p
+_i32, _i64, _f = c_int32, c_int64, c_float
+_CD, _LD, _ND = POINTER(ConvDesc), POINTER(LossDesc), POINTER(NmsDesc)
+
+# name -> (restype, argtypes); mirrors include/sgx_hip.h one to one
+PROTOTYPES = {
+    "sgx_version": (_i32, []),
+    "sgx_last_error": (c_char_p, []),
+    "sgx_conv2d_fwd": (_i32, [_CD, _P, _P, _P, _P, _P, _i32, _P, _P]),
+    "sgx_conv2d_fwd_stat_blocks": (_i32, [_CD]),
+    "sgx_conv2d_bwd_data_workspace": (_i64, [_CD]),
+    "sgx_conv2d_bwd_data": (_i32, [_CD, _P, _P, _P, _P, _i32, _P, _i64, _P]),
+    "sgx_conv2d_bwd_weight_workspace": (_i64, [_CD]),
+    "sgx_conv2d_bwd_weight": (_i32, [_CD, _P, _P, _P, _P, _P, _i64, _P]),
+    "sgx_convT2x2_workspace": (_i64, [_i32] * 5),
+    "sgx_convT2x2_fwd": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _P, _i64, _i64, _P, _i64, _P]),
+    "sgx_convT2x2_bwd_data": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _i64, _i64, _P]),
+    "sgx_convT2x2_bwd_weight": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _i64, _i64, _P, _P, _P, _i64, _P]),
+    "sgx_nchw_to_nhwc": (_i32, [_i32] * 5 + [_P, _P, _P]),
+    "sgx_nhwc_to_nchw": (_i32, [_i32] * 4 + [_P, _i64, _i64, _P, _P]),
+    "sgx_stats_blocks": (_i32, [_i64]),
+    "sgx_channel_stats_partial": (_i32, [_P, _i64, _i32, _i64, _P, _P]),
+    "sgx_bn_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P, _P]),
+    "sgx_bn_eval_scale_shift": (_i32, [_i32, _P, _P, _P, _P, _f, _P, _P, _P]),
+    "sgx_affine_act_fwd": (_i32, [_P, _i64, _P, _P, _P, _i64, _f, _P, _P, _i64, _f, _P, _i64, _i64, _i32, _i32, _P, _P]),
+    "sgx_bn_bwd_reduce": (_i32, [_P, _i64, _P, _i64, _P, _P, _i64, _i32, _i32, _P, _P]),
+    "sgx_bn_bwd_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _P, _P, _P, _P, _P]),
+    "sgx_bn_bwd_apply": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _P, _i64, _P, _i64, _i64, _i32, _i32, _P]),
+    "sgx_dot_partial": (_i32, [_P, _i64, _P, _i64, _i64, _i32, _P, _P]),
+    "sgx_sum_partials": (_i32, [_P, _i32, _f, _P, _i32, _P]),
+    "sgx_axpy": (_i32, [_P, _i64, _f, _P, _P, _i64, _i64, _i32, _i32, _P]),
+    "sgx_colsum": (_i32, [_P, _i64, _i64, _i32, _i64, _i64, _P, _i32, _P, _P]),
+    "sgx_maxpool_fwd": (_i32, [_i32] * 7 + [_P, _i64, _i64, _P, _i64, _i64, _P, _P]),
+    "sgx_maxpool_bwd": (_i32, [_i32] * 7 + [_P, _P, _i64, _i64, _P, _i64, _i64, _i32, _P]),
+    "sgx_avgpool_fwd": (_i32, [_i32] * 3 + [_P, _i64, _i64, _P, _P]),
+    "sgx_avgpool_bwd": (_i32, [_i32] * 3 + [_P, _P, _i64, _i64, _P]),
+    "sgx_dfl_decode": (_i32, [_i32] * 4 + [_P] * 6 + [_P]),
+    "sgx_targets_index": (_i32, [_P, _i32, _i32, _i32, _P, _P, _P, _P]),
+    "sgx_ppyoloe_loss_workspace": (_i64, [_LD]),
+    "sgx_ppyoloe_loss_fwd": (_i32, [_LD] + [_P] * 14 + [_P, _i64, _P]),
+    "sgx_ppyoloe_loss_finalize": (_i32, [_P, _f, _f, _f, _f, _P, _P, _P]),
+    "sgx_scale_by_device_scalar": (_i32, [_P, _P, _P, _P, _i64, _P]),
+    "sgx_nms_workspace": (_i64, [_ND]),
+    "sgx_nms": (_i32, [_ND, _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
+    "sgx_softmax_ce_fwd_bwd": (_i32, [_i32, _i32, _P, _P, _f, _P, _P, _P]),
+    "sgx_adamw_step": (_i32, [_P, _P, _P, _P, _i64, _f, _f, _f, _f, _i32, _P, _P, _i32, _P, _P]),
+    "sgx_sgd_step": (_i32, [_P, _P, _P, _i64, _f, _f, _f, _i32, _i32, _P, _P, _i32, _P]),
+    "sgx_ema_update": (_i32, [_P, _P, _i64, _f, _P]),
+    "sgx_fill": (_i32, [_P, _i64, _f, _P]),
+}
+
+
+def bind(cdll):
+    """Attach restype/argtypes for every symbol include/sgx_hip.h declares; raises if one is missing."""
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(cdll, name)  # AttributeError -> the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+def _check_single_runtime():
+    try:
+        with open("/proc/self/maps") as f:
+            libs = {line.split()[-1] for line in f if "libamdhip64" in line}
+    except OSError:
+        return
+    if len(libs) > 1:
+        raise RuntimeError(
+            "two HIP runtimes are mapped in this process (%s): import torch before loading libsgx_hip.so" % sorted(libs)
+        )
+
+
+def lib():
+    """The bound library.  Fails loudly when it has not been built (python __graft_entry__.py / csrc/build.py)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). Build it with "
+                "`python super_gradients_amd/csrc/build.py` (hipcc --offload-arch=gfx950)."
+            )
+        _LIB = bind(ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL))
+        _check_single_runtime()
+    return _LIB
+
+
+class SgxError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().sgx_last_error()
+        raise SgxError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must live on the HIP device."""
+    if t is None:
+        return None
+    if not t.is_cuda and not _TEST_HOST_MODE:
+        raise SgxError("libsgx_hip kernels need tensors on the HIP device (got a CPU tensor); there is no CPU fallback")
+    if t.dtype not in (torch.float32, torch.int32, torch.int64, torch.uint8):
+        raise SgxError(f"unsupported dtype {t.dtype}")
+    return t.data_ptr()
+
+
+def stream():
+    if _TEST_HOST_MODE:
+        return None
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,417 @@
+// BatchNorm (training) statistics, the fused affine/residual/activation passes around it, and their
+// backward - HBM-bound row x channel sweeps over NHWC tensors (rows = pixels, columns = channels).
+//
+// One sweep skeleton serves all of them: a 256-thread workgroup owns a contiguous run of rows and a
+// strip of up to 256 channels; a thread owns one float4 channel group and every RL-th row, so a wave's
+// loads are 16-byte, channel-contiguous (coalesced), and per-channel reductions are lane-local until a
+// single LDS fold at the end.  Reductions are two-stage and deterministic: per-workgroup partials in
+// fp32, a tiny finalize kernel accumulating them in fp64 in a fixed order (no float atomics).
+// Reference call sites: include/sgx_hip.h (BatchNorm section).
+#include "sgx_common.h"
+
+#define SW_THREADS 256
+#define SW_MAXCG 64  // float4 channel groups per workgroup strip (256 channels)
+
+struct SweepGeom {
+    long M;
+    int C, C4, CG, RL, nblk, rows_per_blk, ctiles;
+};
+
+extern "C" int32_t sgx_stats_blocks(int64_t M) {
+    long n = (M + 255) / 256;
+    if (n < 1) n = 1;
+    if (n > 1024) n = 1024;
+    return (int32_t)n;
+}
+
+static SweepGeom sweep_geom(long M, int C) {
+    SweepGeom g;
+    g.M = M;
+    g.C = C;
+    g.C4 = C / 4;
+    g.CG = g.C4 < SW_MAXCG ? g.C4 : SW_MAXCG;
+    g.RL = SW_THREADS / g.CG;
+    g.nblk = sgx_stats_blocks(M);
+    g.rows_per_blk = (int)((M + g.nblk - 1) / g.nblk);
+    g.ctiles = (g.C4 + g.CG - 1) / g.CG;
+    return g;
+}
+
+// F: struct with  __device__ void row(long r, int c, float4& q0, float4& q1)  doing the per-element work
+// (loads, stores) for row r, channels c..c+3 and accumulating up to two per-channel quantities.
+template <typename F, int NQ>
+__global__ __launch_bounds__(SW_THREADS) void sweep_kernel(F f, SweepGeom g, float* partials) {
+    __shared__ float4 red[NQ > 0 ? NQ : 1][SW_THREADS];
+    const int tid = threadIdx.x;
+    const int cg = tid % g.CG, rl = tid / g.CG;
+    const int c4 = blockIdx.y * g.CG + cg;
+    const bool live = (rl < g.RL) && (c4 < g.C4);
+    const int c = c4 * 4;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+    if (live) {
+        long r0 = (long)blockIdx.x * g.rows_per_blk;
+        long r1 = r0 + g.rows_per_blk;
+        if (r1 > g.M) r1 = g.M;
+        for (long r = r0 + rl; r < r1; r += g.RL) f.row(r, c, q0, q1);
+    }
+    if (NQ > 0 && partials) {
+        red[0][tid] = q0;
+        if (NQ > 1) red[NQ > 1 ? 1 : 0][tid] = q1;
+        __syncthreads();
+        if (live && rl == 0) {
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+            for (int k = 0; k < g.RL; ++k) {
+                float4 a = red[0][k * g.CG + cg];
+                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+                if (NQ > 1) {
+                    float4 b = red[NQ > 1 ? 1 : 0][k * g.CG + cg];
+                    s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+                }
+            }
+            sgx_st4(partials + (long)blockIdx.x * g.C + c, s0);
+            if (NQ > 1) sgx_st4(partials + ((long)g.nblk + blockIdx.x) * g.C + c, s1);
+        }
+    }
+}
+
+template <typename F, int NQ>
+static int32_t run_sweep(const F& f, long M, int C, float* partials, void* stream, const char* what) {
+    SGX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "%s: need M>0 and C%%4==0 (C=%d)", what, C);
+    SweepGeom g = sweep_geom(M, C);
+    SGX_LAUNCH((sweep_kernel<F, NQ>), dim3(g.nblk, g.ctiles), dim3(SW_THREADS), 0, stream, f, g, partials);
+    SGX_CHECK_LAUNCH(what);
+    return SGX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct StatsF {
+    const float* x;
+    long ld;
+    __device__ void row(long r, int c, float4& q0, float4& q1) const {
+        float4 v = sgx_ld4(x + r * ld + c);
+        q0.x += v.x; q0.y += v.y; q0.z += v.z; q0.w += v.w;
+        q1.x += v.x * v.x; q1.y += v.y * v.y; q1.z += v.z * v.z; q1.w += v.w * v.w;
+    }
+};
+extern "C" int32_t sgx_channel_stats_partial(const float* x, int64_t M, int32_t C, int64_t ld, float* partials, void* stream) {
+    SGX_CHECK_ARG(x && partials, "channel_stats: null pointer");
+    StatsF f{x, ld};
+    return run_sweep<StatsF, 2>(f, M, C, partials, stream, "channel_stats");
+}
+
+__global__ void bn_finalize_kernel(const float* partials, int nblk, long M, int C, const float* gamma, const float* beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                                   float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)partials[(long)b * C + c];
+        q += (double)partials[((long)nblk + b) * C + c];
+    }
+    double mean = s / (double)M;
+    double var = q / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    double invstd = 1.0 / sqrt(var + (double)eps);
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+    if (running_var) {
+        double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_invstd) save_invstd[c] = (float)invstd;
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    float sc = g * (float)invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+}
+extern "C" int32_t sgx_bn_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma, const float* beta,
+                                   float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                                   float* save_invstd, float* scale, float* shift, void* stream) {
+    SGX_CHECK_ARG(partials && scale && shift && nblk > 0, "bn_finalize: bad args");
+    SGX_LAUNCH(bn_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, partials, nblk, (long)M, C, gamma, beta, eps, momentum,
+               running_mean, running_var, save_mean, save_invstd, scale, shift);
+    SGX_CHECK_LAUNCH("bn_finalize");
+    return SGX_OK;
+}
+
+__global__ void bn_eval_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float invstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+    float sc = (gamma ? gamma[c] : 1.f) * invstd;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+extern "C" int32_t sgx_bn_eval_scale_shift(int32_t C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                           float eps, float* scale, float* shift, void* stream) {
+    SGX_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "bn_eval: bad args");
+    SGX_LAUNCH(bn_eval_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, C, gamma, beta, running_mean, running_var, eps, scale, shift);
+    SGX_CHECK_LAUNCH("bn_eval");
+    return SGX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct AffineActF {
+    const float* x; long x_ld;
+    const float* scale; const float* shift;
+    const float* r1; long r1_ld; float a1; const float* a1_dev;
+    const float* r2; long r2_ld; float a2;
+    float* y; long y_ld;
+    int act;
+    __device__ void row(long r, int c, float4& q0, float4& q1) const {
+        float4 v = sgx_ld4(x + r * x_ld + c);
+        if (scale) {
+            float4 s = sgx_ld4(scale + c), t = sgx_ld4(shift + c);
+            v.x = s.x * v.x + t.x; v.y = s.y * v.y + t.y; v.z = s.z * v.z + t.z; v.w = s.w * v.w + t.w;
+        }
+        if (r1) {
+            float a = a1_dev ? a1_dev[0] : a1;
+            float4 u = sgx_ld4(r1 + r * r1_ld + c);
+            v.x += a * u.x; v.y += a * u.y; v.z += a * u.z; v.w += a * u.w;
+        }
+        if (r2) {
+            float4 u = sgx_ld4(r2 + r * r2_ld + c);
+            v.x += a2 * u.x; v.y += a2 * u.y; v.z += a2 * u.z; v.w += a2 * u.w;
+        }
+        q0.x += v.x; q0.y += v.y; q0.z += v.z; q0.w += v.w;
+        q1.x += v.x * v.x; q1.y += v.y * v.y; q1.z += v.z * v.z; q1.w += v.w * v.w;
+        float4 o = make_float4(sgx_act(v.x, act), sgx_act(v.y, act), sgx_act(v.z, act), sgx_act(v.w, act));
+        sgx_st4(y + r * y_ld + c, o);
+    }
+};
+extern "C" int32_t sgx_affine_act_fwd(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* r1,
+                                      int64_t r1_ld, float a1, const float* a1_dev, const float* r2, int64_t r2_ld, float a2, float* y,
+                                      int64_t y_ld, int64_t M, int32_t C, int32_t act, float* partials, void* stream) {
+    SGX_CHECK_ARG(x && y, "affine_act: null pointer");
+    SGX_CHECK_ARG((scale == nullptr) == (shift == nullptr), "affine_act: scale and shift go together");
+    AffineActF f{x, x_ld, scale, shift, r1, r1_ld, a1, a1_dev, r2, r2_ld, a2, y, y_ld, act};
+    return run_sweep<AffineActF, 2>(f, M, C, partials, stream, "affine_act");
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bn_masked(float dy, float x, float s, float t, int act) {
+    return act == SGX_ACT_NONE ? dy : dy * sgx_act_grad(s * x + t, act);
+}
+struct BnBwdReduceF {
+    const float* dy; long dy_ld; const float* x; long x_ld; const float* scale; const float* shift; int act;
+    __device__ void row(long r, int c, float4& q0, float4& q1) const {
+        float4 d = sgx_ld4(dy + r * dy_ld + c), v = sgx_ld4(x + r * x_ld + c);
+        float4 s = sgx_ld4(scale + c), t = sgx_ld4(shift + c);
+        float gx = bn_masked(d.x, v.x, s.x, t.x, act), gy = bn_masked(d.y, v.y, s.y, t.y, act);
+        float gz = bn_masked(d.z, v.z, s.z, t.z, act), gw = bn_masked(d.w, v.w, s.w, t.w, act);
+        q0.x += gx; q0.y += gy; q0.z += gz; q0.w += gw;
+        q1.x += gx * v.x; q1.y += gy * v.y; q1.z += gz * v.z; q1.w += gw * v.w;
+    }
+};
+extern "C" int32_t sgx_bn_bwd_reduce(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale, const float* shift,
+                                     int64_t M, int32_t C, int32_t act, float* partials, void* stream) {
+    SGX_CHECK_ARG(dy && x && scale && shift && partials, "bn_bwd_reduce: null pointer");
+    BnBwdReduceF f{dy, dy_ld, x, x_ld, scale, shift, act};
+    return run_sweep<BnBwdReduceF, 2>(f, M, C, partials, stream, "bn_bwd_reduce");
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* partials, int nblk, long M, int C, const float* gamma, const float* save_mean,
+                                       const float* save_invstd, float* dgamma, float* dbeta, float* coef) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sg = 0.0, sgx = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        sg += (double)partials[(long)b * C + c];
+        sgx += (double)partials[((long)nblk + b) * C + c];
+    }
+    double mean = save_mean[c], invstd = save_invstd[c], g = gamma ? (double)gamma[c] : 1.0;
+    double sgxhat = invstd * (sgx - mean * sg);
+    if (dgamma) dgamma[c] += (float)sgxhat;
+    if (dbeta) dbeta[c] += (float)sg;
+    double mg = sg / (double)M, mgx = sgxhat / (double)M;
+    coef[c] = (float)(g * invstd);
+    coef[C + c] = (float)(-g * invstd * invstd * mgx);
+    coef[2 * C + c] = (float)(-g * invstd * mg + g * invstd * invstd * mean * mgx);
+}
+extern "C" int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma, const float* save_mean,
+                                       const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
+    SGX_CHECK_ARG(partials && save_mean && save_invstd && coef, "bn_bwd_finalize: null pointer");
+    SGX_LAUNCH(bn_bwd_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, partials, nblk, (long)M, C, gamma, save_mean, save_invstd,
+               dgamma, dbeta, coef);
+    SGX_CHECK_LAUNCH("bn_bwd_finalize");
+    return SGX_OK;
+}
+
+struct BnBwdApplyF {
+    const float* dy; long dy_ld; const float* x; long x_ld; const float* scale; const float* shift; const float* coef; int C;
+    float* dx; long dx_ld; float* g_out; long g_ld; int act;
+    __device__ void row(long r, int c, float4& q0, float4& q1) const {
+        (void)q0; (void)q1;
+        float4 d = sgx_ld4(dy + r * dy_ld + c), v = sgx_ld4(x + r * x_ld + c);
+        float4 s = sgx_ld4(scale + c), t = sgx_ld4(shift + c);
+        float4 c1 = sgx_ld4(coef + c), c2 = sgx_ld4(coef + C + c), c3 = sgx_ld4(coef + 2 * C + c);
+        float4 g = make_float4(bn_masked(d.x, v.x, s.x, t.x, act), bn_masked(d.y, v.y, s.y, t.y, act),
+                               bn_masked(d.z, v.z, s.z, t.z, act), bn_masked(d.w, v.w, s.w, t.w, act));
+        float4 o = make_float4(c1.x * g.x + c2.x * v.x + c3.x, c1.y * g.y + c2.y * v.y + c3.y,
+                               c1.z * g.z + c2.z * v.z + c3.z, c1.w * g.w + c2.w * v.w + c3.w);
+        sgx_st4(dx + r * dx_ld + c, o);
+        if (g_out) sgx_st4(g_out + r * g_ld + c, g);
+    }
+};
+extern "C" int32_t sgx_bn_bwd_apply(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale, const float* shift,
+                                    const float* coef, float* dx, int64_t dx_ld, float* g_out, int64_t g_ld, int64_t M, int32_t C,
+                                    int32_t act, void* stream) {
+    SGX_CHECK_ARG(dy && x && scale && shift && coef && dx, "bn_bwd_apply: null pointer");
+    BnBwdApplyF f{dy, dy_ld, x, x_ld, scale, shift, coef, C, dx, dx_ld, g_out, g_ld, act};
+    return run_sweep<BnBwdApplyF, 0>(f, M, C, nullptr, stream, "bn_bwd_apply");
+}
+
+// ---------------------------------------------------------------------------------------------
+struct DotF {
+    const float* a; long a_ld; const float* b; long b_ld;
+    __device__ void row(long r, int c, float4& q0, float4& q1) const {
+        (void)q1;
+        float4 u = sgx_ld4(a + r * a_ld + c), v = sgx_ld4(b + r * b_ld + c);
+        q0.x += u.x * v.x; q0.y += u.y * v.y; q0.z += u.z * v.z; q0.w += u.w * v.w;
+    }
+};
+// per-(block, channel) partial products: partials [nblk][C]; reduce with sgx_sum_partials(n = nblk*C)
+extern "C" int32_t sgx_dot_partial(const float* a, int64_t a_ld, const float* b, int64_t b_ld, int64_t M, int32_t C, float* partials,
+                                   void* stream) {
+    SGX_CHECK_ARG(a && b && partials, "dot_partial: null pointer");
+    DotF f{a, a_ld, b, b_ld};
+    return run_sweep<DotF, 1>(f, M, C, partials, stream, "dot_partial");
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* partials, int n, float scale, float* out, int accumulate) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float v = (float)(red[0] * (double)scale);
+        out[0] = accumulate ? out[0] + v : v;
+    }
+}
+extern "C" int32_t sgx_sum_partials(const float* partials, int32_t n, float scale, float* out, int32_t accumulate, void* stream) {
+    SGX_CHECK_ARG(partials && out && n >= 0, "sum_partials: bad args");
+    SGX_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, n, scale, out, accumulate);
+    SGX_CHECK_LAUNCH("sum_partials");
+    return SGX_OK;
+}
+
+struct AxpyF {
+    const float* x; long x_ld; float a; const float* a_dev; float* y; long y_ld; int accumulate;
+    __device__ void row(long r, int c, float4& q0, float4& q1) const {
+        (void)q0; (void)q1;
+        float s = a_dev ? a_dev[0] : a;
+        float4 v = sgx_ld4(x + r * x_ld + c);
+        float4 o = make_float4(s * v.x, s * v.y, s * v.z, s * v.w);
+        if (accumulate) {
+            float4 u = sgx_ld4(y + r * y_ld + c);
+            o.x += u.x; o.y += u.y; o.z += u.z; o.w += u.w;
+        }
+        sgx_st4(y + r * y_ld + c, o);
+    }
+};
+extern "C" int32_t sgx_axpy(const float* x, int64_t x_ld, float a, const float* a_dev, float* y, int64_t y_ld, int64_t M, int32_t C,
+                            int32_t accumulate, void* stream) {
+    SGX_CHECK_ARG(x && y, "axpy: null pointer");
+    AxpyF f{x, x_ld, a, a_dev, y, y_ld, accumulate};
+    return run_sweep<AxpyF, 0>(f, M, C, nullptr, stream, "axpy");
+}
+
+struct ColsumF {
+    const float* x; long ld; long rows_per_img; long ld_img;
+    __device__ void row(long r, int c, float4& q0, float4& q1) const {
+        (void)q1;
+        long img = r / rows_per_img;
+        float4 v = sgx_ld4(x + img * ld_img + (r - img * rows_per_img) * ld + c);
+        q0.x += v.x; q0.y += v.y; q0.z += v.z; q0.w += v.w;
+    }
+};
+__global__ void colsum_finalize_kernel(const float* partials, int nblk, int C, float* out, int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)partials[(long)b * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+// ws: sgx_stats_blocks(M) * C floats
+extern "C" int32_t sgx_colsum(const float* x, int64_t ld, int64_t M, int32_t C, int64_t rows_per_img, int64_t ld_img, float* out,
+                              int32_t accumulate, float* ws, void* stream) {
+    SGX_CHECK_ARG(x && out && ws && rows_per_img > 0, "colsum: bad args");
+    ColsumF f{x, ld, rows_per_img, ld_img};
+    int32_t rc = run_sweep<ColsumF, 1>(f, M, C, ws, stream, "colsum");
+    if (rc) return rc;
+    SGX_LAUNCH(colsum_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, (const float*)ws, sgx_stats_blocks(M), C, out, accumulate);
+    SGX_CHECK_LAUNCH("colsum_finalize");
+    return SGX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void fill_kernel(float* p, long n, float v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+extern "C" int32_t sgx_fill(float* p, int64_t n, float v, void* stream) {
+    if (n <= 0) return SGX_OK;
+    SGX_CHECK_ARG(p, "fill: null pointer");
+    long blocks = (n + 255) / 256;
+    SGX_LAUNCH(fill_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream, p, (long)n, v);
+    SGX_CHECK_LAUNCH("fill");
+    return SGX_OK;
+}
+
+__global__ void scale_dev_kernel(const float* x, const float* s, const float* t, float* y, long n) {
+    float f = s[0] * (t ? t[0] : 1.f);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * f;
+}
+extern "C" int32_t sgx_scale_by_device_scalar(const float* x, const float* s, const float* t, float* y, int64_t n, void* stream) {
+    if (n <= 0) return SGX_OK;
+    SGX_CHECK_ARG(x && s && y, "scale: null pointer");
+    long blocks = (n + 255) / 256;
+    SGX_LAUNCH(scale_dev_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream, x, s, t, y, (long)n);
+    SGX_CHECK_LAUNCH("scale_by_device_scalar");
+    return SGX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout changes at the model boundary
+__global__ void nchw_to_nhwc_kernel(int N, int C, int H, int W, int Cpad, const float* x, float* y) {
+    long n = (long)N * H * W * Cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % Cpad);
+        long pix = i / Cpad;
+        long hw = (long)H * W;
+        long img = pix / hw, rem = pix - img * hw;
+        y[i] = c < C ? x[(img * C + c) * hw + rem] : 0.f;
+    }
+}
+extern "C" int32_t sgx_nchw_to_nhwc(int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cpad, const float* x, float* y, void* stream) {
+    SGX_CHECK_ARG(x && y && Cpad >= C && Cpad % 4 == 0, "nchw_to_nhwc: bad args");
+    long n = (long)N * H * W * Cpad, blocks = (n + 255) / 256;
+    SGX_LAUNCH(nchw_to_nhwc_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, stream, N, C, H, W, Cpad, x, y);
+    SGX_CHECK_LAUNCH("nchw_to_nhwc");
+    return SGX_OK;
+}
+__global__ void nhwc_to_nchw_kernel(int N, int C, int H, int W, const float* x, long ld_pix, long ld_img, float* y) {
+    long n = (long)N * C * H * W;
+    long hw = (long)H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        long rem = i % hw;
+        long t = i / hw;
+        int c = (int)(t % C);
+        long img = t / C;
+        y[i] = x[img * ld_img + rem * ld_pix + c];
+    }
+}
+extern "C" int32_t sgx_nhwc_to_nchw(int32_t N, int32_t C, int32_t H, int32_t W, const float* x, int64_t x_ld_pix, int64_t x_ld_img, float* y,
+                                    void* stream) {
+    SGX_CHECK_ARG(x && y, "nhwc_to_nchw: null pointer");
+    long n = (long)N * C * H * W, blocks = (n + 255) / 256;
+    SGX_LAUNCH(nhwc_to_nchw_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, stream, N, C, H, W, x, (long)x_ld_pix,
+               (long)x_ld_img, y);
+    SGX_CHECK_LAUNCH("nhwc_to_nchw");
+    return SGX_OK;
+}

@@ -1,0 +1,58 @@
+"""Builds libsgx_hip.so (gfx950 device code + C-ABI host code) in-tree with hipcc.
+
+    python super_gradients_amd/csrc/build.py            # incremental
+    python super_gradients_amd/csrc/build.py --force
+
+hipcc cross-compiles gfx950 code objects without a GPU.  The library is linked against libamdhip64.so.7;
+when it is loaded into a process that already imported torch, the dynamic loader resolves that SONAME
+to the runtime torch already loaded (torch/lib/libamdhip64.so has the same SONAME), so kernels run on
+torch's streams and allocations - see super_gradients_amd/_lib.py.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "libsgx_hip.so")
+SOURCES = ["conv.hip", "bn.hip", "pool.hip", "loss.hip", "nms.hip", "optim.hip", "api.cpp"]
+# decisions in loss/nms must round like the CPU op-by-op arithmetic: no fma contraction there
+NO_CONTRACT = {"loss.hip", "nms.hip"}
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hdrs = [os.path.join(HERE, "sgx_common.h"), os.path.join(HERE, "..", "..", "include", "sgx_hip.h")]
+    objdir = os.path.join(HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for src in SOURCES:
+        sp = os.path.join(HERE, src)
+        obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [sp] + hdrs):
+            cmd = [HIPCC] + COMMON + (["-ffp-contract=off"] if src in NO_CONTRACT else []) + ["-x", "hip", "-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    if force or procs or _stale(OUT, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

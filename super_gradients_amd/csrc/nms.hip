@@ -1,0 +1,260 @@
+// Detection post-processing on gfx950: score filter -> exact top-k -> greedy NMS, one 1024-thread workgroup
+// per image, everything after the score stream stays in LDS.  No MFMA: the score stream is HBM/L2-bound
+// (B*L*C*4 bytes per pass), the suppression loop is latency-bound (one barrier per KEPT box).
+//
+// Replaces PPYoloEPostPredictionCallback.forward (pp_yolo_e/post_prediction_callback.py:42-123) and the
+// torchvision.ops.nms / batched_nms it calls (:85,87).  Ordering rule (matches a stable descending sort):
+// candidates are ranked by (score desc, candidate index asc), candidate index = anchor*C + class
+// (the row-major order of `(scores > thr).nonzero()`), or the anchor index in single-label mode.
+// The exact k-th composite key is found by a 5-digit radix select over (score bits, ~index) - no sort of
+// the 672k scores - then <=1024 survivors are bitonic-sorted in LDS.
+// Compile with -ffp-contract=off: the IoU test must round exactly like the CPU restatement.
+#include "sgx_common.h"
+
+#define NMS_THREADS 1024
+#define NMS_MAXK 1024
+#define NMS_IDXBITS 22
+#define NMS_HBINS 2048
+
+typedef unsigned long long u64;
+
+extern "C" int64_t sgx_nms_workspace(const sgx_nms_desc* d) {
+    (void)d;
+    return 256;  // everything lives in LDS; kept for ABI stability
+}
+
+__device__ __forceinline__ bool nms_candidate(const sgx_nms_desc& d, const float* sc, long e, float& score, int& cls) {
+    if (d.multi_label) {
+        score = sc[e];
+        cls = (int)(e % d.C);
+        return score > d.score_threshold;
+    }
+    const float* row = sc + e * d.C;
+    float m = row[0];
+    int mi = 0;
+    for (int c = 1; c < d.C; ++c)
+        if (row[c] > m) {
+            m = row[c];
+            mi = c;
+        }
+    score = m;
+    cls = mi;
+    return m >= d.score_threshold;
+}
+__device__ __forceinline__ u64 nms_key(float score, long e) {
+    return ((u64)__float_as_uint(score) << NMS_IDXBITS) | (u64)(((1u << NMS_IDXBITS) - 1u) - (unsigned)e);
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const float* boxes, const float* scores, float* out, int* out_count,
+                                                          int* out_index, int* num_candidates) {
+    __shared__ int hist[NMS_HBINS];
+    __shared__ u64 keys[NMS_MAXK];
+    __shared__ float bx[NMS_MAXK][4];
+    __shared__ float area[NMS_MAXK];
+    __shared__ int cls_s[NMS_MAXK];
+    __shared__ unsigned char sup[NMS_MAXK];
+    __shared__ int s_count, s_n, s_kept, s_remaining;
+    __shared__ u64 s_prefix;
+    __shared__ float s_maxc;
+    __shared__ int keep_list[NMS_MAXK];
+    __shared__ float wmax[NMS_THREADS / 64];
+    __shared__ float cur[5];
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* sc = scores + (long)b * d.L * d.C;
+    const float* bxs = boxes + (long)b * d.L * 4;
+    const long E = d.multi_label ? (long)d.L * d.C : (long)d.L;
+    const int K = d.nms_top_k < NMS_MAXK ? d.nms_top_k : NMS_MAXK;
+
+    // ---- pass 0: count candidates ----
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    {
+        int local = 0;
+        for (long e = tid; e < E; e += NMS_THREADS) {
+            float s;
+            int c;
+            if (nms_candidate(d, sc, e, s, c)) ++local;
+        }
+        if (local) atomicAdd(&s_count, local);
+    }
+    __syncthreads();
+    const int count = s_count;
+    const int n = count < K ? count : K;
+    // ---- radix select of the n-th largest composite key (only when count > K) ----
+    u64 thr_key = 0;  // select keys >= thr_key
+    if (count > K) {
+        const int total_bits = 31 + NMS_IDXBITS;  // 53
+        const int widths[5] = {11, 11, 11, 11, total_bits - 44};
+        if (tid == 0) {
+            s_prefix = 0;
+            s_remaining = K;
+        }
+        int shift = total_bits;
+        for (int pass = 0; pass < 5; ++pass) {
+            const int wbits = widths[pass];
+            shift -= wbits;
+            for (int i = tid; i < NMS_HBINS; i += NMS_THREADS) hist[i] = 0;
+            __syncthreads();
+            const u64 prefix = s_prefix;
+            for (long e = tid; e < E; e += NMS_THREADS) {
+                float s;
+                int c;
+                if (nms_candidate(d, sc, e, s, c)) {
+                    u64 k = nms_key(s, e);
+                    if ((k >> (shift + wbits)) == prefix) atomicAdd(&hist[(int)((k >> shift) & ((1u << wbits) - 1u))], 1);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int rem = s_remaining, cum = 0, dsel = 0;
+                for (int bin = (1 << wbits) - 1; bin >= 0; --bin) {
+                    if (cum + hist[bin] >= rem) {
+                        dsel = bin;
+                        break;
+                    }
+                    cum += hist[bin];
+                }
+                s_remaining = rem - cum;
+                s_prefix = (prefix << wbits) | (u64)dsel;
+            }
+            __syncthreads();
+        }
+        thr_key = s_prefix;
+    }
+    // ---- gather survivors (unordered), then bitonic sort descending ----
+    if (tid == 0) s_n = 0;
+    for (int i = tid; i < NMS_MAXK; i += NMS_THREADS) keys[i] = 0;  // 0 sorts last (real keys have score bits > 0)
+    __syncthreads();
+    for (long e = tid; e < E; e += NMS_THREADS) {
+        float s;
+        int c;
+        if (nms_candidate(d, sc, e, s, c)) {
+            u64 k = nms_key(s, e);
+            if (k >= thr_key) {
+                int slot = atomicAdd(&s_n, 1);
+                if (slot < NMS_MAXK) keys[slot] = k;
+            }
+        }
+    }
+    __syncthreads();
+    for (int size = 2; size <= NMS_MAXK; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            int i = tid;
+            int j = i ^ stride;
+            if (j > i) {
+                u64 a = keys[i], c = keys[j];
+                bool desc = (i & size) == 0;
+                if (desc ? (a < c) : (a > c)) {
+                    keys[i] = c;
+                    keys[j] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- load boxes / classes of the n survivors ----
+    if (tid == 0) s_maxc = -INFINITY;
+    __syncthreads();
+    float mymax = -INFINITY;
+    if (tid < n) {
+        u64 k = keys[tid];
+        long e = (long)(((1u << NMS_IDXBITS) - 1u) - (unsigned)(k & ((1u << NMS_IDXBITS) - 1u)));
+        long anchor = d.multi_label ? e / d.C : e;
+        int c;
+        if (d.multi_label) c = (int)(e % d.C);
+        else {
+            float s;
+            nms_candidate(d, sc, e, s, c);
+        }
+        cls_s[tid] = c;
+        for (int q = 0; q < 4; ++q) {
+            float v = bxs[anchor * 4 + q];
+            bx[tid][q] = v;
+            mymax = fmaxf(mymax, v);
+        }
+    }
+    sup[tid] = 0;
+    if (d.class_mode == 1) {
+        // torchvision batched_nms coordinate trick: boxes + cls * (max_coordinate + 1)
+        for (int off = 32; off > 0; off >>= 1) mymax = fmaxf(mymax, __shfl_xor(mymax, off));
+        if ((tid & 63) == 0) wmax[tid >> 6] = mymax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = wmax[0];
+            for (int w = 1; w < NMS_THREADS / 64; ++w) m = fmaxf(m, wmax[w]);
+            s_maxc = m;
+        }
+        __syncthreads();
+    }
+    float nb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < n) {
+        float offv = 0.f;
+        if (d.class_mode == 1) offv = (float)cls_s[tid] * (s_maxc + 1.f);
+        for (int q = 0; q < 4; ++q) nb[q] = bx[tid][q] + offv;
+        area[tid] = (nb[2] - nb[0]) * (nb[3] - nb[1]);
+    }
+    __syncthreads();
+    // keep original boxes for output; nb[] (offset boxes) stay in registers of thread j = tid
+    if (tid == 0) s_kept = 0;
+    __syncthreads();
+    // ---- greedy scan: one barrier per kept box ----
+    // To test (i, j) every thread needs box i: broadcast through LDS (offset form).
+    for (int i = 0; i < n; ++i) {
+        if (sup[i]) continue;  // uniform: flags only change before a barrier
+        if (tid == i) {
+            cur[0] = nb[0]; cur[1] = nb[1]; cur[2] = nb[2]; cur[3] = nb[3]; cur[4] = area[i];
+            keep_list[s_kept] = i;
+            s_kept = s_kept + 1;
+        }
+        __syncthreads();
+        if (tid > i && tid < n && !sup[tid] && (d.class_mode != 2 || cls_s[tid] == cls_s[i])) {
+            float xx1 = fmaxf(cur[0], nb[0]), yy1 = fmaxf(cur[1], nb[1]);
+            float xx2 = fminf(cur[2], nb[2]), yy2 = fminf(cur[3], nb[3]);
+            float w = xx2 - xx1; w = w < 0.f ? 0.f : w;
+            float h = yy2 - yy1; h = h < 0.f ? 0.f : h;
+            float inter = w * h;
+            float ovr = inter / (cur[4] + area[tid] - inter);
+            if (ovr > d.iou_threshold) sup[tid] = 1;
+        }
+        __syncthreads();
+        if (s_kept >= d.max_predictions) break;  // uniform
+    }
+    __syncthreads();
+    const int kept = s_kept < d.max_predictions ? s_kept : d.max_predictions;
+    if (tid == 0) {
+        out_count[b] = kept;
+        if (num_candidates) num_candidates[b] = n;
+    }
+    for (int r = tid; r < d.max_predictions; r += NMS_THREADS) {
+        float* o = out + ((long)b * d.max_predictions + r) * 6;
+        if (r < kept) {
+            int i = keep_list[r];
+            u64 k = keys[i];
+            unsigned e = ((1u << NMS_IDXBITS) - 1u) - (unsigned)(k & ((1u << NMS_IDXBITS) - 1u));
+            o[0] = bx[i][0]; o[1] = bx[i][1]; o[2] = bx[i][2]; o[3] = bx[i][3];
+            o[4] = __uint_as_float((unsigned)(k >> NMS_IDXBITS));
+            o[5] = (float)cls_s[i];
+            if (out_index) out_index[(long)b * d.max_predictions + r] = (int)e;
+        } else {
+            for (int q = 0; q < 6; ++q) o[q] = 0.f;
+            if (out_index) out_index[(long)b * d.max_predictions + r] = -1;
+        }
+    }
+}
+
+extern "C" int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const float* scores, float* out, int32_t* out_count, int32_t* out_index,
+                           int32_t* num_candidates, void* ws, int64_t ws_bytes, void* stream) {
+    (void)ws;
+    (void)ws_bytes;
+    SGX_CHECK_ARG(d && boxes && scores && out && out_count, "nms: null pointer");
+    SGX_CHECK_ARG(d->B > 0 && d->L > 0 && d->C > 0, "nms: bad dims");
+    SGX_CHECK_ARG(d->nms_top_k > 0 && d->nms_top_k <= NMS_MAXK, "nms: nms_top_k=%d unsupported (max %d)", d->nms_top_k, NMS_MAXK);
+    SGX_CHECK_ARG(d->max_predictions > 0 && d->max_predictions <= NMS_MAXK, "nms: bad max_predictions");
+    SGX_CHECK_ARG((long)d->L * (d->multi_label ? d->C : 1) <= (1L << NMS_IDXBITS), "nms: too many candidates for the %d-bit index field", NMS_IDXBITS);
+    SGX_CHECK_ARG(d->class_mode >= 0 && d->class_mode <= 2, "nms: bad class_mode");
+    SGX_CHECK_ARG(d->score_threshold >= 0.f, "nms: negative score threshold unsupported (keys assume non-negative scores)");
+    SGX_LAUNCH(nms_kernel, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates);
+    SGX_CHECK_LAUNCH("nms");
+    return SGX_OK;
+}

@@ -1,0 +1,432 @@
+"""Tensor-level wrappers over the C ABI (include/sgx_hip.h): shape/stride marshalling only, no math.
+
+Tensor convention on the hot path: activations are torch tensors of logical shape [N, H, W, C]
+(NHWC), last dim contiguous, possibly a channel slice of a wider buffer (stride(2) = ld_pix >= C).
+Everything here enqueues on the current torch stream and returns immediately.
+"""
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, LossDesc, NmsDesc, check, lib, ptr, stream
+
+ACT = {None: 0, "none": 0, "relu": 1, "silu": 2}
+
+
+# --------------------------------------------------------------------------------------------- workspace
+class _Workspace:
+    """One grow-only scratch buffer per device.  Kernels that use it are ordered on the same stream."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        key = str(device)
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b
+
+
+WORKSPACE = _Workspace()
+
+
+# --------------------------------------------------------------------------------------------- layout helpers
+def nhwc_strides(t: torch.Tensor) -> Tuple[int, int]:
+    if t.dim() != 4 or t.stride(3) != 1 or t.stride(1) != t.shape[2] * t.stride(2):
+        raise _lib.SgxError(f"tensor is not an NHWC view with contiguous channels: shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(2), t.stride(0)
+
+
+def rows(t: torch.Tensor) -> Tuple[int, int]:
+    """(M, ld) of an NHWC view whose pixels are uniformly strided across images (sweep kernels)."""
+    ld_pix, ld_img = nhwc_strides(t)
+    n, h, w, _ = t.shape
+    if n > 1 and ld_img != h * w * ld_pix:
+        raise _lib.SgxError("tensor rows are not uniformly strided across images")
+    return n * h * w, ld_pix
+
+
+def conv_desc(x: torch.Tensor, K: int, R: int, S: int, stride: int, pad: int, y: Optional[torch.Tensor] = None) -> ConvDesc:
+    n, h, w, c = x.shape
+    ho = (h + 2 * pad - R) // stride + 1
+    wo = (w + 2 * pad - S) // stride + 1
+    d = ConvDesc()
+    d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = n, h, w, c, K, R, S, stride, pad, ho, wo
+    d.x_ld_pix, d.x_ld_img = nhwc_strides(x)
+    if y is not None:
+        if tuple(y.shape) != (n, ho, wo, K):
+            raise _lib.SgxError(f"conv output shape {tuple(y.shape)} != {(n, ho, wo, K)}")
+        d.y_ld_pix, d.y_ld_img = nhwc_strides(y)
+    else:
+        d.y_ld_pix, d.y_ld_img = K, ho * wo * K
+    return d
+
+
+def conv_out_shape(x, K, R, S, stride, pad):
+    n, h, w, _ = x.shape
+    return (n, (h + 2 * pad - R) // stride + 1, (w + 2 * pad - S) // stride + 1, K)
+
+
+def _chk_w(w: torch.Tensor, K, R, S, C):
+    """weights are logical [K, C, R, S] with physical OHWI layout (strides (R*S*C, 1, S*C, C))."""
+    if tuple(w.shape) != (K, C, R, S) or w.stride() != (R * S * C, 1, S * C, C):
+        if not (tuple(w.shape) == (K, C, R, S) and R == 1 and S == 1 and w.stride(0) == C and w.stride(1) == 1):
+            raise _lib.SgxError(f"weight must be logical [K,C,R,S] in OHWI memory order; got shape {tuple(w.shape)} strides {w.stride()}")
+
+
+def ohwi_empty(K, C, R, S, device) -> torch.Tensor:
+    return torch.empty(K, R, S, C, device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+
+
+def to_ohwi(w: torch.Tensor) -> torch.Tensor:
+    """logical [K,C,R,S] tensor (any strides) -> same logical tensor stored OHWI."""
+    out = ohwi_empty(*[w.shape[i] for i in (0, 1, 2, 3)], device=w.device)
+    out.copy_(w)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- convolution
+def conv2d_fwd(x, w, bias=None, addend=None, out=None, act=None, stride=1, pad=0, stat_partials=False):
+    K, C, R, S = w.shape
+    _chk_w(w, K, R, S, x.shape[3])
+    if out is None:
+        out = torch.empty(conv_out_shape(x, K, R, S, stride, pad), device=x.device, dtype=torch.float32)
+    d = conv_desc(x, K, R, S, stride, pad, out)
+    parts = None
+    if stat_partials:
+        nblk = lib().sgx_conv2d_fwd_stat_blocks(ctypes.byref(d))
+        parts = torch.empty(2, nblk, K, device=x.device, dtype=torch.float32)
+    if addend is not None and nhwc_strides(addend) != nhwc_strides(out):
+        raise _lib.SgxError("conv addend must share the output's strides")
+    check(lib().sgx_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(addend), ptr(out), ACT[act], ptr(parts), stream()), "sgx_conv2d_fwd")
+    return (out, parts) if stat_partials else out
+
+
+def conv2d_bwd_data(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, accumulate=False):
+    K, C, R, S = w.shape
+    n, h, wd, c = x_shape
+    if out is None:
+        out = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+    d = conv_desc(out, K, R, S, stride, pad, dy)
+    if addend is not None and nhwc_strides(addend) != nhwc_strides(out):
+        raise _lib.SgxError("bwd_data addend must share dx's strides")
+    nbytes = lib().sgx_conv2d_bwd_data_workspace(ctypes.byref(d))
+    ws = WORKSPACE.get(nbytes, dy.device)
+    check(lib().sgx_conv2d_bwd_data(ctypes.byref(d), ptr(dy), ptr(w), ptr(addend), ptr(out), int(accumulate), ptr(ws), ws.numel(), stream()),
+          "sgx_conv2d_bwd_data")
+    return out
+
+
+def conv2d_bwd_weight(x, dy, dw, dbias=None, stride=1, pad=0):
+    """dw (logical [K,C,R,S], OHWI memory) += grad; dbias += column sums."""
+    K, C, R, S = dw.shape
+    _chk_w(dw, K, R, S, x.shape[3])
+    d = conv_desc(x, K, R, S, stride, pad, dy)
+    nbytes = lib().sgx_conv2d_bwd_weight_workspace(ctypes.byref(d))
+    ws = WORKSPACE.get(nbytes, x.device)
+    check(lib().sgx_conv2d_bwd_weight(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), stream()), "sgx_conv2d_bwd_weight")
+
+
+def _chk_wt(wt, C, K):
+    """ConvTranspose2d weight: logical [C, K, 2, 2], memory [C][2][2][K]."""
+    if tuple(wt.shape) != (C, K, 2, 2) or wt.stride() != (4 * K, 1, 2 * K, K):
+        raise _lib.SgxError(f"convT weight must be logical [C,K,2,2] stored [C][2][2][K]; got {tuple(wt.shape)} {wt.stride()}")
+
+
+def convT_empty(C, K, device):
+    return torch.empty(C, 2, 2, K, device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+
+
+def convT2x2_fwd(x, wt, bias=None, out=None):
+    n, h, w, c = x.shape
+    K = wt.shape[1]
+    _chk_wt(wt, c, K)
+    if out is None:
+        out = torch.empty(n, 2 * h, 2 * w, K, device=x.device, dtype=torch.float32)
+    xl, xi = nhwc_strides(x)
+    yl, yi = nhwc_strides(out)
+    nbytes = lib().sgx_convT2x2_workspace(n, h, w, c, K)
+    ws = WORKSPACE.get(nbytes, x.device)
+    check(lib().sgx_convT2x2_fwd(n, h, w, c, K, ptr(x), xl, xi, ptr(wt), ptr(bias), ptr(out), yl, yi, ptr(ws), ws.numel(), stream()), "sgx_convT2x2_fwd")
+    return out
+
+
+def convT2x2_bwd_data(dy, wt, out=None):
+    n, h2, w2, K = dy.shape
+    h, w, c = h2 // 2, w2 // 2, wt.shape[0]
+    if out is None:
+        out = torch.empty(n, h, w, c, device=dy.device, dtype=torch.float32)
+    dl, di = nhwc_strides(dy)
+    xl, xi = nhwc_strides(out)
+    check(lib().sgx_convT2x2_bwd_data(n, h, w, c, K, ptr(dy), dl, di, ptr(wt), ptr(out), xl, xi, stream()), "sgx_convT2x2_bwd_data")
+    return out
+
+
+def convT2x2_bwd_weight(x, dy, dwt, dbias=None):
+    n, h, w, c = x.shape
+    K = dwt.shape[1]
+    _chk_wt(dwt, c, K)
+    xl, xi = nhwc_strides(x)
+    dl, di = nhwc_strides(dy)
+    nbytes = lib().sgx_convT2x2_workspace(n, h, w, c, K)
+    ws = WORKSPACE.get(nbytes, x.device)
+    check(lib().sgx_convT2x2_bwd_weight(n, h, w, c, K, ptr(x), xl, xi, ptr(dy), dl, di, ptr(dwt), ptr(dbias), ptr(ws), ws.numel(), stream()),
+          "sgx_convT2x2_bwd_weight")
+
+
+def nchw_to_nhwc(x, cpad=None):
+    n, c, h, w = x.shape
+    cpad = cpad or ((c + 3) // 4) * 4
+    x = x.contiguous()
+    y = torch.empty(n, h, w, cpad, device=x.device, dtype=torch.float32)
+    check(lib().sgx_nchw_to_nhwc(n, c, h, w, cpad, ptr(x), ptr(y), stream()), "sgx_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x):
+    n, h, w, c = x.shape
+    ld_pix, ld_img = nhwc_strides(x)
+    y = torch.empty(n, c, h, w, device=x.device, dtype=torch.float32)
+    check(lib().sgx_nhwc_to_nchw(n, c, h, w, ptr(x), ld_pix, ld_img, ptr(y), stream()), "sgx_nhwc_to_nchw")
+    return y
+
+
+# --------------------------------------------------------------------------------------------- batch norm & sweeps
+def stats_blocks(M: int) -> int:
+    return lib().sgx_stats_blocks(M)
+
+
+def channel_stats_partial(x):
+    M, ld = rows(x)
+    C = x.shape[3]
+    parts = torch.empty(2, stats_blocks(M), C, device=x.device, dtype=torch.float32)
+    check(lib().sgx_channel_stats_partial(ptr(x), M, C, ld, ptr(parts), stream()), "sgx_channel_stats_partial")
+    return parts
+
+
+def bn_finalize(parts, M, gamma, beta, eps, momentum, running_mean, running_var):
+    """-> scale, shift, save_mean, save_invstd (each [C]); running stats updated in place."""
+    C = parts.shape[2]
+    st = torch.empty(4, C, device=parts.device, dtype=torch.float32)
+    check(lib().sgx_bn_finalize(ptr(parts), parts.shape[1], M, C, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean), ptr(running_var),
+                                ptr(st[2]), ptr(st[3]), ptr(st[0]), ptr(st[1]), stream()), "sgx_bn_finalize")
+    return st[0], st[1], st[2], st[3]
+
+
+def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps):
+    C = running_mean.numel()
+    st = torch.empty(2, C, device=running_mean.device, dtype=torch.float32)
+    check(lib().sgx_bn_eval_scale_shift(C, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), eps, ptr(st[0]), ptr(st[1]), stream()),
+          "sgx_bn_eval_scale_shift")
+    return st[0], st[1]
+
+
+def affine_act(x, scale=None, shift=None, r1=None, a1=1.0, a1_dev=None, r2=None, a2=1.0, out=None, act=None, want_stats=False):
+    M, ld = rows(x)
+    C = x.shape[3]
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    Mo, ldo = rows(out)
+    parts = torch.empty(2, stats_blocks(M), C, device=x.device, dtype=torch.float32) if want_stats else None
+    r1_ld = rows(r1)[1] if r1 is not None else 0
+    r2_ld = rows(r2)[1] if r2 is not None else 0
+    check(lib().sgx_affine_act_fwd(ptr(x), ld, ptr(scale), ptr(shift), ptr(r1), r1_ld, float(a1), ptr(a1_dev), ptr(r2), r2_ld, float(a2), ptr(out), ldo,
+                                   M, C, ACT[act], ptr(parts), stream()), "sgx_affine_act_fwd")
+    return (out, parts) if want_stats else out
+
+
+def bn_bwd(dy, x, scale, shift, gamma, save_mean, save_invstd, dgamma, dbeta, act=None, dx_out=None, want_g=False):
+    """Full BN(+activation) backward: returns dx (and the masked upstream gradient g if want_g).
+    dgamma/dbeta (views into the gradient arena) are accumulated in place."""
+    M, ld = rows(x)
+    C = x.shape[3]
+    dl = rows(dy)[1]
+    parts = torch.empty(2, stats_blocks(M), C, device=x.device, dtype=torch.float32)
+    a = ACT[act]
+    check(lib().sgx_bn_bwd_reduce(ptr(dy), dl, ptr(x), ld, ptr(scale), ptr(shift), M, C, a, ptr(parts), stream()), "sgx_bn_bwd_reduce")
+    coef = torch.empty(3, C, device=x.device, dtype=torch.float32)
+    check(lib().sgx_bn_bwd_finalize(ptr(parts), parts.shape[1], M, C, ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(dgamma), ptr(dbeta), ptr(coef),
+                                    stream()), "sgx_bn_bwd_finalize")
+    dx = dx_out if dx_out is not None else torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    g = torch.empty(x.shape, device=x.device, dtype=torch.float32) if want_g else None
+    check(lib().sgx_bn_bwd_apply(ptr(dy), dl, ptr(x), ld, ptr(scale), ptr(shift), ptr(coef), ptr(dx), rows(dx)[1], ptr(g), rows(g)[1] if want_g else 0,
+                                 M, C, a, stream()), "sgx_bn_bwd_apply")
+    return (dx, g) if want_g else dx
+
+
+def dot_sum(a, b, out, accumulate=True, scale=1.0):
+    """out[0] (+)= scale * sum(a*b) over NHWC views a, b."""
+    M, la = rows(a)
+    C = a.shape[3]
+    nblk = stats_blocks(M)
+    parts = torch.empty(nblk * C, device=a.device, dtype=torch.float32)
+    check(lib().sgx_dot_partial(ptr(a), la, ptr(b), rows(b)[1], M, C, ptr(parts), stream()), "sgx_dot_partial")
+    check(lib().sgx_sum_partials(ptr(parts), nblk * C, float(scale), ptr(out), int(accumulate), stream()), "sgx_sum_partials")
+
+
+def axpy(x, a=1.0, a_dev=None, out=None, accumulate=False):
+    M, ld = rows(x)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(lib().sgx_axpy(ptr(x), ld, float(a), ptr(a_dev), ptr(out), rows(out)[1], M, x.shape[3], int(accumulate), stream()), "sgx_axpy")
+    return out
+
+
+def colsum(x, out, accumulate=True):
+    ld_pix, ld_img = nhwc_strides(x)
+    n, h, w, C = x.shape
+    M = n * h * w
+    ws = WORKSPACE.get(stats_blocks(M) * C * 4, x.device)
+    check(lib().sgx_colsum(ptr(x), ld_pix, M, C, h * w, ld_img, ptr(out), int(accumulate), ptr(ws), stream()), "sgx_colsum")
+
+
+def fill(t, v=0.0):
+    check(lib().sgx_fill(ptr(t), t.numel(), float(v), stream()), "sgx_fill")
+
+
+# --------------------------------------------------------------------------------------------- pooling
+def maxpool_fwd(x, k, stride, pad, out=None, want_argmax=True):
+    n, h, w, c = x.shape
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    if out is None:
+        out = torch.empty(n, ho, wo, c, device=x.device, dtype=torch.float32)
+    am = torch.empty(n, ho, wo, c, device=x.device, dtype=torch.int32) if want_argmax else None
+    xl, xi = nhwc_strides(x)
+    yl, yi = nhwc_strides(out)
+    check(lib().sgx_maxpool_fwd(n, h, w, c, k, stride, pad, ptr(x), xl, xi, ptr(out), yl, yi, ptr(am), stream()), "sgx_maxpool_fwd")
+    return out, am
+
+
+def maxpool_bwd(dy, argmax, x_shape, k, stride, pad, out=None, accumulate=False):
+    n, h, w, c = x_shape
+    if out is None:
+        out = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+    dl, di = nhwc_strides(dy)
+    xl, xi = nhwc_strides(out)
+    check(lib().sgx_maxpool_bwd(n, h, w, c, k, stride, pad, ptr(argmax), ptr(dy), dl, di, ptr(out), xl, xi, int(accumulate), stream()), "sgx_maxpool_bwd")
+    return out
+
+
+def avgpool_fwd(x):
+    n, h, w, c = x.shape
+    xl, xi = nhwc_strides(x)
+    y = torch.empty(n, c, device=x.device, dtype=torch.float32)
+    check(lib().sgx_avgpool_fwd(n, h * w, c, ptr(x), xl, xi, ptr(y), stream()), "sgx_avgpool_fwd")
+    return y
+
+
+def avgpool_bwd(dy, x_shape):
+    n, h, w, c = x_shape
+    dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+    check(lib().sgx_avgpool_bwd(n, h * w, c, ptr(dy.contiguous()), ptr(dx), c, h * w * c, stream()), "sgx_avgpool_bwd")
+    return dx
+
+
+# --------------------------------------------------------------------------------------------- detection head / loss / nms
+def dfl_decode(logits, distri, points_grid, strides, reg_max):
+    B, L, C = logits.shape
+    boxes = torch.empty(B, L, 4, device=logits.device, dtype=torch.float32)
+    scores = torch.empty(B, L, C, device=logits.device, dtype=torch.float32)
+    check(lib().sgx_dfl_decode(B, L, C, reg_max, ptr(logits), ptr(distri), ptr(points_grid), ptr(strides), ptr(boxes), ptr(scores), stream()),
+          "sgx_dfl_decode")
+    return boxes, scores
+
+
+def loss_desc(B, L, C, reg_max, nmax, static, vfl, counts, weights) -> LossDesc:
+    d = LossDesc()
+    d.B, d.L, d.C, d.reg_max, d.nmax = B, L, C, reg_max, nmax
+    d.use_static_assigner, d.use_varifocal = int(static), int(vfl)
+    d.num_levels = len(counts)
+    for i, c in enumerate(counts):
+        d.level_count[i] = int(c)
+    d.w_cls, d.w_iou, d.w_dfl = [float(w) for w in weights]
+    return d
+
+
+def ppyoloe_loss_fwd(logits, distri, anchors, points, strides, targets, counts, static, vfl, weights):
+    """-> dict(sums[4], label[B,L] int32, box[B,L,4], score[B,L], g_logits, g_distri)"""
+    B, L, C = logits.shape
+    reg_max = distri.shape[2] // 4 - 1
+    dev = logits.device
+    T = int(targets.shape[0])
+    nmax = T
+    targets = targets.contiguous().float()
+    gt_count = torch.empty(B, device=dev, dtype=torch.int32)
+    gt_index = torch.empty(B, max(nmax, 1), device=dev, dtype=torch.int32)
+    overflow = torch.empty(1, device=dev, dtype=torch.int32)
+    check(lib().sgx_targets_index(ptr(targets) if T else None, T, B, nmax, ptr(gt_count), ptr(gt_index) if nmax else None, ptr(overflow), stream()),
+          "sgx_targets_index")
+    d = loss_desc(B, L, C, reg_max, nmax, static, vfl, counts, weights)
+    out = dict(
+        sums=torch.empty(4, device=dev, dtype=torch.float32),
+        label=torch.empty(B, L, device=dev, dtype=torch.int32),
+        box=torch.empty(B, L, 4, device=dev, dtype=torch.float32),
+        score=torch.empty(B, L, device=dev, dtype=torch.float32),
+        g_logits=torch.empty(B, L, C, device=dev, dtype=torch.float32),
+        g_distri=torch.empty(B, L, 4 * (reg_max + 1), device=dev, dtype=torch.float32),
+    )
+    nbytes = lib().sgx_ppyoloe_loss_workspace(ctypes.byref(d))
+    ws = WORKSPACE.get(nbytes, dev)
+    check(lib().sgx_ppyoloe_loss_fwd(ctypes.byref(d), ptr(logits.contiguous()), ptr(distri.contiguous()), ptr(anchors.contiguous()), ptr(points.contiguous()),
+                                     ptr(strides.contiguous()), ptr(targets) if T else None, ptr(gt_count), ptr(gt_index) if nmax else None,
+                                     ptr(out["sums"]), ptr(out["label"]), ptr(out["box"]), ptr(out["score"]), ptr(out["g_logits"]), ptr(out["g_distri"]),
+                                     ptr(ws), ws.numel(), stream()), "sgx_ppyoloe_loss_fwd")
+    return out
+
+
+def ppyoloe_loss_finalize(sums, weights, score_div=1.0):
+    items = torch.empty(4, device=sums.device, dtype=torch.float32)
+    inv = torch.empty(1, device=sums.device, dtype=torch.float32)
+    check(lib().sgx_ppyoloe_loss_finalize(ptr(sums), float(weights[0]), float(weights[1]), float(weights[2]), float(score_div), ptr(items), ptr(inv),
+                                          stream()), "sgx_ppyoloe_loss_finalize")
+    return items, inv
+
+
+def scale_by_device_scalar(x, s, t=None):
+    y = torch.empty_like(x)
+    check(lib().sgx_scale_by_device_scalar(ptr(x), ptr(s), ptr(t), ptr(y), x.numel(), stream()), "sgx_scale_by_device_scalar")
+    return y
+
+
+def nms(boxes, scores, score_threshold, iou_threshold, nms_top_k, max_predictions, multi_label=True, class_mode=0):
+    B, L, C = scores.shape
+    d = NmsDesc()
+    d.B, d.L, d.C, d.multi_label, d.class_mode = B, L, C, int(multi_label), int(class_mode)
+    d.nms_top_k, d.max_predictions = int(nms_top_k), int(max_predictions)
+    d.score_threshold, d.iou_threshold = float(score_threshold), float(iou_threshold)
+    dev = scores.device
+    out = torch.empty(B, max_predictions, 6, device=dev, dtype=torch.float32)
+    cnt = torch.empty(B, device=dev, dtype=torch.int32)
+    idx = torch.empty(B, max_predictions, device=dev, dtype=torch.int32)
+    ncand = torch.empty(B, device=dev, dtype=torch.int32)
+    check(lib().sgx_nms(ctypes.byref(d), ptr(boxes.contiguous().float()), ptr(scores.contiguous().float()), ptr(out), ptr(cnt), ptr(idx), ptr(ncand), None, 0,
+                        stream()), "sgx_nms")
+    return out, cnt, idx, ncand
+
+
+def softmax_ce(logits, labels, smoothing=0.0):
+    B, K = logits.shape
+    loss = torch.empty(B + 1, device=logits.device, dtype=torch.float32)
+    dlogits = torch.empty(B, K, device=logits.device, dtype=torch.float32)
+    check(lib().sgx_softmax_ce_fwd_bwd(B, K, ptr(logits.contiguous()), ptr(labels.contiguous().long()), float(smoothing), ptr(loss), ptr(dlogits), stream()),
+          "sgx_softmax_ce_fwd_bwd")
+    return loss[0], dlogits
+
+
+# --------------------------------------------------------------------------------------------- optimizer
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, step, seg_end, seg_wd, grad_scale=None):
+    check(lib().sgx_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, ptr(seg_end), ptr(seg_wd), seg_end.numel(),
+                               ptr(grad_scale), stream()), "sgx_adamw_step")
+
+
+def sgd_step(p, g, mom, lr, momentum, dampening, nesterov, first_step, seg_end, seg_wd):
+    check(lib().sgx_sgd_step(ptr(p), ptr(g), ptr(mom), p.numel(), lr, momentum, dampening, int(nesterov), int(first_step), ptr(seg_end), ptr(seg_wd),
+                             seg_end.numel(), stream()), "sgx_sgd_step")
+
+
+def ema_update(ema, p, decay):
+    check(lib().sgx_ema_update(ptr(ema), ptr(p), ema.numel(), float(decay), stream()), "sgx_ema_update")
