@@ -65,10 +65,10 @@ def nms_python(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
     return np.asarray(keep, dtype=np.int64)
 
 
-def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float, force_vanilla: bool = False) -> torch.Tensor:
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64)
-    if boxes.numel() > 4000:  # CPU rule of torchvision/ops/boxes.py
+    if boxes.numel() > 4000 or force_vanilla:  # CPU rule of torchvision/ops/boxes.py (_batched_nms_vanilla)
         keep_mask = torch.zeros_like(scores, dtype=torch.bool)
         for c in torch.unique(idxs):
             ci = torch.where(idxs == c)[0]
@@ -82,7 +82,7 @@ def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, i
 
 
 def post_prediction(pred_bboxes, pred_scores, *, score_threshold, nms_threshold, nms_top_k, max_predictions,
-                    multi_label_per_box=True, class_agnostic_nms=False):
+                    multi_label_per_box=True, class_agnostic_nms=False, force_vanilla=False):
     """[B,L,4], [B,L,C] -> list of [Ni,6] (x1,y1,x2,y2,conf,class) + list of candidate indices kept."""
     res = []
     for bx, sc in zip(pred_bboxes.float(), pred_scores.float()):
@@ -96,7 +96,7 @@ def post_prediction(pred_bboxes, pred_scores, *, score_threshold, nms_threshold,
         if conf.size(0) > nms_top_k:
             order = torch.tensor(sorted(range(conf.size(0)), key=lambda t: (-float(conf[t]), t))[:nms_top_k], dtype=torch.long)
             conf, lab, bb = conf[order], lab[order], bb[order]
-        keep = nms(bb, conf, nms_threshold) if class_agnostic_nms else batched_nms(bb, conf, lab, nms_threshold)
+        keep = nms(bb, conf, nms_threshold) if class_agnostic_nms else batched_nms(bb, conf, lab, nms_threshold, force_vanilla)
         out = torch.cat([bb[keep], conf[keep, None], lab[keep, None].float()], 1)
         res.append(out[:max_predictions])
     return res

@@ -1,0 +1,402 @@
+"""Parity of every C-ABI kernel (include/sgx_hip.h) against the CPU path the reference executes: ATen CPU ops
+(F.conv2d, F.batch_norm, ...) for the conv stacks, oracle/ for the loss and NMS.
+
+Each test runs twice through the `backend` fixture:
+  gpu  (marked gpu)  the product library libsgx_hip.so on cuda:0;
+  emu                the same kernel sources compiled against tests/emu (host threads) - logic check, small shapes.
+Tolerances: fp32 with a different summation order -> 2e-5 of the tensor's max-abs (north star: 1e-4 rel);
+integer/index outputs bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close, empty_nhwc, to_nchw_cpu, to_nhwc
+
+from super_gradients_amd import kernels as K
+
+TOL = 2e-5
+
+
+def _sizes(backend, gpu, emu):
+    return gpu if backend.type == "cuda" else emu
+
+
+# (N, H, W, C, K, R, stride, pad)
+CONV_GPU = [
+    (2, 40, 40, 64, 64, 3, 1, 1),
+    (2, 33, 31, 96, 48, 3, 1, 1),      # ragged spatial, N tile 96->48
+    (4, 64, 64, 4, 48, 3, 2, 1),       # stem (3 channels padded to 4), stride 2
+    (2, 40, 40, 192, 384, 3, 2, 1),    # downsample
+    (2, 20, 20, 1536, 768, 1, 1, 0),   # SPP cv2: long K
+    (3, 40, 40, 128, 80, 1, 1, 0),     # cls_pred
+    (2, 23, 17, 64, 68, 1, 1, 0),      # reg_pred, ragged
+    (2, 56, 56, 4, 64, 7, 2, 3),       # ResNet stem
+    (2, 28, 28, 64, 128, 1, 2, 0),     # ResNet 1x1 s2 shortcut
+    (1, 160, 160, 32, 32, 3, 1, 1),    # many row tiles
+]
+CONV_EMU = [
+    (1, 9, 7, 8, 36, 3, 1, 1),
+    (1, 8, 8, 4, 32, 3, 2, 1),
+    (2, 5, 6, 20, 8, 1, 1, 0),
+    (1, 9, 9, 4, 8, 7, 2, 3),
+    (1, 6, 6, 8, 4, 1, 2, 0),
+]
+
+
+def _conv_case(shape, seed=0):
+    n, h, w, c, k, r, s, p = shape
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(k, c, r, r, generator=g) / (c * r * r) ** 0.5
+    b = torch.randn(k, generator=g)
+    return x, wt, b
+
+
+@pytest.mark.parametrize("idx", range(max(len(CONV_GPU), len(CONV_EMU))))
+def test_conv_fwd(backend, idx):
+    shapes = _sizes(backend, CONV_GPU, CONV_EMU)
+    if idx >= len(shapes):
+        pytest.skip("no such case")
+    shape = shapes[idx]
+    n, h, w, c, k, r, s, p = shape
+    x, wt, b = _conv_case(shape)
+    ref = F.conv2d(x, wt, b, stride=s, padding=p)
+    xd = to_nhwc(x, backend)
+    wd = K.to_ohwi(wt.to(backend))
+    y = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s, pad=p)
+    assert_close(to_nchw_cpu(y), ref, TOL, f"conv fwd {shape}")
+    # fused epilogue: bias + addend + relu, output written into a channel slice of a wider (concat) buffer,
+    # input read from a channel slice; BN statistics partials of the pre-activation value
+    add = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1))
+    xs = to_nhwc(x, backend, ld_pix=c + 8, c_off=4)
+    out = empty_nhwc(n, ref.shape[2], ref.shape[3], k, backend, ld_pix=k + 12, c_off=8)
+    addd = to_nhwc(add, backend, ld_pix=k + 12, c_off=8)
+    y2, parts = K.conv2d_fwd(xs, wd, bias=b.to(backend), addend=addd, out=out, act="relu", stride=s, pad=p, stat_partials=True)
+    pre = ref + add
+    assert_close(to_nchw_cpu(y2), F.relu(pre), TOL, f"conv fwd fused {shape}")
+    M = pre.numel() // k
+    s1 = parts[0].sum(0).cpu()
+    s2 = parts[1].sum(0).cpu()
+    assert_close(s1 / M, pre.mean((0, 2, 3)), 1e-4, "stat sum")
+    assert_close(s2 / M, (pre * pre).mean((0, 2, 3)), 1e-4, "stat sumsq")
+
+
+@pytest.mark.parametrize("idx", range(max(len(CONV_GPU), len(CONV_EMU))))
+def test_conv_bwd(backend, idx):
+    shapes = _sizes(backend, CONV_GPU, CONV_EMU)
+    if idx >= len(shapes):
+        pytest.skip("no such case")
+    shape = shapes[idx]
+    n, h, w, c, k, r, s, p = shape
+    if k % 4:
+        pytest.skip("bwd needs K % 4 == 0")
+    x, wt, b = _conv_case(shape)
+    x.requires_grad_(True)
+    wt.requires_grad_(True)
+    b.requires_grad_(True)
+    y = F.conv2d(x, wt, b, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+    y.backward(dy)
+    xd = to_nhwc(x.detach(), backend)
+    wd = K.to_ohwi(wt.detach().to(backend))
+    dyd = to_nhwc(dy, backend)
+    dx = K.conv2d_bwd_data(dyd, wd, tuple(xd.shape), stride=s, pad=p)
+    assert_close(to_nchw_cpu(dx), x.grad, TOL, f"dgrad {shape}")
+    # accumulate + addend form
+    add = torch.randn(x.shape, generator=torch.Generator().manual_seed(3))
+    dx2 = to_nhwc(torch.ones_like(x.detach()), backend)
+    K.conv2d_bwd_data(dyd, wd, tuple(xd.shape), stride=s, pad=p, addend=to_nhwc(add, backend), out=dx2, accumulate=True)
+    assert_close(to_nchw_cpu(dx2), x.grad + add + 1.0, TOL, f"dgrad acc {shape}")
+    dw = K.ohwi_empty(k, c, r, r, backend)
+    dw.fill_(0.5)
+    db = torch.zeros(k, device=backend)
+    K.conv2d_bwd_weight(xd, dyd, dw, db, stride=s, pad=p)
+    assert_close(dw.cpu(), wt.grad + 0.5, TOL, f"wgrad {shape}")
+    assert_close(db.cpu(), b.grad, TOL, f"dbias {shape}")
+
+
+def test_conv_transpose(backend):
+    n, h, w, c, k = _sizes(backend, (2, 20, 20, 192, 192), (1, 3, 4, 8, 4))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(c, k, 2, 2, generator=g) / c ** 0.5).requires_grad_(True)
+    b = torch.randn(k, generator=g, requires_grad=True)
+    y = F.conv_transpose2d(x, wt, b, stride=2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = to_nhwc(x.detach(), backend)
+    wd = K.convT_empty(c, k, backend)
+    wd.copy_(wt.detach().to(backend))
+    yd = K.convT2x2_fwd(xd, wd, b.detach().to(backend))
+    assert_close(to_nchw_cpu(yd), y, TOL, "convT fwd")
+    dyd = to_nhwc(dy, backend)
+    assert_close(to_nchw_cpu(K.convT2x2_bwd_data(dyd, wd)), x.grad, TOL, "convT dgrad")
+    dw = K.convT_empty(c, k, backend)
+    dw.zero_()
+    db = torch.zeros(k, device=backend)
+    K.convT2x2_bwd_weight(xd, dyd, dw, db)
+    assert_close(dw.cpu(), wt.grad, TOL, "convT wgrad")
+    assert_close(db.cpu(), b.grad, TOL, "convT dbias")
+
+
+def test_layout(backend):
+    n, c, h, w = _sizes(backend, (3, 3, 37, 41), (2, 3, 5, 4))
+    x = torch.randn(n, c, h, w)
+    y = K.nchw_to_nhwc(x.to(backend))
+    assert y.shape == (n, h, w, 4)
+    assert torch.equal(y[..., :3].cpu(), x.permute(0, 2, 3, 1)) and float(y[..., 3].abs().max()) == 0.0
+    z = K.nhwc_to_nchw(y[..., :3] if False else y)
+    assert torch.equal(z[:, :3].cpu(), x)
+
+
+@pytest.mark.parametrize("act", ["relu", "silu", None])
+def test_batchnorm_train(backend, act):
+    n, h, w, c = _sizes(backend, (4, 40, 40, 96), (2, 5, 6, 8))
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(n, c, h, w, generator=g) * 2 + 0.5).requires_grad_(True)
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(c, generator=g).requires_grad_(True)
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    eps, mom = 1e-3, 0.03
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    pre = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, mom, eps)
+    y = {"relu": F.relu, "silu": F.silu, None: lambda t: t}[act](pre)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+
+    xd = to_nhwc(x.detach(), backend)
+    parts = K.channel_stats_partial(xd)
+    rmd, rvd = rm.to(backend), rv.to(backend)
+    M = n * h * w
+    scale, shift, mean, invstd = K.bn_finalize(parts, M, gamma.detach().to(backend), beta.detach().to(backend), eps, mom, rmd, rvd)
+    yd = K.affine_act(xd, scale, shift, act=act)
+    assert_close(to_nchw_cpu(yd), y, TOL, "bn fwd")
+    assert_close(rmd.cpu(), rm_ref, TOL, "running_mean")
+    assert_close(rvd.cpu(), rv_ref, TOL, "running_var")
+    dgamma = torch.zeros(c, device=backend)
+    dbeta = torch.zeros(c, device=backend)
+    dx = K.bn_bwd(to_nhwc(dy, backend), xd, scale, shift, gamma.detach().to(backend), mean, invstd, dgamma, dbeta, act=act)
+    assert_close(to_nchw_cpu(dx), x.grad, 5e-5, "bn dx")
+    assert_close(dgamma.cpu(), gamma.grad, 5e-5, "bn dgamma")
+    assert_close(dbeta.cpu(), beta.grad, 5e-5, "bn dbeta")
+    # eval-mode affine
+    es, eh = K.bn_eval_scale_shift(gamma.detach().to(backend), beta.detach().to(backend), rmd, rvd, eps)
+    ye = K.affine_act(xd, es, eh)
+    assert_close(to_nchw_cpu(ye), F.batch_norm(x.detach(), rm_ref, rv_ref, gamma.detach(), beta.detach(), False, mom, eps), TOL, "bn eval")
+
+
+def test_affine_residuals_and_sweeps(backend):
+    n, h, w, c = _sizes(backend, (2, 20, 20, 192), (1, 4, 5, 8))
+    g = torch.Generator().manual_seed(0)
+    x, r1, r2 = [torch.randn(n, c, h, w, generator=g) for _ in range(3)]
+    sc, sh = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    alpha = torch.tensor([0.7])
+    xd, r1d, r2d = [to_nhwc(t, backend, ld_pix=c + 4) for t in (x, r1, r2)]
+    y, parts = K.affine_act(xd, sc.to(backend), sh.to(backend), r1=r1d, a1_dev=alpha.to(backend), r2=r2d, a2=1.5, act="relu", want_stats=True)
+    pre = x * sc.view(1, c, 1, 1) + sh.view(1, c, 1, 1) + 0.7 * r1 + 1.5 * r2
+    assert_close(to_nchw_cpu(y), F.relu(pre), TOL, "affine_act")
+    assert_close(parts[0].sum(0).cpu(), pre.sum((0, 2, 3)), 1e-4, "affine stats")
+    out = torch.zeros(1, device=backend)
+    K.dot_sum(xd, r1d, out, accumulate=False)
+    assert_close(out.cpu(), (x * r1).sum().view(1), 1e-4, "dot")
+    z = K.axpy(xd, a_dev=alpha.to(backend))
+    K.axpy(r1d, a=2.0, out=z, accumulate=True)
+    assert_close(to_nchw_cpu(z), 0.7 * x + 2 * r1, TOL, "axpy")
+    cs = torch.ones(c, device=backend)
+    K.colsum(xd, cs, accumulate=True)
+    assert_close(cs.cpu(), x.sum((0, 2, 3)) + 1, 1e-4, "colsum")
+    s = K.scale_by_device_scalar(z, alpha.to(backend), torch.tensor([2.0], device=backend))
+    assert_close(s.cpu(), z.cpu() * 1.4, TOL, "scale")
+    t = torch.empty(1000, device=backend)
+    K.fill(t, 3.0)
+    assert float(t.min()) == 3.0 and float(t.max()) == 3.0
+
+
+@pytest.mark.parametrize("k,stride,pad", [(5, 1, 2), (9, 1, 4), (13, 1, 6), (3, 2, 1)])
+def test_maxpool(backend, k, stride, pad):
+    n, h, w, c = _sizes(backend, (2, 20, 20, 384), (1, 7, 6, 8))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, c, h, w, generator=g).round(decimals=1).requires_grad_(True)  # ties on purpose
+    y = F.max_pool2d(x, k, stride, pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = to_nhwc(x.detach(), backend)
+    yd, am = K.maxpool_fwd(xd, k, stride, pad)
+    assert torch.equal(to_nchw_cpu(yd), y.detach())
+    dx = K.maxpool_bwd(to_nhwc(dy, backend), am, tuple(xd.shape), k, stride, pad)
+    assert_close(to_nchw_cpu(dx), x.grad, TOL, "maxpool bwd")
+
+
+def test_avgpool(backend):
+    n, h, w, c = _sizes(backend, (4, 7, 7, 2048), (2, 3, 3, 8))
+    x = torch.randn(n, c, h, w, requires_grad=True)
+    y = F.adaptive_avg_pool2d(x, 1).flatten(1)
+    dy = torch.randn(y.shape)
+    y.backward(dy)
+    xd = to_nhwc(x.detach(), backend)
+    assert_close(K.avgpool_fwd(xd).cpu(), y, TOL, "avgpool")
+    assert_close(to_nchw_cpu(K.avgpool_bwd(dy.to(backend), tuple(xd.shape))), x.grad, TOL, "avgpool bwd")
+
+
+def test_softmax_ce(backend):
+    B, Kc = _sizes(backend, (64, 1000), (5, 10))
+    for smoothing in (0.0, 0.1):
+        logits = (torch.randn(B, Kc) * 3).requires_grad_(True)
+        labels = torch.randint(0, Kc, (B,))
+        loss = F.cross_entropy(logits, labels, label_smoothing=smoothing)
+        loss.backward()
+        l, dl = K.softmax_ce(logits.detach().to(backend), labels.to(backend), smoothing)
+        assert_close(l.cpu().view(1), loss.detach().view(1), TOL, "ce")
+        assert_close(dl.cpu(), logits.grad, TOL, "ce grad")
+
+
+def test_optimizers(backend):
+    n = _sizes(backend, 1_000_003, 1003)
+    g = torch.Generator().manual_seed(0)
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    seg = [n // 3, n]
+    wds = [1e-2, 0.0]
+    # AdamW: two param groups with different weight decay, 3 steps
+    pa, pb = p0[: seg[0]].clone().requires_grad_(True), p0[seg[0]:].clone().requires_grad_(True)
+    opt = torch.optim.AdamW([{"params": [pa], "weight_decay": wds[0]}, {"params": [pb], "weight_decay": wds[1]}], lr=2e-3, betas=(0.9, 0.999), eps=1e-8)
+    pd, m, v = p0.clone().to(backend), torch.zeros(n, device=backend), torch.zeros(n, device=backend)
+    se = torch.tensor(seg, dtype=torch.int64, device=backend)
+    sw = torch.tensor(wds, dtype=torch.float32, device=backend)
+    for step in range(1, 4):
+        gi = gr * step
+        pa.grad, pb.grad = gi[: seg[0]].clone(), gi[seg[0]:].clone()
+        opt.step()
+        K.adamw_step(pd, gi.to(backend), m, v, 2e-3, 0.9, 0.999, 1e-8, step, se, sw)
+    assert_close(pd.cpu(), torch.cat([pa.detach(), pb.detach()]), 1e-5, "adamw")
+    # SGD momentum
+    pa, pb = p0[: seg[0]].clone().requires_grad_(True), p0[seg[0]:].clone().requires_grad_(True)
+    opt = torch.optim.SGD([{"params": [pa], "weight_decay": wds[0]}, {"params": [pb], "weight_decay": wds[1]}], lr=0.1, momentum=0.9)
+    pd, mom = p0.clone().to(backend), torch.zeros(n, device=backend)
+    for step in range(1, 4):
+        gi = gr * step
+        pa.grad, pb.grad = gi[: seg[0]].clone(), gi[seg[0]:].clone()
+        opt.step()
+        K.sgd_step(pd, gi.to(backend), mom, 0.1, 0.9, 0.0, False, step == 1, se, sw)
+    assert_close(pd.cpu(), torch.cat([pa.detach(), pb.detach()]), 1e-5, "sgd")
+    e = p0.clone().to(backend)
+    K.ema_update(e, gr.to(backend), 0.9)
+    assert_close(e.cpu(), p0 * 0.9 + gr * (1 - 0.9), 1e-6, "ema")
+
+
+# ------------------------------------------------------------------------------------------------ loss / head / nms
+def _head_case(B, hw, C, seed=0, size=None, kmax=6):
+    """Synthetic raw head outputs on the anchor grid of a (hw[0][0]*8)-pixel image + targets."""
+    from oracle.yolo_nas import make_anchors
+    from util import synthetic_targets
+
+    g = torch.Generator().manual_seed(seed)
+    anchors, pts, pts_grid, counts, strides = make_anchors(hw, [8, 16, 32])
+    L = anchors.shape[0]
+    logits = torch.randn(B, L, C, generator=g) * 1.5 - 2.0
+    distri = torch.randn(B, L, 68, generator=g) * 1.2
+    size = size or hw[0][0] * 8
+    targets = synthetic_targets(B, seed=seed, kmax=kmax, size=size, num_classes=C)
+    return logits, distri, anchors, pts, pts_grid, counts, strides, targets
+
+
+@pytest.mark.parametrize("static", [False, True])
+@pytest.mark.parametrize("vfl", [True, False])
+def test_ppyoloe_loss(backend, static, vfl):
+    from oracle.ppyolo_loss import PPYoloELossOracle
+
+    B, hw, C = _sizes(backend, (4, [(40, 40), (20, 20), (10, 10)], 80), (2, [(12, 12), (6, 6), (3, 3)], 8))
+    logits, distri, anchors, pts, pts_grid, counts, strides, targets = _head_case(B, hw, C, seed=3)
+    if B > 2:
+        targets = targets[targets[:, 0] != 1]  # image 1 has no boxes
+    logits.requires_grad_(True)
+    distri.requires_grad_(True)
+    w = (1.0, 2.5, 0.5)
+    orc = PPYoloELossOracle(C, use_varifocal_loss=vfl, use_static_assigner=static)
+    cls_sum, iou_sum, dfl_sum, score_sum = orc.sums((logits, distri, anchors, pts, counts, strides), targets)
+    (w[0] * cls_sum + w[1] * iou_sum + w[2] * dfl_sum).backward()
+    _, a_label, a_box, a_score = orc.assign((logits.detach(), distri.detach(), anchors, pts, counts, strides), targets)
+
+    dev = backend
+    out = K.ppyoloe_loss_fwd(logits.detach().to(dev), distri.detach().to(dev), anchors.to(dev), pts.to(dev), strides.to(dev), targets.to(dev), counts,
+                             static, vfl, w)
+    assert torch.equal(out["label"].cpu().long(), a_label), "assigned labels differ"
+    pos = a_label != C
+    assert int(pos.sum()) > 0
+    assert_close(out["box"].cpu()[pos], a_box[pos], 1e-6, "assigned boxes")
+    assert_close(out["score"].cpu(), a_score, 2e-5, "assigned scores")
+    ref = torch.stack([cls_sum, iou_sum, dfl_sum, score_sum]).detach()
+    for i, name in enumerate(["cls", "iou", "dfl", "score"]):
+        assert_close(out["sums"].cpu()[i:i + 1], ref[i:i + 1], 2e-5, f"sum {name}")
+    assert_close(out["g_logits"].cpu(), logits.grad, 5e-5, "g_logits")
+    assert_close(out["g_distri"].cpu(), distri.grad, 5e-5, "g_distri")
+    items, inv = K.ppyoloe_loss_finalize(out["sums"], w, 1.0)
+    loss, log_items = orc((None, (logits, distri, anchors, pts, counts, strides)), targets)
+    assert_close(items.cpu(), log_items, 2e-5, "loss items")
+
+
+def test_ppyoloe_loss_empty_targets(backend):
+    from oracle.ppyolo_loss import PPYoloELossOracle
+
+    B, hw, C = 2, [(12, 12), (6, 6), (3, 3)], 8
+    logits, distri, anchors, pts, pts_grid, counts, strides, _ = _head_case(B, hw, C)
+    targets = torch.zeros(0, 6)
+    for static in (False, True):
+        orc = PPYoloELossOracle(C, use_static_assigner=static)
+        loss, items = orc((None, (logits, distri, anchors, pts, counts, strides)), targets)
+        out = K.ppyoloe_loss_fwd(logits.to(backend), distri.to(backend), anchors.to(backend), pts.to(backend), strides.to(backend), targets.to(backend),
+                                 counts, static, True, (1.0, 2.5, 0.5))
+        it, _ = K.ppyoloe_loss_finalize(out["sums"], (1.0, 2.5, 0.5), 1.0)
+        assert_close(it.cpu(), items, 2e-5, "empty-target loss items")
+        assert float(it[1]) == 0.0 and float(it[2]) == 0.0
+        assert int((out["label"] != C).sum()) == 0
+
+
+def test_dfl_decode(backend):
+    B, hw, C = _sizes(backend, (3, [(40, 40), (20, 20), (10, 10)], 80), (2, [(4, 4), (2, 2), (1, 1)], 8))
+    logits, distri, anchors, pts, pts_grid, counts, strides, _ = _head_case(B, hw, C)
+    from oracle.ppyolo_loss import decode_distribution
+
+    boxes_ref = decode_distribution(pts_grid, distri) * strides
+    boxes, scores = K.dfl_decode(logits.to(backend), distri.to(backend), pts_grid.to(backend), strides.to(backend), 16)
+    assert_close(boxes.cpu(), boxes_ref, 2e-5, "decoded boxes")
+    assert_close(scores.cpu(), logits.sigmoid(), 2e-5, "scores")
+
+
+def _nms_case(B, L, C, seed, clusters=12, size=640.0):
+    g = np.random.RandomState(seed)
+    cen = g.uniform(0.15 * size, 0.85 * size, (B, clusters, 2))
+    which = g.randint(0, clusters, (B, L))
+    c = np.take_along_axis(cen, which[..., None].repeat(2, -1), 1) + g.normal(0, 6, (B, L, 2))
+    wh = g.uniform(20, 120, (B, L, 2))
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], -1).astype(np.float32)
+    scores = g.beta(0.5, 0.5, (B, L, C)).astype(np.float32) ** 4
+    # engineered exact ties in score and duplicated boxes
+    scores[:, 1::7] = scores[:, 0:-1:7][:, : scores[:, 1::7].shape[1]]
+    boxes[:, 2::11] = boxes[:, 0:-2:11][:, : boxes[:, 2::11].shape[1]]
+    return torch.from_numpy(boxes), torch.from_numpy(scores)
+
+
+@pytest.mark.parametrize("multi_label,class_mode", [(True, 0), (False, 0), (True, 1), (False, 2), (True, 2)])
+def test_nms(backend, multi_label, class_mode):
+    from oracle import nms as onms
+
+    B, L, C, topk, maxp = _sizes(backend, (4, 8400, 80, 1000, 300), (2, 84, 4, 40, 12))
+    boxes, scores = _nms_case(B, L, C, seed=5)
+    thr = 0.25 if multi_label else 0.05
+    if class_mode == 1:
+        topk = min(topk, 1000)  # coordinate-offset trick applies while 4*K <= 4000
+    kw = dict(score_threshold=thr, nms_threshold=0.6, nms_top_k=topk, max_predictions=maxp, multi_label_per_box=multi_label)
+    if class_mode == 0:
+        ref = onms.post_prediction(boxes, scores, class_agnostic_nms=True, **kw)
+    elif class_mode == 1:
+        ref = onms.post_prediction(boxes, scores, class_agnostic_nms=False, **kw)
+    else:
+        ref = onms.post_prediction(boxes, scores, class_agnostic_nms=False, force_vanilla=True, **kw)
+    out, cnt, idx, ncand = K.nms(boxes.to(backend), scores.to(backend), thr, 0.6, topk, maxp, multi_label=multi_label, class_mode=class_mode)
+    out, cnt = out.cpu(), cnt.cpu()
+    for b in range(B):
+        n = int(cnt[b])
+        assert n == ref[b].shape[0], f"image {b}: kept {n} vs oracle {ref[b].shape[0]}"
+        assert torch.equal(out[b, :n], ref[b]), f"image {b}: rows differ"  # bit-exact boxes/scores/classes
