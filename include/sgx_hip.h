@@ -217,7 +217,8 @@ int32_t sgx_scale_by_device_scalar(const float* x, const float* s, const float* 
  * -> at most max_predictions rows [x1,y1,x2,y2,score,class].  out [B][max_predictions][6], out_count[B],
  * out_index[B][max_predictions] = candidate index (anchor*C + class for multi-label, anchor otherwise).
  * class_mode: 0 = class-agnostic (nms), 1 = per-class via coordinate offsets (batched_nms, numel<=4000),
- *             2 = per-class exact (batched_nms vanilla loop).                                       */
+ *             2 = per-class exact (batched_nms vanilla loop),
+ *             3 = batched_nms as torchvision dispatches it on CPU: mode 1 while 4*candidates <= 4000, else mode 2.  */
 typedef struct sgx_nms_desc {
     int32_t B, L, C;
     int32_t multi_label, class_mode;

@@ -175,7 +175,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
         }
     }
     sup[tid] = 0;
-    if (d.class_mode == 1) {
+    // class_mode 3 = torchvision's own CPU dispatch (ops/boxes.py batched_nms): coordinate trick while boxes.numel() <= 4000
+    const int class_mode = d.class_mode == 3 ? (4 * n > 4000 ? 2 : 1) : d.class_mode;
+    if (class_mode == 1) {
         // torchvision batched_nms coordinate trick: boxes + cls * (max_coordinate + 1)
         for (int off = 32; off > 0; off >>= 1) mymax = fmaxf(mymax, __shfl_xor(mymax, off));
         if ((tid & 63) == 0) wmax[tid >> 6] = mymax;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
     float nb[4] = {0.f, 0.f, 0.f, 0.f};
     if (tid < n) {
         float offv = 0.f;
-        if (d.class_mode == 1) offv = (float)cls_s[tid] * (s_maxc + 1.f);
+        if (class_mode == 1) offv = (float)cls_s[tid] * (s_maxc + 1.f);
         for (int q = 0; q < 4; ++q) nb[q] = bx[tid][q] + offv;
         area[tid] = (nb[2] - nb[0]) * (nb[3] - nb[1]);
     }
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
             s_kept = s_kept + 1;
         }
         __syncthreads();
-        if (tid > i && tid < n && !sup[tid] && (d.class_mode != 2 || cls_s[tid] == cls_s[i])) {
+        if (tid > i && tid < n && !sup[tid] && (class_mode != 2 || cls_s[tid] == cls_s[i])) {
             float xx1 = fmaxf(cur[0], nb[0]), yy1 = fmaxf(cur[1], nb[1]);
             float xx2 = fminf(cur[2], nb[2]), yy2 = fminf(cur[3], nb[3]);
             float w = xx2 - xx1; w = w < 0.f ? 0.f : w;
@@ -252,7 +254,7 @@ extern "C" int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const floa
     SGX_CHECK_ARG(d->nms_top_k > 0 && d->nms_top_k <= NMS_MAXK, "nms: nms_top_k=%d unsupported (max %d)", d->nms_top_k, NMS_MAXK);
     SGX_CHECK_ARG(d->max_predictions > 0 && d->max_predictions <= NMS_MAXK, "nms: bad max_predictions");
     SGX_CHECK_ARG((long)d->L * (d->multi_label ? d->C : 1) <= (1L << NMS_IDXBITS), "nms: too many candidates for the %d-bit index field", NMS_IDXBITS);
-    SGX_CHECK_ARG(d->class_mode >= 0 && d->class_mode <= 2, "nms: bad class_mode");
+    SGX_CHECK_ARG(d->class_mode >= 0 && d->class_mode <= 3, "nms: bad class_mode");
     SGX_CHECK_ARG(d->score_threshold >= 0.f, "nms: negative score threshold unsupported (keys assume non-negative scores)");
     SGX_LAUNCH(nms_kernel, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates);
     SGX_CHECK_LAUNCH("nms");

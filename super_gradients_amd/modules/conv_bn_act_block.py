@@ -1,0 +1,99 @@
+"""conv -> BatchNorm -> activation blocks on the HIP kernels.
+
+Reference classes mirrored (same constructor arguments for the supported subset, same state_dict keys):
+  Conv        modules/conv_bn_act_block.py:80-93    keys conv.weight, bn.*       (autopad, no conv bias)
+  ConvBNAct   modules/conv_bn_act_block.py:9-69     keys seq.conv.*, seq.bn.*
+  ConvBNReLU  modules/conv_bn_relu_block.py:8-60    keys seq.conv.*, seq.bn.*
+Kernel sequence (training):  conv (BN partial statistics emitted by the conv epilogue) -> bn_finalize (tiny)
+-> affine+activation sweep.  Backward: BN(+act) backward in three sweeps (activation mask recomputed from the saved
+conv output, nothing else stored) -> weight gradient -> data gradient.
+"""
+import torch
+from torch import nn
+
+from .. import kernels as K
+from .engine import SgxBlock
+from .layers import BatchNorm, ConvLayer, act_name
+
+
+class _ConvBN(SgxBlock):
+    """Shared implementation; subclasses only choose where `conv`/`bn` are registered (key names)."""
+
+    def _parts(self):
+        raise NotImplementedError
+
+    def on_materialize(self):
+        pass
+
+    def fwd(self, x, out=None):
+        conv, bn = self._parts()
+        if self.training:
+            t, parts = conv.conv(x, stats=True)
+            M = t.shape[0] * t.shape[1] * t.shape[2]
+            scale, shift, mean, invstd = bn.scale_shift(parts, M, True)
+            y = K.affine_act(t, scale, shift, act=self.act, out=out)
+            self._ctx = (x, t, scale, shift, mean, invstd)
+            return y
+        t = conv.conv(x)
+        scale, shift, _, _ = bn.scale_shift(None, 0, False)
+        return K.affine_act(t, scale, shift, act=self.act, out=out if out is not None else t)
+
+    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
+        conv, bn = self._parts()
+        (x, t, scale, shift, mean, invstd), self._ctx = self._ctx, None
+        dt = bn.backward(dy, t, scale, shift, mean, invstd, self.act, dx_out=t)  # in place over the saved conv output
+        conv.wgrad(x, dt)
+        if not need_dx:
+            return None
+        return conv.dgrad(dt, tuple(x.shape), out=dx_out, accumulate=accumulate, addend=addend)
+
+
+class Conv(_ConvBN):
+    """Reference `Conv` (conv_bn_act_block.py:80): Conv2d(k, stride, autopad, bias=False) + BatchNorm2d + activation."""
+
+    def __init__(self, input_channels, output_channels, kernel, stride, activation_type, padding: int = None, groups: int = None):
+        super().__init__()
+        if groups not in (None, 1):
+            raise NotImplementedError("grouped convolution is outside the MI355X hot path (SURVEY.md 8: groups=1 only)")
+        pad = kernel // 2 if padding is None else padding
+        self.conv = ConvLayer(input_channels, output_channels, kernel, stride, pad, bias=False)
+        self.bn = BatchNorm(output_channels)
+        self.act = act_name(activation_type)
+
+    def _parts(self):
+        return self.conv, self.bn
+
+
+class _Seq(nn.Module):
+    """Namespace module so that keys read seq.conv.weight / seq.bn.* like the reference's nn.Sequential."""
+
+
+class ConvBNAct(_ConvBN):
+    """Reference `ConvBNAct` (conv_bn_act_block.py:9-69), supported subset: groups=1, dilation=1, zero padding, use_normalization=True."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding=0, activation_type=None, stride=1, dilation=1, groups=1, bias=True,
+                 padding_mode="zeros", use_normalization=True, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True,
+                 device=None, dtype=None, activation_kwargs=None):
+        super().__init__()
+        if groups != 1 or dilation != 1 or padding_mode != "zeros" or not use_normalization or not affine or not track_running_stats:
+            raise NotImplementedError("ConvBNAct on the HIP path supports groups=1, dilation=1, zero padding, affine BN with running stats")
+        if bias:
+            raise NotImplementedError("conv bias followed by BatchNorm is redundant; the HIP path implements bias=False (as all hot-path call sites use)")
+        self.seq = _Seq()
+        self.seq.add_module("conv", ConvLayer(in_channels, out_channels, kernel_size, stride, padding, bias=False))
+        self.seq.add_module("bn", BatchNorm(out_channels, eps=eps, momentum=momentum))
+        self.act = act_name(activation_type)
+
+    def _parts(self):
+        return self.seq.conv, self.seq.bn
+
+
+class ConvBNReLU(ConvBNAct):
+    """Reference `ConvBNReLU` (conv_bn_relu_block.py:8-60)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True, padding_mode="zeros",
+                 use_normalization=True, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, device=None, dtype=None,
+                 use_activation=True, inplace=False):
+        super().__init__(in_channels, out_channels, kernel_size, padding=padding, activation_type="relu" if use_activation else None, stride=stride,
+                         dilation=dilation, groups=groups, bias=bias, padding_mode=padding_mode, use_normalization=use_normalization, eps=eps,
+                         momentum=momentum, affine=affine, track_running_stats=track_running_stats)

@@ -1,0 +1,98 @@
+"""NStageBackbone and SPP on the HIP kernels.
+
+Reference: NStageBackbone modules/detection_modules.py:34-102 (stem -> N stages -> context module, returns the layers
+named in out_layers); SPP training/models/detection_models/csp_darknet53.py:136-157 (1x1 -> max-pool 5/9/13 stride 1 ->
+concat -> 1x1).  The SPP concat is one NHWC buffer: cv1 and the three pooling kernels write their channel slices.
+"""
+from typing import List
+
+import torch
+
+from .. import kernels as K
+from ..common.factories import DetectionModulesFactory
+from ..common.registry import register_detection_module
+from .base_modules import BaseDetectionModule
+from .conv_bn_act_block import Conv
+from .layers import MaxPool, act_name
+
+
+@register_detection_module()
+class SPP(BaseDetectionModule):
+    def __init__(self, in_channels, output_channels, k, activation_type):
+        super().__init__(in_channels)
+        self._output_channels = output_channels
+        hidden = in_channels // 2
+        act = act_name(activation_type)
+        self.hidden = hidden
+        self.cv1 = Conv(in_channels, hidden, 1, 1, act)
+        self.cv2 = Conv(hidden * (len(k) + 1), output_channels, 1, 1, act)
+        self.m = torch.nn.ModuleList([MaxPool(kernel_size=x, stride=1, padding=x // 2) for x in k])
+
+    @property
+    def out_channels(self):
+        return self._output_channels
+
+    def fwd(self, x, out=None):
+        n, h, w, _ = x.shape
+        hid = self.hidden
+        cat = torch.empty(n, h, w, hid * (len(self.m) + 1), device=x.device, dtype=torch.float32)
+        y = self.cv1.fwd(x, out=cat[..., :hid])
+        for i, m in enumerate(self.m):
+            m.fwd(y, out=cat[..., (i + 1) * hid:(i + 2) * hid])
+        return self.cv2.fwd(cat, out=out)
+
+    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
+        hid = self.hidden
+        dcat = self.cv2.bwd(dy)
+        g = dcat[..., :hid]  # gradient of cv1's output: its own slice + the three pooling backward passes, accumulated in place
+        for i, m in enumerate(self.m):
+            m.bwd(dcat[..., (i + 1) * hid:(i + 2) * hid], dx_out=g, accumulate=True)
+        return self.cv1.bwd(g, dx_out=dx_out, accumulate=accumulate, addend=addend, need_dx=need_dx)
+
+
+@register_detection_module()
+class NStageBackbone(BaseDetectionModule):
+    def __init__(self, in_channels: int, out_layers: List[str], stem, stages, context_module):
+        super().__init__(in_channels)
+        factory = DetectionModulesFactory()
+        self.num_stages = len(stages)
+        self.stem = factory.get(factory.insert_module_param(stem, "in_channels", in_channels))
+        prev = self.stem.out_channels
+        for i in range(self.num_stages):
+            stage = factory.get(factory.insert_module_param(stages[i], "in_channels", prev))
+            setattr(self, f"stage{i + 1}", stage)
+            prev = stage.out_channels
+        self.context_module = factory.get(factory.insert_module_param(context_module, "in_channels", prev)) if context_module is not None else None
+        self.out_layers = list(out_layers)
+        self._all_layers = ["stem"] + [f"stage{i}" for i in range(1, self.num_stages + 1)] + (["context_module"] if self.context_module is not None else [])
+        self._out_channels = [getattr(self, layer).out_channels for layer in self.out_layers]
+
+    @property
+    def out_channels(self):
+        return self._out_channels
+
+    def get_input_channels(self) -> int:
+        return self.stem.get_input_channels()
+
+    def fwd(self, x, out=None):
+        outs = []
+        for layer in self._all_layers:
+            x = getattr(self, layer).fwd(x)
+            if layer in self.out_layers:
+                outs.append(x)
+        return outs
+
+    def bwd(self, grads: dict):
+        """grads: {layer_name: gradient of that layer's output coming from outside the backbone (the neck)} for the
+        layers in out_layers.  Walks the chain backwards, adding each external gradient where its tensor was produced."""
+        g = None
+        for layer in reversed(self._all_layers):
+            ext = grads.get(layer)
+            if g is None:
+                g = ext
+            elif ext is not None:
+                K.axpy(ext, out=g, accumulate=True)
+            if g is None:
+                continue
+            g = getattr(self, layer).bwd(g, need_dx=layer != self._all_layers[0])
+        return g

@@ -1,0 +1,239 @@
+"""Execution substrate of the MI355X train-step: flat HBM arenas + the forward/backward protocol of the blocks.
+
+Why not torch.autograd per op: the reference executes ~1 800 ATen ops per YOLO-NAS-S step; here every block owns a
+hand-written forward and backward that enqueue libsgx_hip kernels (include/sgx_hip.h) on the current HIP stream, the
+whole network is ONE node in torch's autograd graph (modules/engine.py:NetFunction), and parameters / gradients / BN
+buffers live in three flat fp32 arenas so that the optimizer step, EMA, zero_grad and the data-parallel all-reduce are
+each a single launch / a handful of large collectives over contiguous HBM.
+
+Protocol (all tensors NHWC, fp32, on the HIP device):
+    y  = block.fwd(x, out=None)         out: optional preallocated NHWC view (e.g. a channel slice of a concat buffer)
+    dx = block.bwd(dy, dx_out=None, accumulate=False, addend=None, need_dx=True)
+         dx_out/accumulate: write (or add) the input gradient into an existing buffer - used where a tensor has
+         several consumers; addend: extra tensor summed into dx inside the data-gradient epilogue.
+State-dict compatibility: parameter/buffer names and logical shapes equal the reference's;
+the physical layout (OHWI, channel padding) is hidden behind strided views into the arena.
+"""
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+ALIGN = 64  # floats: every arena segment starts 256-byte aligned
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class SgxBlock(nn.Module):
+    """Base of every block that runs on libsgx_hip kernels."""
+
+    def fwd(self, x, out=None):
+        raise NotImplementedError
+
+    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
+        raise NotImplementedError
+
+    def forward(self, *a, **k):  # nn.Module protocol is only exposed on whole networks (SgxNetwork)
+        raise RuntimeError(f"{type(self).__name__} runs inside an SgxNetwork; call the network, not the block")
+
+
+class Arena:
+    """A flat fp32 buffer with named, aligned segments."""
+
+    def __init__(self):
+        self.segments = []  # (name, start, numel_physical)
+        self.size = 0
+        self.buf: Optional[torch.Tensor] = None
+
+    def reserve(self, name, numel):
+        start = self.size
+        self.segments.append((name, start, numel))
+        self.size = _round_up(start + numel, ALIGN)
+        return start
+
+    def allocate(self, device, dtype=torch.float32):
+        self.buf = torch.zeros(max(self.size, ALIGN), device=device, dtype=dtype)
+        return self.buf
+
+
+def _conv_weight_view(flat, K, C, R, S):
+    """OHWI storage with C padded to a multiple of 4; logical [K,C,R,S] view (state_dict shape)."""
+    Cp = _round_up(C, 4)
+    return flat[: K * R * S * Cp].view(K, R, S, Cp)[..., :C].permute(0, 3, 1, 2), flat[: K * R * S * Cp].view(K, R, S, Cp).permute(0, 3, 1, 2)
+
+
+class ParamSlot:
+    """Book-keeping for one parameter inside the arenas."""
+
+    __slots__ = ("name", "param", "start", "numel", "kind", "kernel_view", "grad_kernel_view", "no_wd")
+
+    def __init__(self, name, param, kind):
+        self.name, self.param, self.kind = name, param, kind
+        self.start = self.numel = 0
+        self.kernel_view = self.grad_kernel_view = None
+        self.no_wd = False
+
+
+class SgxNetwork(nn.Module):
+    """A whole model (YoloNAS, ResNet) executing on the kernels.  Subclasses implement `_fwd(x_nhwc)` and `_bwd(*grads)`.
+
+    materialize(device) moves every parameter into the parameter arena (p.data becomes a strided view, p.grad a view
+    of the gradient arena) and every BN buffer into the buffer arena.  It is idempotent and is called automatically on
+    the first forward; `.to()/.cuda()` before that are fine, after that they are rejected (the arenas are the model)."""
+
+    _materialized = False
+
+    # ----------------------------------------------------------------------------------------- arenas
+    def dead_parameter(self, name: str) -> bool:
+        """Parameters that never receive a gradient (reference: QARepVGGBlock.rbr_reparam):
+        kept in state_dict, excluded from arenas / optimizer / all-reduce / EMA."""
+        return ".rbr_reparam." in name or name.startswith("rbr_reparam.")
+
+    def materialize(self, device=None):
+        if self._materialized:
+            return self
+        from .. import kernels as K  # noqa: F401  (fails loudly if the HIP library is missing)
+
+        device = torch.device(device if device is not None else "cuda")
+        self.p_arena, self.g_arena, self.b_arena = Arena(), Arena(), Arena()
+        self.slots: List[ParamSlot] = []
+        mods = dict(self.named_modules())
+        for name, p in self.named_parameters():
+            if self.dead_parameter(name):
+                p.data = p.data.to(device)
+                p.requires_grad_(False)
+                continue
+            owner = mods[name.rsplit(".", 1)[0]] if "." in name else self
+            kind = getattr(owner, "_param_kinds", {}).get(name.rsplit(".", 1)[-1], "flat")
+            slot = ParamSlot(name, p, kind)
+            if kind == "conv":
+                K_, C_, R_, S_ = p.shape
+                slot.numel = K_ * R_ * S_ * _round_up(C_, 4)
+            else:
+                slot.numel = p.numel()
+            slot.no_wd = p.dim() <= 1  # biases, BN affine, scalars (optimizer_utils.py:32-59 zero-WD group)
+            slot.start = self.p_arena.reserve(name, slot.numel)
+            self.g_arena.reserve(name, slot.numel)
+            self.slots.append(slot)
+        pbuf = self.p_arena.allocate(device)
+        gbuf = self.g_arena.allocate(device)
+        for s in self.slots:
+            flat, gflat = pbuf[s.start: s.start + s.numel], gbuf[s.start: s.start + s.numel]
+            old = s.param.data
+            if s.kind == "conv":
+                K_, C_, R_, S_ = old.shape
+                view, s.kernel_view = _conv_weight_view(flat, K_, C_, R_, S_)
+                gview, s.grad_kernel_view = _conv_weight_view(gflat, K_, C_, R_, S_)
+            elif s.kind == "convT":  # logical [C,K,2,2], stored [C][2][2][K]
+                C_, K_ = old.shape[:2]
+                view = flat.view(C_, 2, 2, K_).permute(0, 3, 1, 2)
+                gview = gflat.view(C_, 2, 2, K_).permute(0, 3, 1, 2)
+                s.kernel_view, s.grad_kernel_view = view, gview
+            else:
+                view, gview = flat.view(old.shape), gflat.view(old.shape)
+                s.kernel_view, s.grad_kernel_view = view, gview
+            view.copy_(old.to(device))
+            s.param.data = view
+            s.param.grad = gview
+        # buffers: BN running stats -> buffer arena (fp32); num_batches_tracked -> one int64 arena
+        fbufs, ibufs = [], []
+        for mname, m in self.named_modules():
+            for bname, b in list(m._buffers.items()):
+                if b is None:
+                    continue
+                (fbufs if b.dtype == torch.float32 else ibufs).append((m, bname, b))
+        for m, bname, b in fbufs:
+            self.b_arena.reserve(bname, b.numel())
+        bbuf = self.b_arena.allocate(device)
+        for (m, bname, b), (_, start, n) in zip(fbufs, self.b_arena.segments):
+            v = bbuf[start: start + n].view(b.shape)
+            v.copy_(b.to(device))
+            m._buffers[bname] = v
+        self.i_arena = torch.zeros(max(len(ibufs), 1), dtype=torch.int64, device=device)
+        for i, (m, bname, b) in enumerate(ibufs):
+            self.i_arena[i] = int(b)
+            m._buffers[bname] = self.i_arena[i]
+        self._device = device
+        self._materialized = True
+        for m in self.modules():
+            if isinstance(m, SgxBlock):
+                object.__setattr__(m, "_net", self)  # plain attribute: must not register the network as a child module
+                m.on_materialize()
+        return self
+
+    def _apply(self, fn, recurse=True):
+        if self._materialized:
+            probe = fn(torch.empty(0, device=self._device))
+            if probe.device != self._device or probe.dtype != torch.float32:
+                raise RuntimeError("this model is materialized in HBM arenas; move it before the first forward, not after")
+            return self
+        return super()._apply(fn, recurse)
+
+    def zero_grad(self, set_to_none: bool = False):
+        if self._materialized:
+            from .. import kernels as K
+
+            K.fill(self.g_arena.buf, 0.0)
+        else:
+            super().zero_grad(set_to_none)
+
+    def live_parameters(self):
+        return [s.param for s in self.slots]
+
+    # ----------------------------------------------------------------------------------------- autograd bridge
+    def _fwd(self, x):
+        raise NotImplementedError
+
+    def _bwd(self, *grads):
+        raise NotImplementedError
+
+    def forward(self, x):
+        if not self._materialized:
+            self.materialize(x.device if x.is_cuda else None)
+        from .. import _lib
+
+        if not x.is_cuda and not _lib._TEST_HOST_MODE:  # _TEST_HOST_MODE: tests/emu only (kernel-logic checks on host memory)
+            raise RuntimeError("super_gradients_amd models run on the HIP device only (no CPU fallback): move the batch to cuda")
+        if self.training:
+            self.i_arena.add_(1)  # every BatchNorm's num_batches_tracked in one launch
+        if self.training and torch.is_grad_enabled():
+            flat = NetFunction.apply(self, x, self._grad_anchor())
+        else:
+            with torch.no_grad():
+                flat = self._fwd(x)
+        return self._pack(flat)
+
+    def _pack(self, flat):
+        """flat tuple of output tensors -> the structure the reference model returns."""
+        return flat[0] if len(flat) == 1 else tuple(flat)
+
+    def _differentiable_outputs(self, n):
+        return [True] * n
+
+    def _grad_anchor(self):
+        # a leaf that requires grad so that autograd calls NetFunction.backward; parameter gradients themselves are
+        # written straight into the gradient arena by the blocks' bwd() (p.grad are views of it).
+        a = getattr(self, "_anchor", None)
+        if a is None:
+            a = self._anchor = torch.zeros(1, device=self._device, requires_grad=True)
+        return a
+
+
+class NetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, anchor):
+        ctx.net = net
+        flat = tuple(net._fwd(x))
+        ctx.mark_non_differentiable(*[t for t, d in zip(flat, net._differentiable_outputs(len(flat))) if not d])
+        return flat
+
+    @staticmethod
+    def backward(ctx, *grads):
+        net = ctx.net
+        net._bwd(*grads)
+        hook = getattr(net, "_post_backward_hook", None)
+        if hook is not None:
+            hook()
+        return None, None, torch.zeros_like(net._anchor)

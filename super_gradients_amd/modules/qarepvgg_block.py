@@ -1,0 +1,91 @@
+"""QARepVGGBlock (training form) on the HIP kernels.
+
+Reference: modules/qarepvgg_block.py:10-204 -
+    y = act(post_bn( bn3(conv3x3(x)) + alpha * (conv1x1(x) + b) + [x] ))
+with state_dict keys branch_3x3.{conv.weight,bn.*}, branch_1x1.{weight,bias}, post_bn.*, rbr_reparam.{weight,bias}
+(the last one is the reference's unused deployment placeholder, qarepvgg_block.py:166-176: kept so checkpoints load,
+never touched by any kernel, excluded from optimizer / all-reduce / EMA).
+
+Kernel sequence (training), 4 launches + 2 tiny finalizes instead of the reference's 2 conv + 2 BN + 2 add + ReLU ops:
+  t3 = conv3x3(x)                      BN3 partial statistics from the conv epilogue
+  t1 = conv1x1(x) + b
+  s  = scale3*t3 + shift3 + alpha*t1 + x     one sweep, emits post_bn partial statistics
+  y  = act(scale_p*s + shift_p)              one sweep
+Backward: post_bn(+act) backward over s (in place) -> 1x1 wgrad/dbias; BN3 backward over t3 (in place) -> 3x3 wgrad;
+dx = dgrad3x3(dt3) + dgrad1x1(alpha*ds) + ds, the two extra terms folded into the data-gradient epilogues.
+"""
+from torch import nn
+import torch
+
+from .. import kernels as K
+from .engine import SgxBlock
+from .layers import BatchNorm, ConvLayer, act_name
+
+
+class _Branch(nn.Module):
+    pass
+
+
+class QARepVGGBlock(SgxBlock):
+    def __init__(self, in_channels, out_channels, stride=1, dilation=1, groups=1, activation_type="relu", activation_kwargs=None,
+                 se_type=None, se_kwargs=None, build_residual_branches=True, use_residual_connection=True, use_alpha=False,
+                 use_1x1_bias=True, use_post_bn=True):
+        super().__init__()
+        if dilation != 1 or groups != 1:
+            raise NotImplementedError("QARepVGGBlock on the HIP path: dilation=1, groups=1")
+        if se_type not in (None, nn.Identity):
+            raise NotImplementedError("QARepVGGBlock on the HIP path: no SE block (YOLO-NAS uses none)")
+        if not (build_residual_branches and use_1x1_bias and use_post_bn):
+            raise NotImplementedError("QARepVGGBlock on the HIP path implements the training form (3 branches, 1x1 bias, post-BN)")
+        if use_alpha:
+            raise NotImplementedError("QARepVGGBlock(use_alpha=True) is not used by YOLO-NAS; alpha is the constant 1.0 here")
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        self.act = act_name(activation_type)
+        self.alpha = 1.0
+        self.branch_3x3 = _Branch()
+        self.branch_3x3.add_module("conv", ConvLayer(in_channels, out_channels, 3, stride, 1, bias=False))
+        self.branch_3x3.add_module("bn", BatchNorm(out_channels))
+        self.branch_1x1 = ConvLayer(in_channels, out_channels, 1, stride, 0, bias=True)
+        self.use_residual_connection = bool(use_residual_connection and in_channels == out_channels and stride == 1)
+        self.post_bn = BatchNorm(out_channels)
+        # reference placeholder (requires_grad=True there, never used in training mode): state_dict compatibility only
+        self.rbr_reparam = nn.Conv2d(in_channels, out_channels, 3, stride, 1, bias=True)
+
+    def on_materialize(self):
+        pass
+
+    def fwd(self, x, out=None):
+        c3, bn3, c1, pbn = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1, self.post_bn
+        res = x if self.use_residual_connection else None
+        if self.training:
+            t3, parts = c3.conv(x, stats=True)
+            M = t3.shape[0] * t3.shape[1] * t3.shape[2]
+            sc3, sh3, m3, i3 = bn3.scale_shift(parts, M, True)
+            t1 = c1.conv(x)
+            s, parts_s = K.affine_act(t3, sc3, sh3, r1=t1, a1=self.alpha, r2=res, a2=1.0, out=t1, want_stats=True)  # s overwrites t1
+            scp, shp, mp, ip = pbn.scale_shift(parts_s, M, True)
+            y = K.affine_act(s, scp, shp, act=self.act, out=out)
+            self._ctx = (x, t3, s, sc3, sh3, m3, i3, scp, shp, mp, ip)
+            return y
+        t3 = c3.conv(x)
+        sc3, sh3, _, _ = bn3.scale_shift(None, 0, False)
+        t1 = c1.conv(x)
+        s = K.affine_act(t3, sc3, sh3, r1=t1, a1=self.alpha, r2=res, a2=1.0, out=t1)
+        scp, shp, _, _ = pbn.scale_shift(None, 0, False)
+        return K.affine_act(s, scp, shp, act=self.act, out=out if out is not None else s)
+
+    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
+        c3, bn3, c1, pbn = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1, self.post_bn
+        (x, t3, s, sc3, sh3, m3, i3, scp, shp, mp, ip), self._ctx = self._ctx, None
+        ds = pbn.backward(dy, s, scp, shp, mp, ip, self.act, dx_out=s)           # in place over s
+        c1.wgrad(x, ds)                                                         # alpha == 1.0
+        dt3 = bn3.backward(ds, t3, sc3, sh3, m3, i3, None, dx_out=t3)           # in place over t3
+        c3.wgrad(x, dt3)
+        if not need_dx:
+            return None
+        shape = tuple(x.shape)
+        if self.use_residual_connection:
+            dx = c3.dgrad(dt3, shape, out=dx_out, accumulate=accumulate, addend=ds)
+            return c1.dgrad(ds, shape, out=dx, accumulate=True, addend=addend)
+        dx = c3.dgrad(dt3, shape, out=dx_out, accumulate=accumulate, addend=addend)
+        return c1.dgrad(ds, shape, out=dx, accumulate=True)

@@ -1,0 +1,3 @@
+from .model_factory import get, get_model_name, instantiate_model  # noqa: F401
+from .detection_models.yolo_nas import YoloNAS, YoloNAS_L, YoloNAS_M, YoloNAS_S  # noqa: F401
+from .detection_models.customizable_detector import CustomizableDetector  # noqa: F401

@@ -1,0 +1,74 @@
+"""CustomizableDetector on the HIP kernels: backbone -> neck -> heads built from `{TypeName: {kwargs}}` configs.
+
+Reference: training/models/detection_models/customizable_detector.py:30-104 (constructor, forward, BN eps/momentum
+override).  The model is one SgxNetwork: a single autograd node whose backward walks heads -> neck -> backbone with the
+hand-written block backwards; the NCHW fp32 batch the reference's loaders deliver is re-laid to NHWC (channels padded
+to 4) by one kernel at the entrance.
+"""
+from typing import Optional
+
+import torch
+
+from .... import kernels as K
+from ....common.factories import DetectionModulesFactory
+from ....modules.engine import SgxNetwork
+from ....modules.layers import BatchNorm
+
+
+class CustomizableDetector(SgxNetwork):
+    def __init__(self, backbone, heads, neck=None, num_classes: int = None, bn_eps: Optional[float] = None, bn_momentum: Optional[float] = None,
+                 inplace_act: Optional[bool] = True, in_channels: int = 3):
+        super().__init__()
+        if neck is None:
+            raise NotImplementedError("CustomizableDetector on the HIP path needs a neck (YOLO-NAS / PP-YOLOE style models)")
+        self.heads_params = heads
+        self.bn_eps, self.bn_momentum, self.inplace_act, self.in_channels = bn_eps, bn_momentum, inplace_act, in_channels
+        f = DetectionModulesFactory()
+        if num_classes is not None:
+            self.heads_params = f.insert_module_param(self.heads_params, "num_classes", num_classes)
+        self.backbone = f.get(f.insert_module_param(backbone, "in_channels", in_channels))
+        self.neck = f.get(f.insert_module_param(neck, "in_channels", self.backbone.out_channels))
+        self.heads = f.get(f.insert_module_param(self.heads_params, "in_channels", self.neck.out_channels))
+        self._initialize_weights(bn_eps, bn_momentum, inplace_act)
+        self._default_nms_iou, self._default_nms_conf, self._default_nms_top_k = 0.7, 0.5, 1024
+        self._default_max_predictions, self._default_multi_label_per_box, self._default_class_agnostic_nms = 300, True, False
+
+    def _initialize_weights(self, bn_eps=None, bn_momentum=None, inplace_act=True):
+        for m in self.modules():
+            if isinstance(m, BatchNorm):
+                m.eps = bn_eps if bn_eps else m.eps
+                m.momentum = bn_momentum if bn_momentum else m.momentum
+
+    # ---- SgxNetwork protocol -------------------------------------------------------------------------------------
+    def _fwd(self, x):
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected an NCHW batch with {self.in_channels} channels, got {tuple(x.shape)}")
+        xh = K.nchw_to_nhwc(x.float())
+        feats = self.backbone.fwd(xh)
+        p = self.neck.fwd(feats)
+        boxes, scores, logits, distri, anchors, pts, counts, strides = self.heads.fwd(p)
+        self._aux = (anchors, pts, list(counts), strides)  # constants of the feature-map sizes (cached in the heads)
+        self._out_shapes = (tuple(logits.shape), tuple(distri.shape))
+        return boxes, scores, logits, distri
+
+    def _differentiable_outputs(self, n):
+        return [False, False, True, True]
+
+    def _pack(self, flat):
+        boxes, scores, logits, distri = flat
+        anchors, pts, counts, strides = self._aux
+        return (boxes, scores), (logits, distri, anchors, pts, list(counts), strides)
+
+    def forward(self, x):
+        return super().forward(x)
+
+    def _bwd(self, d_boxes, d_scores, d_logits, d_distri):
+        dev = self._device
+        like_l, like_d = self._out_shapes
+        if d_logits is None:
+            d_logits = torch.zeros(like_l, device=dev)
+        if d_distri is None:
+            d_distri = torch.zeros(like_d, device=dev)
+        dps = self.heads.bwd(d_logits.contiguous(), d_distri.contiguous())
+        dcs = self.neck.bwd(*dps)
+        self.backbone.bwd(dict(zip(self.backbone.out_layers, dcs)))

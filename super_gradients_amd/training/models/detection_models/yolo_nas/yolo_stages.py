@@ -1,0 +1,285 @@
+"""YOLO-NAS stages on the HIP kernels: stem, backbone stage, CSP layer, bottleneck, up/down neck stages.
+
+Reference (training/models/detection_models/yolo_nas/yolo_stages.py): YoloNASBottleneck :23-63, YoloNASCSPLayer :85-150,
+YoloNASStem :153-184, YoloNASStage :187-235, YoloNASUpStage :238-332, YoloNASDownStage :335-395.  Same constructor
+arguments (the ones the arch YAMLs use), same child names -> same state_dict keys.
+
+MI355X-specific structure: there is no torch.cat.  Every producer of a concatenated tensor writes its NHWC output
+straight into its channel slice of one preallocated buffer (the conv / sweep kernels take explicit pixel strides), and
+in backward the consumers read their slice of the concat gradient in place.
+"""
+from functools import partial
+from typing import List
+
+import torch
+from torch import nn
+
+from ..... import kernels as K
+from .....common.registry import register_detection_module
+from .....modules.base_modules import BaseDetectionModule, width_multiplier
+from .....modules.conv_bn_act_block import Conv
+from .....modules.engine import SgxBlock
+from .....modules.layers import ConvTranspose2x2, act_name
+from .....modules.qarepvgg_block import QARepVGGBlock
+
+
+def _empty(n, h, w, c, like):
+    return torch.empty(n, h, w, c, device=like.device, dtype=torch.float32)
+
+
+class YoloNASBottleneck(SgxBlock):
+    """z = alpha * x + cv2(cv1(x))   (yolo_stages.py:61-63); alpha is a learnable [1] parameter when use_alpha."""
+
+    def __init__(self, input_channels, output_channels, block_type, activation_type, shortcut: bool, use_alpha: bool, drop_path_rate: float = 0.0):
+        super().__init__()
+        if drop_path_rate > 0.0:
+            raise NotImplementedError("drop_path inside YOLO-NAS bottlenecks is not used by the S/M/L recipes")
+        self.cv1 = block_type(input_channels, output_channels, activation_type=activation_type)
+        self.cv2 = block_type(output_channels, output_channels, activation_type=activation_type)
+        self.add = shortcut and input_channels == output_channels
+        if use_alpha:
+            self.alpha = nn.Parameter(torch.tensor([1.0]), requires_grad=True)
+        else:
+            self.alpha = 1.0
+
+    def on_materialize(self):
+        pass
+
+    def _alpha(self):
+        return (1.0, self.alpha) if isinstance(self.alpha, torch.Tensor) else (float(self.alpha), None)
+
+    def fwd(self, x, out=None):
+        if not self.add:
+            return self.cv2.fwd(self.cv1.fwd(x), out=out)
+        y = self.cv2.fwd(self.cv1.fwd(x))
+        a, a_dev = self._alpha()
+        z = K.affine_act(y, r1=x, a1=a, a1_dev=a_dev, out=out if out is not None else y)
+        self._x = x if self.training else None
+        return z
+
+    def bwd(self, dz, dx_out=None, accumulate=False, addend=None, need_dx=True):
+        if not self.add:
+            return self.cv1.bwd(self.cv2.bwd(dz), dx_out=dx_out, accumulate=accumulate, addend=addend, need_dx=need_dx)
+        x, self._x = self._x, None
+        a, a_dev = self._alpha()
+        if a_dev is not None:
+            K.dot_sum(x, dz, self.alpha.grad, accumulate=True)
+        dmid = self.cv2.bwd(dz)
+        if dx_out is not None:
+            K.axpy(dz, a=a, a_dev=a_dev, out=dx_out, accumulate=accumulate)
+            pre = dx_out
+        else:
+            pre = K.axpy(dz, a=a, a_dev=a_dev)
+        return self.cv1.bwd(dmid, dx_out=pre, accumulate=True, addend=addend)
+
+
+class _BottleneckList(nn.Module):
+    """Holds bottlenecks under integer child names (state_dict keys bottlenecks.{i}.*), like the reference's
+    SequentialWithIntermediates (yolo_stages.py:66-82)."""
+
+    def __init__(self, output_intermediates, *mods):
+        super().__init__()
+        self.output_intermediates = output_intermediates
+        for i, m in enumerate(mods):
+            self.add_module(str(i), m)
+
+    def __iter__(self):
+        return iter(self._modules.values())
+
+    def __len__(self):
+        return len(self._modules)
+
+
+class YoloNASCSPLayer(SgxBlock):
+    def __init__(self, in_channels, out_channels, num_bottlenecks, block_type, activation_type, shortcut=True, use_alpha=True, expansion=0.5,
+                 hidden_channels=None, concat_intermediates=False, drop_path_rates=None, dropout_rate=0.0):
+        super().__init__()
+        if dropout_rate > 0.0:
+            raise NotImplementedError("dropout inside YoloNASCSPLayer is not used by the S/M/L recipes")
+        drop_path_rates = [0.0] * num_bottlenecks if drop_path_rates is None else tuple(drop_path_rates)
+        if len(drop_path_rates) != num_bottlenecks:
+            raise ValueError(f"Argument drop_path_rates ({drop_path_rates}, len {len(drop_path_rates)} must have the length equal to the "
+                             f"num_bottlenecks ({num_bottlenecks}).")
+        if hidden_channels is None:
+            hidden_channels = int(out_channels * expansion)
+        self.hidden = hidden_channels
+        self.conv1 = Conv(in_channels, hidden_channels, 1, stride=1, activation_type=activation_type)
+        self.conv2 = Conv(in_channels, hidden_channels, 1, stride=1, activation_type=activation_type)
+        self.n_cat = 2 + int(bool(concat_intermediates)) * num_bottlenecks
+        self.conv3 = Conv(hidden_channels * self.n_cat, out_channels, 1, stride=1, activation_type=activation_type)
+        self.bottlenecks = _BottleneckList(
+            concat_intermediates,
+            *[YoloNASBottleneck(hidden_channels, hidden_channels, block_type, activation_type, shortcut, use_alpha, drop_path_rate=drop_path_rates[i])
+              for i in range(num_bottlenecks)])
+        self.concat_intermediates = bool(concat_intermediates)
+
+    def on_materialize(self):
+        pass
+
+    def fwd(self, x, out=None):
+        n, h, w, _ = x.shape
+        hid = self.hidden
+        cat = _empty(n, h, w, hid * self.n_cat, x)
+        sl = lambda i: cat[..., i * hid:(i + 1) * hid]  # noqa: E731
+        blocks = list(self.bottlenecks)
+        if self.concat_intermediates:
+            cur = self.conv1.fwd(x, out=sl(0))
+            for i, b in enumerate(blocks):
+                cur = b.fwd(cur, out=sl(i + 1))
+        else:
+            cur = self.conv1.fwd(x, out=sl(0) if not blocks else None)
+            for i, b in enumerate(blocks):
+                cur = b.fwd(cur, out=sl(0) if i == len(blocks) - 1 else None)
+        self.conv2.fwd(x, out=sl(self.n_cat - 1))
+        return self.conv3.fwd(cat, out=out)
+
+    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
+        hid = self.hidden
+        dcat = self.conv3.bwd(dy)
+        sl = lambda i: dcat[..., i * hid:(i + 1) * hid]  # noqa: E731
+        dx = self.conv2.bwd(sl(self.n_cat - 1), dx_out=dx_out, accumulate=accumulate, addend=addend)
+        blocks = list(self.bottlenecks)
+        if self.concat_intermediates:
+            g = sl(len(blocks))
+            for i in range(len(blocks) - 1, -1, -1):
+                g = blocks[i].bwd(g)
+                K.axpy(sl(i), out=g, accumulate=True)
+        else:
+            g = sl(0)
+            for i in range(len(blocks) - 1, -1, -1):
+                g = blocks[i].bwd(g)
+        return self.conv1.bwd(g, dx_out=dx, accumulate=True)
+
+
+@register_detection_module()
+class YoloNASStem(BaseDetectionModule):
+    def __init__(self, in_channels: int, out_channels: int, stride: int = 2):
+        super().__init__(in_channels)
+        self._out_channels = out_channels
+        self.conv = QARepVGGBlock(in_channels, out_channels, stride=stride, use_residual_connection=False)
+
+    @property
+    def out_channels(self):
+        return self._out_channels
+
+    def fwd(self, x, out=None):
+        return self.conv.fwd(x, out=out)
+
+    def bwd(self, dy, **kw):
+        return self.conv.bwd(dy, **kw)
+
+    def get_input_channels(self) -> int:
+        return self.conv.in_channels
+
+
+@register_detection_module()
+class YoloNASStage(BaseDetectionModule):
+    def __init__(self, in_channels, out_channels, num_blocks, activation_type, hidden_channels=None, concat_intermediates=False,
+                 drop_path_rates=None, dropout_rate=0.0, stride=2):
+        super().__init__(in_channels)
+        self._out_channels = out_channels
+        act = act_name(activation_type)
+        self.downsample = QARepVGGBlock(in_channels, out_channels, stride=stride, activation_type=act, use_residual_connection=False)
+        self.blocks = YoloNASCSPLayer(out_channels, out_channels, num_blocks, QARepVGGBlock, act, True, hidden_channels=hidden_channels,
+                                      concat_intermediates=concat_intermediates, drop_path_rates=drop_path_rates, dropout_rate=dropout_rate)
+
+    @property
+    def out_channels(self):
+        return self._out_channels
+
+    def fwd(self, x, out=None):
+        return self.blocks.fwd(self.downsample.fwd(x), out=out)
+
+    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
+        return self.downsample.bwd(self.blocks.bwd(dy), dx_out=dx_out, accumulate=accumulate, addend=addend, need_dx=need_dx)
+
+
+@register_detection_module()
+class YoloNASUpStage(BaseDetectionModule):
+    """inputs (x, skip1, skip2) -> (x_inter, out)   (yolo_stages.py:319-332).  Three-input form with reduce_channels
+    and ConvTranspose2d upsampling - the configuration every YOLO-NAS arch YAML uses."""
+
+    def __init__(self, in_channels: List[int], out_channels, width_mult, num_blocks, depth_mult, activation_type, hidden_channels=None,
+                 concat_intermediates=False, reduce_channels=False, drop_path_rates=None, dropout_rate=0.0, upsample_mode="conv_transpose"):
+        super().__init__(in_channels)
+        if len(in_channels) != 3 or not reduce_channels or str(upsample_mode).lower() not in ("conv_transpose", "upsamplemode.conv_transpose"):
+            raise NotImplementedError("YoloNASUpStage on the HIP path: 3 inputs, reduce_channels=True, conv_transpose upsampling")
+        cin, cs1, cs2 = in_channels
+        out_channels = width_multiplier(out_channels, width_mult, 8)
+        num_blocks = max(round(num_blocks * depth_mult), 1) if num_blocks > 1 else num_blocks
+        act = act_name(activation_type)
+        self.reduce_skip1 = Conv(cs1, out_channels, 1, 1, act)
+        self.reduce_skip2 = Conv(cs2, out_channels, 1, 1, act)
+        self.conv = Conv(cin, out_channels, 1, 1, act)
+        self.upsample = ConvTranspose2x2(out_channels, out_channels)
+        self.downsample = Conv(out_channels, out_channels, kernel=3, stride=2, activation_type=act)
+        self.reduce_after_concat = Conv(3 * out_channels, out_channels, 1, 1, act)
+        self.blocks = YoloNASCSPLayer(out_channels, out_channels, num_blocks, QARepVGGBlock, act, hidden_channels=hidden_channels,
+                                      concat_intermediates=concat_intermediates, drop_path_rates=drop_path_rates, dropout_rate=dropout_rate)
+        self._oc = out_channels
+        self._out_channels = [out_channels, out_channels]
+
+    @property
+    def out_channels(self):
+        return self._out_channels
+
+    def fwd(self, inputs, out=None):
+        x, s1, s2 = inputs
+        n, h, w, _ = s1.shape
+        oc = self._oc
+        cat = _empty(n, h, w, 3 * oc, x)
+        self.reduce_skip1.fwd(s1, out=cat[..., oc:2 * oc])
+        self.downsample.fwd(self.reduce_skip2.fwd(s2), out=cat[..., 2 * oc:])
+        x_inter = self.conv.fwd(x)
+        self.upsample.fwd(x_inter, out=cat[..., :oc])
+        return x_inter, self.blocks.fwd(self.reduce_after_concat.fwd(cat), out=out)
+
+    def bwd(self, d_inter, d_out, dx=None, ds1=None, ds2=None):
+        """d_inter: gradient arriving at x_inter from its other consumer (a down stage), or None.
+        dx/ds1/ds2: (buffer, accumulate) destinations for the three input gradients."""
+        oc = self._oc
+        dcat = self.reduce_after_concat.bwd(self.blocks.bwd(d_out))
+        g_inter = self.upsample.bwd(dcat[..., :oc])
+        if d_inter is not None:
+            K.axpy(d_inter, out=g_inter, accumulate=True)
+        gx = self.conv.bwd(g_inter, dx_out=dx[0], accumulate=dx[1])
+        g1 = self.reduce_skip1.bwd(dcat[..., oc:2 * oc], dx_out=ds1[0], accumulate=ds1[1])
+        g2 = self.reduce_skip2.bwd(self.downsample.bwd(dcat[..., 2 * oc:]), dx_out=ds2[0], accumulate=ds2[1])
+        return gx, g1, g2
+
+
+@register_detection_module()
+class YoloNASDownStage(BaseDetectionModule):
+    """inputs (x, skip) -> out   (yolo_stages.py:390-395); bottlenecks are plain 3x3 Conv blocks."""
+
+    def __init__(self, in_channels: List[int], out_channels, width_mult, num_blocks, depth_mult, activation_type, hidden_channels=None,
+                 concat_intermediates=False, drop_path_rates=None, dropout_rate=0.0):
+        super().__init__(in_channels)
+        cin, cskip = in_channels
+        out_channels = width_multiplier(out_channels, width_mult, 8)
+        num_blocks = max(round(num_blocks * depth_mult), 1) if num_blocks > 1 else num_blocks
+        act = act_name(activation_type)
+        self.conv = Conv(cin, out_channels // 2, 3, 2, act)
+        self._half, self._cskip = out_channels // 2, cskip
+        self.blocks = YoloNASCSPLayer(in_channels=out_channels // 2 + cskip, out_channels=out_channels, num_bottlenecks=num_blocks,
+                                      block_type=partial(Conv, kernel=3, stride=1), activation_type=act, hidden_channels=hidden_channels,
+                                      concat_intermediates=concat_intermediates, drop_path_rates=drop_path_rates, dropout_rate=dropout_rate)
+        self._out_channels = out_channels
+
+    @property
+    def out_channels(self):
+        return self._out_channels
+
+    def fwd(self, inputs, out=None):
+        x, skip = inputs
+        n, h, w, _ = skip.shape
+        cat = _empty(n, h, w, self._half + self._cskip, x)
+        self.conv.fwd(x, out=cat[..., : self._half])
+        K.axpy(skip, out=cat[..., self._half:])
+        return self.blocks.fwd(cat, out=out)
+
+    def bwd(self, d_out, dx=None):
+        """-> (gx, d_skip view); d_skip is a channel slice of the concat gradient (read in place by the up stage)."""
+        dcat = self.blocks.bwd(d_out)
+        gx = self.conv.bwd(dcat[..., : self._half], dx_out=dx[0], accumulate=dx[1])
+        return gx, dcat[..., self._half:]
