@@ -123,16 +123,17 @@ int32_t sgx_bn_eval_scale_shift(int32_t C, const float* gamma, const float* beta
 int32_t sgx_affine_act_fwd(const float* x, int64_t x_ld, const float* scale, const float* shift, const float* r1,
                            int64_t r1_ld, float a1, const float* a1_dev, const float* r2, int64_t r2_ld, float a2,
                            float* y, int64_t y_ld, int64_t M, int32_t C, int32_t act, float* partials, void* stream);
-/* BN backward, stage 1: g = dy * act'(scale*x+shift) ; partial sums of g and g*x per channel
+/* BN backward, stage 1: g = dy * act'(scale*x+shift) ; partial sums of g and g*(x - mean) per channel
  * (partials [2][nblk][C]).  act mask is recomputed from x, scale, shift (nothing else is stored).  */
 int32_t sgx_bn_bwd_reduce(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale,
-                          const float* shift, int64_t M, int32_t C, int32_t act, float* partials, void* stream);
+                          const float* shift, const float* save_mean, int64_t M, int32_t C, int32_t act, float* partials,
+                          void* stream);
 /* stage 2 (tiny): dgamma += sum g*xhat, dbeta += sum g; coefficients for stage 3:
- * dx = c1[c]*g + c2[c]*x + c3[c].  coef: [3][C].                                                    */
+ * dx = c1[c] * ((g - mg[c]) - (x - mean[c]) * k[c]).  coef: [4][C] = c1, mg, k, mean.               */
 int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma,
                             const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                             float* coef, void* stream);
-/* stage 3: dx = c1*g + c2*x + c3 with g recomputed as in stage 1.  Optionally also writes g itself
+/* stage 3: dx from the stage-2 coefficients with g recomputed as in stage 1.  Optionally also writes g itself
  * (g_out != NULL) for consumers that need the masked upstream gradient.                            */
 int32_t sgx_bn_bwd_apply(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale,
                          const float* shift, const float* coef, float* dx, int64_t dx_ld, float* g_out, int64_t g_ld,

@@ -70,7 +70,7 @@ PROTOTYPES = {
     "sgx_bn_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P, _P]),
     "sgx_bn_eval_scale_shift": (_i32, [_i32, _P, _P, _P, _P, _f, _P, _P, _P]),
     "sgx_affine_act_fwd": (_i32, [_P, _i64, _P, _P, _P, _i64, _f, _P, _P, _i64, _f, _P, _i64, _i64, _i32, _i32, _P, _P]),
-    "sgx_bn_bwd_reduce": (_i32, [_P, _i64, _P, _i64, _P, _P, _i64, _i32, _i32, _P, _P]),
+    "sgx_bn_bwd_reduce": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _i64, _i32, _i32, _P, _P]),
     "sgx_bn_bwd_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _P, _P, _P, _P, _P]),
     "sgx_bn_bwd_apply": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _P, _i64, _P, _i64, _i64, _i32, _i32, _P]),
     "sgx_dot_partial": (_i32, [_P, _i64, _P, _i64, _i64, _i32, _P, _P]),

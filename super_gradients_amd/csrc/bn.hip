@@ -194,20 +194,21 @@ __device__ __forceinline__ float bn_masked(float dy, float x, float s, float t, 
     return act == SGX_ACT_NONE ? dy : dy * sgx_act_grad(s * x + t, act);
 }
 struct BnBwdReduceF {
-    const float* dy; long dy_ld; const float* x; long x_ld; const float* scale; const float* shift; int act;
+    const float* dy; long dy_ld; const float* x; long x_ld; const float* scale; const float* shift; const float* mean; int act;
     __device__ void row(long r, int c, float4& q0, float4& q1) const {
         float4 d = sgx_ld4(dy + r * dy_ld + c), v = sgx_ld4(x + r * x_ld + c);
-        float4 s = sgx_ld4(scale + c), t = sgx_ld4(shift + c);
+        float4 s = sgx_ld4(scale + c), t = sgx_ld4(shift + c), mu = sgx_ld4(mean + c);
         float gx = bn_masked(d.x, v.x, s.x, t.x, act), gy = bn_masked(d.y, v.y, s.y, t.y, act);
         float gz = bn_masked(d.z, v.z, s.z, t.z, act), gw = bn_masked(d.w, v.w, s.w, t.w, act);
         q0.x += gx; q0.y += gy; q0.z += gz; q0.w += gw;
-        q1.x += gx * v.x; q1.y += gy * v.y; q1.z += gz * v.z; q1.w += gw * v.w;
+        // centred second moment: sum g*(x - mean) (no large-term cancellation later, cf. ATen's batch_norm backward)
+        q1.x += gx * (v.x - mu.x); q1.y += gy * (v.y - mu.y); q1.z += gz * (v.z - mu.z); q1.w += gw * (v.w - mu.w);
     }
 };
 extern "C" int32_t sgx_bn_bwd_reduce(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale, const float* shift,
-                                     int64_t M, int32_t C, int32_t act, float* partials, void* stream) {
-    SGX_CHECK_ARG(dy && x && scale && shift && partials, "bn_bwd_reduce: null pointer");
-    BnBwdReduceF f{dy, dy_ld, x, x_ld, scale, shift, act};
+                                     const float* save_mean, int64_t M, int32_t C, int32_t act, float* partials, void* stream) {
+    SGX_CHECK_ARG(dy && x && scale && shift && save_mean && partials, "bn_bwd_reduce: null pointer");
+    BnBwdReduceF f{dy, dy_ld, x, x_ld, scale, shift, save_mean, act};
     return run_sweep<BnBwdReduceF, 2>(f, M, C, partials, stream, "bn_bwd_reduce");
 }
 
@@ -221,13 +222,15 @@ __global__ void bn_bwd_finalize_kernel(const float* partials, int nblk, long M, 
         sgx += (double)partials[((long)nblk + b) * C + c];
     }
     double mean = save_mean[c], invstd = save_invstd[c], g = gamma ? (double)gamma[c] : 1.0;
-    double sgxhat = invstd * (sgx - mean * sg);
+    double sgxhat = invstd * sgx;  // sgx is already centred: sum g*(x - mean)
     if (dgamma) dgamma[c] += (float)sgxhat;
     if (dbeta) dbeta[c] += (float)sg;
-    double mg = sg / (double)M, mgx = sgxhat / (double)M;
+    // dx = c1 * ((g - mg) - (x - mean) * k): differences first, then the scale - the order ATen's CPU kernel uses, so a
+    // nearly constant upstream gradient does not lose its small remainder to cancellation between large products
     coef[c] = (float)(g * invstd);
-    coef[C + c] = (float)(-g * invstd * invstd * mgx);
-    coef[2 * C + c] = (float)(-g * invstd * mg + g * invstd * invstd * mean * mgx);
+    coef[C + c] = (float)(sg / (double)M);
+    coef[2 * C + c] = (float)(invstd * invstd * sgx / (double)M);
+    coef[3 * C + c] = (float)mean;
 }
 extern "C" int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma, const float* save_mean,
                                        const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
@@ -245,11 +248,11 @@ struct BnBwdApplyF {
         (void)q0; (void)q1;
         float4 d = sgx_ld4(dy + r * dy_ld + c), v = sgx_ld4(x + r * x_ld + c);
         float4 s = sgx_ld4(scale + c), t = sgx_ld4(shift + c);
-        float4 c1 = sgx_ld4(coef + c), c2 = sgx_ld4(coef + C + c), c3 = sgx_ld4(coef + 2 * C + c);
+        float4 c1 = sgx_ld4(coef + c), mg = sgx_ld4(coef + C + c), k = sgx_ld4(coef + 2 * C + c), mu = sgx_ld4(coef + 3 * C + c);
         float4 g = make_float4(bn_masked(d.x, v.x, s.x, t.x, act), bn_masked(d.y, v.y, s.y, t.y, act),
                                bn_masked(d.z, v.z, s.z, t.z, act), bn_masked(d.w, v.w, s.w, t.w, act));
-        float4 o = make_float4(c1.x * g.x + c2.x * v.x + c3.x, c1.y * g.y + c2.y * v.y + c3.y,
-                               c1.z * g.z + c2.z * v.z + c3.z, c1.w * g.w + c2.w * v.w + c3.w);
+        float4 o = make_float4(c1.x * ((g.x - mg.x) - (v.x - mu.x) * k.x), c1.y * ((g.y - mg.y) - (v.y - mu.y) * k.y),
+                               c1.z * ((g.z - mg.z) - (v.z - mu.z) * k.z), c1.w * ((g.w - mg.w) - (v.w - mu.w) * k.w));
         sgx_st4(dx + r * dx_ld + c, o);
         if (g_out) sgx_st4(g_out + r * g_ld + c, g);
     }

@@ -247,8 +247,8 @@ def bn_bwd(dy, x, scale, shift, gamma, save_mean, save_invstd, dgamma, dbeta, ac
     dl = rows(dy)[1]
     parts = torch.empty(2, stats_blocks(M), C, device=x.device, dtype=torch.float32)
     a = ACT[act]
-    check(lib().sgx_bn_bwd_reduce(ptr(dy), dl, ptr(x), ld, ptr(scale), ptr(shift), M, C, a, ptr(parts), stream()), "sgx_bn_bwd_reduce")
-    coef = torch.empty(3, C, device=x.device, dtype=torch.float32)
+    check(lib().sgx_bn_bwd_reduce(ptr(dy), dl, ptr(x), ld, ptr(scale), ptr(shift), ptr(save_mean), M, C, a, ptr(parts), stream()), "sgx_bn_bwd_reduce")
+    coef = torch.empty(4, C, device=x.device, dtype=torch.float32)
     check(lib().sgx_bn_bwd_finalize(ptr(parts), parts.shape[1], M, C, ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(dgamma), ptr(dbeta), ptr(coef),
                                     stream()), "sgx_bn_bwd_finalize")
     dx = dx_out if dx_out is not None else torch.empty(x.shape, device=x.device, dtype=torch.float32)

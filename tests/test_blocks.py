@@ -1,0 +1,117 @@
+"""Block-level parity (forward, input gradient, every parameter gradient, BN running stats) of the HIP blocks against the
+oracle's CPU modules (oracle/yolo_nas.py, which restate the reference's blocks with identical state_dict keys)."""
+import pytest
+import torch
+from torch import nn
+
+from util import assert_close, to_nchw_cpu, to_nhwc
+
+
+class _Net(nn.Module):
+    """Minimal SgxNetwork around one block, so that arenas / materialisation are exercised exactly as in a model."""
+
+
+def _wrap(block, device):
+    from super_gradients_amd.modules.engine import SgxNetwork
+
+    class One(SgxNetwork):
+        def __init__(self):
+            super().__init__()
+            self.b = block
+
+    net = One()
+    net.materialize(device)
+    return net
+
+
+def _randomize(mod, seed):
+    g = torch.Generator().manual_seed(seed)
+    for name, p in mod.named_parameters():
+        if name.endswith("bn.weight") or name.endswith("post_bn.weight"):
+            p.data.uniform_(0.5, 1.5, generator=g)
+        elif p.dim() <= 1:
+            p.data.add_(torch.randn(p.shape, generator=g) * 0.2)
+    for m in mod.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+
+
+def _check(ref, blk, x, device, tol=2e-5, key_prefix="b."):
+    from super_gradients_amd.modules.layers import BatchNorm
+
+    _randomize(ref, 1)
+    for m in blk.modules():
+        if isinstance(m, BatchNorm):
+            m.eps, m.momentum = 1e-3, 0.03
+    net = _wrap(blk, device)
+    missing = blk.load_state_dict(ref.state_dict(), strict=True)
+    assert not missing.missing_keys
+    ref.train()
+    net.train()
+    xr = x.clone().requires_grad_(True)
+    y = ref(xr)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+    y.backward(dy)
+    net.zero_grad()
+    yd = blk.fwd(to_nhwc(x, device))
+    assert_close(to_nchw_cpu(yd), y, tol, "forward")
+    dx = blk.bwd(to_nhwc(dy, device))
+    assert_close(to_nchw_cpu(dx), xr.grad, 5 * tol, "input gradient")
+    rp = dict(ref.named_parameters())
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    for name, p in blk.named_parameters():
+        if "rbr_reparam" in name:
+            continue
+        rg = rp[name].grad
+        e = float((p.grad.cpu().double() - rg.double()).abs().max()) / max(float(rg.abs().max()), 1e-2 * gmax)
+        assert e <= 5 * tol, f"grad {name}: {e:.3e}"
+    rb = dict(ref.named_buffers())
+    for name, b in blk.named_buffers():
+        if not name.endswith("num_batches_tracked"):
+            assert_close(b.cpu(), rb[name], tol, name)
+
+
+def _shape(backend, gpu, emu):
+    return gpu if backend.type == "cuda" else emu
+
+
+@pytest.mark.parametrize("k,s", [(1, 1), (3, 1), (3, 2)])
+def test_conv_block(backend, k, s):
+    from oracle.yolo_nas import ConvBnAct
+    from super_gradients_amd.modules import Conv
+
+    n, c, h, w, co = _shape(backend, (2, 96, 10, 10, 64), (1, 8, 6, 6, 4))
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
+    _check(ConvBnAct(c, co, k, s), Conv(c, co, k, s, "relu"), x, backend)
+
+
+@pytest.mark.parametrize("stride,cout", [(1, None), (2, 2)])
+def test_qarepvgg_block(backend, stride, cout):
+    from oracle.yolo_nas import QARep
+    from super_gradients_amd.modules import QARepVGGBlock
+
+    n, c, h, w = _shape(backend, (2, 64, 10, 10), (1, 8, 6, 6))
+    co = c if cout is None else c * cout
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
+    _check(QARep(c, co, stride, residual=stride == 1), QARepVGGBlock(c, co, stride=stride, use_residual_connection=stride == 1), x, backend)
+
+
+@pytest.mark.parametrize("concat", [False, True])
+def test_csp_layer(backend, concat):
+    from oracle.yolo_nas import CSP, _qa
+    from super_gradients_amd.modules import QARepVGGBlock
+    from super_gradients_amd.training.models.detection_models.yolo_nas.yolo_stages import YoloNASCSPLayer
+
+    n, c, h, w, hid, nb = _shape(backend, (2, 96, 10, 10, 32, 2), (1, 8, 4, 4, 4, 2))
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
+    _check(CSP(c, c, nb, hid, concat, _qa), YoloNASCSPLayer(c, c, nb, QARepVGGBlock, "relu", True, hidden_channels=hid, concat_intermediates=concat), x,
+           backend)
+
+
+def test_spp(backend):
+    from oracle.yolo_nas import SPP as OSPP
+    from super_gradients_amd.modules.detection_modules import SPP
+
+    n, c, h, w = _shape(backend, (2, 64, 10, 10), (1, 8, 6, 6))
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
+    _check(OSPP(c, c), SPP(c, c, (5, 9, 13), "relu"), x, backend)
