@@ -1,0 +1,187 @@
+"""bench.py - the north-star measurement: YOLO-NAS-S 640x640 train-step throughput (images/s) on N MI355X.
+
+One "step" = one pass of the hot path over one synthetic batch that is already resident in HBM:
+    forward (libsgx_hip conv/BN kernels) -> PPYoloELoss (TaskAligned assigner, VFL+GIoU+DFL) -> backward ->
+    [gradient all-reduce over RCCL/xGMI, overlapped with backward, N > 1] -> AdamW (wd 1e-5, zero-WD on bias/BN) -> EMA.
+Precision: fp32 end to end (dtype "fp32": the parity mode, conv on v_mfma_f32_32x32x2_f32; roofline peak 157.3 TFLOP/s).
+Weak scaling: 32 images per GPU, global batch 32*N.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--size 640] [--model s] [--no-cpu-baseline]
+N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
+  roofline      dominant kernel class = the implicit-GEMM conv kernel (forward + data gradient launches): algorithmic
+                FLOPs (2*M*N*K of the real problem) / HIP-event time of those launches, measured live in the timed steps
+                on the launch stream; peak = fp32 MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md).  `wgrad` gives the same
+                for the weight-gradient kernel, `step_mfma_frac` the whole-step figure SURVEY 8(d) defines
+                (images/s x 101.634 GFLOP / peak).
+  cpu_baseline  the CPU oracle (the reference's arithmetic, oracle/yolo_nas.py + oracle/ppyolo_loss.py, ATen/oneDNN
+                kernels) timed on this box's host cores on a bounded sample of the same workload (kind "port").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+TRAIN_GFLOP_PER_IMG = {"s": 101.634, "m": 282.556, "l": 386.959}  # 3 x forward conv FLOPs @640^2
+PEAK_FP32_MFMA_TFLOPS = 157.3
+
+
+def synthetic_batch(batch, size, seed, device):
+    import torch
+    from util import synthetic_targets
+
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(batch, 3, size, size, generator=g)
+    t = synthetic_targets(batch, seed=seed, kmax=20, size=size, num_classes=80)
+    return x.to(device), t.to(device)
+
+
+def cpu_baseline(model, size, seconds_budget=25.0):
+    """Oracle train step on the host cores: bounded sample (batch 8, 1 warm-up + up to 3 timed steps)."""
+    import torch
+    from oracle.ppyolo_loss import PPYoloELossOracle
+    from oracle.yolo_nas import YoloNAS as OracleYoloNAS
+    from util import synthetic_targets
+
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    net = OracleYoloNAS(model, num_classes=80).train()
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-5)
+    crit = PPYoloELossOracle(80, use_static_assigner=False)
+    bs = 8
+    x = torch.rand(bs, 3, size, size)
+    t = synthetic_targets(bs, seed=0, kmax=20, size=size)
+
+    def step():
+        loss, _ = crit(net(x), t)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+
+    step()
+    t0 = time.time()
+    n = 0
+    while n < 3 and time.time() - t0 < seconds_budget:
+        step()
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(bs * n / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"oracle YOLO-NAS-{model.upper()} {size}x{size} fp32 train step (fwd+PPYoloELoss+bwd+AdamW), batch {bs}, {n} timed steps after 1 warm-up, "
+                      f"{threads} threads of {cores} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--model", default="s", choices=["s", "m", "l"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ema", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd.training import models
+    from super_gradients_amd.training.losses import PPYoloELoss
+    from super_gradients_amd.training.utils.distributed_training_utils import GradientAllReducer, setup_device_from_env
+    from super_gradients_amd.training.utils.ema import ModelEMA
+    from super_gradients_amd.training.utils.optimizers import ArenaAdamW
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a HIP GPU (the product has no CPU path)")
+    rank, world, device = setup_device_from_env()
+    if world != args.gpus:
+        raise RuntimeError(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run --nproc-per-node {args.gpus}")
+
+    torch.manual_seed(42)  # identical initial weights on every rank (the reference's default seed)
+    net = models.get(f"yolo_nas_{args.model}", num_classes=80)
+    net.materialize(device)
+    net.train()
+    reducer = GradientAllReducer(net, net.gradient_buckets())
+    reducer.broadcast_parameters(0)
+    crit = PPYoloELoss(num_classes=80, use_static_assigner=False)
+    opt = ArenaAdamW(net, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, zero_weight_decay_on_bias_and_bn=True)
+    ema = None if args.no_ema else ModelEMA.from_params(net, decay=0.9997, decay_type="threshold")
+    x, targets = synthetic_batch(args.batch, args.size, 42 + rank, device)
+
+    state = {"step": 0}
+
+    def step():
+        out = net(x)
+        loss, _ = crit(out, targets)
+        loss.backward()
+        opt.step(grad_scale=reducer.grad_scale if world > 1 else None)
+        opt.zero_grad()
+        if ema is not None:
+            ema.update(net, state["step"], 100000)
+        state["step"] += 1
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    K.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ig_ms, ig_fl, ig_n = K.prof_summary(0)
+    wg_ms, wg_fl, wg_n = K.prof_summary(1)
+    K.prof_enable(False)
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    loss_val = float(loss.detach())
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        value = imgs / dt
+        ig_tf = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
+        wg_tf = wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
+        per_gpu = value / world
+        rec = {
+            "metric": f"images/sec/node YOLO-NAS-{args.model.upper()} {args.size}x{args.size} train-step",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": f"YOLO-NAS-{args.model.upper()} synthetic COCO {args.size}x{args.size}, bs={args.batch}/GPU, PPYoloELoss(TAL)+AdamW"
+                                   + ("" if args.no_ema else "+EMA") + ", random-init weights",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data gradient, v_mfma_f32_32x32x2_f32)",
+                         "achieved": round(ig_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": None, "launches_per_step": ig_n // max(args.steps, 1), "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
+                         "gflop_per_launch": round(ig_fl / max(ig_n, 1) / 1e9, 3), "kernel_ms_per_step": round(ig_ms / args.steps, 3),
+                         "wgrad": {"achieved": round(wg_tf, 2), "frac": round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4), "launches_per_step": wg_n // max(args.steps, 1),
+                                   "kernel_ms_per_step": round(wg_ms / args.steps, 3)},
+                         "step_mfma_frac": round(per_gpu * TRAIN_GFLOP_PER_IMG[args.model] * (args.size / 640.0) ** 2 / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(args.model, args.size)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,13 @@ extern "C" {
 int32_t sgx_version(void);
 const char* sgx_last_error(void);
 
+/* Measurement aid (bench.py roofline leg).  While enabled, every launch of the two MFMA kernel classes is bracketed by
+ * HIP events on its own launch stream and its algorithmic FLOPs (2*M*N*K of the real, unpadded problem) are tallied.
+ * cls 0 = implicit-GEMM kernel (conv forward and data gradient), cls 1 = weight-gradient kernel.
+ * sgx_prof_summary synchronises on the recorded events and returns the sums since the last sgx_prof_enable().      */
+int32_t sgx_prof_enable(int32_t on);
+int32_t sgx_prof_summary(int32_t cls, double* ms, double* flops, int64_t* launches);
+
 /* ---------------------------------------------------------------------------------------------
  * Convolution (implicit GEMM on fp32 MFMA, v_mfma_f32_32x32x2_f32).
  * Replaces torch.nn.functional.conv2d fwd/bwd issued by nn.Conv2d inside

@@ -53,6 +53,8 @@ _CD, _LD, _ND = POINTER(ConvDesc), POINTER(LossDesc), POINTER(NmsDesc)
 PROTOTYPES = {
     "sgx_version": (_i32, []),
     "sgx_last_error": (c_char_p, []),
+    "sgx_prof_enable": (_i32, [_i32]),
+    "sgx_prof_summary": (_i32, [_i32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "sgx_conv2d_fwd": (_i32, [_CD, _P, _P, _P, _P, _P, _i32, _P, _P]),
     "sgx_conv2d_fwd_stat_blocks": (_i32, [_CD]),
     "sgx_conv2d_bwd_data_workspace": (_i64, [_CD]),

@@ -19,6 +19,95 @@
 
 #define SGX_MAX_TAPS 64
 
+// ------------------------------------------------------------------------------------------------
+// Optional per-launch timing of the two MFMA kernel classes (bench.py's roofline leg): HIP events recorded on the
+// launch stream around every igemm / wgrad launch, algorithmic FLOPs tallied next to them.  Off by default.
+// ------------------------------------------------------------------------------------------------
+#ifndef SGX_EMU
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec {
+    hipEvent_t a, b;
+    double flops;
+    int cls;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) {
+        hipEvent_t e = g_prof_pool.back();
+        g_prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    bool on;
+    ProfRec r;
+    hipStream_t st;
+    ProfScope(int cls, double flops, void* stream) : on(false), st((hipStream_t)stream) {
+        std::lock_guard<std::mutex> g(g_prof_mu);
+        if (!g_prof_on) return;
+        on = true;
+        r.cls = cls;
+        r.flops = flops;
+        r.a = prof_event();
+        r.b = prof_event();
+        (void)hipEventRecord(r.a, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, st);
+        std::lock_guard<std::mutex> g(g_prof_mu);
+        g_prof_recs.push_back(r);
+    }
+};
+}  // namespace
+extern "C" int32_t sgx_prof_enable(int32_t on) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    for (auto& r : g_prof_recs) {
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof_recs.clear();
+    g_prof_on = on != 0;
+    return SGX_OK;
+}
+extern "C" int32_t sgx_prof_summary(int32_t cls, double* ms, double* flops, int64_t* launches) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    double t = 0.0, f = 0.0;
+    long n = 0;
+    for (auto& r : g_prof_recs) {
+        if (r.cls != cls) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) SGX_FAIL(SGX_ERR_HIP, "prof: event sync failed");
+        float e = 0.f;
+        if (hipEventElapsedTime(&e, r.a, r.b) != hipSuccess) SGX_FAIL(SGX_ERR_HIP, "prof: elapsed failed");
+        t += e;
+        f += r.flops;
+        ++n;
+    }
+    if (ms) *ms = t;
+    if (flops) *flops = f;
+    if (launches) *launches = n;
+    return SGX_OK;
+}
+#define SGX_PROF(cls, flops, stream) ProfScope prof_scope__((cls), (flops), (stream))
+#else
+extern "C" int32_t sgx_prof_enable(int32_t) { return SGX_OK; }
+extern "C" int32_t sgx_prof_summary(int32_t, double* ms, double* flops, int64_t* launches) {
+    if (ms) *ms = 0;
+    if (flops) *flops = 0;
+    if (launches) *launches = 0;
+    return SGX_OK;
+}
+#define SGX_PROF(cls, flops, stream)
+#endif
+
 struct IgemmParams {
     const float* A;
     const float* Wt;
@@ -281,6 +370,7 @@ static void launch_igemm(IgemmParams& p, void* stream) {
 
 static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
     if (p.T > SGX_MAX_TAPS) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: more than %d taps", SGX_MAX_TAPS);
+    SGX_PROF(0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * (double)p.T, stream);
     if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2>(p, stream);
     else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1>(p, stream);
     else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2>(p, stream);
@@ -626,6 +716,8 @@ extern "C" int32_t sgx_conv2d_bwd_weight(const sgx_conv_desc* d, const float* x,
     p.M = d->N * d->Ho * d->Wo; p.ksplit = pl.ksplit; p.mchunk = pl.mchunk; p.kt_tiles = pl.kt_tiles; p.ct_tiles = pl.ct_tiles;
     long nblk = (long)pl.ksplit * pl.kt_tiles * pl.ct_tiles * d->R * d->S;
     dim3 grid((unsigned)nblk);
+    {
+    SGX_PROF(1, 2.0 * (double)p.M * (double)d->K * (double)d->C * (double)(d->R * d->S), stream);
 #define WG_CASE(BK_, BC_, WK_, WC_) \
     if (pl.bnk == BK_ && pl.bc == BC_) SGX_LAUNCH((wgrad_kernel<BK_, BC_, WK_, WC_>), grid, dim3(WK_ * WC_ * 64), 0, stream, p)
     WG_CASE(128, 128, 2, 2);
@@ -638,6 +730,7 @@ extern "C" int32_t sgx_conv2d_bwd_weight(const sgx_conv_desc* d, const float* x,
     WG_CASE(32, 64, 1, 2);
     WG_CASE(32, 32, 1, 1);
 #undef WG_CASE
+    }
     SGX_CHECK_LAUNCH("wgrad");
     long n = (long)d->K * d->R * d->S * d->C;
     int rg = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);

@@ -7,10 +7,15 @@
 // Per-segment weight decay reproduces the zero-WD groups of optimizer_utils.py:32-59.
 #include "sgx_common.h"
 
+// first segment whose end is beyond i (segments ascend): binary search, ~9 L1-resident probes for a 500-tensor model
 __device__ __forceinline__ float seg_wd_of(long i, const long long* seg_end, const float* seg_wd, int nseg) {
-    for (int s = 0; s < nseg; ++s)
-        if (i < (long)seg_end[s]) return seg_wd[s];
-    return 0.f;
+    int lo = 0, hi = nseg;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (i < (long)seg_end[mid]) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo < nseg ? seg_wd[lo] : 0.f;
 }
 
 __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float bc1, float bc2s,

@@ -430,3 +430,15 @@ def sgd_step(p, g, mom, lr, momentum, dampening, nesterov, first_step, seg_end, 
 
 def ema_update(ema, p, decay):
     check(lib().sgx_ema_update(ptr(ema), ptr(p), ema.numel(), float(decay), stream()), "sgx_ema_update")
+
+
+# --------------------------------------------------------------------------------------------- measurement aid
+def prof_enable(on: bool):
+    check(lib().sgx_prof_enable(int(on)), "sgx_prof_enable")
+
+
+def prof_summary(cls: int):
+    """-> (total ms, algorithmic FLOPs, launches) of kernel class cls (0 = implicit GEMM fwd/dgrad, 1 = weight gradient)."""
+    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    check(lib().sgx_prof_summary(cls, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "sgx_prof_summary")
+    return ms.value, fl.value, n.value

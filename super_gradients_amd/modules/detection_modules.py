@@ -82,7 +82,7 @@ class NStageBackbone(BaseDetectionModule):
                 outs.append(x)
         return outs
 
-    def bwd(self, grads: dict):
+    def bwd(self, grads: dict, on_layer_done=None):
         """grads: {layer_name: gradient of that layer's output coming from outside the backbone (the neck)} for the
         layers in out_layers.  Walks the chain backwards, adding each external gradient where its tensor was produced."""
         g = None
@@ -95,4 +95,6 @@ class NStageBackbone(BaseDetectionModule):
             if g is None:
                 continue
             g = getattr(self, layer).bwd(g, need_dx=layer != self._all_layers[0])
+            if on_layer_done is not None:
+                on_layer_done(layer)
         return g

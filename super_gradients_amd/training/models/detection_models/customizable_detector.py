@@ -69,6 +69,13 @@ class CustomizableDetector(SgxNetwork):
             d_logits = torch.zeros(like_l, device=dev)
         if d_distri is None:
             d_distri = torch.zeros(like_d, device=dev)
+        ready = getattr(self, "_grad_ready", None) or (lambda prefix: None)
         dps = self.heads.bwd(d_logits.contiguous(), d_distri.contiguous())
+        ready("heads.")
         dcs = self.neck.bwd(*dps)
-        self.backbone.bwd(dict(zip(self.backbone.out_layers, dcs)))
+        ready("neck.")
+        self.backbone.bwd(dict(zip(self.backbone.out_layers, dcs)), on_layer_done=lambda layer: ready(f"backbone.{layer}."))
+
+    def gradient_buckets(self):
+        """Arena ranges in backward-completion order (see training/utils/distributed_training_utils.GradientAllReducer)."""
+        return [f"backbone.{layer}." for layer in self.backbone._all_layers] + ["neck.", "heads."]
