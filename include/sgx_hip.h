@@ -200,6 +200,9 @@ typedef struct sgx_loss_desc {
     int32_t num_levels;         /* ATSS: pyramid levels                                           */
     int32_t level_count[8];     /* ATSS: anchors per level                                        */
     float w_cls, w_iou, w_dfl;  /* 1.0, 2.5, 0.5                                                  */
+    int32_t sequential_assignment; /* 1 = use_batched_assignment=False semantics (ppyolo_loss.py:854-942): the
+                                    * assigners run with pad_gt_mask=None, so TAL drops a GT whose best candidate metric
+                                    * is <= 1e-9 (gather_topk_anchors :224-226) and no GT row is masked by sum(coords)>0 */
 } sgx_loss_desc;
 
 int64_t sgx_ppyoloe_loss_workspace(const sgx_loss_desc* d);

@@ -1,0 +1,144 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.pt by running the REAL reference source files
+(/root/reference/src/super_gradients/..., unmodified, through oracle/ref_shim.py) on CPU fp32.
+
+    python oracle/make_golden.py          # only works in the build container, where /root/reference exists
+
+Fixtures (all inputs are regenerated from seeds by oracle/golden_util.py; only reference OUTPUTS are stored):
+  yolo_nas_{s,m,l}.pt  reference YoloNAS (customizable_detector.py:30, yolo_nas_variants.py:75-146) with
+                       deterministic_fill weights, train-mode forward on a seeded image batch: decoded boxes / scores,
+                       raw logits / distribution logits, anchors, points, strides; reference PPYoloELoss (TAL and ATSS)
+                       loss items; per-parameter gradient L2 norms and sums of the TAL loss; BN running-stat checksums.
+  ppyoloe_loss.pt      reference PPYoloELoss on random head outputs: {ATSS,TAL} x {varifocal,focal} x {batched,
+                       sequential}, with the reference unit test's own fixed target tensor and with a seeded target set
+                       that contains an empty image, plus the all-empty case: loss, items, d loss / d logits, d loss / d distri.
+  post_prediction.pt   reference PPYoloEPostPredictionCallback.forward (post_prediction_callback.py:42-123) with
+                       torchvision.ops.boxes.{nms,batched_nms} bound to oracle/nms.py (torchvision is not installed and
+                       not vendored: the NMS arithmetic itself stays "parity unpinned", the code around it is pinned).
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import golden_util as G  # noqa: E402
+from oracle import nms as onms  # noqa: E402
+from oracle import ref_shim  # noqa: E402
+
+MODEL_CASES = {"s": dict(batch=2, size=128), "m": dict(batch=1, size=128), "l": dict(batch=1, size=128)}
+
+
+def _ref_anchors(hw, strides):
+    ref_shim.install()
+    from super_gradients.training.models.detection_models.pp_yolo_e.pp_yolo_head import generate_anchors_for_grid_cell
+
+    feats = [torch.zeros(1, 1, h, w) for h, w in hw]
+    return generate_anchors_for_grid_cell(feats, strides)
+
+
+def make_model_fixture(variant):
+    cfg = MODEL_CASES[variant]
+    torch.manual_seed(0)
+    net = ref_shim.build_reference_yolo_nas(variant, num_classes=80)
+    G.deterministic_fill(net, seed=1)
+    net.train()
+    x = G.seeded_input(cfg["batch"], 3, cfg["size"], seed=2)
+    targets = G.detection_targets(cfg["batch"], cfg["size"], seed=3, kmax=3, empty_last=False)
+    out = net(x)
+    (boxes, scores), (logits, distri, anchors, points, counts, strides) = out
+    fx = dict(variant=variant, batch=cfg["batch"], size=cfg["size"], state_keys=list(net.state_dict().keys()),
+              state_shapes=[tuple(v.shape) for v in net.state_dict().values()],
+              boxes=boxes.detach().clone(), scores=scores.detach().clone(), logits=logits.detach().clone(), distri=distri.detach().clone(),
+              anchors=anchors.clone(), points=points.clone(), counts=list(counts), strides=strides.clone(), targets=targets)
+    # the same reference modules in fp64 (the "truth" the fp32 paths are judged against where fp32 round-off through ~60
+    # training-mode BatchNorms exceeds the 1e-4 bar on its own)
+    import copy
+
+    net64 = copy.deepcopy(net).double()
+    (b64, s64), (l64, d64, *_rest) = net64(x.double())
+    fx.update(boxes_f64=b64.detach().clone(), scores_f64=s64.detach().clone(), logits_f64=l64.detach().clone(), distri_f64=d64.detach().clone())
+    del net64
+    for static in (False, True):
+        crit = ref_shim.reference_ppyolo_loss(num_classes=80, use_static_assigner=static)
+        loss, items = crit(out, targets)
+        fx["loss_items_atss" if static else "loss_items_tal"] = items.detach().clone()
+        if not static:
+            net.zero_grad()
+            loss.backward(retain_graph=True)
+            names, norms, sums = [], [], []
+            for n, p in net.named_parameters():
+                if p.grad is None:
+                    continue
+                names.append(n)
+                norms.append(float(p.grad.double().norm()))
+                sums.append(float(p.grad.double().sum()))
+            fx["grad_names"], fx["grad_norms"], fx["grad_sums"] = names, torch.tensor(norms, dtype=torch.float64), torch.tensor(sums, dtype=torch.float64)
+    bn = {k: float(v.double().sum()) for k, v in net.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+    fx["bn_running_checksum"] = bn
+    # eval-mode forward returns the same 2-tuple (SURVEY 8c edge case)
+    net.eval()
+    with torch.no_grad():
+        (eb, es), _ = net(x)
+    fx["eval_boxes"], fx["eval_scores"] = eb.clone(), es.clone()
+    return fx
+
+
+def make_loss_fixture():
+    cases = []
+    sizes = [8, 4, 3]  # 89 anchors: keeps the fixture small; level 3 still holds the 9 anchors ATSS's per-level top-9 needs
+    preds = G.synthetic_predictions(3, sizes, 80, 16, seed=5, make_anchors=_ref_anchors)
+    tsets = {
+        "reference_unit_test": G.REFERENCE_UNIT_TEST_TARGETS * torch.tensor([1, 1, 0.125, 0.125, 0.125, 0.125]),  # scaled into the 64-px canvas
+        "seeded_with_empty_image": G.detection_targets(3, 64, seed=6, kmax=5, empty_last=True),
+        "no_targets": torch.zeros(0, 6),
+    }
+    for tname, t in tsets.items():
+        for static in (True, False):
+            for vfl in (True, False):
+                for batched in (True, False):
+                    logits = preds[0].clone().requires_grad_(True)
+                    distri = preds[1].clone().requires_grad_(True)
+                    crit = ref_shim.reference_ppyolo_loss(num_classes=80, use_varifocal_loss=vfl, use_static_assigner=static, reg_max=16,
+                                                          use_batched_assignment=batched)
+                    loss, items = crit((None, (logits, distri) + tuple(preds[2:])), t)
+                    loss.backward()
+                    case = dict(targets=tname, static=static, vfl=vfl, batched=batched, loss=loss.detach().clone(), items=items.detach().clone())
+                    if batched:  # the sequential path must reproduce the batched one (the reference's own unit test); its gradients are not stored
+                        case.update(g_logits=logits.grad.clone(), g_distri=distri.grad.clone())
+                    cases.append(case)
+    return dict(sizes=sizes, batch=3, seed=5, target_sets=tsets, cases=cases)
+
+
+def make_post_prediction_fixture():
+    out = []
+    for case in G.nms_cases():
+        for multi_label in (True, False):
+            for agnostic in (True, False):
+                cb = ref_shim.reference_post_prediction_callback(onms.nms, onms.batched_nms, score_threshold=case["score_threshold"],
+                                                                 nms_threshold=case["nms_threshold"], nms_top_k=case["nms_top_k"],
+                                                                 max_predictions=case["max_predictions"], multi_label_per_box=multi_label,
+                                                                 class_agnostic_nms=agnostic)
+                res = cb(((case["boxes"], case["scores"]), None))
+                out.append(dict(name=case["name"], multi_label=multi_label, class_agnostic=agnostic, rows=[r.clone() for r in res]))
+    return out
+
+
+def main():
+    if not ref_shim.available():
+        raise SystemExit("reference tree not found: make_golden.py runs in the build container only")
+    os.makedirs(G.GOLDEN_DIR, exist_ok=True)
+    torch.set_num_threads(8)
+    for v in MODEL_CASES:
+        fx = make_model_fixture(v)
+        torch.save(fx, os.path.join(G.GOLDEN_DIR, f"yolo_nas_{v}.pt"))
+        print(v, "loss items TAL", fx["loss_items_tal"].tolist(), "ATSS", fx["loss_items_atss"].tolist())
+    torch.save(make_loss_fixture(), os.path.join(G.GOLDEN_DIR, "ppyoloe_loss.pt"))
+    torch.save(make_post_prediction_fixture(), os.path.join(G.GOLDEN_DIR, "post_prediction.pt"))
+    for f in sorted(os.listdir(G.GOLDEN_DIR)):
+        print(f, os.path.getsize(os.path.join(G.GOLDEN_DIR, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -86,7 +86,7 @@ def _resolve(mask: torch.Tensor, ious: torch.Tensor):
     return mask, count > 0, gt_index
 
 
-def tal_assign_image(scores, boxes_px, points_px, labels, gts, valid, num_classes, topk=13, alpha=1.0, beta=6.0, eps=1e-9):
+def tal_assign_image(scores, boxes_px, points_px, labels, gts, valid, num_classes, topk=13, alpha=1.0, beta=6.0, eps=1e-9, sequential=False):
     """scores [L,C] (sigmoid), boxes_px [L,4], points_px [L,2], labels [n], gts [n,4], valid [n] bool.
     -> assigned label [L] (bg = num_classes), box [L,4], score [L] (value at the assigned class), gt index [L]."""
     L = scores.shape[0]
@@ -98,7 +98,11 @@ def tal_assign_image(scores, boxes_px, points_px, labels, gts, valid, num_classe
     metric = cls_sc.pow(alpha) * ious.pow(beta)
     inside = points_in_boxes(points_px, gts)
     k = min(topk, L)
-    _, top_idx = torch.topk(metric * inside, k, dim=-1, largest=True)
+    top_val, top_idx = torch.topk(metric * inside, k, dim=-1, largest=True)
+    if sequential:
+        # use_batched_assignment=False passes pad_gt_mask=None (ppyolo_loss.py:908-917): the zero-padding mask is replaced
+        # by gather_topk_anchors' own gate, "best candidate metric > eps" (:224-226), and mask_positive is not masked (:525).
+        valid = top_val.max(-1).values > eps
     in_top = torch.zeros(n, L, dtype=torch.bool)
     in_top.scatter_(1, top_idx, True)
     in_top &= valid[:, None]
@@ -113,9 +117,11 @@ def tal_assign_image(scores, boxes_px, points_px, labels, gts, valid, num_classe
     return a_label, a_box, a_score, gi, pos
 
 
-def atss_assign_image(anchors, counts: List[int], pred_boxes_px, labels, gts, valid, num_classes, topk=9):
+def atss_assign_image(anchors, counts: List[int], pred_boxes_px, labels, gts, valid, num_classes, topk=9, sequential=False):
     L = anchors.shape[0]
     n = gts.shape[0]
+    if sequential:  # pad_gt_mask=None (ppyolo_loss.py:896-905): no GT row is masked out (:294-295, :387-388, :401-402)
+        valid = torch.ones_like(valid)
     if n == 0:
         return torch.full([L], num_classes), torch.zeros(L, 4), torch.zeros(L), torch.zeros(L, dtype=torch.long), torch.zeros(L, dtype=torch.bool)
     ious = pair_iou(gts, anchors, 1e-10)
@@ -169,7 +175,8 @@ def dfl_loss(dist_logits: torch.Tensor, target: torch.Tensor):
 
 class PPYoloELossOracle:
     def __init__(self, num_classes, use_varifocal_loss=True, use_static_assigner=True,
-                 classification_loss_weight=1.0, iou_loss_weight=2.5, dfl_loss_weight=0.5):
+                 classification_loss_weight=1.0, iou_loss_weight=2.5, dfl_loss_weight=0.5, use_batched_assignment=True):
+        self.sequential = not use_batched_assignment
         self.nc = num_classes
         self.vfl = use_varifocal_loss
         self.static = use_static_assigner
@@ -185,9 +192,9 @@ class PPYoloELossOracle:
         with torch.no_grad():
             for b, (lab, gts, valid) in enumerate(per_img):
                 if self.static:
-                    out.append(atss_assign_image(anchors, counts, boxes[b] * strides, lab, gts, valid, self.nc))
+                    out.append(atss_assign_image(anchors, counts, boxes[b] * strides, lab, gts, valid, self.nc, sequential=self.sequential))
                 else:
-                    out.append(tal_assign_image(logits[b].sigmoid(), boxes[b] * strides, points, lab, gts, valid, self.nc))
+                    out.append(tal_assign_image(logits[b].sigmoid(), boxes[b] * strides, points, lab, gts, valid, self.nc, sequential=self.sequential))
         a_label = torch.stack([o[0] for o in out])
         a_box = torch.stack([o[1] for o in out])
         a_score = torch.stack([o[2] for o in out])

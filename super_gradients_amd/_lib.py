@@ -34,7 +34,7 @@ class LossDesc(ctypes.Structure):
     _fields_ = [
         ("B", c_int32), ("L", c_int32), ("C", c_int32), ("reg_max", c_int32), ("nmax", c_int32),
         ("use_static_assigner", c_int32), ("use_varifocal", c_int32), ("num_levels", c_int32),
-        ("level_count", c_int32 * 8), ("w_cls", c_float), ("w_iou", c_float), ("w_dfl", c_float),
+        ("level_count", c_int32 * 8), ("w_cls", c_float), ("w_iou", c_float), ("w_dfl", c_float), ("sequential_assignment", c_int32),
     ]
 
 

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void tal_candidates_kernel(sgx_loss_d
     const float* t = targets + (long)gt_index[(long)b * d.nmax + g] * 6;
     const Box gt = target_box(t);
     const int cls = (int)t[1];
-    const bool valid = (gt.x1 + gt.y1 + gt.x2 + gt.y2) > 0.f;  // pad_gt_mask, ppyolo_loss.py:754
+    bool valid = (gt.x1 + gt.y1 + gt.x2 + gt.y2) > 0.f;  // pad_gt_mask, ppyolo_loss.py:754
     const int L = d.L;
     for (int l = threadIdx.x; l < L; l += LOSS_THREADS) {
         const float* pb = w.pbox + ((long)b * L + l) * 4;
@@ -240,6 +240,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void tal_candidates_kernel(sgx_loss_d
         int ri;
         block_argbest(bv, bi, true, sv, si, rv, ri);
         if (ri < 0) break;  // uniform
+        // sequential assignment (pad_gt_mask = None): the GT is kept iff its best candidate metric exceeds eps
+        // (gather_topk_anchors, ppyolo_loss.py:224-226); round 0 delivers that maximum.
+        if (round == 0 && d.sequential_assignment) valid = rv > 1e-9f;
         if (threadIdx.x == 0) {
             metric[ri] = -2.f;  // taken
             if (valid && point_in_box(points[2 * ri], points[2 * ri + 1], gt)) {
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void atss_candidates_kernel(sgx_loss_
     if (g >= gt_count[b]) return;
     const float* t = targets + (long)gt_index[(long)b * d.nmax + g] * 6;
     const Box gt = target_box(t);
-    const bool valid = (gt.x1 + gt.y1 + gt.x2 + gt.y2) > 0.f;
+    const bool valid = d.sequential_assignment ? true : (gt.x1 + gt.y1 + gt.x2 + gt.y2) > 0.f;  // pad_gt_mask (None when sequential)
     const int L = d.L;
     const float gcx = (gt.x1 + gt.x2) / 2.f, gcy = (gt.y1 + gt.y2) / 2.f;
     for (int l = threadIdx.x; l < L; l += LOSS_THREADS) {

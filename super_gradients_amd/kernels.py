@@ -336,7 +336,7 @@ def dfl_decode(logits, distri, points_grid, strides, reg_max):
     return boxes, scores
 
 
-def loss_desc(B, L, C, reg_max, nmax, static, vfl, counts, weights) -> LossDesc:
+def loss_desc(B, L, C, reg_max, nmax, static, vfl, counts, weights, sequential=False) -> LossDesc:
     d = LossDesc()
     d.B, d.L, d.C, d.reg_max, d.nmax = B, L, C, reg_max, nmax
     d.use_static_assigner, d.use_varifocal = int(static), int(vfl)
@@ -344,10 +344,11 @@ def loss_desc(B, L, C, reg_max, nmax, static, vfl, counts, weights) -> LossDesc:
     for i, c in enumerate(counts):
         d.level_count[i] = int(c)
     d.w_cls, d.w_iou, d.w_dfl = [float(w) for w in weights]
+    d.sequential_assignment = int(sequential)
     return d
 
 
-def ppyoloe_loss_fwd(logits, distri, anchors, points, strides, targets, counts, static, vfl, weights):
+def ppyoloe_loss_fwd(logits, distri, anchors, points, strides, targets, counts, static, vfl, weights, sequential=False):
     """-> dict(sums[4], label[B,L] int32, box[B,L,4], score[B,L], g_logits, g_distri)"""
     B, L, C = logits.shape
     reg_max = distri.shape[2] // 4 - 1
@@ -360,7 +361,7 @@ def ppyoloe_loss_fwd(logits, distri, anchors, points, strides, targets, counts, 
     overflow = torch.empty(1, device=dev, dtype=torch.int32)
     check(lib().sgx_targets_index(ptr(targets) if T else None, T, B, nmax, ptr(gt_count), ptr(gt_index) if nmax else None, ptr(overflow), stream()),
           "sgx_targets_index")
-    d = loss_desc(B, L, C, reg_max, nmax, static, vfl, counts, weights)
+    d = loss_desc(B, L, C, reg_max, nmax, static, vfl, counts, weights, sequential)
     out = dict(
         sums=torch.empty(4, device=dev, dtype=torch.float32),
         label=torch.empty(B, L, device=dev, dtype=torch.int32),

@@ -24,8 +24,8 @@ from ...common.registry import register_loss
 class _PPYoloELossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, distri, anchors, points, strides, targets, counts, cfg):
-        static, vfl, w, world = cfg
-        out = K.ppyoloe_loss_fwd(logits, distri, anchors, points, strides, targets, counts, static, vfl, w)
+        static, vfl, w, world, sequential = cfg
+        out = K.ppyoloe_loss_fwd(logits, distri, anchors, points, strides, targets, counts, static, vfl, w, sequential)
         sums = out["sums"]
         if world > 1:
             torch.distributed.all_reduce(sums, op=torch.distributed.ReduceOp.SUM)
@@ -56,8 +56,10 @@ class PPYoloELoss(nn.Module):
         self.use_static_assigner = use_static_assigner
         self.num_classes = num_classes
         self.reg_max = reg_max
-        # batched and sequential assignment are the same function of the inputs (the reference's own unit test,
-        # tests/unit_tests/ppyoloe_unit_test.py:42-81); the kernels implement it once, per (image, GT) workgroup.
+        # The kernels implement assignment once, per (image, GT) workgroup.  The flag only selects the reference's
+        # masking rule: batched = zero-padding mask (sum(coords) > 0, ppyolo_loss.py:754); sequential = pad_gt_mask None,
+        # i.e. TAL keeps a GT iff its best candidate metric > 1e-9 (:224-226).  They coincide on the reference's own unit
+        # test (tests/unit_tests/ppyoloe_unit_test.py:42-81) and differ when every candidate of a GT has a vanishing metric.
         self.use_batched_assignment = use_batched_assignment
 
     def forward(self, outputs, targets: Tensor) -> Tuple[Tensor, Tensor]:
@@ -67,7 +69,7 @@ class PPYoloELoss(nn.Module):
             raise ValueError(f"model predicts {logits.shape[-1]} classes, loss was built for {self.num_classes}")
         world = torch.distributed.get_world_size() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         cfg = (bool(self.use_static_assigner), bool(self.use_varifocal_loss),
-               (float(self.classification_loss_weight), float(self.iou_loss_weight), float(self.dfl_loss_weight)), world)
+               (float(self.classification_loss_weight), float(self.iou_loss_weight), float(self.dfl_loss_weight)), world, not self.use_batched_assignment)
         targets = targets.to(logits.device, non_blocking=True).float()
         loss, items = _PPYoloELossFn.apply(logits, distri, anchors, points, strides, targets, [int(c) for c in counts], cfg)
         return loss, items

@@ -1,0 +1,284 @@
+"""Pins, in both directions, around the CPU oracle (oracle/*.py):
+
+  golden fixtures (tests/golden/*.pt, produced by oracle/make_golden.py from the REAL reference source files)
+        -> oracle            test_oracle_*_golden      (CPU, always)
+        -> product kernels   test_product_*_golden     (backend 'emu' on CPU = the same kernel sources on the host
+                                                        emulation; backend 'gpu' on the MI355X through libsgx_hip.so)
+  live reference (only where /root/reference exists, i.e. the build container)
+        -> oracle            test_oracle_*_live
+
+Tolerances: fp32 both sides; 1e-4 relative is the north star's bar for activations / losses (BASELINE.json); the oracle
+itself executes the reference's ATen op sequence and is held to 2e-5.  Indices / rows from NMS: bit-exact.
+"""
+import os
+
+import pytest
+import torch
+
+from oracle import golden_util as G
+from oracle import ref_shim
+from util import rel_err
+
+GOLD = G.GOLDEN_DIR
+
+
+def _load(name):
+    return torch.load(os.path.join(GOLD, name), weights_only=False)
+
+
+def _oracle_anchors(hw, strides):
+    from oracle.yolo_nas import make_anchors
+
+    anchors, pts, _pts_grid, counts, strd = make_anchors(hw, strides)
+    return anchors, pts, counts, strd
+
+
+def _close(a, b, tol, what):
+    assert tuple(a.shape) == tuple(b.shape), f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    e = rel_err(a, b)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol}"
+
+
+# ------------------------------------------------------------------------------------------------ oracle <- golden
+@pytest.mark.parametrize("variant", ["s", "m", "l"])
+def test_oracle_model_golden(variant):
+    from oracle.ppyolo_loss import PPYoloELossOracle
+    from oracle.yolo_nas import YoloNAS
+
+    fx = _load(f"yolo_nas_{variant}.pt")
+    net = YoloNAS(variant, num_classes=80)
+    sd = net.state_dict()
+    assert list(sd.keys()) == fx["state_keys"], "state_dict keys / order differ from the reference"
+    assert [tuple(v.shape) for v in sd.values()] == fx["state_shapes"]
+    G.deterministic_fill(net, seed=1)
+    net.train()
+    x = G.seeded_input(fx["batch"], 3, fx["size"], seed=2)
+    out = net(x)
+    (boxes, scores), (logits, distri, anchors, points, counts, strides) = out
+    assert torch.equal(anchors, fx["anchors"]) and torch.equal(points, fx["points"]) and torch.equal(strides, fx["strides"])
+    assert list(counts) == fx["counts"]
+    for name, t in (("boxes", boxes), ("scores", scores), ("logits", logits), ("distri", distri)):
+        _close(t, fx[name], 2e-5, f"{variant} {name}")
+    for static, key in ((False, "loss_items_tal"), (True, "loss_items_atss")):
+        loss, items = PPYoloELossOracle(80, use_static_assigner=static)(out, fx["targets"])
+        for i in range(4):
+            _close(items[i:i + 1], fx[key][i:i + 1], 2e-5, f"{variant} {key}[{i}]")
+        if not static:
+            loss.backward()
+            grads = dict((n, p.grad) for n, p in net.named_parameters() if p.grad is not None)
+            assert list(grads.keys()) == fx["grad_names"], "set of parameters that receive a gradient differs"
+            norms = torch.tensor([float(g.double().norm()) for g in grads.values()], dtype=torch.float64)
+            scale = fx["grad_norms"].max()
+            big = fx["grad_norms"] > 1e-3 * scale
+            assert float(((norms - fx["grad_norms"]).abs() / fx["grad_norms"].clamp_min(1e-30))[big].max()) < 5e-3
+    for k, v in fx["bn_running_checksum"].items():
+        got = float(net.state_dict()[k].double().sum())
+        assert abs(got - v) <= 2e-5 * max(abs(v), 1.0), k
+    net.eval()
+    with torch.no_grad():
+        (eb, es), _ = net(x)
+    _close(eb, fx["eval_boxes"], 2e-5, "eval boxes")
+    _close(es, fx["eval_scores"], 2e-5, "eval scores")
+
+
+def test_oracle_loss_golden():
+    from oracle.ppyolo_loss import PPYoloELossOracle
+
+    fx = _load("ppyoloe_loss.pt")
+    preds = G.synthetic_predictions(fx["batch"], fx["sizes"], 80, 16, seed=fx["seed"], make_anchors=_oracle_anchors)
+    for case in fx["cases"]:
+        t = fx["target_sets"][case["targets"]]
+        logits = preds[0].clone().requires_grad_(True)
+        distri = preds[1].clone().requires_grad_(True)
+        crit = PPYoloELossOracle(80, use_varifocal_loss=case["vfl"], use_static_assigner=case["static"], use_batched_assignment=case["batched"])
+        loss, items = crit((None, (logits, distri) + tuple(preds[2:])), t)
+        tag = f"{case['targets']} static={case['static']} vfl={case['vfl']} batched={case['batched']}"
+        for i in range(4):
+            if float(case["items"][i]) == 0.0:
+                assert float(items[i]) == 0.0, tag
+            else:
+                _close(items[i:i + 1], case["items"][i:i + 1], 2e-5, f"{tag} item {i}")
+        if case["batched"]:
+            loss.backward()
+            _close(logits.grad, case["g_logits"], 2e-5, f"{tag} d/dlogits")
+            _close(distri.grad, case["g_distri"], 2e-5, f"{tag} d/ddistri")
+
+
+def test_oracle_post_prediction_golden():
+    from oracle import nms as onms
+
+    fx = _load("post_prediction.pt")
+    cases = {c["name"]: c for c in G.nms_cases()}
+    for rec in fx:
+        c = cases[rec["name"]]
+        res = onms.post_prediction(c["boxes"], c["scores"], score_threshold=c["score_threshold"], nms_threshold=c["nms_threshold"],
+                                   nms_top_k=c["nms_top_k"], max_predictions=c["max_predictions"], multi_label_per_box=rec["multi_label"],
+                                   class_agnostic_nms=rec["class_agnostic"])
+        assert len(res) == len(rec["rows"])
+        for a, b in zip(res, rec["rows"]):
+            assert torch.equal(a, b), f"{rec['name']} multi_label={rec['multi_label']} agnostic={rec['class_agnostic']}"
+
+
+def test_oracle_nms_c_equals_python():
+    """The C restatement (oracle/nms.c, the timed CPU baseline of the NMS metric) and the pure-Python loop agree bit-exactly."""
+    import numpy as np
+
+    from oracle import nms as onms
+
+    for c in G.nms_cases():
+        for b in range(c["boxes"].shape[0]):
+            s, _ = c["scores"][b].max(-1)
+            keep_c = onms.nms(c["boxes"][b], s, c["nms_threshold"]).numpy()
+            keep_py = onms.nms_python(c["boxes"][b].numpy(), s.numpy(), c["nms_threshold"])
+            assert np.array_equal(keep_c, keep_py), c["name"]
+
+
+# ------------------------------------------------------------------------------------------------ product <- golden
+def _product_model_case(variant, device):
+    from super_gradients_amd.training import models
+    from super_gradients_amd.training.losses import PPYoloELoss
+
+    fx = _load(f"yolo_nas_{variant}.pt")
+    net = models.get(f"yolo_nas_{variant}", num_classes=80)
+    sd = net.state_dict()
+    assert list(sd.keys()) == fx["state_keys"] and [tuple(v.shape) for v in sd.values()] == fx["state_shapes"]
+    G.deterministic_fill(net, seed=1)
+    net.materialize(device)
+    net.train()
+    x = G.seeded_input(fx["batch"], 3, fx["size"], seed=2).to(device)
+    out = net(x)
+    (boxes, scores), (logits, distri, anchors, points, counts, strides) = out
+    tol = 1e-4
+    assert torch.equal(anchors.cpu(), fx["anchors"]) and torch.equal(points.cpu(), fx["points"]) and torch.equal(strides.cpu(), fx["strides"])
+    for name, t in (("boxes", boxes), ("scores", scores), ("logits", logits), ("distri", distri)):
+        # within 1e-4 of the reference's fp32 CPU output, or - where that output is itself further than 1e-4 from the fp64
+        # run of the same reference modules - at least as close to the fp64 truth as twice the reference fp32 is
+        e_pair = rel_err(t.cpu(), fx[name])
+        e_hip, e_cpu = rel_err(t.cpu().double(), fx[name + "_f64"]), rel_err(fx[name].double(), fx[name + "_f64"])
+        assert e_pair <= tol or e_hip <= max(tol, 2.0 * e_cpu), f"{variant} {name}: hip-ref32 {e_pair:.2e}, hip-ref64 {e_hip:.2e}, ref32-ref64 {e_cpu:.2e}"
+    for static, key in ((True, "loss_items_atss"), (False, "loss_items_tal")):
+        loss, items = PPYoloELoss(80, use_static_assigner=static)(out, fx["targets"].to(device))
+        for i in range(4):
+            _close(items[i:i + 1].cpu(), fx[key][i:i + 1], tol, f"{variant} {key}[{i}]")
+    loss.backward()  # TAL
+    params = dict(net.named_parameters())
+    norms = torch.tensor([float(params[n].grad.double().norm()) for n in fx["grad_names"]], dtype=torch.float64)
+    scale = fx["grad_norms"].max()
+    big = fx["grad_norms"] > 1e-3 * scale
+    worst = float(((norms - fx["grad_norms"]).abs() / fx["grad_norms"].clamp_min(1e-30))[big].max())
+    assert worst < 2e-2, f"gradient norms differ from the reference by {worst:.2e}"
+    for k, v in fx["bn_running_checksum"].items():
+        got = float(net.state_dict()[k].double().sum())
+        assert abs(got - v) <= 1e-4 * max(abs(v), 1.0), k
+    net.eval()
+    with torch.no_grad():
+        (eb, es), _ = net(x)
+    _close(eb.cpu(), fx["eval_boxes"], tol, "eval boxes")
+    _close(es.cpu(), fx["eval_scores"], tol, "eval scores")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["s", "m", "l"])
+def test_product_model_golden(gpu_device, variant):
+    """GPU only: a whole model on the host emulation of the kernels takes minutes (the block-level emu tests in
+    test_blocks.py cover the same kernels on CPU)."""
+    _product_model_case(variant, gpu_device)
+
+
+def test_product_loss_golden(backend):
+    from super_gradients_amd.training.losses import PPYoloELoss
+
+    fx = _load("ppyoloe_loss.pt")
+    preds = G.synthetic_predictions(fx["batch"], fx["sizes"], 80, 16, seed=fx["seed"], make_anchors=_oracle_anchors)
+    dev = backend
+    fixed = [p.to(dev) if torch.is_tensor(p) else p for p in preds[2:]]
+    for case in fx["cases"]:
+        if dev.type == "cpu" and (case["targets"] == "reference_unit_test" or (not case["vfl"] and not case["batched"])):
+            continue  # host emulation of the kernels is slow: the CPU run keeps the two target sets with empty images
+        t = fx["target_sets"][case["targets"]].to(dev)
+        logits = preds[0].clone().to(dev).requires_grad_(True)
+        distri = preds[1].clone().to(dev).requires_grad_(True)
+        crit = PPYoloELoss(80, use_varifocal_loss=case["vfl"], use_static_assigner=case["static"], use_batched_assignment=case["batched"])
+        loss, items = crit((None, (logits, distri) + tuple(fixed)), t)
+        tag = f"{case['targets']} static={case['static']} vfl={case['vfl']} batched={case['batched']}"
+        for i in range(4):
+            if float(case["items"][i]) == 0.0:
+                assert float(items[i]) == 0.0, tag
+            else:
+                _close(items[i:i + 1].cpu(), case["items"][i:i + 1], 1e-4, f"{tag} item {i}")
+        if case["batched"]:
+            loss.backward()
+            _close(logits.grad.cpu(), case["g_logits"], 1e-4, f"{tag} d/dlogits")
+            _close(distri.grad.cpu(), case["g_distri"], 1e-4, f"{tag} d/ddistri")
+
+
+def test_product_post_prediction_golden(backend):
+    from super_gradients_amd.training.models.detection_models.pp_yolo_e.post_prediction_callback import PPYoloEPostPredictionCallback
+
+    fx = _load("post_prediction.pt")
+    cases = {c["name"]: c for c in G.nms_cases()}
+    for rec in fx:
+        c = cases[rec["name"]]
+        if backend.type == "cpu" and c["boxes"].shape[1] > 300:
+            continue  # host emulation is slow: the three big cases run on the GPU only
+        cb = PPYoloEPostPredictionCallback(score_threshold=c["score_threshold"], nms_threshold=c["nms_threshold"], nms_top_k=c["nms_top_k"],
+                                           max_predictions=c["max_predictions"], multi_label_per_box=rec["multi_label"],
+                                           class_agnostic_nms=rec["class_agnostic"])
+        res = cb(((c["boxes"].to(backend), c["scores"].to(backend)), None))
+        assert len(res) == len(rec["rows"])
+        for b, (a, r) in enumerate(zip(res, rec["rows"])):
+            assert torch.equal(a.cpu(), r), f"{rec['name']} image {b} multi_label={rec['multi_label']} agnostic={rec['class_agnostic']}: rows differ"
+
+
+# ------------------------------------------------------------------------------------------------ oracle <- live reference
+live = pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present (GPU box): the committed fixtures pin the oracle there")
+
+
+@live
+@pytest.mark.parametrize("variant", ["s", "m", "l"])
+def test_oracle_model_live(variant):
+    from oracle.ppyolo_loss import PPYoloELossOracle
+    from oracle.yolo_nas import YoloNAS
+
+    torch.manual_seed(10)
+    ref = ref_shim.build_reference_yolo_nas(variant, num_classes=80).train()
+    net = YoloNAS(variant, num_classes=80).train()
+    net.load_state_dict(ref.state_dict(), strict=True)
+    x = G.seeded_input(1, 3, 128, seed=11)
+    t = G.detection_targets(1, 128, seed=12, kmax=4, empty_last=False)
+    o_ref, o = ref(x), net(x)
+    for a, b in zip(o[0] + o[1][:2], o_ref[0] + o_ref[1][:2]):
+        _close(a, b, 1e-6, f"{variant} forward")
+    for static in (False, True):
+        l_ref, i_ref = ref_shim.reference_ppyolo_loss(num_classes=80, use_static_assigner=static)(o_ref, t)
+        l, i = PPYoloELossOracle(80, use_static_assigner=static)(o, t)
+        _close(i, i_ref, 2e-5, f"{variant} loss items static={static}")
+    l_ref.backward()
+    l.backward()
+    rp = dict(ref.named_parameters())
+    # gradients that are mathematically zero (a bias feeding a training-mode BatchNorm) are pure round-off on both sides:
+    # errors are measured against max(own norm, 1e-3 x the largest gradient norm in the model)
+    floor = 1e-3 * max(float(q.grad.norm()) for q in rp.values() if q.grad is not None)
+    for n, p in net.named_parameters():
+        if rp[n].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        e = float((p.grad - rp[n].grad).norm()) / max(float(rp[n].grad.norm()), floor)
+        assert e < 1e-3, f"{n}: grad rel L2 {e:.2e}"
+
+
+@live
+def test_reference_unit_test_batched_equals_sequential_on_product(backend):
+    """tests/unit_tests/ppyoloe_unit_test.py:42-81 transplanted: the product loss (one code path for both flags) against the
+    reference's sequential AND batched implementations on the same head outputs, places=4 as the reference asserts."""
+    from super_gradients_amd.training.losses import PPYoloELoss
+
+    preds = G.synthetic_predictions(4, [20, 10, 5] if backend.type == "cuda" else [10, 5, 3], 80, 16, seed=21, make_anchors=_oracle_anchors)
+    t = G.REFERENCE_UNIT_TEST_TARGETS * torch.tensor([1, 1, 0.3, 0.3, 0.3, 0.3])
+    for static in (True, False):
+        ours = PPYoloELoss(80, use_static_assigner=static)((None, tuple(p.to(backend) if torch.is_tensor(p) else p for p in preds)), t.to(backend))
+        for batched in (True, False):
+            ref = ref_shim.reference_ppyolo_loss(num_classes=80, use_static_assigner=static, reg_max=16, use_batched_assignment=batched)((None, preds), t)
+            assert abs(float(ours[0]) - float(ref[0])) < 0.5e-4 * max(1.0, abs(float(ref[0])))
+            for i in range(4):
+                assert abs(float(ours[1][i]) - float(ref[1][i])) < 0.5e-4 * max(1.0, abs(float(ref[1][i])))

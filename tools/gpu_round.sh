@@ -1,0 +1,57 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, smoke, bench, rocprofv3 kernel stats + PMC passes.  Outputs under gpurun_out/$TAG/.
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round.sh r1a'
+# Stages are individually time-boxed so that one hang cannot eat the box budget.  STAGES env selects a subset.
+TAG=${1:-r1}
+STAGES=${STAGES:-"bench stats pmc tests smoke"}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+
+rocminfo 2>/dev/null | grep -m3 -E "gfx950|Compute Unit|Max Clock" > "$OUT/rocminfo.txt"
+nproc > "$OUT/nproc.txt"
+
+if has bench; then
+  timeout 600 python bench.py ${BENCH_ARGS:-} > "$OUT/bench.log" 2> "$OUT/bench.err"
+  echo "bench rc=$?" >> "$OUT/bench.err"
+  cat "$OUT/bench.log"; tail -3 "$OUT/bench.err"
+fi
+PROF_CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline"
+if has stats; then
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o bench -- bash -c "cd $REPO && $PROF_CMD" > "$OUT/stats.log" 2>&1
+  echo "stats rc=$?" >> "$OUT/stats.log"
+  cd "$REPO"
+  python tools/prof_summary.py stats "$OUT/stats" > "$OUT/kernel_stats_summary.txt" 2>&1
+  head -40 "$OUT/kernel_stats_summary.txt"
+  # the raw per-dispatch trace is large; keep the stats csv only
+  find "$OUT/stats" -name "*kernel_trace.csv" -size +8M -delete
+fi
+if has pmc; then
+  PMC_CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+  i=0
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    cd /tmp
+    timeout 420 rocprofv3 --pmc $set --kernel-trace -f csv -d "$OUT/pmc$i" -o bench -- bash -c "cd $REPO && $PMC_CMD" > "$OUT/pmc$i.log" 2>&1
+    echo "pmc$i ($set) rc=$?" >> "$OUT/pmc$i.log"
+    cd "$REPO"
+    python tools/prof_summary.py pmc "$OUT/pmc$i" > "$OUT/pmc${i}_summary.txt" 2>&1
+    head -12 "$OUT/pmc${i}_summary.txt"
+    find "$OUT/pmc$i" -name "*.csv" -size +8M -delete
+  done
+fi
+if has tests; then
+  timeout 600 python -m pytest tests -m gpu -x -q --durations=15 > "$OUT/pytest_gpu.log" 2>&1
+  echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
+  tail -5 "$OUT/pytest_gpu.log"
+fi
+if has smoke; then
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1
+  echo "smoke rc=$?" >> "$OUT/smoke.log"
+  tail -2 "$OUT/smoke.log"
+fi
+du -sh "$OUT"
