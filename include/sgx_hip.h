@@ -115,12 +115,15 @@ int32_t sgx_nhwc_to_nchw(int32_t N, int32_t C, int32_t H, int32_t W, const float
  * ------------------------------------------------------------------------------------------- */
 /* Two-stage deterministic per-channel reduction.  partials: [2][nblk][C], nblk = sgx_stats_blocks(M). */
 int32_t sgx_stats_blocks(int64_t M);
+/* Scratch (bytes) the *_finalize entry points need to fold nblk partial rows of C channels: when nblk is large they run a
+ * wide fp64 pre-reduction into this workspace before the per-channel finalisation.                                        */
+int64_t sgx_reduce_workspace(int32_t nblk, int32_t C);
 int32_t sgx_channel_stats_partial(const float* x, int64_t M, int32_t C, int64_t ld, float* partials, void* stream);
 /* From partial sums: batch mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale;
  * saves mean & invstd; updates running stats in place (momentum, unbiased var) like nn.BatchNorm2d.  */
 int32_t sgx_bn_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma,
                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                        float* save_mean, float* save_invstd, float* scale, float* shift, void* stream);
+                        float* save_mean, float* save_invstd, float* scale, float* shift, void* ws, int64_t ws_bytes, void* stream);
 /* eval-mode BatchNorm folded to an affine map from the running statistics.                          */
 int32_t sgx_bn_eval_scale_shift(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                                 const float* running_var, float eps, float* scale, float* shift, void* stream);
@@ -139,7 +142,7 @@ int32_t sgx_bn_bwd_reduce(const float* dy, int64_t dy_ld, const float* x, int64_
  * dx = c1[c] * ((g - mg[c]) - (x - mean[c]) * k[c]).  coef: [4][C] = c1, mg, k, mean.               */
 int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma,
                             const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                            float* coef, void* stream);
+                            float* coef, void* ws, int64_t ws_bytes, void* stream);
 /* stage 3: dx from the stage-2 coefficients with g recomputed as in stage 1.  Optionally also writes g itself
  * (g_out != NULL) for consumers that need the masked upstream gradient.                            */
 int32_t sgx_bn_bwd_apply(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale,
@@ -155,7 +158,8 @@ int32_t sgx_axpy(const float* x, int64_t x_ld, float a, const float* a_dev, floa
                  int32_t C, int32_t accumulate, void* stream);
 /* per-channel column sum: out[c] (+)= sum_rows x[row][c]  (conv bias gradients).                     */
 /* rows_per_img/ld_img: rows are grouped in images of rows_per_img rows, image i starts at x + i*ld_img
- * (pass rows_per_img = M, ld_img = 0 for a plain [M,C] matrix).  ws: sgx_stats_blocks(M)*C floats.  */
+ * (pass rows_per_img = M, ld_img = 0 for a plain [M,C] matrix).  ws: sgx_colsum_workspace(M, C) bytes.  */
+int64_t sgx_colsum_workspace(int64_t M, int32_t C);
 int32_t sgx_colsum(const float* x, int64_t ld, int64_t M, int32_t C, int64_t rows_per_img, int64_t ld_img, float* out,
                    int32_t accumulate, float* ws, void* stream);
 

@@ -69,11 +69,13 @@ PROTOTYPES = {
     "sgx_nhwc_to_nchw": (_i32, [_i32] * 4 + [_P, _i64, _i64, _P, _P]),
     "sgx_stats_blocks": (_i32, [_i64]),
     "sgx_channel_stats_partial": (_i32, [_P, _i64, _i32, _i64, _P, _P]),
-    "sgx_bn_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P, _P]),
+    "sgx_reduce_workspace": (_i64, [_i32, _i32]),
+    "sgx_colsum_workspace": (_i64, [_i64, _i32]),
+    "sgx_bn_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
     "sgx_bn_eval_scale_shift": (_i32, [_i32, _P, _P, _P, _P, _f, _P, _P, _P]),
     "sgx_affine_act_fwd": (_i32, [_P, _i64, _P, _P, _P, _i64, _f, _P, _P, _i64, _f, _P, _i64, _i64, _i32, _i32, _P, _P]),
     "sgx_bn_bwd_reduce": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _i64, _i32, _i32, _P, _P]),
-    "sgx_bn_bwd_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _P, _P, _P, _P, _P]),
+    "sgx_bn_bwd_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
     "sgx_bn_bwd_apply": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _P, _i64, _P, _i64, _i64, _i32, _i32, _P]),
     "sgx_dot_partial": (_i32, [_P, _i64, _P, _i64, _i64, _i32, _P, _P]),
     "sgx_sum_partials": (_i32, [_P, _i32, _f, _P, _i32, _P]),

@@ -99,16 +99,89 @@ extern "C" int32_t sgx_channel_stats_partial(const float* x, int64_t M, int32_t 
     return run_sweep<StatsF, 2>(f, M, C, partials, stream, "channel_stats");
 }
 
-__global__ void bn_finalize_kernel(const float* partials, int nblk, long M, int C, const float* gamma, const float* beta, float eps,
+// ---------------------------------------------------------------------------------------------
+// Second stage of the per-channel reductions.  The producers (conv epilogue, sweeps) leave up to tens of thousands of
+// fp32 partial rows per plane ([planes][nblk][C]); a single thread per channel walking them serially was the slowest
+// kernel of the whole train step (r1a profile: bn_finalize 30 % of GPU time).  So: when nblk is large a wide
+// pre-reduction (grid = channel strips x slices, one wave per row lane, 256-byte coalesced row reads, fp64 accumulate,
+// fixed order) folds the rows into <= CR_MAX_SLICES fp64 rows per plane in the caller's workspace, and the finalize
+// kernels then read at most that many.  Deterministic: every sum has a fixed association order.
+// ---------------------------------------------------------------------------------------------
+#define CR_MAX_SLICES 64
+#define CR_DIRECT 32  // up to this many partial rows the finalize kernels read the fp32 partials directly
+
+struct ColSrc {  // what a finalize kernel sums over: either the fp32 partials or the fp64 slices
+    const float* f;
+    const double* d;
+    int n;  // rows per plane
+};
+__device__ __forceinline__ double colsrc_sum(const ColSrc& s, int plane, int C, int c) {
+    double acc = 0.0;
+    if (s.d) {
+        const double* p = s.d + (long)plane * s.n * C + c;
+#pragma unroll 8
+        for (int b = 0; b < s.n; ++b) acc += p[(long)b * C];
+    } else {
+        const float* p = s.f + (long)plane * s.n * C + c;
+#pragma unroll 8
+        for (int b = 0; b < s.n; ++b) acc += (double)p[(long)b * C];
+    }
+    return acc;
+}
+static int cr_slices(int nblk) {
+    if (nblk <= CR_DIRECT) return 0;
+    int s = (nblk + 31) / 32;
+    return s > CR_MAX_SLICES ? CR_MAX_SLICES : s;
+}
+extern "C" int64_t sgx_reduce_workspace(int32_t nblk, int32_t C) { return (int64_t)2 * cr_slices(nblk) * C * (int64_t)sizeof(double) + 256; }
+
+template <int PLANES>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* partials, int nblk, int C, int S, int chunk, double* out) {
+    __shared__ double red[PLANES][256];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, s = blockIdx.y;
+    const int b0 = s * chunk, b1 = min(nblk, b0 + chunk);
+    double acc[PLANES];
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p) acc[p] = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int b = b0 + rl; b < b1; b += 4) {
+#pragma unroll
+            for (int p = 0; p < PLANES; ++p) acc[p] += (double)partials[((long)p * nblk + b) * C + c];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p) red[p][threadIdx.x] = acc[p];
+    __syncthreads();
+    if (rl == 0 && c < C) {
+#pragma unroll
+        for (int p = 0; p < PLANES; ++p)
+            out[((long)p * S + s) * C + c] = ((red[p][cl] + red[p][64 + cl]) + red[p][128 + cl]) + red[p][192 + cl];
+    }
+}
+// -> the source the finalize kernel should read; launches the pre-reduction when it pays
+template <int PLANES>
+static int32_t col_prereduce(const float* partials, int nblk, int C, void* ws, int64_t ws_bytes, void* stream, ColSrc* src) {
+    const int S = cr_slices(nblk);
+    if (S == 0) {
+        *src = ColSrc{partials, nullptr, nblk};
+        return SGX_OK;
+    }
+    if (!ws || ws_bytes < (int64_t)PLANES * S * C * (int64_t)sizeof(double)) SGX_FAIL(SGX_ERR_WORKSPACE, "column reduce: workspace too small (sgx_reduce_workspace)");
+    const int chunk = (nblk + S - 1) / S;
+    SGX_LAUNCH((colreduce_kernel<PLANES>), dim3(sgx_cdiv(C, 64), S), dim3(256), 0, stream, partials, nblk, C, S, chunk, (double*)ws);
+    SGX_CHECK_LAUNCH("colreduce");
+    *src = ColSrc{nullptr, (const double*)ws, S};
+    return SGX_OK;
+}
+
+__global__ void bn_finalize_kernel(ColSrc src, long M, int C, const float* gamma, const float* beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                                    float* scale, float* shift) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += (double)partials[(long)b * C + c];
-        q += (double)partials[((long)nblk + b) * C + c];
-    }
+    double s = colsrc_sum(src, 0, C, c), q = colsrc_sum(src, 1, C, c);
     double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -127,9 +200,12 @@ __global__ void bn_finalize_kernel(const float* partials, int nblk, long M, int 
 }
 extern "C" int32_t sgx_bn_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma, const float* beta,
                                    float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
-                                   float* save_invstd, float* scale, float* shift, void* stream) {
+                                   float* save_invstd, float* scale, float* shift, void* ws, int64_t ws_bytes, void* stream) {
     SGX_CHECK_ARG(partials && scale && shift && nblk > 0, "bn_finalize: bad args");
-    SGX_LAUNCH(bn_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, partials, nblk, (long)M, C, gamma, beta, eps, momentum,
+    ColSrc src;
+    int32_t rc = col_prereduce<2>(partials, nblk, C, ws, ws_bytes, stream, &src);
+    if (rc) return rc;
+    SGX_LAUNCH(bn_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, src, (long)M, C, gamma, beta, eps, momentum,
                running_mean, running_var, save_mean, save_invstd, scale, shift);
     SGX_CHECK_LAUNCH("bn_finalize");
     return SGX_OK;
@@ -212,15 +288,11 @@ extern "C" int32_t sgx_bn_bwd_reduce(const float* dy, int64_t dy_ld, const float
     return run_sweep<BnBwdReduceF, 2>(f, M, C, partials, stream, "bn_bwd_reduce");
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* partials, int nblk, long M, int C, const float* gamma, const float* save_mean,
+__global__ void bn_bwd_finalize_kernel(ColSrc src, long M, int C, const float* gamma, const float* save_mean,
                                        const float* save_invstd, float* dgamma, float* dbeta, float* coef) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double sg = 0.0, sgx = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        sg += (double)partials[(long)b * C + c];
-        sgx += (double)partials[((long)nblk + b) * C + c];
-    }
+    double sg = colsrc_sum(src, 0, C, c), sgx = colsrc_sum(src, 1, C, c);
     double mean = save_mean[c], invstd = save_invstd[c], g = gamma ? (double)gamma[c] : 1.0;
     double sgxhat = invstd * sgx;  // sgx is already centred: sum g*(x - mean)
     if (dgamma) dgamma[c] += (float)sgxhat;
@@ -233,9 +305,13 @@ __global__ void bn_bwd_finalize_kernel(const float* partials, int nblk, long M, 
     coef[3 * C + c] = (float)mean;
 }
 extern "C" int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma, const float* save_mean,
-                                       const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
+                                       const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* ws, int64_t ws_bytes,
+                                       void* stream) {
     SGX_CHECK_ARG(partials && save_mean && save_invstd && coef, "bn_bwd_finalize: null pointer");
-    SGX_LAUNCH(bn_bwd_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, partials, nblk, (long)M, C, gamma, save_mean, save_invstd,
+    ColSrc src;
+    int32_t rc = col_prereduce<2>(partials, nblk, C, ws, ws_bytes, stream, &src);
+    if (rc) return rc;
+    SGX_LAUNCH(bn_bwd_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, src, (long)M, C, gamma, save_mean, save_invstd,
                dgamma, dbeta, coef);
     SGX_CHECK_LAUNCH("bn_bwd_finalize");
     return SGX_OK;
@@ -334,21 +410,29 @@ struct ColsumF {
         q0.x += v.x; q0.y += v.y; q0.z += v.z; q0.w += v.w;
     }
 };
-__global__ void colsum_finalize_kernel(const float* partials, int nblk, int C, float* out, int accumulate) {
+__global__ void colsum_finalize_kernel(ColSrc src, int C, float* out, int accumulate) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partials[(long)b * C + c];
+    double s = colsrc_sum(src, 0, C, c);
     out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
-// ws: sgx_stats_blocks(M) * C floats
+extern "C" int64_t sgx_colsum_workspace(int64_t M, int32_t C) {
+    int nblk = sgx_stats_blocks(M);
+    return (((int64_t)nblk * C * (int64_t)sizeof(float) + 255) & ~255L) + sgx_reduce_workspace(nblk, C);
+}
+// ws: sgx_colsum_workspace(M, C) bytes = the fp32 partial rows followed by the fp64 slices of the pre-reduction
 extern "C" int32_t sgx_colsum(const float* x, int64_t ld, int64_t M, int32_t C, int64_t rows_per_img, int64_t ld_img, float* out,
                               int32_t accumulate, float* ws, void* stream) {
     SGX_CHECK_ARG(x && out && ws && rows_per_img > 0, "colsum: bad args");
     ColsumF f{x, ld, rows_per_img, ld_img};
     int32_t rc = run_sweep<ColsumF, 1>(f, M, C, ws, stream, "colsum");
     if (rc) return rc;
-    SGX_LAUNCH(colsum_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, (const float*)ws, sgx_stats_blocks(M), C, out, accumulate);
+    const int nblk = sgx_stats_blocks(M);
+    const int64_t part_bytes = ((int64_t)nblk * C * (int64_t)sizeof(float) + 255) & ~255L;
+    ColSrc src;
+    rc = col_prereduce<1>(ws, nblk, C, (char*)ws + part_bytes, sgx_reduce_workspace(nblk, C), stream, &src);
+    if (rc) return rc;
+    SGX_LAUNCH(colsum_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, src, C, out, accumulate);
     SGX_CHECK_LAUNCH("colsum_finalize");
     return SGX_OK;
 }

@@ -648,11 +648,24 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgradParams p) {
         }
 }
 
-__global__ void wgrad_reduce_kernel(const float* part, float* dw, long n, int ksplit) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += part[(long)k * n + i];
-        dw[i] += s;
+// dw[i] += sum_k part[k][i]: a workgroup owns EL consecutive elements and walks the split slabs with KL lanes per element
+// (KL * EL = 256), then folds the KL lane sums through LDS in a fixed order (deterministic, no atomics).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dw, long n, int ksplit, int KL) {
+    __shared__ float red[256];
+    const int EL = 256 / KL;
+    const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
+    const long i = (long)blockIdx.x * EL + el;
+    float s = 0.f;
+    if (i < n) {
+#pragma unroll 8
+        for (int k = kl; k < ksplit; k += KL) s += part[(long)k * n + i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (kl == 0 && i < n) {
+        float t = 0.f;
+        for (int k = 0; k < KL; ++k) t += red[k * EL + el];
+        dw[i] += t;
     }
 }
 
@@ -672,6 +685,7 @@ static int wg_tile(int n) {  // least padding among {32,64,128}, ties to the wid
     return b;
 }
 extern "C" int32_t sgx_stats_blocks(int64_t M);
+extern "C" int64_t sgx_colsum_workspace(int64_t M, int32_t C);
 static WgradPlan wgrad_plan(const sgx_conv_desc* d) {
     WgradPlan pl;
     pl.bnk = wg_tile(d->K);
@@ -680,7 +694,7 @@ static WgradPlan wgrad_plan(const sgx_conv_desc* d) {
     pl.ct_tiles = sgx_cdiv(d->C, pl.bc);
     long M = (long)d->N * d->Ho * d->Wo;
     long tiles = (long)pl.kt_tiles * pl.ct_tiles * d->R * d->S;
-    long ks = (2048 + tiles - 1) / tiles;   // ~2048 workgroups in flight
+    long ks = (1024 + tiles - 1) / tiles;   // ~1024 workgroups (4 per CU)
     long maxsplit = (M + 255) / 256;         // at least 256 pixels (16 slabs) per split
     if (ks > maxsplit) ks = maxsplit;
     if (ks < 1) ks = 1;
@@ -695,7 +709,7 @@ static WgradPlan wgrad_plan(const sgx_conv_desc* d) {
 extern "C" int64_t sgx_conv2d_bwd_weight_workspace(const sgx_conv_desc* d) {
     WgradPlan pl = wgrad_plan(d);
     int64_t slabs = (int64_t)pl.ksplit * d->K * d->R * d->S * d->C * sizeof(float);
-    int64_t bias = (int64_t)sgx_stats_blocks((int64_t)d->N * d->Ho * d->Wo) * d->K * sizeof(float);
+    int64_t bias = sgx_colsum_workspace((int64_t)d->N * d->Ho * d->Wo, d->K);
     return (slabs > bias ? slabs : bias) + 256;
 }
 
@@ -733,8 +747,10 @@ extern "C" int32_t sgx_conv2d_bwd_weight(const sgx_conv_desc* d, const float* x,
     }
     SGX_CHECK_LAUNCH("wgrad");
     long n = (long)d->K * d->R * d->S * d->C;
-    int rg = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    SGX_LAUNCH(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)ws, dw, n, pl.ksplit);
+    int KL = 1;
+    while (KL < 16 && KL < pl.ksplit) KL *= 2;
+    const int EL = 256 / KL;
+    SGX_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n + EL - 1) / EL)), dim3(256), 0, stream, (const float*)ws, dw, n, pl.ksplit, KL);
     SGX_CHECK_LAUNCH("wgrad_reduce");
     if (dbias) {
         // column sum of dy: reuse the partial buffer tail is not safe while reduce may still read -> stream order makes it safe
@@ -756,7 +772,7 @@ static sgx_conv_desc convT_adjoint_desc(int N, int H, int W, int C, int K, long 
 extern "C" int64_t sgx_convT2x2_workspace(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K) {
     sgx_conv_desc d = convT_adjoint_desc(N, H, W, C, K, C, (long)H * W * C, K, 4L * H * W * K);
     int64_t a = sgx_conv2d_bwd_data_workspace(&d), b = sgx_conv2d_bwd_weight_workspace(&d);
-    int64_t c = (int64_t)sgx_stats_blocks(4L * N * H * W) * K * (int64_t)sizeof(float) + 256;
+    int64_t c = sgx_colsum_workspace(4L * N * H * W, K) + 256;
     a = a > b ? a : b;
     return a > c ? a : c;
 }
@@ -780,7 +796,7 @@ extern "C" int32_t sgx_convT2x2_bwd_weight(int32_t N, int32_t H, int32_t W, int3
     if (dbias) {
         // bias gradient = column sum of dy over all 4*N*H*W output pixels (contiguous-image layout required)
         int64_t M = 4L * N * H * W;
-        if (ws_bytes < (int64_t)sgx_stats_blocks(M) * K * (int64_t)sizeof(float)) SGX_FAIL(SGX_ERR_WORKSPACE, "convT bwd_weight: workspace too small");
+        if (ws_bytes < sgx_colsum_workspace(M, K)) SGX_FAIL(SGX_ERR_WORKSPACE, "convT bwd_weight: workspace too small");
         return sgx_colsum(dy, dy_ld_pix, M, K, 4L * H * W, dy_ld_img, dbias, 1, (float*)ws, stream);
     }
     return SGX_OK;

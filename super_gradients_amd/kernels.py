@@ -212,8 +212,9 @@ def bn_finalize(parts, M, gamma, beta, eps, momentum, running_mean, running_var)
     """-> scale, shift, save_mean, save_invstd (each [C]); running stats updated in place."""
     C = parts.shape[2]
     st = torch.empty(4, C, device=parts.device, dtype=torch.float32)
+    ws = WORKSPACE.get(lib().sgx_reduce_workspace(parts.shape[1], C), parts.device)
     check(lib().sgx_bn_finalize(ptr(parts), parts.shape[1], M, C, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean), ptr(running_var),
-                                ptr(st[2]), ptr(st[3]), ptr(st[0]), ptr(st[1]), stream()), "sgx_bn_finalize")
+                                ptr(st[2]), ptr(st[3]), ptr(st[0]), ptr(st[1]), ptr(ws), ws.numel(), stream()), "sgx_bn_finalize")
     return st[0], st[1], st[2], st[3]
 
 
@@ -249,8 +250,9 @@ def bn_bwd(dy, x, scale, shift, gamma, save_mean, save_invstd, dgamma, dbeta, ac
     a = ACT[act]
     check(lib().sgx_bn_bwd_reduce(ptr(dy), dl, ptr(x), ld, ptr(scale), ptr(shift), ptr(save_mean), M, C, a, ptr(parts), stream()), "sgx_bn_bwd_reduce")
     coef = torch.empty(4, C, device=x.device, dtype=torch.float32)
+    ws = WORKSPACE.get(lib().sgx_reduce_workspace(parts.shape[1], C), x.device)
     check(lib().sgx_bn_bwd_finalize(ptr(parts), parts.shape[1], M, C, ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(dgamma), ptr(dbeta), ptr(coef),
-                                    stream()), "sgx_bn_bwd_finalize")
+                                    ptr(ws), ws.numel(), stream()), "sgx_bn_bwd_finalize")
     dx = dx_out if dx_out is not None else torch.empty(x.shape, device=x.device, dtype=torch.float32)
     g = torch.empty(x.shape, device=x.device, dtype=torch.float32) if want_g else None
     check(lib().sgx_bn_bwd_apply(ptr(dy), dl, ptr(x), ld, ptr(scale), ptr(shift), ptr(coef), ptr(dx), rows(dx)[1], ptr(g), rows(g)[1] if want_g else 0,
@@ -280,7 +282,7 @@ def colsum(x, out, accumulate=True):
     ld_pix, ld_img = nhwc_strides(x)
     n, h, w, C = x.shape
     M = n * h * w
-    ws = WORKSPACE.get(stats_blocks(M) * C * 4, x.device)
+    ws = WORKSPACE.get(lib().sgx_colsum_workspace(M, C), x.device)
     check(lib().sgx_colsum(ptr(x), ld_pix, M, C, h * w, ld_img, ptr(out), int(accumulate), ptr(ws), stream()), "sgx_colsum")
 
 

@@ -42,6 +42,7 @@ CONV_EMU = [
     (2, 5, 6, 20, 8, 1, 1, 0),
     (1, 9, 9, 4, 8, 7, 2, 3),
     (1, 6, 6, 8, 4, 1, 2, 0),
+    (1, 48, 48, 4, 8, 1, 1, 0),        # 2304 pixels: weight gradient split over 9 slabs (parallel slab reduce)
 ]
 
 
@@ -151,9 +152,12 @@ def test_layout(backend):
     assert torch.equal(z[:, :3].cpu(), x)
 
 
-@pytest.mark.parametrize("act", ["relu", "silu", None])
+@pytest.mark.parametrize("act", ["relu", "silu", None, "relu-many-rows"])
 def test_batchnorm_train(backend, act):
     n, h, w, c = _sizes(backend, (4, 40, 40, 96), (2, 5, 6, 8))
+    if act == "relu-many-rows":  # > 32 partial rows: the finalize kernels go through the wide fp64 pre-reduction
+        act = "relu"
+        n, h, w, c = _sizes(backend, (8, 80, 80, 48), (1, 96, 96, 4))
     g = torch.Generator().manual_seed(0)
     x = (torch.randn(n, c, h, w, generator=g) * 2 + 0.5).requires_grad_(True)
     gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)

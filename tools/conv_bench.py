@@ -1,0 +1,130 @@
+"""Per-shape timing of the three conv kernels over the convolution problems of one real train step.
+
+    python tools/conv_bench.py [--model s] [--batch 32] [--size 640] [--iters 10] [--out gpurun_out/conv_bench.txt]
+
+Records every K.conv2d_fwd / conv2d_bwd_data / conv2d_bwd_weight call of one YOLO-NAS train step (shape, strides,
+epilogue options), then replays each distinct problem `iters` times between HIP events and prints, per problem: calls per
+step, average microseconds, algorithmic TFLOP/s (2*M*K*C*R*S) and its share of the per-step conv time.  Measurement tool:
+uses only the product library.
+"""
+import argparse
+import collections
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="s")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+
+    import torch
+
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd.training import models
+    from super_gradients_amd.training.losses import PPYoloELoss
+    from util import synthetic_targets
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = models.get(f"yolo_nas_{args.model}", num_classes=80).materialize(dev).train()
+    x = torch.rand(args.batch, 3, args.size, args.size, device=dev)
+    t = synthetic_targets(args.batch, seed=0, kmax=20, size=args.size).to(dev)
+    crit = PPYoloELoss(80, use_static_assigner=False)
+
+    rec = collections.OrderedDict()
+    orig = (K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight)
+
+    def key_of(kind, xs, K_, R, stride, pad, xl, yl, extra):
+        return (kind,) + tuple(xs) + (K_, R, stride, pad, xl, yl) + extra
+
+    def fwd(x, w, bias=None, addend=None, out=None, act=None, stride=1, pad=0, stat_partials=False):
+        y = orig[0](x, w, bias=bias, addend=addend, out=out, act=act, stride=stride, pad=pad, stat_partials=stat_partials)
+        yo = y[0] if stat_partials else y
+        k = key_of("fwd", x.shape, w.shape[0], w.shape[2], stride, pad, x.stride(2), yo.stride(2),
+                   (bias is not None, addend is not None, act, stat_partials))
+        rec[k] = rec.get(k, 0) + 1
+        return y
+
+    def dgrad(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, accumulate=False):
+        o = orig[1](dy, w, x_shape, stride=stride, pad=pad, addend=addend, out=out, accumulate=accumulate)
+        k = key_of("dgrad", x_shape, w.shape[0], w.shape[2], stride, pad, o.stride(2), dy.stride(2), (addend is not None, bool(accumulate)))
+        rec[k] = rec.get(k, 0) + 1
+        return o
+
+    def wgrad(x, dy, dw, dbias=None, stride=1, pad=0):
+        orig[2](x, dy, dw, dbias, stride=stride, pad=pad)
+        k = key_of("wgrad", x.shape, dw.shape[0], dw.shape[2], stride, pad, x.stride(2), dy.stride(2), (dbias is not None,))
+        rec[k] = rec.get(k, 0) + 1
+
+    K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight = fwd, dgrad, wgrad
+    loss, _ = crit(net(x), t)
+    loss.backward()
+    K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight = orig
+    torch.cuda.synchronize()
+
+    def buf(n, h, w, c, ld):
+        return torch.randn(n, h, w, ld, device=dev)[..., :c]
+
+    rows = []
+    for k, calls in rec.items():
+        kind, n, h, w, c, K_, R, stride, pad, xl, yl = k[:11]
+        extra = k[11:]
+        ho, wo = (h + 2 * pad - R) // stride + 1, (w + 2 * pad - R) // stride + 1
+        xin = buf(n, h, w, c, xl)
+        yout = buf(n, ho, wo, K_, yl)
+        wt = K.to_ohwi(torch.randn(K_, c, R, R, device=dev) / (c * R * R) ** 0.5)
+        flops = 2.0 * n * ho * wo * K_ * c * R * R
+        if kind == "fwd":
+            has_b, has_add, act, stats = extra
+            b = torch.randn(K_, device=dev) if has_b else None
+            add = buf(n, ho, wo, K_, yl) if has_add else None
+            fn = lambda: orig[0](xin, wt, bias=b, addend=add, out=yout, act=act, stride=stride, pad=pad, stat_partials=stats)  # noqa: E731
+        elif kind == "dgrad":
+            has_add, acc = extra
+            add = buf(n, h, w, c, xl) if has_add else None
+            fn = lambda: orig[1](yout, wt, (n, h, w, c), stride=stride, pad=pad, addend=add, out=xin, accumulate=acc)  # noqa: E731
+        else:
+            (has_b,) = extra
+            dw = torch.zeros_like(wt)
+            db = torch.zeros(K_, device=dev) if has_b else None
+            fn = lambda: orig[2](xin, yout, dw, db, stride=stride, pad=pad)  # noqa: E731
+        fn()
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        rows.append((kind, n, h, w, c, K_, R, stride, xl, yl, extra, calls, us, flops / us / 1e6))
+    tot = sum(r[11] * r[12] for r in rows)
+    lines = [f"# YOLO-NAS-{args.model.upper()} bs={args.batch} {args.size}x{args.size}: {len(rows)} distinct conv problems, {sum(r[11] for r in rows)} conv calls/step, "
+             f"{tot / 1e3:.2f} ms/step of conv kernels when replayed back to back; total {sum(r[11] * 2.0 * r[1] * ((r[2] + 2 * (r[6] // 2) - r[6]) // r[7] + 1) * ((r[3] + 2 * (r[6] // 2) - r[6]) // r[7] + 1) * r[5] * r[4] * r[6] * r[6] for r in rows) / 1e12:.3f} TFLOP",
+             f"{'kind':<6}{'N':>3}{'H':>5}{'W':>5}{'C':>6}{'K':>6}{'R':>3}{'s':>3}{'x_ld':>6}{'y_ld':>6} {'calls':>5}{'us':>10}{'TFLOP/s':>9}{'step%':>7}  options"]
+    for r in sorted(rows, key=lambda r: -r[11] * r[12]):
+        kind, n, h, w, c, K_, R, stride, xl, yl, extra, calls, us, tf = r
+        lines.append(f"{kind:<6}{n:>3}{h:>5}{w:>5}{c:>6}{K_:>6}{R:>3}{stride:>3}{xl:>6}{yl:>6} {calls:>5}{us:>10.1f}{tf:>9.1f}{100 * calls * us / tot:>7.2f}  {extra}")
+    for kind in ("fwd", "dgrad", "wgrad"):
+        sel = [r for r in rows if r[0] == kind]
+        t_us = sum(r[11] * r[12] for r in sel)
+        fl = sum(r[11] * r[13] * r[12] * 1e6 for r in sel)
+        lines.append(f"# {kind}: {t_us / 1e3:.2f} ms/step, {fl / t_us / 1e6:.1f} TFLOP/s aggregate")
+    text = "\n".join(lines)
+    print(text)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        open(args.out, "w").write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -19,6 +19,11 @@ if has bench; then
   echo "bench rc=$?" >> "$OUT/bench.err"
   cat "$OUT/bench.log"; tail -3 "$OUT/bench.err"
 fi
+if has convbench; then
+  timeout 400 python tools/conv_bench.py --out "$OUT/conv_bench.txt" > "$OUT/conv_bench.log" 2>&1
+  echo "convbench rc=$?" >> "$OUT/conv_bench.log"
+  tail -4 "$OUT/conv_bench.log"
+fi
 PROF_CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline"
 if has stats; then
   cd /tmp
