@@ -7,12 +7,13 @@
 // with a 20-float row pitch (conflict-free ds_read_b128: 16 consecutive rows hit 16 disjoint 4-bank
 // groups), and every wave reads its 32x32x2 MFMA fragments as two 128-bit LDS loads per 8 k-steps.
 // Double-buffered LDS, register-staged prefetch of the next slab issued before the MFMA block, one
-// barrier per slab.  Workgroup -> tile mapping is XCD-aware: the 8 XCDs (private L2s) each get a
+// barrier per slab.  Global operands are fetched with buffer loads (32-bit lane offset, hardware
+// bounds check returning zeros for padding) so that no load in the main loop waits on another.  Workgroup -> tile mapping is XCD-aware: the 8 XCDs (private L2s) each get a
 // contiguous run of tiles, N-tiles of the same pixel slab adjacent, so halo rows and the slab itself
 // are re-read from that XCD's L2.
 //
 // One "gather GEMM" kernel serves forward and data-gradient: output row m <-> a pixel of an output
-// grid, tap t contributes input pixel (a*si + dh[t], b*si + dw[t]).  Stride-s data gradients are
+// grid, tap (i,j) contributes input pixel (a*si + dh0 + dstep*i, b*si + dw0 + dstep*j).  Stride-s data gradients are
 // decomposed into s*s output-parity classes, each a dense stride-1 problem over the dY grid with its
 // own tap subset (no multiply-by-zero work).  Reference call sites: see include/sgx_hip.h.
 #include "sgx_common.h"
@@ -108,6 +109,18 @@ extern "C" int32_t sgx_prof_summary(int32_t, double* ms, double* flops, int64_t*
 #define SGX_PROF(cls, flops, stream)
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// Gather GEMM (forward and data gradient).
+//
+// Addressing is split so that NO memory instruction of the main loop depends on another one (the r1a kernel read
+// its tap table from kernel-argument memory each slab and hipcc serialised every load behind s_waitcnt vmcnt(0)):
+//   per lane, once   : a 32-bit byte offset of the lane's 16-byte chunk at tap (0,0) relative to the workgroup's first
+//                      image, and a 64-bit mask "tap t reads inside the image" (zero padding / tile edge);
+//   per slab, scalar : the tap's byte offset and bit index from three SALU counters (tap row, tap column, channel
+//                      chunk) - taps are described arithmetically: tap (i,j) reads pixel (a*si+dh0+dstep*i, b*si+dw0+dstep*j);
+//   per load         : one v_add + one v_cndmask (masked lanes get SGX_BUF_OOB and the buffer bounds check returns 0).
+// FLAT (C < 16, the RGB stem): the GEMM-K axis is the flattened (tap, channel) axis, a 16-wide slab spans 16/C taps.
+// ------------------------------------------------------------------------------------------------
 struct IgemmParams {
     const float* A;
     const float* Wt;
@@ -115,20 +128,22 @@ struct IgemmParams {
     const float* addend;
     float* Y;
     float* stat_partials;
-    int M, Ha, Wa, Hin, Win, C, Nout, T;
+    int M, Ha, Wa, Hin, Win, C, Nout;
+    int Th, Tw;            // taps along h / w
+    int dh0, dw0, dstep;   // tap (i,j) -> input pixel (a*si + dh0 + dstep*i, b*si + dw0 + dstep*j)
     int si, so, ph, pw, Hout, Wout;
     long a_ld_pix, a_ld_img, y_ld_pix, y_ld_img;
-    long w_ld_n;
+    long w_ld_n;           // weight row pitch (elements); row n holds [tap][c]
+    long a_bytes, w_bytes; // extents for the buffer descriptors
     int act, accumulate;
     int mt, nt, nblk, chunk;  // tile counts and XCD chunk
     int stat_nblk;
-    signed char dh[SGX_MAX_TAPS], dw[SGX_MAX_TAPS];
 };
 
 #define IG_BK 16
 #define IG_LD 20
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool FLAT>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     constexpr int NTH = WM * WN * 64;   // threads per workgroup
     constexpr int RPP = NTH / 4;        // slab rows staged per pass (4 threads x 16 B per 16-float row)
@@ -152,80 +167,118 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     if (lin >= p.nblk) return;  // whole workgroup leaves together (before any barrier)
     const int mtile = lin / p.nt, ntile = lin - mtile * p.nt;
     const int m0 = mtile * BM, n0 = ntile * BN;
+    const int hw = p.Ha * p.Wa;
+    const int T = p.Th * p.Tw;
+
+    // buffer descriptors: A is re-based at the workgroup's first image so that lane offsets fit 31 bits
+    const int img0 = m0 / hw;
+    const sgx_buf bufA = sgx_make_buf(p.A + (long)img0 * p.a_ld_img, p.a_bytes - (long)img0 * p.a_ld_img * 4);
+    const sgx_buf bufB = sgx_make_buf(p.Wt, p.w_bytes);
 
     const int lrow = tid >> 2, chunk4 = (tid & 3) * 4;
-    long abase[AJ];
-    int ah[AJ], aw[AJ];
-    const int hw = p.Ha * p.Wa;
+    int aoff[AJ];
+    unsigned long long amask[AJ];
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-        int row = lrow + RPP * j;
-        int m = m0 + row;
+        const int row = lrow + RPP * j;
+        const int m = m0 + row;
+        aoff[j] = 0;
+        amask[j] = 0ull;
         if (row < BM && m < p.M) {
-            int img = m / hw;
-            int rem = m - img * hw;
-            int a = rem / p.Wa;
-            int b = rem - a * p.Wa;
-            abase[j] = (long)img * p.a_ld_img;
-            ah[j] = a * p.si;
-            aw[j] = b * p.si;
-        } else {
-            abase[j] = 0;
-            ah[j] = -(1 << 28);
-            aw[j] = 0;
+            const int img = m / hw;
+            const int rem = m - img * hw;
+            const int a = rem / p.Wa;
+            const int b = rem - a * p.Wa;
+            const int hi0 = a * p.si + p.dh0, wi0 = b * p.si + p.dw0;
+            aoff[j] = (int)(((long)(img - img0) * p.a_ld_img + ((long)hi0 * p.Win + wi0) * p.a_ld_pix + (FLAT ? 0 : chunk4)) * 4);
+            unsigned long long mk = 0ull;
+            for (int i = 0; i < p.Th; ++i) {
+                const int hi = hi0 + p.dstep * i;
+                for (int jj = 0; jj < p.Tw; ++jj) {
+                    const int wi = wi0 + p.dstep * jj;
+                    if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win) mk |= 1ull << (i * p.Tw + jj);
+                }
+            }
+            amask[j] = mk;
         }
     }
     if (tid < BM) {
-        int m = m0 + tid;
+        const int m = m0 + tid;
         long long off = -1;
         if (m < p.M) {
-            int img = m / hw;
-            int rem = m - img * hw;
-            int a = rem / p.Wa;
-            int b = rem - a * p.Wa;
+            const int img = m / hw;
+            const int rem = m - img * hw;
+            const int a = rem / p.Wa;
+            const int b = rem - a * p.Wa;
             off = (long long)img * p.y_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.y_ld_pix;
         }
         rowoff[tid] = off;
     }
-    long bbase[BJ];
+    int boff[BJ];
     bool bok[BJ];
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        int row = lrow + RPP * j;
-        int n = n0 + row;
+        const int row = lrow + RPP * j;
+        const int n = n0 + row;
         bok[j] = (row < BN) && (n < p.Nout);
-        bbase[j] = (long)n * p.w_ld_n;
+        boff[j] = (int)(((long)n * p.w_ld_n + (FLAT ? 0 : chunk4)) * 4);
     }
 
     const int cpt = (p.C + IG_BK - 1) / IG_BK;
-    const int nkt = p.T * cpt;
+    const int nkt = FLAT ? (T * p.C + IG_BK - 1) / IG_BK : T * cpt;
+    const int pixstep = p.dstep * (int)p.a_ld_pix * 4;      // bytes per tap step along w
+    const int rowstep = pixstep * p.Win;                     // bytes per tap step along h
 
+    // scalar slab state of the NEXT slab to load (non-FLAT): tap row, tap column, channel chunk
+    int s_ti = 0, s_tj = 0, s_ck = 0, s_kt = 0;
     float4 ra[AJ], rb[BJ];
-    auto load_tile = [&](int kt) {
-        int tap = kt / cpt;
-        int c0 = (kt - tap * cpt) * IG_BK + chunk4;
-        int dh = p.dh[tap], dw = p.dw[tap];
-        bool cok = c0 < p.C;
+    auto load_tile = [&]() {
+        if (FLAT) {
+            const int kk = s_kt * IG_BK + chunk4;  // flattened (tap, c) index of this lane's chunk
+            const int t = kk / p.C;
+            const int c = kk - t * p.C;
+            const int ti = t / p.Tw, tj = t - ti * p.Tw;
+            const bool kok = t < T;
+            const int tapoff = ti * rowstep + tj * pixstep + c * 4;
+            const int tb = kok ? t : 0;
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            int hi = ah[j] + dh, wi = aw[j] + dw;
-            bool ok = cok && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
-            ra[j] = ok ? sgx_ld4(p.A + abase[j] + ((long)hi * p.Win + wi) * p.a_ld_pix + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+            for (int j = 0; j < AJ; ++j) {
+                const bool ok = kok && ((amask[j] >> tb) & 1ull);
+                ra[j] = sgx_buf_ld4(bufA, ok ? (unsigned)(aoff[j] + tapoff) : SGX_BUF_OOB);
+            }
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            rb[j] = (cok && bok[j]) ? sgx_ld4(p.Wt + bbase[j] + (long)tap * p.C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < BJ; ++j) rb[j] = sgx_buf_ld4(bufB, (kok && bok[j]) ? (unsigned)(boff[j] + kk * 4) : SGX_BUF_OOB);
+        } else {
+            const int tbit = s_ti * p.Tw + s_tj;
+            const int tapoff = s_ti * rowstep + s_tj * pixstep + s_ck * (IG_BK * 4);
+            const int woff = (tbit * p.C + s_ck * IG_BK) * 4;
+            const bool cok = s_ck * IG_BK + chunk4 < p.C;
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const bool ok = cok && ((amask[j] >> tbit) & 1ull);
+                ra[j] = sgx_buf_ld4(bufA, ok ? (unsigned)(aoff[j] + tapoff) : SGX_BUF_OOB);
+            }
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) rb[j] = sgx_buf_ld4(bufB, (cok && bok[j]) ? (unsigned)(boff[j] + woff) : SGX_BUF_OOB);
+            if (++s_ck == cpt) {
+                s_ck = 0;
+                if (++s_tj == p.Tw) {
+                    s_tj = 0;
+                    ++s_ti;
+                }
+            }
         }
+        ++s_kt;
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            int row = lrow + RPP * j;
+            const int row = lrow + RPP * j;
             if (row < BM) sgx_st4(&As[buf * BM * IG_LD + row * IG_LD + chunk4], ra[j]);
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            int row = lrow + RPP * j;
+            const int row = lrow + RPP * j;
             if (row < BN) sgx_st4(&Bs[buf * BN * IG_LD + row * IG_LD + chunk4], rb[j]);
         }
     };
@@ -239,7 +292,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (nkt > 0) {
-        load_tile(0);
+        load_tile();
         store_tile(0);
     }
     __syncthreads();
@@ -247,7 +300,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     const int frow = lane & 31, fk = (lane >> 5) * 8;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);  // global loads in flight under the MFMA block
+        if (kt + 1 < nkt) load_tile();  // global loads in flight under the MFMA block
 
         float af[TM][8], bf[TN][8];
 #pragma unroll
@@ -358,30 +411,50 @@ static TileCfg pick_tile(long M, int N) {
     return TileCfg{bm, bn};
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool FLAT>
 static void launch_igemm(IgemmParams& p, void* stream) {
     p.mt = sgx_cdiv(p.M, BM);
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
     p.chunk = sgx_cdiv(p.nblk, 8);
     int grid = p.chunk * 8;
-    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
+    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
 }
 
 static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
-    if (p.T > SGX_MAX_TAPS) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: more than %d taps", SGX_MAX_TAPS);
-    SGX_PROF(0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * (double)p.T, stream);
-    if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2>(p, stream);
-    else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1>(p, stream);
-    else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2>(p, stream);
-    else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1>(p, stream);
-    else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2>(p, stream);
-    else if (bm == 64 && bn == 96) launch_igemm<64, 96, 2, 1>(p, stream);
-    else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2>(p, stream);
-    else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1>(p, stream);
+    const int T = p.Th * p.Tw;
+    if (T > SGX_MAX_TAPS) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: more than %d taps", SGX_MAX_TAPS);
+    if (p.w_bytes > SGX_BUF_MAX) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: weight tensor larger than 2 GiB");
+    {
+        const long hw = (long)p.Ha * p.Wa;
+        const long imgs = (bm + hw - 1) / hw + 1;  // images a pixel tile can touch
+        if (imgs * p.a_ld_img * 4 > SGX_BUF_MAX) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: one pixel tile spans more than 2 GiB of input");
+    }
+    SGX_PROF(0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * (double)T, stream);
+    const bool flat = p.C < IG_BK && T > 1;
+    if (flat) {
+        if (bn > 64) bn = 64;  // the flat variants exist for the narrow tiles only (stem layers have few output channels)
+        if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, true>(p, stream);
+        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, true>(p, stream);
+        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, true>(p, stream);
+        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true>(p, stream);
+        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no flat tile %dx%d", bm, bn);
+    } else if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false>(p, stream);
+    else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false>(p, stream);
+    else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false>(p, stream);
+    else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false>(p, stream);
+    else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2, false>(p, stream);
+    else if (bm == 64 && bn == 96) launch_igemm<64, 96, 2, 1, false>(p, stream);
+    else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false>(p, stream);
+    else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false>(p, stream);
     else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no tile %dx%d", bm, bn);
     SGX_CHECK_LAUNCH("igemm");
     return SGX_OK;
+}
+static TileCfg igemm_tile(const IgemmParams& p) {
+    TileCfg t = pick_tile(p.M, p.Nout);
+    if (p.C < IG_BK && p.Th * p.Tw > 1 && t.bn > 64) t.bn = 64;
+    return t;
 }
 
 static int32_t check_desc(const sgx_conv_desc* d) {
@@ -395,16 +468,14 @@ static int32_t check_desc(const sgx_conv_desc* d) {
     SGX_CHECK_ARG(d->x_ld_pix >= d->C && d->x_ld_pix % 4 == 0 && d->y_ld_pix >= d->K, "conv: bad pixel strides");
     return SGX_OK;
 }
-
-static int env_tile(const char* name) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : 0;
+// bytes from the first element of an NHWC view to one past its last
+static long view_bytes(int N, int H, int W, int C, long ld_pix, long ld_img) {
+    return ((long)(N - 1) * ld_img + ((long)H * W - 1) * ld_pix + C) * 4;
 }
 
 extern "C" int32_t sgx_conv2d_fwd_stat_blocks(const sgx_conv_desc* d) {
     long M = (long)d->N * d->Ho * d->Wo;
     TileCfg t = pick_tile(M, d->K);
-    if (env_tile("SGX_CONV_BM")) t.bm = env_tile("SGX_CONV_BM");
     return sgx_cdiv(M, t.bm);
 }
 
@@ -417,21 +488,18 @@ extern "C" int32_t sgx_conv2d_fwd(const sgx_conv_desc* d, const float* x, const 
     memset(&p, 0, sizeof(p));
     p.A = x; p.Wt = w; p.bias = bias; p.addend = addend; p.Y = y; p.stat_partials = stat_partials;
     p.M = d->N * d->Ho * d->Wo; p.Ha = d->Ho; p.Wa = d->Wo; p.Hin = d->H; p.Win = d->W;
-    p.C = d->C; p.Nout = d->K; p.T = d->R * d->S;
+    p.C = d->C; p.Nout = d->K; p.Th = d->R; p.Tw = d->S;
+    p.dh0 = -d->pad; p.dw0 = -d->pad; p.dstep = 1;
     p.si = d->stride; p.so = 1; p.ph = 0; p.pw = 0; p.Hout = d->Ho; p.Wout = d->Wo;
     p.a_ld_pix = d->x_ld_pix; p.a_ld_img = d->x_ld_img; p.y_ld_pix = d->y_ld_pix; p.y_ld_img = d->y_ld_img;
-    p.w_ld_n = (long)p.T * d->C;
+    p.w_ld_n = (long)d->R * d->S * d->C;
+    p.a_bytes = view_bytes(d->N, d->H, d->W, d->C, d->x_ld_pix, d->x_ld_img);
+    p.w_bytes = (long)d->K * p.w_ld_n * 4;
     p.act = act; p.accumulate = 0;
-    for (int r = 0; r < d->R; ++r)
-        for (int s = 0; s < d->S; ++s) {
-            p.dh[r * d->S + s] = (signed char)(r - d->pad);
-            p.dw[r * d->S + s] = (signed char)(s - d->pad);
-        }
-    TileCfg t = pick_tile(p.M, p.Nout);
-    if (env_tile("SGX_CONV_BM")) t.bm = env_tile("SGX_CONV_BM");
-    if (env_tile("SGX_CONV_BN")) t.bn = env_tile("SGX_CONV_BN");
+    TileCfg t = pick_tile(p.M, p.Nout);  // the statistics rows follow the M tile: keep it in step with sgx_conv2d_fwd_stat_blocks
     p.stat_nblk = sgx_cdiv(p.M, t.bm);
-    return run_igemm(p, t.bm, t.bn, stream);
+    TileCfg u = igemm_tile(p);
+    return run_igemm(p, t.bm, u.bn, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -449,6 +517,28 @@ __global__ void wtrans_kernel(const float* w, float* wt, int K, int C, int RS, i
         int t = (int)(r % T);
         int c = (int)(r / T);
         wt[i] = w[((long)k * RS + taps.idx[t]) * C + c];
+    }
+}
+__global__ void dgrad_fill_kernel(IgemmParams p) {
+    // a parity class no tap reaches: dx = addend (+ dx if accumulate), else 0
+    const int hw = p.Ha * p.Wa;
+    const long n = (long)p.M * (p.Nout / 4);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (p.Nout / 4)) * 4;
+        const int m = (int)(i / (p.Nout / 4));
+        const int img = m / hw, rem = m - img * hw, a = rem / p.Wa, b = rem - a * p.Wa;
+        const long off = (long)img * p.y_ld_img + ((long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.y_ld_pix + c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) v = sgx_ld4(p.bias + c4);
+        if (p.addend) {
+            float4 u = sgx_ld4(p.addend + off);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        if (p.accumulate) {
+            float4 u = sgx_ld4(p.Y + off);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        sgx_st4(p.Y + off, v);
     }
 }
 
@@ -475,41 +565,49 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
         for (int pw = 0; pw < s; ++pw) {
             IgemmParams p;
             memset(&p, 0, sizeof(p));
-            int T = 0;
+            // taps of this output-parity class: filter rows r with (ph + pad - r) % s == 0, in increasing r; the input (dY)
+            // row they read is (ph + pad - r)/s, i.e. it DEcreases by one per tap: dstep = -1
             TapList taps;
             memset(&taps, 0, sizeof(taps));
-            for (int r = 0; r < d->R; ++r) {
-                int vh = ph + d->pad - r;
-                if (((vh % s) + s) % s) continue;
-                for (int q = 0; q < d->S; ++q) {
-                    int vw = pw + d->pad - q;
-                    if (((vw % s) + s) % s) continue;
-                    p.dh[T] = (signed char)(vh / s);
-                    p.dw[T] = (signed char)(vw / s);
-                    taps.idx[T] = (unsigned char)(r * d->S + q);
-                    ++T;
-                }
-            }
+            int rows[SGX_MAX_TAPS], cols[SGX_MAX_TAPS], Th = 0, Tw = 0;
+            for (int r = 0; r < d->R; ++r)
+                if ((((ph + d->pad - r) % s) + s) % s == 0) rows[Th++] = r;
+            for (int q = 0; q < d->S; ++q)
+                if ((((pw + d->pad - q) % s) + s) % s == 0) cols[Tw++] = q;
+            const int T = Th * Tw;
+            for (int i = 0; i < Th; ++i)
+                for (int j = 0; j < Tw; ++j) taps.idx[i * Tw + j] = (unsigned char)(rows[i] * d->S + cols[j]);
             const int Ha = (d->H - ph + s - 1) / s, Wa = (d->W - pw + s - 1) / s;
             if (Ha <= 0 || Wa <= 0) continue;
             p.A = dy; p.Wt = wt; p.bias = bias; p.addend = addend; p.Y = dx; p.stat_partials = nullptr;
             p.M = d->N * Ha * Wa; p.Ha = Ha; p.Wa = Wa; p.Hin = d->Ho; p.Win = d->Wo;
-            p.C = d->K; p.Nout = d->C; p.T = T;
+            p.C = d->K; p.Nout = d->C; p.Th = Th; p.Tw = Tw;
+            // floor division: (ph + pad - r) is a multiple of s for the selected taps
+            p.dh0 = T ? (ph + d->pad - rows[0]) / s : 0;
+            p.dw0 = T ? (pw + d->pad - cols[0]) / s : 0;
+            p.dstep = -1;
             p.si = 1; p.so = s; p.ph = ph; p.pw = pw; p.Hout = d->H; p.Wout = d->W;
             p.a_ld_pix = d->y_ld_pix; p.a_ld_img = d->y_ld_img; p.y_ld_pix = d->x_ld_pix; p.y_ld_img = d->x_ld_img;
             p.w_ld_n = (long)T * d->K;
+            p.a_bytes = view_bytes(d->N, d->Ho, d->Wo, d->K, d->y_ld_pix, d->y_ld_img);
+            p.w_bytes = (long)d->C * p.w_ld_n * 4;
             p.act = SGX_ACT_NONE; p.accumulate = accumulate;
-            if (T > 0) {
-                long n = (long)d->C * T * d->K;
-                int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-                SGX_LAUNCH(wtrans_kernel, dim3(grid), dim3(256), 0, stream, w, wt, d->K, d->C, d->R * d->S, T, taps);
-                SGX_CHECK_LAUNCH("wtrans");
+            if (T == 0) {
+                // no filter tap reaches this parity class (e.g. 1x1 stride 2): nothing to add when accumulating
+                if (accumulate && !addend && !bias) continue;
+                long n = (long)p.M * (p.Nout / 4);
+                int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+                SGX_LAUNCH(dgrad_fill_kernel, dim3(grid), dim3(256), 0, stream, p);
+                SGX_CHECK_LAUNCH("dgrad_fill");
+                continue;
             }
-            // T == 0: the class receives no contribution; the kernel still writes addend/accumulate/zero.
-            TileCfg t = pick_tile(p.M, p.Nout);
-            if (env_tile("SGX_CONV_BM")) t.bm = env_tile("SGX_CONV_BM");
-            if (env_tile("SGX_CONV_BN")) t.bn = env_tile("SGX_CONV_BN");
-            rc = run_igemm(p, t.bm, t.bn, stream);
+            long n = (long)d->C * T * d->K;
+            int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+            SGX_LAUNCH(wtrans_kernel, dim3(grid), dim3(256), 0, stream, w, wt, d->K, d->C, d->R * d->S, T, taps);
+            SGX_CHECK_LAUNCH("wtrans");
+            TileCfg t = igemm_tile(p);
+            TileCfg m = pick_tile(p.M, p.Nout);
+            rc = run_igemm(p, m.bm, t.bn, stream);
             if (rc) return rc;
             wt += (long)d->C * T * d->K;
         }
@@ -517,89 +615,128 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight gradient: for one tap, dW[k][c] = sum_m dY[m][k] * X[pix(m,tap)][c]; split over pixel chunks,
-// partial slabs reduced by a second kernel in a fixed order (deterministic, no float atomics).
+// Weight gradient as ONE GEMM over the flattened filter axis:  dW[k][j] = sum_m dY[m][k] * Xcol[m][j],  j = tap*C + c
+// (exactly the OHWI memory order of the weights, so a tile of j may span several taps: narrow-channel layers - the
+// 3->48 stem, the 32/48/64-channel CSP blocks - still fill a 96- or 128-wide MFMA tile).  Pixels are the GEMM-K axis:
+// a workgroup owns a (k tile, j tile) and a contiguous pixel range [split], stages 16-pixel slabs of dY and of the
+// shifted X in LDS (pixel-major, so MFMA fragments are conflict-free ds_read_b32), and writes its partial tile;
+// a second kernel folds the splits in a fixed order (deterministic, no float atomics).
+// A lane owns ONE pixel row of the slab and walks it forward 16 pixels per step (no divisions in the loop); its column
+// groups have fixed (tap, channel) -> fixed byte deltas, so each load is base + delta with a 4-compare bounds mask.
 // ------------------------------------------------------------------------------------------------
 struct WgradParams {
     const float* X;
     const float* DY;
-    float* part;  // [ksplit][K][T][C]
+    float* part;  // [ksplit][K][J]
     int N, H, W, C, K, R, S, stride, pad, Ho, Wo;
     long x_ld_pix, x_ld_img, y_ld_pix, y_ld_img;
-    int M, ksplit, mchunk;  // pixels per split (multiple of 16)
-    int kt_tiles, ct_tiles;
+    long x_bytes, dy_bytes;
+    int M, J, ksplit, mchunk;  // pixels per split (multiple of 16)
+    int kt_tiles, jt_tiles;
 };
 
 #define WG_BKP 16
 
-template <int BNK, int BC, int WK, int WC>
+template <int BNK, int BJ, int WK, int WC>
 __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgradParams p) {
     constexpr int NTH = WK * WC * 64;
-    constexpr int TK = BNK / (WK * 32), TC = BC / (WC * 32);
-    static_assert(TK >= 1 && TC >= 1 && TK * WK * 32 == BNK && TC * WC * 32 == BC, "bad tile");
-    constexpr int DJ = (WG_BKP * BNK / 4 + NTH - 1) / NTH, XJ = (WG_BKP * BC / 4 + NTH - 1) / NTH;
+    constexpr int TK = BNK / (WK * 32), TC = BJ / (WC * 32);
+    static_assert(TK >= 1 && TC >= 1 && TK * WK * 32 == BNK && TC * WC * 32 == BJ, "bad tile");
+    constexpr int G = NTH / WG_BKP;  // lanes per pixel row
+    constexpr int DJ = (BNK / 4 + G - 1) / G, XJ = (BJ / 4 + G - 1) / G;
     __shared__ float Ds[2 * WG_BKP * BNK];
-    __shared__ float Xs[2 * WG_BKP * BC];
+    __shared__ float Xs[2 * WG_BKP * BJ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave / WC, wc = wave % WC;
-    // blockIdx.x = ((split * kt_tiles + ktile) * ct_tiles + ctile) * T + tap   (taps of one slab adjacent)
-    const int T = p.R * p.S;
+    // blockIdx.x = (split * kt_tiles + ktile) * jt_tiles + jtile
     int b = blockIdx.x;
-    const int tap = b % T; b /= T;
-    const int ctile = b % p.ct_tiles; b /= p.ct_tiles;
+    const int jtile = b % p.jt_tiles; b /= p.jt_tiles;
     const int ktile = b % p.kt_tiles; b /= p.kt_tiles;
     const int split = b;
-    const int k0 = ktile * BNK, c0 = ctile * BC;
-    const int tr = tap / p.S, ts = tap - tr * p.S;
+    const int k0 = ktile * BNK, j0 = jtile * BJ;
     const int mbeg = split * p.mchunk;
     const int mend = min(p.M, mbeg + p.mchunk);
     const int nkt = (mend > mbeg) ? (mend - mbeg + WG_BKP - 1) / WG_BKP : 0;
     const int hw = p.Ho * p.Wo;
 
+    // descriptors re-based at the split's first image
+    const int img0 = mbeg / hw;
+    const sgx_buf bufX = sgx_make_buf(p.X + (long)img0 * p.x_ld_img, p.x_bytes - (long)img0 * p.x_ld_img * 4);
+    const sgx_buf bufD = sgx_make_buf(p.DY + (long)img0 * p.y_ld_img, p.dy_bytes - (long)img0 * p.y_ld_img * 4);
+
+    const int prow = tid / G, cg = tid % G;  // this lane's pixel row of the slab and first column group
+    // pixel of slab 0
+    int m = mbeg + prow;
+    int img = m / hw, rem = m - img * hw;
+    int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    img -= img0;
+
+    // fixed per column group: dY channel, X (tap, channel) -> byte delta and tap shift
+    int dcol[DJ];
+    bool dok[DJ];
+#pragma unroll
+    for (int q = 0; q < DJ; ++q) {
+        const int c4 = (cg + q * G) * 4;
+        dcol[q] = c4;
+        dok[q] = c4 < BNK && k0 + c4 < p.K;
+    }
+    int xcol[XJ], xdelta[XJ], xdh[XJ], xdw[XJ];
+    bool xok[XJ];
+#pragma unroll
+    for (int q = 0; q < XJ; ++q) {
+        const int c4 = (cg + q * G) * 4;
+        const int j = j0 + c4;
+        xcol[q] = c4;
+        xok[q] = c4 < BJ && j < p.J;
+        const int tap = xok[q] ? j / p.C : 0;
+        const int c = j - tap * p.C;
+        const int tr = tap / p.S, ts = tap - tr * p.S;
+        xdh[q] = tr - p.pad;
+        xdw[q] = ts - p.pad;
+        xdelta[q] = (int)((((long)xdh[q] * p.W + xdw[q]) * p.x_ld_pix + c) * 4);
+    }
+
     float4 rd[DJ], rx[XJ];
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&]() {
+        const bool pok = m < mend;
+        const int dbase = (int)(((long)img * p.y_ld_img + ((long)ho * p.Wo + wo) * p.y_ld_pix + k0) * 4);
+        const int hi0 = ho * p.stride, wi0 = wo * p.stride;
+        const int xbase = (int)(((long)img * p.x_ld_img + ((long)hi0 * p.W + wi0) * p.x_ld_pix) * 4);
 #pragma unroll
-        for (int j = 0; j < DJ; ++j) {
-            int idx = tid + NTH * j;
-            int row = idx / (BNK / 4), c4 = (idx % (BNK / 4)) * 4;
-            int m = mbeg + kt * WG_BKP + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < WG_BKP * BNK / 4 && m < mend && k0 + c4 < p.K) {
-                int img = m / hw;
-                int rem = m - img * hw;
-                v = sgx_ld4(p.DY + (long)img * p.y_ld_img + (long)rem * p.y_ld_pix + k0 + c4);
-            }
-            rd[j] = v;
+        for (int q = 0; q < DJ; ++q) rd[q] = sgx_buf_ld4(bufD, (pok && dok[q]) ? (unsigned)(dbase + dcol[q] * 4) : SGX_BUF_OOB);
+#pragma unroll
+        for (int q = 0; q < XJ; ++q) {
+            const int hi = hi0 + xdh[q], wi = wi0 + xdw[q];
+            const bool ok = pok && xok[q] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+            rx[q] = sgx_buf_ld4(bufX, ok ? (unsigned)(xbase + xdelta[q]) : SGX_BUF_OOB);
         }
-#pragma unroll
-        for (int j = 0; j < XJ; ++j) {
-            int idx = tid + NTH * j;
-            int row = idx / (BC / 4), c4 = (idx % (BC / 4)) * 4;
-            int m = mbeg + kt * WG_BKP + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < WG_BKP * BC / 4 && m < mend && c0 + c4 < p.C) {
-                int img = m / hw;
-                int rem = m - img * hw;
-                int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                int hi = ho * p.stride + tr - p.pad, wi = wo * p.stride + ts - p.pad;
-                if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
-                    v = sgx_ld4(p.X + (long)img * p.x_ld_img + ((long)hi * p.W + wi) * p.x_ld_pix + c0 + c4);
+        // advance this lane's pixel by one slab
+        m += WG_BKP;
+        if (p.Wo >= WG_BKP) {
+            wo += WG_BKP;
+            if (wo >= p.Wo) {
+                wo -= p.Wo;
+                if (++ho >= p.Ho) {
+                    ho = 0;
+                    ++img;
+                }
             }
-            rx[j] = v;
+        } else {
+            int mm = m < p.M ? m : p.M - 1;
+            int im = mm / hw, rm = mm - im * hw;
+            ho = rm / p.Wo;
+            wo = rm - ho * p.Wo;
+            img = im - img0;
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < DJ; ++j) {
-            int idx = tid + NTH * j;
-            if (idx < WG_BKP * BNK / 4) sgx_st4(&Ds[buf * WG_BKP * BNK + idx * 4], rd[j]);
-        }
+        for (int q = 0; q < DJ; ++q)
+            if (dcol[q] < BNK) sgx_st4(&Ds[buf * WG_BKP * BNK + prow * BNK + dcol[q]], rd[q]);
 #pragma unroll
-        for (int j = 0; j < XJ; ++j) {
-            int idx = tid + NTH * j;
-            if (idx < WG_BKP * BC / 4) sgx_st4(&Xs[buf * WG_BKP * BC + idx * 4], rx[j]);
-        }
+        for (int q = 0; q < XJ; ++q)
+            if (xcol[q] < BJ) sgx_st4(&Xs[buf * WG_BKP * BJ + prow * BJ + xcol[q]], rx[q]);
     };
 
     sgx_f32x16 acc[TK][TC];
@@ -611,21 +748,21 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgradParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (nkt > 0) {
-        load_tile(0);
+        load_tile();
         store_tile(0);
     }
     __syncthreads();
     const int fcol = lane & 31, fkh = lane >> 5;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        if (kt + 1 < nkt) load_tile();
 #pragma unroll
         for (int kk = 0; kk < WG_BKP / 2; ++kk) {
             float af[TK], bf[TC];
 #pragma unroll
             for (int i = 0; i < TK; ++i) af[i] = Ds[buf * WG_BKP * BNK + (2 * kk + fkh) * BNK + wk * TK * 32 + i * 32 + fcol];
 #pragma unroll
-            for (int j = 0; j < TC; ++j) bf[j] = Xs[buf * WG_BKP * BC + (2 * kk + fkh) * BC + wc * TC * 32 + j * 32 + fcol];
+            for (int j = 0; j < TC; ++j) bf[j] = Xs[buf * WG_BKP * BJ + (2 * kk + fkh) * BJ + wc * TC * 32 + j * 32 + fcol];
 #pragma unroll
             for (int i = 0; i < TK; ++i)
 #pragma unroll
@@ -634,16 +771,16 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgradParams p) {
         if (kt + 1 < nkt) store_tile(buf ^ 1);
         __syncthreads();
     }
-    // partial slab: part[split][k][tap][c]
+    // partial tile: part[split][k][j]
 #pragma unroll
     for (int i = 0; i < TK; ++i)
 #pragma unroll
         for (int j = 0; j < TC; ++j) {
-            const int c = c0 + wc * TC * 32 + j * 32 + (lane & 31);
+            const int jj = j0 + wc * TC * 32 + j * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = k0 + wk * TK * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (k < p.K && c < p.C) p.part[(((long)split * p.K + k) * T + tap) * p.C + c] = acc[i][j][r];
+                if (k < p.K && jj < p.J) p.part[((long)split * p.K + k) * p.J + jj] = acc[i][j][r];
             }
         }
 }
@@ -670,12 +807,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
 }
 
 struct WgradPlan {
-    int bnk, bc, kt_tiles, ct_tiles, ksplit, mchunk;
+    int bnk, bj, waves, kt_tiles, jt_tiles, ksplit, mchunk;
 };
-static int wg_tile(int n) {  // least padding among {32,64,128}, ties to the wider tile
-    const int cand[3] = {32, 64, 128};
+static int wg_tile(int n) {  // least padding among {32,64,96,128}, ties to the wider tile
+    const int cand[4] = {32, 64, 96, 128};
     int b = 128, best = 1 << 30;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         int padded = ((n + cand[i] - 1) / cand[i]) * cand[i];
         if (padded <= best) {
             best = padded;
@@ -684,19 +821,37 @@ static int wg_tile(int n) {  // least padding among {32,64,128}, ties to the wid
     }
     return b;
 }
+static int wg_waves(int bnk, int bj) {  // waves per workgroup of the instantiated (bnk, bj) variant
+    if (bnk == 96 && bj == 96) return 3;
+    if (bnk == 96 && bj == 64) return 3;
+    if (bnk == 96 && bj == 32) return 3;
+    if (bnk == 32 && bj == 96) return 3;
+    if (bnk == 64 && bj == 96) return 2;
+    if (bnk == 64 && bj == 32) return 2;
+    if (bnk == 32 && bj == 64) return 2;
+    if (bnk == 32 && bj == 32) return 1;
+    return 4;
+}
 extern "C" int32_t sgx_stats_blocks(int64_t M);
 extern "C" int64_t sgx_colsum_workspace(int64_t M, int32_t C);
 static WgradPlan wgrad_plan(const sgx_conv_desc* d) {
     WgradPlan pl;
+    const int J = d->R * d->S * d->C;
     pl.bnk = wg_tile(d->K);
-    pl.bc = wg_tile(d->C);
+    pl.bj = wg_tile(J);
+    pl.waves = wg_waves(pl.bnk, pl.bj);
     pl.kt_tiles = sgx_cdiv(d->K, pl.bnk);
-    pl.ct_tiles = sgx_cdiv(d->C, pl.bc);
+    pl.jt_tiles = sgx_cdiv(J, pl.bj);
     long M = (long)d->N * d->Ho * d->Wo;
-    long tiles = (long)pl.kt_tiles * pl.ct_tiles * d->R * d->S;
-    long ks = (1024 + tiles - 1) / tiles;   // ~1024 workgroups (4 per CU)
+    long tiles = (long)pl.kt_tiles * pl.jt_tiles;
+    long target = 4096 / pl.waves;            // ~4 waves per SIMD over the chip
+    long ks = (target + tiles - 1) / tiles;
     long maxsplit = (M + 255) / 256;         // at least 256 pixels (16 slabs) per split
     if (ks > maxsplit) ks = maxsplit;
+    // a split's lane offsets are 31-bit: keep every split under 1 GiB of either operand
+    long big = (long)d->N * (d->x_ld_img > d->y_ld_img ? d->x_ld_img : d->y_ld_img) * 4;
+    long need = big / (1L << 30) + 1;
+    if (ks < need) ks = need;
     if (ks < 1) ks = 1;
     long mchunk = (M + ks - 1) / ks;
     mchunk = ((mchunk + WG_BKP - 1) / WG_BKP) * WG_BKP;
@@ -713,7 +868,6 @@ extern "C" int64_t sgx_conv2d_bwd_weight_workspace(const sgx_conv_desc* d) {
     return (slabs > bias ? slabs : bias) + 256;
 }
 
-
 extern "C" int32_t sgx_conv2d_bwd_weight(const sgx_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                                          void* ws, int64_t ws_bytes, void* stream) {
     int32_t rc = check_desc(d);
@@ -727,33 +881,48 @@ extern "C" int32_t sgx_conv2d_bwd_weight(const sgx_conv_desc* d, const float* x,
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.K = d->K; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
     p.Ho = d->Ho; p.Wo = d->Wo;
     p.x_ld_pix = d->x_ld_pix; p.x_ld_img = d->x_ld_img; p.y_ld_pix = d->y_ld_pix; p.y_ld_img = d->y_ld_img;
-    p.M = d->N * d->Ho * d->Wo; p.ksplit = pl.ksplit; p.mchunk = pl.mchunk; p.kt_tiles = pl.kt_tiles; p.ct_tiles = pl.ct_tiles;
-    long nblk = (long)pl.ksplit * pl.kt_tiles * pl.ct_tiles * d->R * d->S;
+    p.x_bytes = view_bytes(d->N, d->H, d->W, d->C, d->x_ld_pix, d->x_ld_img);
+    p.dy_bytes = view_bytes(d->N, d->Ho, d->Wo, d->K, d->y_ld_pix, d->y_ld_img);
+    p.M = d->N * d->Ho * d->Wo; p.J = d->R * d->S * d->C;
+    p.ksplit = pl.ksplit; p.mchunk = pl.mchunk; p.kt_tiles = pl.kt_tiles; p.jt_tiles = pl.jt_tiles;
+    long nblk = (long)pl.ksplit * pl.kt_tiles * pl.jt_tiles;
     dim3 grid((unsigned)nblk);
     {
-    SGX_PROF(1, 2.0 * (double)p.M * (double)d->K * (double)d->C * (double)(d->R * d->S), stream);
-#define WG_CASE(BK_, BC_, WK_, WC_) \
-    if (pl.bnk == BK_ && pl.bc == BC_) SGX_LAUNCH((wgrad_kernel<BK_, BC_, WK_, WC_>), grid, dim3(WK_ * WC_ * 64), 0, stream, p)
-    WG_CASE(128, 128, 2, 2);
-    WG_CASE(128, 64, 2, 2);
-    WG_CASE(128, 32, 4, 1);
-    WG_CASE(64, 128, 2, 2);
-    WG_CASE(64, 64, 2, 2);
-    WG_CASE(64, 32, 2, 1);
-    WG_CASE(32, 128, 1, 4);
-    WG_CASE(32, 64, 1, 2);
-    WG_CASE(32, 32, 1, 1);
+    SGX_PROF(1, 2.0 * (double)p.M * (double)d->K * (double)p.J, stream);
+    bool launched = false;
+#define WG_CASE(BK_, BJ_, WK_, WC_)                                                                                  \
+    if (!launched && pl.bnk == BK_ && pl.bj == BJ_) {                                                                \
+        SGX_LAUNCH((wgrad_kernel<BK_, BJ_, WK_, WC_>), grid, dim3(WK_ * WC_ * 64), 0, stream, p);                    \
+        launched = true;                                                                                             \
+    }
+    WG_CASE(128, 128, 2, 2)
+    WG_CASE(128, 96, 4, 1)
+    WG_CASE(128, 64, 2, 2)
+    WG_CASE(128, 32, 4, 1)
+    WG_CASE(96, 128, 1, 4)
+    WG_CASE(96, 96, 3, 1)
+    WG_CASE(96, 64, 3, 1)
+    WG_CASE(96, 32, 3, 1)
+    WG_CASE(64, 128, 2, 2)
+    WG_CASE(64, 96, 2, 1)
+    WG_CASE(64, 64, 2, 2)
+    WG_CASE(64, 32, 2, 1)
+    WG_CASE(32, 128, 1, 4)
+    WG_CASE(32, 96, 1, 3)
+    WG_CASE(32, 64, 1, 2)
+    WG_CASE(32, 32, 1, 1)
 #undef WG_CASE
+    if (!launched) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv bwd_weight: no tile %dx%d", pl.bnk, pl.bj);
     }
     SGX_CHECK_LAUNCH("wgrad");
-    long n = (long)d->K * d->R * d->S * d->C;
+    long n = (long)d->K * p.J;
     int KL = 1;
     while (KL < 16 && KL < pl.ksplit) KL *= 2;
     const int EL = 256 / KL;
     SGX_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n + EL - 1) / EL)), dim3(256), 0, stream, (const float*)ws, dw, n, pl.ksplit, KL);
     SGX_CHECK_LAUNCH("wgrad_reduce");
     if (dbias) {
-        // column sum of dy: reuse the partial buffer tail is not safe while reduce may still read -> stream order makes it safe
+        // column sum of dy; the workspace is free again once the slab reduce above has run (stream order)
         return sgx_colsum(dy, d->y_ld_pix, (int64_t)d->N * d->Ho * d->Wo, d->K, (int64_t)d->Ho * d->Wo, d->y_ld_img, dbias, 1, (float*)ws, stream);
     }
     return SGX_OK;

@@ -69,5 +69,39 @@ __device__ __forceinline__ float sgx_act_grad(float v, int act) {
     return 1.f;
 }
 
+// ---- buffer (SRD) loads: 32-bit per-lane byte offset against a wave-uniform base, hardware bounds check ----------
+// An offset >= the buffer's byte count returns zeros: the conv kernels encode "this element is padding / outside the
+// tile" as SGX_BUF_OOB instead of branching around the load.  Buffers are limited to 2 GiB - 1 (offsets stay positive).
+#define SGX_BUF_OOB 0x80000000u
+#define SGX_BUF_MAX 0x7fffffffL
+#ifdef SGX_EMU
+struct sgx_buf {
+    const char* base;
+    unsigned bytes;
+};
+static inline sgx_buf sgx_make_buf(const void* p, long bytes) {
+    if (bytes < 0) bytes = 0;
+    return sgx_buf{(const char*)p, (unsigned)(bytes > SGX_BUF_MAX ? SGX_BUF_MAX : bytes)};
+}
+static inline float4 sgx_buf_ld4(const sgx_buf& b, unsigned off) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (off < b.bytes && off + 16u <= b.bytes) memcpy(&v, b.base + off, 16);
+    return v;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t sgx_buf;
+__device__ __forceinline__ sgx_buf sgx_make_buf(const void* p, long bytes) {
+    if (bytes < 0) bytes = 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > SGX_BUF_MAX ? SGX_BUF_MAX : bytes), 0x00020000);
+}
+__device__ __forceinline__ float4 sgx_buf_ld4(sgx_buf b, unsigned off) {
+    typedef unsigned int sgx_u32x4 __attribute__((ext_vector_type(4)));
+    sgx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 0);
+    // bit-cast the WHOLE vector: hipcc (ROCm 7.2) narrows the load to one dword when the lanes are bit-cast one by one
+    sgx_f32x4 f = __builtin_bit_cast(sgx_f32x4, v);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+#endif
+
 __device__ __forceinline__ float4 sgx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void sgx_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
