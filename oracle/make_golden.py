@@ -57,8 +57,19 @@ def make_model_fixture(variant):
     import copy
 
     net64 = copy.deepcopy(net).double()
-    (b64, s64), (l64, d64, *_rest) = net64(x.double())
+    out64 = net64(x.double())
+    (b64, s64), (l64, d64, *_rest) = out64
     fx.update(boxes_f64=b64.detach().clone(), scores_f64=s64.detach().clone(), logits_f64=l64.detach().clone(), distri_f64=d64.detach().clone())
+    # fp64 gradients of the TAL loss: at seeded weights the loss gradient is dominated by a per-channel constant that the
+    # training-mode BatchNorms annihilate, so the fp32 gradients (reference and ours alike) carry amplified round-off; the
+    # product is judged against this truth relative to the reference's own fp32 deviation from it
+    torch.set_default_dtype(torch.float64)  # the loss builds its DFL projection with the default dtype (ppyolo_loss.py:688-696)
+    try:
+        loss64, _ = ref_shim.reference_ppyolo_loss(num_classes=80, use_static_assigner=False)(out64, targets.double())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    loss64.backward()
+    fx["grad_norms_f64"] = torch.tensor([float(p.grad.norm()) for n, p in net64.named_parameters() if p.grad is not None], dtype=torch.float64)
     del net64
     for static in (False, True):
         crit = ref_shim.reference_ppyolo_loss(num_classes=80, use_static_assigner=static)

@@ -136,6 +136,7 @@ struct IgemmParams {
     long w_ld_n;           // weight row pitch (elements); row n holds [tap][c]
     long a_bytes, w_bytes; // extents for the buffer descriptors
     int act, accumulate;
+    int vec;                  // 1: Nout, output strides and pointers allow 16-byte epilogue accesses
     int mt, nt, nblk, chunk;  // tile counts and XCD chunk
     int stat_nblk;
 };
@@ -151,8 +152,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     constexpr int AJ = (BM + RPP - 1) / RPP, BJ = (BN + RPP - 1) / RPP;
     static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "bad tile");
     static_assert(NTH >= BM && NTH >= BN, "epilogue helpers need one thread per tile row/col");
-    __shared__ float As[2 * BM * IG_LD];
-    __shared__ float Bs[2 * BN * IG_LD];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * IG_LD];
+    float* const As = smem;
+    float* const Bs = smem + 2 * BM * IG_LD;
+    static_assert(2 * (BM + BN) * IG_LD >= WM * WN * 32 * 32, "epilogue staging tiles do not fit in the operand slabs");
     __shared__ long long rowoff[BM];
     __shared__ float red[2 * WM * BN];
 
@@ -329,47 +332,94 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias + addend + accumulate + activation, optional BN partial statistics ----
-    float csum[TN], csq[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) csum[j] = csq[j] = 0.f;
+    // ---- epilogue: bias + addend + accumulate + activation, optional BN partial statistics --------------------------
+    // The MFMA accumulator layout gives a lane ONE column and 16 scattered rows (4-byte stores, 128-byte runs).  Each wave
+    // therefore transposes its 32x32 sub-tiles through a private 4 KB LDS patch (the operand slabs are free now) so that
+    // a lane owns 4 consecutive columns of one row: 16-byte loads/stores, 8 lanes covering a 128-byte row segment, and
+    // the addend / accumulate reads vectorised the same way.  Layers with few input channels are bound by exactly this
+    // traffic, not by the matrix pipe.
+    float* const stage = smem + wave * (32 * 32);
+    const int sr = lane >> 3, sc4 = (lane & 7) * 4;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        const int coll = wn * TN * 32 + j * 32 + sc4;  // column inside the tile
+        const int col = n0 + coll;
         const bool colok = col < p.Nout;
-        const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && colok) {
+            if (p.vec) bv = sgx_ld4(p.bias + col);
+            else {
+                bv.x = p.bias[col];
+                if (col + 1 < p.Nout) bv.y = p.bias[col + 1];
+                if (col + 2 < p.Nout) bv.z = p.bias[col + 2];
+                if (col + 3 < p.Nout) bv.w = p.bias[col + 3];
+            }
+        }
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const long long off = rowoff[row];
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rowl = q * 8 + sr;
+                const long long off = rowoff[wm * TM * 32 + i * 32 + rowl];
+                float4 v = sgx_ld4(stage + rowl * 32 + sc4);
                 if (off >= 0 && colok) {
-                    float v = acc[i][j][r] + bv;
-                    if (p.addend) v += p.addend[off + col];
-                    if (p.accumulate) v += p.Y[off + col];
-                    csum[j] += v;
-                    csq[j] += v * v;
-                    p.Y[off + col] = sgx_act(v, p.act);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    float* yp = p.Y + off + col;
+                    if (p.vec) {
+                        if (p.addend) {
+                            float4 u = sgx_ld4(p.addend + off + col);
+                            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                        }
+                        if (p.accumulate) {
+                            float4 u = sgx_ld4(yp);
+                            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                        }
+                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                        cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+                        sgx_st4(yp, make_float4(sgx_act(v.x, p.act), sgx_act(v.y, p.act), sgx_act(v.z, p.act), sgx_act(v.w, p.act)));
+                    } else {
+                        float e[4] = {v.x, v.y, v.z, v.w};
+                        float* se[4] = {&cs.x, &cs.y, &cs.z, &cs.w};
+                        float* qe[4] = {&cq.x, &cq.y, &cq.z, &cq.w};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            if (col + t < p.Nout) {
+                                float w = e[t];
+                                if (p.addend) w += p.addend[off + col + t];
+                                if (p.accumulate) w += yp[t];
+                                *se[t] += w;
+                                *qe[t] += w * w;
+                                yp[t] = sgx_act(w, p.act);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (p.stat_partials) {
+            // the 8 lanes with equal (lane & 7) hold the same 4 columns: fold them, lanes 0-7 publish
+            float vals[8] = {cs.x, cs.y, cs.z, cs.w, cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                vals[t] += __shfl_xor(vals[t], 8);
+                vals[t] += __shfl_xor(vals[t], 16);
+                vals[t] += __shfl_xor(vals[t], 32);
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    red[(0 * WM + wm) * BN + coll + t] = vals[t];
+                    red[(1 * WM + wm) * BN + coll + t] = vals[4 + t];
                 }
             }
         }
     }
     if (p.stat_partials) {
-        // lane l and l^32 hold the same column: fold, then fold the WM waves that share the column
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            csum[j] += __shfl_xor(csum[j], 32);
-            csq[j] += __shfl_xor(csq[j], 32);
-        }
-        if (lane < 32) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int c = wn * TN * 32 + j * 32 + lane;
-                red[(0 * WM + wm) * BN + c] = csum[j];
-                red[(1 * WM + wm) * BN + c] = csq[j];
-            }
-        }
         __syncthreads();
         if (tid < BN) {
             int col = n0 + tid;
@@ -430,6 +480,10 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         const long imgs = (bm + hw - 1) / hw + 1;  // images a pixel tile can touch
         if (imgs * p.a_ld_img * 4 > SGX_BUF_MAX) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: one pixel tile spans more than 2 GiB of input");
     }
+    p.vec = (p.Nout % 4 == 0 && p.y_ld_pix % 4 == 0 && p.y_ld_img % 4 == 0 && ((uintptr_t)p.Y % 16) == 0 && ((uintptr_t)p.addend % 16) == 0 &&
+             ((uintptr_t)p.bias % 16) == 0)
+                ? 1
+                : 0;
     SGX_PROF(0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * (double)T, stream);
     const bool flat = p.C < IG_BK && T > 1;
     if (flat) {

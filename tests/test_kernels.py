@@ -35,6 +35,7 @@ CONV_GPU = [
     (2, 56, 56, 4, 64, 7, 2, 3),       # ResNet stem
     (2, 28, 28, 64, 128, 1, 2, 0),     # ResNet 1x1 s2 shortcut
     (1, 160, 160, 32, 32, 3, 1, 1),    # many row tiles
+    (2, 20, 20, 32, 50, 1, 1, 0),      # K % 4 != 0: scalar epilogue path (forward only)
 ]
 CONV_EMU = [
     (1, 9, 7, 8, 36, 3, 1, 1),
@@ -43,6 +44,7 @@ CONV_EMU = [
     (1, 9, 9, 4, 8, 7, 2, 3),
     (1, 6, 6, 8, 4, 1, 2, 0),
     (1, 48, 48, 4, 8, 1, 1, 0),        # 2304 pixels: weight gradient split over 9 slabs (parallel slab reduce)
+    (1, 5, 5, 8, 6, 3, 1, 1),          # K % 4 != 0: scalar epilogue path (forward only)
 ]
 
 

@@ -165,8 +165,15 @@ def _product_model_case(variant, device):
     norms = torch.tensor([float(params[n].grad.double().norm()) for n in fx["grad_names"]], dtype=torch.float64)
     scale = fx["grad_norms"].max()
     big = fx["grad_norms"] > 1e-3 * scale
-    worst = float(((norms - fx["grad_norms"]).abs() / fx["grad_norms"].clamp_min(1e-30))[big].max())
-    assert worst < 2e-2, f"gradient norms differ from the reference by {worst:.2e}"
+    t64 = fx["grad_norms_f64"]
+    e_hip = ((norms - t64).abs() / t64.clamp_min(1e-30))[big]
+    e_ref = ((fx["grad_norms"] - t64).abs() / t64.clamp_min(1e-30))[big]
+    # distribution over the parameters: worst and mean deviation from the fp64 truth no more than 3x the reference's own
+    # fp32 run (floors 5e-3 / 1e-3); see make_golden.py on why individual fp32 gradients are noisy at seeded weights
+    msg = (f"gradient norms vs fp64: hip worst {float(e_hip.max()):.2e} mean {float(e_hip.mean()):.2e}; "
+           f"reference fp32 worst {float(e_ref.max()):.2e} mean {float(e_ref.mean()):.2e}")
+    assert float(e_hip.max()) <= max(5e-3, 3.0 * float(e_ref.max())) and float(e_hip.mean()) <= max(1e-3, 3.0 * float(e_ref.mean())), msg
+    print(f"[{variant}] {msg}")
     for k, v in fx["bn_running_checksum"].items():
         got = float(net.state_dict()[k].double().sum())
         assert abs(got - v) <= 1e-4 * max(abs(v), 1.0), k
