@@ -57,6 +57,7 @@ def make_model_fixture(variant):
     import copy
 
     net64 = copy.deepcopy(net).double()
+    net64_eval = copy.deepcopy(net64)  # same running statistics as `net` after its single training-mode forward
     out64 = net64(x.double())
     (b64, s64), (l64, d64, *_rest) = out64
     fx.update(boxes_f64=b64.detach().clone(), scores_f64=s64.detach().clone(), logits_f64=l64.detach().clone(), distri_f64=d64.detach().clone())
@@ -71,6 +72,11 @@ def make_model_fixture(variant):
     loss64.backward()
     fx["grad_norms_f64"] = torch.tensor([float(p.grad.norm()) for n, p in net64.named_parameters() if p.grad is not None], dtype=torch.float64)
     del net64
+    net64_eval.eval()
+    with torch.no_grad():
+        _, (el64, ed64, *_r) = net64_eval(x.double())
+    fx.update(eval_logits_f64=el64.clone(), eval_distri_f64=ed64.clone())
+    del net64_eval
     for static in (False, True):
         crit = ref_shim.reference_ppyolo_loss(num_classes=80, use_static_assigner=static)
         loss, items = crit(out, targets)
@@ -91,8 +97,8 @@ def make_model_fixture(variant):
     # eval-mode forward returns the same 2-tuple (SURVEY 8c edge case)
     net.eval()
     with torch.no_grad():
-        (eb, es), _ = net(x)
-    fx["eval_boxes"], fx["eval_scores"] = eb.clone(), es.clone()
+        (eb, es), (el, ed, *_r) = net(x)
+    fx["eval_boxes"], fx["eval_scores"], fx["eval_logits"], fx["eval_distri"] = eb.clone(), es.clone(), el.clone(), ed.clone()
     return fx
 
 

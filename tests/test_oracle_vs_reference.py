@@ -179,9 +179,13 @@ def _product_model_case(variant, device):
         assert abs(got - v) <= 1e-4 * max(abs(v), 1.0), k
     net.eval()
     with torch.no_grad():
-        (eb, es), _ = net(x)
-    _close(eb.cpu(), fx["eval_boxes"], tol, "eval boxes")
-    _close(es.cpu(), fx["eval_scores"], tol, "eval scores")
+        _, (el, ed, *_r) = net(x)
+    # eval mode runs on the seeded running statistics: nothing re-normalises the activations, the class logits are large and
+    # the sigmoid scores saturate - compare the raw head outputs, same three-way criterion as the training-mode forward
+    for name, t in (("eval_logits", el), ("eval_distri", ed)):
+        e_pair = rel_err(t.cpu(), fx[name])
+        e_hip, e_cpu = rel_err(t.cpu().double(), fx[name + "_f64"]), rel_err(fx[name].double(), fx[name + "_f64"])
+        assert e_pair <= tol or e_hip <= max(tol, 2.0 * e_cpu), f"{variant} {name}: hip-ref32 {e_pair:.2e}, hip-ref64 {e_hip:.2e}, ref32-ref64 {e_cpu:.2e}"
 
 
 @pytest.mark.gpu
