@@ -156,6 +156,9 @@ int32_t sgx_sum_partials(const float* partials, int32_t n, float scale, float* o
 /* y = a*x (+ y if accumulate) elementwise over [M,C] with strides; a_dev overrides a if not NULL.   */
 int32_t sgx_axpy(const float* x, int64_t x_ld, float a, const float* a_dev, float* y, int64_t y_ld, int64_t M,
                  int32_t C, int32_t accumulate, void* stream);
+/* g = dy where y > 0, else 0: backward of a ReLU applied after a residual add (classification_models/resnet.py:43-50,72-84). */
+int32_t sgx_relu_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, float* g, int64_t g_ld, int64_t M, int32_t C,
+                     void* stream);
 /* per-channel column sum: out[c] (+)= sum_rows x[row][c]  (conv bias gradients).                     */
 /* rows_per_img/ld_img: rows are grouped in images of rows_per_img rows, image i starts at x + i*ld_img
  * (pass rows_per_img = M, ld_img = 0 for a plain [M,C] matrix).  ws: sgx_colsum_workspace(M, C) bytes.  */

@@ -8,6 +8,9 @@ Fixtures (all inputs are regenerated from seeds by oracle/golden_util.py; only r
                        deterministic_fill weights, train-mode forward on a seeded image batch: decoded boxes / scores,
                        raw logits / distribution logits, anchors, points, strides; reference PPYoloELoss (TAL and ATSS)
                        loss items; per-parameter gradient L2 norms and sums of the TAL loss; BN running-stat checksums.
+  resnet18_cifar.pt, resnet50.pt   reference CifarResNet / ResNet (classification_models/resnet.py) with deterministic_fill
+                       weights, train-mode forward on a seeded batch: logits, mean cross-entropy, per-parameter gradient norms
+                       (fp32 and the same modules in fp64), BN running-stat checksums.
   ppyoloe_loss.pt      reference PPYoloELoss on random head outputs: {ATSS,TAL} x {varifocal,focal} x {batched,
                        sequential}, with the reference unit test's own fixed target tensor and with a seeded target set
                        that contains an empty image, plus the all-empty case: loss, items, d loss / d logits, d loss / d distri.
@@ -102,6 +105,34 @@ def make_model_fixture(variant):
     return fx
 
 
+RESNET_CASES = {"resnet18_cifar": dict(cls="ResNet18Cifar", batch=8, size=32, classes=10), "resnet50": dict(cls="ResNet50", batch=4, size=64, classes=100)}
+
+
+def make_resnet_fixture(name):
+    import copy
+
+    cfg = RESNET_CASES[name]
+    net = ref_shim.reference_resnet(cfg["cls"], cfg["classes"])
+    G.deterministic_fill(net, seed=4)
+    net.train()
+    x = torch.randn(cfg["batch"], 3, cfg["size"], cfg["size"], generator=torch.Generator().manual_seed(5))
+    y = torch.randint(0, cfg["classes"], (cfg["batch"],), generator=torch.Generator().manual_seed(6))
+    net64 = copy.deepcopy(net).double()
+    logits = net(x)
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    loss.backward()
+    l64 = net64(x.double())
+    loss64 = torch.nn.functional.cross_entropy(l64, y)
+    loss64.backward()
+    names = [n for n, p in net.named_parameters()]
+    return dict(name=name, batch=cfg["batch"], size=cfg["size"], classes=cfg["classes"], state_keys=list(net.state_dict().keys()),
+                state_shapes=[tuple(v.shape) for v in net.state_dict().values()], logits=logits.detach().clone(), logits_f64=l64.detach().clone(),
+                loss=loss.detach().clone(), loss_f64=loss64.detach().clone(), labels=y, grad_names=names,
+                grad_norms=torch.tensor([float(p.grad.double().norm()) for p in net.parameters()], dtype=torch.float64),
+                grad_norms_f64=torch.tensor([float(p.grad.norm()) for p in net64.parameters()], dtype=torch.float64),
+                bn_running_checksum={k: float(v.double().sum()) for k, v in net.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")})
+
+
 def make_loss_fixture():
     cases = []
     sizes = [8, 4, 3]  # 89 anchors: keeps the fixture small; level 3 still holds the 9 anchors ATSS's per-level top-9 needs
@@ -151,6 +182,10 @@ def main():
         fx = make_model_fixture(v)
         torch.save(fx, os.path.join(G.GOLDEN_DIR, f"yolo_nas_{v}.pt"))
         print(v, "loss items TAL", fx["loss_items_tal"].tolist(), "ATSS", fx["loss_items_atss"].tolist())
+    for name in RESNET_CASES:
+        fx = make_resnet_fixture(name)
+        torch.save(fx, os.path.join(G.GOLDEN_DIR, f"{name}.pt"))
+        print(name, "CE", float(fx["loss"]), "fp64", float(fx["loss_f64"]))
     torch.save(make_loss_fixture(), os.path.join(G.GOLDEN_DIR, "ppyoloe_loss.pt"))
     torch.save(make_post_prediction_fixture(), os.path.join(G.GOLDEN_DIR, "post_prediction.pt"))
     for f in sorted(os.listdir(G.GOLDEN_DIR)):

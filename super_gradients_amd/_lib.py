@@ -80,6 +80,7 @@ PROTOTYPES = {
     "sgx_dot_partial": (_i32, [_P, _i64, _P, _i64, _i64, _i32, _P, _P]),
     "sgx_sum_partials": (_i32, [_P, _i32, _f, _P, _i32, _P]),
     "sgx_axpy": (_i32, [_P, _i64, _f, _P, _P, _i64, _i64, _i32, _i32, _P]),
+    "sgx_relu_bwd": (_i32, [_P, _i64, _P, _i64, _P, _i64, _i64, _i32, _P]),
     "sgx_colsum": (_i32, [_P, _i64, _i64, _i32, _i64, _i64, _P, _i32, _P, _P]),
     "sgx_maxpool_fwd": (_i32, [_i32] * 7 + [_P, _i64, _i64, _P, _i64, _i64, _P, _P]),
     "sgx_maxpool_bwd": (_i32, [_i32] * 7 + [_P, _P, _i64, _i64, _P, _i64, _i64, _i32, _P]),

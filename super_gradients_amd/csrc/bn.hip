@@ -436,6 +436,25 @@ extern "C" int32_t sgx_axpy(const float* x, int64_t x_ld, float a, const float* 
     return run_sweep<AxpyF, 0>(f, M, C, nullptr, stream, "axpy");
 }
 
+// g = dy where the (post-activation) output y is positive: backward of a ReLU that sits AFTER a residual add
+// (classification_models/resnet.py:43-50, 72-84: out = relu(bn(conv) + shortcut)), where the mask is not a function of one BN output.
+struct ReluBwdF {
+    const float* dy; long dy_ld; const float* y; long y_ld; float* g; long g_ld;
+    struct In { float4 d, v; };
+    __device__ In load(long r, int c) const { return In{sgx_ld4(dy + r * dy_ld + c), sgx_ld4(y + r * y_ld + c)}; }
+    __device__ void apply(long r, int c, const In& in, float4& q0, float4& q1) const {
+        (void)q0; (void)q1;
+        const float4 d = in.d, v = in.v;
+        sgx_st4(g + r * g_ld + c, make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f));
+    }
+};
+extern "C" int32_t sgx_relu_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, float* g, int64_t g_ld, int64_t M, int32_t C,
+                                void* stream) {
+    SGX_CHECK_ARG(dy && y && g, "relu_bwd: null pointer");
+    ReluBwdF f{dy, dy_ld, y, y_ld, g, g_ld};
+    return run_sweep<ReluBwdF, 0>(f, M, C, nullptr, stream, "relu_bwd");
+}
+
 struct ColsumF {
     const float* x; long ld; long rows_per_img; long ld_img;
     struct In { float4 v; };

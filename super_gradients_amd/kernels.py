@@ -278,6 +278,15 @@ def axpy(x, a=1.0, a_dev=None, out=None, accumulate=False):
     return out
 
 
+def relu_bwd(dy, y, out=None):
+    """g = dy * (y > 0) over NHWC views."""
+    M, ld = rows(y)
+    if out is None:
+        out = torch.empty(y.shape, device=y.device, dtype=torch.float32)
+    check(lib().sgx_relu_bwd(ptr(dy), rows(dy)[1], ptr(y), ld, ptr(out), rows(out)[1], M, y.shape[3], stream()), "sgx_relu_bwd")
+    return out
+
+
 def colsum(x, out, accumulate=True):
     ld_pix, ld_img = nhwc_strides(x)
     n, h, w, C = x.shape

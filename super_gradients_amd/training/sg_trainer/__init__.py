@@ -1,0 +1,1 @@
+from .sg_trainer import Accuracy, DDPNotSetupException, Top5, Trainer  # noqa: F401

@@ -48,6 +48,19 @@ def setup_device_from_env(backend: str = None) -> Tuple[int, int, torch.device]:
     return rank, world, device
 
 
+def setup_device(multi_gpu=None, num_gpus: int = None, device: str = "cuda"):
+    """Reference: training/utils/distributed_training_utils.py:229-286.  On the MI355X path the process model is fixed: one
+    process per GPU, launched by `python -m torch.distributed.run` (env:// rendezvous); this call joins the process group
+    when WORLD_SIZE > 1 and selects the local GPU.  `multi_gpu="DDP"`/`num_gpus` are validated against the launch."""
+    if device not in ("cuda", None):
+        raise ValueError("the MI355X path runs on the HIP device only (device='cuda')")
+    rank, world, dev = setup_device_from_env()
+    if num_gpus not in (None, -1) and int(num_gpus) != world:
+        raise ValueError(f"num_gpus={num_gpus} but the launch provides WORLD_SIZE={world}: start one process per GPU with "
+                         "`python -m torch.distributed.run --nproc-per-node N`")
+    return rank, world, dev
+
+
 class GradientAllReducer:
     """Bucketed, backward-overlapped all-reduce of a network's gradient arena."""
 
@@ -72,21 +85,28 @@ class GradientAllReducer:
         if pos != net.g_arena.size and covered:
             raise RuntimeError("gradient buckets must tile the arena")
         self.pending = []
+        self.issued = set()
         self.grad_scale = torch.full((1,), 1.0 / self.world, device=net.g_arena.buf.device)
         net._grad_ready = self.ready
         net._post_backward_hook = self.finish
 
     def ready(self, prefix: str):
         """Called by the network's backward right after the kernels of sub-network `prefix` have been enqueued."""
-        if self.world == 1 or prefix not in self.ranges:
+        if self.world == 1 or prefix not in self.ranges or prefix in self.issued:
             return
         a, b = self.ranges[prefix]
+        self.issued.add(prefix)
         self.pending.append(dist.all_reduce(self.net.g_arena.buf[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
+        """End of backward: exchange whatever the network did not announce itself (a network that never calls `ready` still
+        gets a correct, just un-overlapped, all-reduce), then make the compute stream wait for the collectives."""
+        for prefix in self.ranges:
+            self.ready(prefix)
         for w in self.pending:
             w.wait()  # makes the compute stream wait for RCCL's stream; no host block for NCCL/RCCL work objects
         self.pending = []
+        self.issued = set()
 
     def broadcast_parameters(self, src: int = 0):
         """DDP-constructor semantics: every rank starts from rank `src`'s parameters and buffers."""

@@ -115,3 +115,20 @@ def test_spp(backend):
     n, c, h, w = _shape(backend, (2, 64, 10, 10), (1, 8, 6, 6))
     x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
     _check(OSPP(c, c), SPP(c, c, (5, 9, 13), "relu"), x, backend)
+
+
+@pytest.mark.parametrize("kind,stride", [("basic", 1), ("basic", 2), ("bottleneck", 1), ("bottleneck", 2)])
+def test_resnet_block(backend, kind, stride):
+    """BasicResNetBlock / Bottleneck (classification_models/resnet.py:26-84): identity and conv shortcuts, ReLU after the add."""
+    from oracle.resnet import BasicBlock, BottleneckBlock
+    from super_gradients_amd.training.models.classification_models.resnet import BasicResNetBlock, Bottleneck
+
+    n, cin, planes, hw = _shape(backend, (2, 64, 64, 28), (1, 8, 8, 6))
+    if kind == "basic":
+        cin_eff = cin if stride == 1 else cin // 2
+        ref, blk = BasicBlock(cin_eff, planes, stride, 1), BasicResNetBlock(cin_eff, planes, stride, 1)
+    else:
+        cin_eff = planes * 4 if stride == 1 else cin
+        ref, blk = BottleneckBlock(cin_eff, planes, stride, 4), Bottleneck(cin_eff, planes, stride, 4)
+    x = torch.randn(n, cin_eff, hw, hw, generator=torch.Generator().manual_seed(0))
+    _check(ref, blk, x, backend)

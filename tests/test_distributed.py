@@ -1,0 +1,108 @@
+"""Data-parallel path with world_size 2 over gloo on CPU (the kernels run on the host emulation in each process):
+  * GradientAllReducer: bucketed all-reduce of the gradient arena == sum of the per-rank gradients, parameters broadcast from rank 0,
+    the mean folded into the optimizer (grad_scale) -> identical parameters on both ranks;
+  * PPYoloELoss: the four sums exchanged as ONE collective, normaliser = clip(sum of assigned scores / world, 1)
+    (reference: training/losses/ppyolo_loss.py:971-979), local gradients scaled by the global normaliser.
+On the GPU box the same code runs over RCCL (backend "nccl"); bench.py --gpus N is the multi-GPU measurement."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import emu_env
+
+    emu_env.activate()
+    import torch.distributed as dist
+
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd.training.losses import PPYoloELoss
+    from super_gradients_amd.training.utils.distributed_training_utils import GradientAllReducer, setup_device_from_env
+    from super_gradients_amd.training.utils.optimizers import ArenaSGD
+    from test_trainer import _tiny_models
+    from oracle import golden_util as G
+    from oracle.yolo_nas import make_anchors
+
+    r, w, dev = setup_device_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and dist.is_initialized()
+    out = {}
+    # ---- gradient all-reduce --------------------------------------------------------------------------------------
+    torch.manual_seed(100 + rank)  # different initial weights per rank: broadcast must equalise them
+    _, net = _tiny_models(dev)
+    for p in net.parameters():
+        p.data.add_(torch.randn_like(p) * 0.01 * (rank + 1))
+    net.materialize(dev).train()
+    g = torch.Generator().manual_seed(10 + rank)
+    x, y = torch.randn(4, 4, 8, 8, generator=g), torch.randint(0, 4, (4,), generator=g)
+    from super_gradients_amd.training.losses import CrossEntropyLoss
+
+    crit = CrossEntropyLoss()
+    crit(net(x), y).backward()  # no reducer yet: purely local gradients (of rank-local weights)
+    reducer = GradientAllReducer(net, net.gradient_buckets())
+    reducer.broadcast_parameters(0)
+    out["params_after_broadcast"] = net.p_arena.buf.clone()
+    net.zero_grad()
+    crit(net(x), y).backward()
+    out["reduced"] = net.g_arena.buf.clone()
+    # local gradient at the broadcast weights, computed without communication
+    net._grad_ready, net._post_backward_hook = None, None
+    net.zero_grad()
+    crit(net(x), y).backward()
+    out["local"] = net.g_arena.buf.clone()
+    net.g_arena.buf.copy_(out["reduced"])
+    opt = ArenaSGD(net, lr=0.1, momentum=0.0)
+    K.sgd_step  # noqa: B018  (the arena SGD has no grad_scale argument: scale the arena like Trainer does)
+    net.g_arena.buf.mul_(1.0 / world)
+    opt.step()
+    out["params_after_step"] = net.p_arena.buf.clone()
+    # ---- loss sums exchanged as one collective -----------------------------------------------------------------------
+    def anchors(hw, strides):
+        a, pts, _pg, counts, strd = make_anchors(hw, strides)
+        return a, pts, counts, strd
+
+    preds = G.synthetic_predictions(2, [8, 4, 3], 8, 16, seed=30 + rank, make_anchors=anchors)
+    t = G.detection_targets(2, 64, seed=40 + rank, kmax=3, num_classes=8, empty_last=False)
+    logits = preds[0].clone().requires_grad_(True)
+    distri = preds[1].clone().requires_grad_(True)
+    loss, items = PPYoloELoss(8, use_static_assigner=False)((None, (logits, distri) + tuple(preds[2:])), t)
+    loss.backward()
+    out["items"], out["g_logits"] = items.clone(), logits.grad.clone()
+    loc = K.ppyoloe_loss_fwd(preds[0], preds[1], preds[2], preds[3], preds[5], t, preds[4], False, True, (1.0, 2.5, 0.5))
+    out["local_sums"], out["local_g_logits"] = loc["sums"].clone(), loc["g_logits"].clone()
+    torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"rank{i}.pt")) for i in range(world)]
+    # broadcast: both ranks hold rank 0's parameters
+    assert torch.equal(r[0]["params_after_broadcast"], r[1]["params_after_broadcast"])
+    # all-reduce: every rank's arena == sum of the local gradients
+    total = r[0]["local"] + r[1]["local"]
+    for i in range(world):
+        assert torch.allclose(r[i]["reduced"], total, rtol=1e-6, atol=1e-7)
+    assert torch.equal(r[0]["params_after_step"], r[1]["params_after_step"])
+    expect = r[0]["params_after_broadcast"] - 0.1 * total / world
+    assert torch.allclose(r[0]["params_after_step"], expect, rtol=1e-6, atol=1e-7)
+    # loss: items from the global sums, normaliser = clip(score_sum / world, 1); gradients = local gradient of the weighted sums / normaliser
+    s = r[0]["local_sums"] + r[1]["local_sums"]
+    norm = max(float(s[3]) / world, 1.0)
+    items = torch.tensor([1.0 * float(s[0]) / norm, 2.5 * float(s[1]) / norm, 0.5 * float(s[2]) / norm])
+    for i in range(world):
+        assert torch.allclose(r[i]["items"][:3], items, rtol=2e-5), (r[i]["items"], items)
+        assert abs(float(r[i]["items"][3]) - float(items.sum())) <= 2e-5 * float(items.sum())
+        assert torch.allclose(r[i]["g_logits"], r[i]["local_g_logits"] / norm, rtol=2e-5, atol=1e-8)

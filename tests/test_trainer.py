@@ -1,0 +1,231 @@
+"""Trainer plumbing: required parameters, LR warm-up + schedules, zero-weight-decay grouping, EMA,
+the per-batch order of operations, checkpoints - on a tiny conv network, against the same loop written with torch.optim on the
+CPU oracle modules.  `backend` = host emulation of the kernels (CPU) and the MI355X (gpu)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+def _tiny_models(device):
+    from super_gradients_amd.modules.conv_bn_act_block import Conv
+    from super_gradients_amd.modules.engine import SgxNetwork
+    from super_gradients_amd.modules.layers import LinearLayer
+    from super_gradients_amd import kernels as K
+
+    class Tiny(SgxNetwork):
+        def __init__(self):
+            super().__init__()
+            self.c1 = Conv(4, 8, 3, 1, "relu")
+            self.c2 = Conv(8, 8, 3, 2, "relu")
+            self.linear = LinearLayer(8, 4)
+
+        def _fwd(self, x):
+            a = self.c2.fwd(self.c1.fwd(K.nchw_to_nhwc(x.float())))
+            self._shape = tuple(a.shape)
+            return (self.linear.fwd(K.avgpool_fwd(a)).contiguous(),)
+
+        def _bwd(self, d):
+            d = K.avgpool_bwd(self.linear.bwd(d.contiguous()).contiguous(), self._shape)
+            self.c1.bwd(self.c2.bwd(d), need_dx=False)
+
+        def gradient_buckets(self):
+            return ["c1.", "c2.", "linear."]
+
+    class Ref(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = nn.Sequential()
+            self.c1.add_module("conv", nn.Conv2d(4, 8, 3, 1, 1, bias=False))
+            self.c1.add_module("bn", nn.BatchNorm2d(8))
+            self.c2 = nn.Sequential()
+            self.c2.add_module("conv", nn.Conv2d(8, 8, 3, 2, 1, bias=False))
+            self.c2.add_module("bn", nn.BatchNorm2d(8))
+            self.linear = nn.Linear(8, 4)
+
+        def forward(self, x):
+            x = F.relu(self.c1.bn(self.c1.conv(x)))
+            x = F.relu(self.c2.bn(self.c2.conv(x)))
+            return self.linear(x.mean((2, 3)))
+
+    torch.manual_seed(0)
+    ref = Ref()
+    net = Tiny()
+    net.load_state_dict(ref.state_dict(), strict=True)
+    return ref, net
+
+
+def _loader(n_batches, bs, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(bs, 4, 8, 8, generator=g), torch.randint(0, 4, (bs,), generator=g)) for _ in range(n_batches)]
+
+
+def _reference_lr(step_in_epoch, epoch, n, max_epochs, initial_lr, warmup_steps, warmup_initial_lr, final_ratio):
+    """LinearBatchLRWarmup (callbacks.py:374-392) + CosineLRScheduler (:489-514) as the reference applies them: the warm-up value
+    is set at batch start; the cosine value is set after the optimizer step and holds for the NEXT batch."""
+    g = step_in_epoch + epoch * n
+    if g < warmup_steps:
+        return float(np.linspace(warmup_initial_lr, initial_lr, warmup_steps)[g])
+    return None
+
+
+@pytest.mark.parametrize("opt", ["SGD", "AdamW"])
+def test_trainer_matches_torch_loop(backend, tmp_path, opt):
+    from super_gradients_amd.training import Trainer
+    from super_gradients_amd.training.losses import CrossEntropyLoss
+    from super_gradients_amd.training.utils.callbacks import CosineLRScheduler
+
+    ref, net = _tiny_models(backend)
+    n, epochs, bs = 3, 2, 4
+    loader = _loader(n, bs, 1)
+    initial_lr, warm_steps, warm_lr, ratio = 0.05, 2, 1e-3, 0.1
+    oparams = dict(momentum=0.9, weight_decay=1e-2) if opt == "SGD" else dict(weight_decay=1e-2, betas=(0.9, 0.99))
+    tp = dict(max_epochs=epochs, lr_mode="CosineLRScheduler", initial_lr=initial_lr, loss=CrossEntropyLoss(), optimizer=opt, optimizer_params=oparams,
+              zero_weight_decay_on_bias_and_bn=True, warmup_mode="LinearBatchLRWarmup", lr_warmup_steps=warm_steps, warmup_initial_lr=warm_lr,
+              cosine_final_lr_ratio=ratio, ema=True, ema_params=dict(decay=0.9, decay_type="threshold"), silent_mode=True, seed=7,
+              valid_metrics_list=["Accuracy"], metric_to_watch="Accuracy")
+    trainer = Trainer("tiny", ckpt_root_dir=str(tmp_path))
+    res = trainer.train(net, tp, loader, valid_loader=loader)
+
+    # the same loop on the torch modules (what the reference Trainer executes: sg_trainer.py:461-647)
+    decay = [p for nme, p in ref.named_parameters() if p.dim() > 1]
+    no_decay = [p for nme, p in ref.named_parameters() if p.dim() <= 1]
+    groups = [{"params": no_decay, "weight_decay": 0.0}, {"params": decay}]
+    o = torch.optim.SGD(groups, lr=initial_lr, **oparams) if opt == "SGD" else torch.optim.AdamW(groups, lr=initial_lr, **oparams)
+    ema = {k: v.clone() for k, v in ref.state_dict().items() if v.dtype.is_floating_point}
+    ref.train()
+    losses = []
+    for epoch in range(epochs):
+        tot = 0.0
+        for b, (x, y) in enumerate(loader):
+            g = b + epoch * n
+            if g < warm_steps:
+                for pg in o.param_groups:
+                    pg["lr"] = float(np.linspace(warm_lr, initial_lr, warm_steps)[g])
+            loss = F.cross_entropy(ref(x), y)
+            loss.backward()
+            o.step()
+            o.zero_grad()
+            step = g + 1
+            d = min(0.9, (1 + step) / (10 + step))
+            for k, v in ref.state_dict().items():
+                if v.dtype.is_floating_point:
+                    ema[k].mul_(d).add_(v.detach(), alpha=1 - d)
+            if g >= warm_steps:
+                it, max_it = max(0, g - warm_steps), n * epochs - warm_steps
+                lr = float(CosineLRScheduler.compute_learning_rate(it, max_it, initial_lr, ratio))
+                for pg in o.param_groups:
+                    pg["lr"] = lr
+            tot += float(loss) * bs
+        losses.append(tot / (n * bs))
+    for r, l in zip(res, losses):
+        assert abs(r["train"]["CrossEntropyLoss"] - l) <= 2e-4 * abs(l), (r, l)
+    assert abs(res[-1]["lr"] - o.param_groups[0]["lr"]) < 1e-12
+    sd = net.state_dict()
+    for k, v in ref.state_dict().items():
+        if v.dtype.is_floating_point:
+            e = float((sd[k].cpu() - v).abs().max()) / max(float(v.abs().max()), 1e-3)
+            assert e <= 5e-4, f"{k}: {e:.2e}"
+    ema_sd = trainer.ema_model.state_dict()
+    for k, v in ema.items():
+        e = float((ema_sd[k].cpu() - v).abs().max()) / max(float(v.abs().max()), 1e-3)
+        assert e <= 5e-4, f"ema {k}: {e:.2e}"
+    # checkpoints with the reference's layout, resumable
+    ck = torch.load(os.path.join(str(tmp_path), "tiny", "ckpt_latest.pth"), weights_only=False)
+    assert set(["net", "ema_net", "optimizer_state_dict", "epoch"]).issubset(ck.keys()) and ck["epoch"] == epochs - 1
+    assert os.path.exists(os.path.join(str(tmp_path), "tiny", "ckpt_best.pth"))
+    assert "Accuracy" in res[-1]["valid"] and 0.0 <= res[-1]["valid"]["Accuracy"] <= 1.0
+
+
+def test_trainer_argument_contract(tmp_path):
+    from super_gradients_amd.training import Trainer
+
+    with pytest.raises(KeyError):
+        Trainer("x", device="cuda")
+    with pytest.raises(KeyError):
+        Trainer("x", multi_gpu="DDP")
+    t = Trainer("x", ckpt_root_dir=str(tmp_path))
+    with pytest.raises(ValueError):
+        t.train(nn.Linear(2, 2), {"max_epochs": 1}, train_loader=None)
+    with pytest.raises(TypeError):
+        t.train(nn.Linear(2, 2), {"max_epochs": 1, "lr_mode": "StepLRScheduler", "initial_lr": 0.1, "loss": "CrossEntropyLoss"}, train_loader=[1])
+
+
+def test_lr_schedules_match_reference():
+    """Closed forms of the schedules against the reference's own callback classes (live, when /root/reference is present) and
+    against the values the YOLO-NAS recipe implies (coco2017_yolo_nas_train_params.yaml: warm-up 1e-6 -> 2e-4 over 1000 steps, cosine to 0.1)."""
+    from oracle import ref_shim
+    from super_gradients_amd.training.utils import callbacks as C
+    from super_gradients_amd.training.utils.utils import HpmStruct
+
+    tp = HpmStruct(max_epochs=5, lr_warmup_epochs=0, lr_warmup_steps=7, lr_cooldown_epochs=0, batch_accumulate=1, warmup_initial_lr=1e-6)
+    n = 10
+
+    class Opt:
+        param_groups = [{"name": "default", "lr": 0.0}]
+
+    ours = [C.LinearBatchLRWarmup(warmup_initial_lr=1e-6, initial_lr=2e-4, train_loader_len=n, lr_warmup_steps=7, training_params=tp, net=None),
+            C.CosineLRScheduler(max_epochs=5, cosine_final_lr_ratio=0.1, initial_lr=2e-4, update_param_groups=False, train_loader_len=n, net=None, training_params=tp)]
+    refs = None
+    if ref_shim.available():
+        ref_shim.install()
+        import super_gradients.training.utils.callbacks.callbacks as R
+
+        refs = [R.LinearBatchLRWarmup(warmup_initial_lr=1e-6, initial_lr=2e-4, train_loader_len=n, lr_warmup_steps=7, training_params=tp, net=None),
+                R.CosineLRScheduler(max_epochs=5, cosine_final_lr_ratio=0.1, initial_lr=2e-4, update_param_groups=False, train_loader_len=n, net=None,
+                                    training_params=tp)]
+    trace = []
+    for side in ([ours] + ([refs] if refs else [])):
+        o = Opt()
+        o.param_groups = [{"name": "default", "lr": 2e-4}]
+        vals = []
+        for epoch in range(5):
+            for b in range(n):
+                ctx = C.PhaseContext(epoch=epoch, batch_idx=b, optimizer=o)
+                side[0].on_train_batch_start(ctx)
+                vals.append(o.param_groups[0]["lr"])
+                side[1].on_train_batch_gradient_step_end(ctx) if hasattr(side[1], "on_train_batch_gradient_step_end") else side[1](ctx)
+        trace.append(vals)
+    v = trace[0]
+    assert abs(v[0] - 1e-6) < 1e-15 and abs(v[6] - 2e-4) < 1e-15  # linspace end points
+    it, max_it = 49 - 1 - 7, 50 - 7  # lr in force during the last batch was set after batch 48
+    expect = 0.5 * 2e-4 * (1 + math.cos(it / (max_it + 1) * math.pi)) * 0.9 + 2e-4 * 0.1
+    assert abs(v[-1] - expect) < 1e-15
+    if refs:
+        assert np.allclose(trace[0], trace[1], rtol=0, atol=1e-18)
+
+
+@pytest.mark.gpu
+def test_trainer_resnet18_cifar_recipe_shape(gpu_device, tmp_path):
+    """BASELINE.json configs[0] in miniature: ResNet-18 CIFAR, bs 32, SGD lr 0.1 momentum 0.9 wd 1e-4, CE, step LR
+    (recipes/training_hyperparams/cifar10_resnet_train_params.yaml) - a few batches through Trainer.train() against the same loop
+    on the CPU oracle with torch.optim.SGD."""
+    from oracle.resnet import build
+    from super_gradients_amd.training import Trainer, models
+
+    torch.manual_seed(1)
+    ref = build("resnet18_cifar", 10).train()
+    net = models.get("resnet18_cifar", num_classes=10)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(2)
+    loader = [(torch.randn(32, 3, 32, 32, generator=g), torch.randint(0, 10, (32,), generator=g)) for _ in range(4)]
+    tp = dict(max_epochs=1, lr_mode="StepLRScheduler", lr_updates=[100, 150, 200], lr_decay_factor=0.1, initial_lr=0.1, loss="CrossEntropyLoss", optimizer="SGD",
+              optimizer_params=dict(momentum=0.9, weight_decay=1e-4), silent_mode=True, valid_metrics_list=["Accuracy"], metric_to_watch="Accuracy")
+    trainer = Trainer("cifar_resnet18", ckpt_root_dir=str(tmp_path))
+    res = trainer.train(net, tp, loader, valid_loader=loader[:1])
+    o = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    tot = 0.0
+    for x, y in loader:
+        loss = F.cross_entropy(ref(x), y)
+        loss.backward()
+        o.step()
+        o.zero_grad()
+        tot += float(loss.detach()) * 32
+    assert abs(res[0]["train"]["CrossEntropyLoss"] - tot / 128) <= 2e-3 * tot / 128, (res[0], tot / 128)
+    sd = net.state_dict()
+    worst = max(float((sd[k].cpu() - v).norm() / v.norm().clamp_min(1e-6)) for k, v in ref.state_dict().items() if v.dtype.is_floating_point and v.dim() > 1)
+    assert worst <= 2e-2, f"weights after 4 SGD steps differ by {worst:.2e} (relative L2, worst tensor)"
