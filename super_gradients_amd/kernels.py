@@ -36,9 +36,10 @@ WORKSPACE = _Workspace()
 
 # --------------------------------------------------------------------------------------------- layout helpers
 def nhwc_strides(t: torch.Tensor) -> Tuple[int, int]:
-    if t.dim() != 4 or t.stride(3) != 1 or t.stride(1) != t.shape[2] * t.stride(2):
+    if t.dim() != 4 or t.stride(3) != 1 or (t.shape[1] > 1 and t.stride(1) != t.shape[2] * t.stride(2)):
         raise _lib.SgxError(f"tensor is not an NHWC view with contiguous channels: shape {tuple(t.shape)} strides {t.stride()}")
-    return t.stride(2), t.stride(0)
+    ld_pix = t.stride(2)
+    return ld_pix, (t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2] * ld_pix)  # strides of size-1 dims carry no information
 
 
 def rows(t: torch.Tensor) -> Tuple[int, int]:

@@ -22,7 +22,7 @@ def _tiny_models(device):
             super().__init__()
             self.c1 = Conv(4, 8, 3, 1, "relu")
             self.c2 = Conv(8, 8, 3, 2, "relu")
-            self.linear = LinearLayer(8, 4)
+            self.linear = LinearLayer(8, 6)  # 6 outputs: exercises the padded (multiple-of-4) linear path
 
         def _fwd(self, x):
             a = self.c2.fwd(self.c1.fwd(K.nchw_to_nhwc(x.float())))
@@ -45,7 +45,7 @@ def _tiny_models(device):
             self.c2 = nn.Sequential()
             self.c2.add_module("conv", nn.Conv2d(8, 8, 3, 2, 1, bias=False))
             self.c2.add_module("bn", nn.BatchNorm2d(8))
-            self.linear = nn.Linear(8, 4)
+            self.linear = nn.Linear(8, 6)
 
         def forward(self, x):
             x = F.relu(self.c1.bn(self.c1.conv(x)))
