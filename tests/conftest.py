@@ -22,6 +22,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU test")
 
 
+@pytest.fixture(autouse=True)
+def _seed_global_rng():
+    """Module constructors draw their initial weights from torch's global generator: seed it per test so that every test sees
+    the same weights whatever ran before it (parity checks with ReLU masks are deterministic then, not order-dependent)."""
+    import torch
+
+    torch.manual_seed(1234)
+    yield
+
+
 def _has_gpu():
     import torch
 
