@@ -147,6 +147,13 @@ def main():
     ig_ms, ig_fl, ig_n = K.prof_summary(0)
     wg_ms, wg_fl, wg_n = K.prof_summary(1)
     K.prof_enable(False)
+    # host side of one step: enqueue time of a step with the device idle at the start (no sync inside)
+    fence()
+    h0 = time.perf_counter()
+    for _ in range(2):
+        step()
+    host_ms = (time.perf_counter() - h0) / 2 * 1e3
+    fence()
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -162,7 +169,7 @@ def main():
         rec = {
             "metric": f"images/sec/node YOLO-NAS-{args.model.upper()} {args.size}x{args.size} train-step",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(host_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32", "data": "synthetic",
             "config": {"workload": f"YOLO-NAS-{args.model.upper()} synthetic COCO {args.size}x{args.size}, bs={args.batch}/GPU, PPYoloELoss(TAL)+AdamW"
                                    + ("" if args.no_ema else "+EMA") + ", random-init weights",

@@ -17,13 +17,14 @@ ACT = {None: 0, "none": 0, "relu": 1, "silu": 2}
 
 # --------------------------------------------------------------------------------------------- workspace
 class _Workspace:
-    """One grow-only scratch buffer per device.  Kernels that use it are ordered on the same stream."""
+    """One grow-only scratch buffer per (device, stream).  Kernels that share one are ordered on that stream; work forked
+    onto a side stream (weight gradients, modules/engine.py) gets its own."""
 
     def __init__(self):
         self.buf = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        key = str(device)
+        key = (str(device), torch.cuda.current_stream().cuda_stream if (torch.cuda.is_available() and not _lib._TEST_HOST_MODE) else 0)
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)

@@ -157,6 +157,12 @@ class SgxNetwork(nn.Module):
             m._buffers[bname] = self.i_arena[i]
         self._device = device
         self._materialized = True
+        # Weight gradients are independent of the data-gradient chain: they are forked onto a side HIP stream so that they fill
+        # the CUs the (dependent) main-stream kernels leave idle in their tails (most YOLO-NAS layers are 1-2 waves of
+        # workgroups).  SGX_SIDE_STREAM=0 disables the fork.
+        import os
+
+        self.side_stream = torch.cuda.Stream(device=device) if (device.type == "cuda" and os.environ.get("SGX_SIDE_STREAM", "1") != "0") else None
         for m in self.modules():
             if isinstance(m, SgxBlock):
                 object.__setattr__(m, "_net", self)  # plain attribute: must not register the network as a child module
@@ -170,6 +176,26 @@ class SgxNetwork(nn.Module):
                 raise RuntimeError("this model is materialized in HBM arenas; move it before the first forward, not after")
             return self
         return super()._apply(fn, recurse)
+
+    def fork_side(self, fn, *tensors):
+        """Run fn() on the side stream after everything enqueued so far on the current stream; `tensors` are what fn reads
+        (their memory must not be recycled by the caching allocator before the side stream is done with it)."""
+        side = getattr(self, "side_stream", None)
+        if side is None:
+            return fn()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            out = fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
+        return out
+
+    def join_side(self):
+        """Make the current stream wait for the side stream (before anything consumes the weight gradients)."""
+        side = getattr(self, "side_stream", None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
 
     def zero_grad(self, set_to_none: bool = False):
         if self._materialized:
@@ -233,6 +259,7 @@ class NetFunction(torch.autograd.Function):
     def backward(ctx, *grads):
         net = ctx.net
         net._bwd(*grads)
+        net.join_side()
         hook = getattr(net, "_post_backward_hook", None)
         if hook is not None:
             hook()

@@ -67,7 +67,8 @@ class ConvLayer(SgxBlock):
         return K.conv2d_fwd(x, self._w, bias=self.bias, addend=addend, out=out, act=act, stride=self.stride, pad=self.padding, stat_partials=stats)
 
     def wgrad(self, x, dy):
-        K.conv2d_bwd_weight(x, dy, self._gw, self.bias.grad if self.bias is not None else None, stride=self.stride, pad=self.padding)
+        self._net.fork_side(lambda: K.conv2d_bwd_weight(x, dy, self._gw, self.bias.grad if self.bias is not None else None, stride=self.stride,
+                                                        pad=self.padding), x, dy)
 
     def dgrad(self, dy, x_shape, out=None, accumulate=False, addend=None):
         return K.conv2d_bwd_data(dy, self._w, x_shape, stride=self.stride, pad=self.padding, addend=addend, out=out, accumulate=accumulate)
@@ -123,7 +124,7 @@ class ConvTranspose2x2(SgxBlock):
 
     def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
         x, self._x = self._x, None
-        K.convT2x2_bwd_weight(x, dy, self._gw, self.bias.grad)
+        self._net.fork_side(lambda: K.convT2x2_bwd_weight(x, dy, self._gw, self.bias.grad), x, dy)
         if not need_dx:
             return None
         if accumulate or addend is not None:

@@ -96,6 +96,7 @@ class GradientAllReducer:
             return
         a, b = self.ranges[prefix]
         self.issued.add(prefix)
+        self.net.join_side()  # the bucket's weight gradients were forked onto the side stream
         self.pending.append(dist.all_reduce(self.net.g_arena.buf[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):

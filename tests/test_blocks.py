@@ -56,6 +56,7 @@ def _check(ref, blk, x, device, tol=2e-5, key_prefix="b."):
     yd = blk.fwd(to_nhwc(x, device))
     assert_close(to_nchw_cpu(yd), y, tol, "forward")
     dx = blk.bwd(to_nhwc(dy, device))
+    net.join_side()  # weight gradients run on the network's side stream
     assert_close(to_nchw_cpu(dx), xr.grad, 5 * tol, "input gradient")
     rp = dict(ref.named_parameters())
     gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
