@@ -58,10 +58,13 @@ class QARepVGGBlock(SgxBlock):
         c3, bn3, c1, pbn = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1, self.post_bn
         res = x if self.use_residual_connection else None
         if self.training:
+            # the two branches read the same x and are independent: the 1x1 branch runs on the side stream beside the 3x3 one
+            t1 = torch.empty(K.conv_out_shape(x, self.out_channels, 1, 1, self.stride, 0), device=x.device, dtype=torch.float32)
+            self._net.fork_side(lambda: c1.conv(x, out=t1), x, t1)
             t3, parts = c3.conv(x, stats=True)
             M = t3.shape[0] * t3.shape[1] * t3.shape[2]
             sc3, sh3, m3, i3 = bn3.scale_shift(parts, M, True)
-            t1 = c1.conv(x)
+            self._net.join_side()
             s, parts_s = K.affine_act(t3, sc3, sh3, r1=t1, a1=self.alpha, r2=res, a2=1.0, out=t1, want_stats=True)  # s overwrites t1
             scp, shp, mp, ip = pbn.scale_shift(parts_s, M, True)
             y = K.affine_act(s, scp, shp, act=self.act, out=out)
