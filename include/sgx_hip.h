@@ -46,6 +46,9 @@ const char* sgx_last_error(void);
 int32_t sgx_prof_enable(int32_t on);
 int32_t sgx_prof_summary(int32_t cls, double* ms, double* flops, int64_t* launches);
 
+/* Measurement aid (tools/conv_tune.py): force the conv tile shapes (0 = built-in heuristic).  Not thread-safe; never set by the product. */
+int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk, int32_t wgrad_bj, int32_t wgrad_split_target);
+
 /* ---------------------------------------------------------------------------------------------
  * Convolution (implicit GEMM on fp32 MFMA, v_mfma_f32_32x32x2_f32).
  * Replaces torch.nn.functional.conv2d fwd/bwd issued by nn.Conv2d inside

@@ -450,7 +450,20 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 struct TileCfg {
     int bm, bn;
 };
+// measurement aid (tools/conv_tune.py): force tile shapes / split target; 0 = heuristic
+static int g_ovr_bm = 0, g_ovr_bn = 0, g_ovr_wk = 0, g_ovr_wj = 0, g_ovr_split = 0;
+extern "C" int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk, int32_t wgrad_bj, int32_t wgrad_split_target) {
+    g_ovr_bm = bm; g_ovr_bn = bn; g_ovr_wk = wgrad_bnk; g_ovr_wj = wgrad_bj; g_ovr_split = wgrad_split_target;
+    return SGX_OK;
+}
+static TileCfg pick_tile_heuristic(long M, int N);
 static TileCfg pick_tile(long M, int N) {
+    TileCfg t = pick_tile_heuristic(M, N);
+    if (g_ovr_bm) t.bm = g_ovr_bm;
+    if (g_ovr_bn) t.bn = g_ovr_bn;
+    return t;
+}
+static TileCfg pick_tile_heuristic(long M, int N) {
     // N tile: least channel padding among {32,64,96,128}, ties to the wider tile (more operand reuse).
     // M tile: 128 pixels unless that leaves the 256 CUs with fewer than two workgroups each.
     const int cand[4] = {32, 64, 96, 128};
@@ -902,14 +915,14 @@ extern "C" int64_t sgx_colsum_workspace(int64_t M, int32_t C);
 static WgradPlan wgrad_plan(const sgx_conv_desc* d) {
     WgradPlan pl;
     const int J = d->R * d->S * d->C;
-    pl.bnk = wg_tile(d->K);
-    pl.bj = wg_tile(J);
+    pl.bnk = g_ovr_wk ? g_ovr_wk : wg_tile(d->K);
+    pl.bj = g_ovr_wj ? g_ovr_wj : wg_tile(J);
     pl.waves = wg_waves(pl.bnk, pl.bj);
     pl.kt_tiles = sgx_cdiv(d->K, pl.bnk);
     pl.jt_tiles = sgx_cdiv(J, pl.bj);
     long M = (long)d->N * d->Ho * d->Wo;
     long tiles = (long)pl.kt_tiles * pl.jt_tiles;
-    long target = 4096 / pl.waves;            // ~4 waves per SIMD over the chip
+    long target = (g_ovr_split ? g_ovr_split : 4096) / pl.waves;  // ~4 waves per SIMD over the chip
     long ks = (target + tiles - 1) / tiles;
     long maxsplit = (M + 255) / 256;         // at least 256 pixels (16 slabs) per split
     if (ks > maxsplit) ks = maxsplit;

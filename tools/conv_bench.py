@@ -17,15 +17,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="s")
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--out", default=None)
-    args = ap.parse_args()
-
+def record_problems(model, batch, size, dev):
+    """One real train step; returns OrderedDict problem-key -> calls per step."""
     import torch
 
     from super_gradients_amd import kernels as K
@@ -33,13 +26,11 @@ def main():
     from super_gradients_amd.training.losses import PPYoloELoss
     from util import synthetic_targets
 
-    dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    net = models.get(f"yolo_nas_{args.model}", num_classes=80).materialize(dev).train()
-    x = torch.rand(args.batch, 3, args.size, args.size, device=dev)
-    t = synthetic_targets(args.batch, seed=0, kmax=20, size=args.size).to(dev)
+    net = models.get(f"yolo_nas_{model}", num_classes=80).materialize(dev).train()
+    x = torch.rand(batch, 3, size, size, device=dev)
+    t = synthetic_targets(batch, seed=0, kmax=20, size=size).to(dev)
     crit = PPYoloELoss(80, use_static_assigner=False)
-
     rec = collections.OrderedDict()
     orig = (K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight)
 
@@ -49,8 +40,7 @@ def main():
     def fwd(x, w, bias=None, addend=None, out=None, act=None, stride=1, pad=0, stat_partials=False):
         y = orig[0](x, w, bias=bias, addend=addend, out=out, act=act, stride=stride, pad=pad, stat_partials=stat_partials)
         yo = y[0] if stat_partials else y
-        k = key_of("fwd", x.shape, w.shape[0], w.shape[2], stride, pad, x.stride(2), yo.stride(2),
-                   (bias is not None, addend is not None, act, stat_partials))
+        k = key_of("fwd", x.shape, w.shape[0], w.shape[2], stride, pad, x.stride(2), yo.stride(2), (bias is not None, addend is not None, act, stat_partials))
         rec[k] = rec.get(k, 0) + 1
         return y
 
@@ -66,37 +56,66 @@ def main():
         rec[k] = rec.get(k, 0) + 1
 
     K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight = fwd, dgrad, wgrad
-    loss, _ = crit(net(x), t)
-    loss.backward()
-    K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight = orig
+    try:
+        loss, _ = crit(net(x), t)
+        loss.backward()
+    finally:
+        K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight = orig
     torch.cuda.synchronize()
+    del net
+    return rec
+
+
+def make_runner(k, dev):
+    """-> (callable replaying the problem once, its algorithmic FLOPs)"""
+    import torch
+
+    from super_gradients_amd import kernels as K
 
     def buf(n, h, w, c, ld):
         return torch.randn(n, h, w, ld, device=dev)[..., :c]
 
+    kind, n, h, w, c, K_, R, stride, pad, xl, yl = k[:11]
+    extra = k[11:]
+    ho, wo = (h + 2 * pad - R) // stride + 1, (w + 2 * pad - R) // stride + 1
+    xin = buf(n, h, w, c, xl)
+    yout = buf(n, ho, wo, K_, yl)
+    wt = K.to_ohwi(torch.randn(K_, c, R, R, device=dev) / (c * R * R) ** 0.5)
+    flops = 2.0 * n * ho * wo * K_ * c * R * R
+    if kind == "fwd":
+        has_b, has_add, act, stats = extra
+        b = torch.randn(K_, device=dev) if has_b else None
+        add = buf(n, ho, wo, K_, yl) if has_add else None
+        return (lambda: K.conv2d_fwd(xin, wt, bias=b, addend=add, out=yout, act=act, stride=stride, pad=pad, stat_partials=stats)), flops
+    if kind == "dgrad":
+        has_add, acc = extra
+        add = buf(n, h, w, c, xl) if has_add else None
+        return (lambda: K.conv2d_bwd_data(yout, wt, (n, h, w, c), stride=stride, pad=pad, addend=add, out=xin, accumulate=acc)), flops
+    (has_b,) = extra
+    dw = torch.zeros_like(wt)
+    db = torch.zeros(K_, device=dev) if has_b else None
+    return (lambda: K.conv2d_bwd_weight(xin, yout, dw, db, stride=stride, pad=pad)), flops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="s")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+
+    import torch
+
+    os.environ["SGX_SIDE_STREAM"] = "0"  # isolated per-kernel timing
+    dev = torch.device("cuda:0")
+    rec = record_problems(args.model, args.batch, args.size, dev)
     rows = []
     for k, calls in rec.items():
         kind, n, h, w, c, K_, R, stride, pad, xl, yl = k[:11]
         extra = k[11:]
-        ho, wo = (h + 2 * pad - R) // stride + 1, (w + 2 * pad - R) // stride + 1
-        xin = buf(n, h, w, c, xl)
-        yout = buf(n, ho, wo, K_, yl)
-        wt = K.to_ohwi(torch.randn(K_, c, R, R, device=dev) / (c * R * R) ** 0.5)
-        flops = 2.0 * n * ho * wo * K_ * c * R * R
-        if kind == "fwd":
-            has_b, has_add, act, stats = extra
-            b = torch.randn(K_, device=dev) if has_b else None
-            add = buf(n, ho, wo, K_, yl) if has_add else None
-            fn = lambda: orig[0](xin, wt, bias=b, addend=add, out=yout, act=act, stride=stride, pad=pad, stat_partials=stats)  # noqa: E731
-        elif kind == "dgrad":
-            has_add, acc = extra
-            add = buf(n, h, w, c, xl) if has_add else None
-            fn = lambda: orig[1](yout, wt, (n, h, w, c), stride=stride, pad=pad, addend=add, out=xin, accumulate=acc)  # noqa: E731
-        else:
-            (has_b,) = extra
-            dw = torch.zeros_like(wt)
-            db = torch.zeros(K_, device=dev) if has_b else None
-            fn = lambda: orig[2](xin, yout, dw, db, stride=stride, pad=pad)  # noqa: E731
+        fn, flops = make_runner(k, dev)
         fn()
         fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

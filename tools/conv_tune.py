@@ -1,0 +1,83 @@
+"""Exhaustive tile search over the conv problems of one train step (measurement tool; uses sgx_debug_set_tiles).
+
+    python tools/conv_tune.py [--model s] [--batch 32] [--size 640] [--out gpurun_out/conv_tune.txt]
+For every distinct problem recorded by tools/conv_bench.py's recorder: time the heuristic choice and every legal override,
+print the best and the gain.  Output feeds the tile heuristics in csrc/conv.hip (pick_tile_heuristic / wgrad_plan)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="s")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    import torch
+
+    import conv_bench as CB
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd._lib import lib
+
+    os.environ["SGX_SIDE_STREAM"] = "0"
+    dev = torch.device("cuda:0")
+    rec = CB.record_problems(args.model, args.batch, args.size, dev)
+
+    def timeit(fn):
+        try:
+            fn()
+        except Exception:
+            return float("inf")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / args.iters
+
+    lines = []
+    tot_base = tot_best = 0.0
+    for key, calls in rec.items():
+        kind = key[0]
+        fn, flops = CB.make_runner(key, dev)
+        lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
+        base = timeit(fn)
+        best, best_cfg = base, "heuristic"
+        if kind in ("fwd", "dgrad"):
+            stats = kind == "fwd" and key[11:][3]
+            for bm in (64, 128):
+                for bn in (32, 64, 96, 128):
+                    lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                    t = timeit(fn)
+                    if t < best:
+                        best, best_cfg = t, f"bm={bm} bn={bn}"
+        else:
+            for bnk in (32, 64, 96, 128):
+                for bj in (32, 64, 96, 128):
+                    for split in (2048, 4096, 8192):
+                        lib().sgx_debug_set_tiles(0, 0, bnk, bj, split)
+                        t = timeit(fn)
+                        if t < best:
+                            best, best_cfg = t, f"bnk={bnk} bj={bj} split={split}"
+        lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
+        tot_base += calls * base
+        tot_best += calls * best
+        lines.append((calls * (base - best), f"{kind:<6}{key[1:11]} x{calls:<3} heuristic {base:8.1f} us  best {best:8.1f} us ({flops / best / 1e6:6.1f} TF)  {best_cfg}"))
+    lines.sort(key=lambda t: -t[0])
+    text = "\n".join([f"# conv tile search: heuristic {tot_base / 1e3:.2f} ms/step -> best-per-problem {tot_best / 1e3:.2f} ms/step"] + [l for _, l in lines])
+    print(text)
+    if args.out:
+        open(args.out, "w").write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()
