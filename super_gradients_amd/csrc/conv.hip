@@ -464,21 +464,15 @@ static TileCfg pick_tile(long M, int N) {
     return t;
 }
 static TileCfg pick_tile_heuristic(long M, int N) {
-    // N tile: least channel padding among {32,64,96,128}, ties to the wider tile (more operand reuse).
-    // M tile: 128 pixels unless that leaves the 256 CUs with fewer than two workgroups each.
-    const int cand[4] = {32, 64, 96, 128};
-    int bn = 128, best = 1 << 30;
-    for (int i = 0; i < 4; ++i) {
-        int padded = ((N + cand[i] - 1) / cand[i]) * cand[i];
-        if (padded <= best) {
-            best = padded;
-            bn = cand[i];
-        }
-    }
-    int bm = 128;
-    long blocks = ((M + 127) / 128) * ((N + bn - 1) / bn);
-    if (blocks < 512) bm = 64;
-    return TileCfg{bm, bn};
+    // Measured (tools/conv_tune.py, profiles/r1m_conv_tune.txt: exhaustive search over the 201 conv problems of a YOLO-NAS-S
+    // step): the 64x64 tile (4 waves x one 32x32 accumulator, 36 VGPRs, 22 KB LDS -> 7 workgroups per CU) wins on 83 of 140
+    // forward / data-gradient problems, large ones included - occupancy and fine tail granularity beat operand reuse on this
+    // matrix pipe (64 cycles per MFMA leave the LDS and L2 idle anyway).  Exceptions: output-channel counts that 64 pads badly
+    // (96 = 3 x 32: a 128x32 tile; large-M 96-wide layers keep 128x96).
+    const int p64 = ((N + 63) / 64) * 64, p32 = ((N + 31) / 32) * 32;
+    if (p64 == p32) return TileCfg{64, 64};
+    if (N % 96 == 0 && M >= 200000) return TileCfg{128, 96};
+    return TileCfg{M >= 16384 ? 128 : 64, 32};
 }
 
 template <int BM, int BN, int WM, int WN, bool FLAT>
@@ -915,14 +909,22 @@ extern "C" int64_t sgx_colsum_workspace(int64_t M, int32_t C);
 static WgradPlan wgrad_plan(const sgx_conv_desc* d) {
     WgradPlan pl;
     const int J = d->R * d->S * d->C;
-    pl.bnk = g_ovr_wk ? g_ovr_wk : wg_tile(d->K);
-    pl.bj = g_ovr_wj ? g_ovr_wj : wg_tile(J);
+    // tile choice from the same exhaustive search: 64x64 where the channel count allows, 96x128 for 96-wide layers
+    int bnk = wg_tile(d->K), bj;
+    if (d->K % 128 == 0 && d->K >= 384) bnk = 128;
+    else if (d->K % 64 == 0) bnk = 64;
+    else if (d->K % 96 == 0) bnk = 96;
+    if (bnk == 96) bj = J >= 128 ? 128 : wg_tile(J);
+    else if (bnk == 32) bj = J >= 128 ? 128 : wg_tile(J);
+    else bj = J >= 64 ? 64 : wg_tile(J);
+    pl.bnk = g_ovr_wk ? g_ovr_wk : bnk;
+    pl.bj = g_ovr_wj ? g_ovr_wj : bj;
     pl.waves = wg_waves(pl.bnk, pl.bj);
     pl.kt_tiles = sgx_cdiv(d->K, pl.bnk);
     pl.jt_tiles = sgx_cdiv(J, pl.bj);
     long M = (long)d->N * d->Ho * d->Wo;
     long tiles = (long)pl.kt_tiles * pl.jt_tiles;
-    long target = (g_ovr_split ? g_ovr_split : 4096) / pl.waves;  // ~4 waves per SIMD over the chip
+    long target = (g_ovr_split ? g_ovr_split : (pl.bnk == 64 && pl.bj == 64 ? 8192 : 4096)) / pl.waves;  // 4-8 waves per SIMD over the chip
     long ks = (target + tiles - 1) / tiles;
     long maxsplit = (M + 255) / 256;         // at least 256 pixels (16 slabs) per split
     if (ks > maxsplit) ks = maxsplit;
