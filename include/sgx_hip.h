@@ -81,6 +81,13 @@ int64_t sgx_conv2d_bwd_data_workspace(const sgx_conv_desc* d);
 int32_t sgx_conv2d_bwd_data(const sgx_conv_desc* d, const float* dy, const float* w, const float* addend,
                             float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream);
 
+/* The data gradient reads the weights transposed per output-parity class ([c][tap][k]).  sgx_conv2d_bwd_data does that transpose
+ * into its workspace on every call; a caller that knows the weights are fixed between forward and backward can do it ahead of
+ * time (e.g. on a side stream under the forward pass) into a buffer of sgx_conv2d_bwd_data_workspace(d) bytes and call the _wt form. */
+int32_t sgx_conv2d_transpose_weights(const sgx_conv_desc* d, const float* w, float* wt, int64_t wt_bytes, void* stream);
+int32_t sgx_conv2d_bwd_data_wt(const sgx_conv_desc* d, const float* dy, const float* wt, const float* addend, float* dx,
+                               int32_t accumulate, void* stream);
+
 /* dw[k][r][s][c] += sum_pixels dy * x   (accumulates into dw: callers zero the gradient arena once per
  * optimizer step).  dbias[k] += sum dy if dbias != NULL.  ws: sgx_conv2d_bwd_weight_workspace(d).  */
 int64_t sgx_conv2d_bwd_weight_workspace(const sgx_conv_desc* d);

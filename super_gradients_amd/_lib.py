@@ -60,6 +60,8 @@ PROTOTYPES = {
     "sgx_conv2d_fwd_stat_blocks": (_i32, [_CD]),
     "sgx_conv2d_bwd_data_workspace": (_i64, [_CD]),
     "sgx_conv2d_bwd_data": (_i32, [_CD, _P, _P, _P, _P, _i32, _P, _i64, _P]),
+    "sgx_conv2d_transpose_weights": (_i32, [_CD, _P, _P, _i64, _P]),
+    "sgx_conv2d_bwd_data_wt": (_i32, [_CD, _P, _P, _P, _P, _i32, _P]),
     "sgx_conv2d_bwd_weight_workspace": (_i64, [_CD]),
     "sgx_conv2d_bwd_weight": (_i32, [_CD, _P, _P, _P, _P, _P, _i64, _P]),
     "sgx_convT2x2_workspace": (_i64, [_i32] * 5),

@@ -618,17 +618,26 @@ extern "C" int64_t sgx_conv2d_bwd_data_workspace(const sgx_conv_desc* d) {
     return (int64_t)d->R * d->S * d->C * d->K * sizeof(float) + 256;
 }
 
+// mode 0: transpose the weights into ws, then run; mode 1: only transpose (dy/dx unused); mode 2: ws already holds the transposed
+// weights of sgx_conv2d_transpose_weights (the host mirror prepares them on a side stream during the forward pass)
 static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const float* w, const float* bias, const float* addend,
-                                  float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream);
+                                  float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream, int mode);
 extern "C" int32_t sgx_conv2d_bwd_data(const sgx_conv_desc* d, const float* dy, const float* w, const float* addend,
                                        float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream) {
-    return conv_bwd_data_impl(d, dy, w, nullptr, addend, dx, accumulate, ws, ws_bytes, stream);
+    return conv_bwd_data_impl(d, dy, w, nullptr, addend, dx, accumulate, ws, ws_bytes, stream, 0);
+}
+extern "C" int32_t sgx_conv2d_transpose_weights(const sgx_conv_desc* d, const float* w, float* wt, int64_t wt_bytes, void* stream) {
+    return conv_bwd_data_impl(d, nullptr, w, nullptr, nullptr, nullptr, 0, wt, wt_bytes, stream, 1);
+}
+extern "C" int32_t sgx_conv2d_bwd_data_wt(const sgx_conv_desc* d, const float* dy, const float* wt, const float* addend, float* dx,
+                                          int32_t accumulate, void* stream) {
+    return conv_bwd_data_impl(d, dy, nullptr, nullptr, addend, dx, accumulate, const_cast<float*>(wt), sgx_conv2d_bwd_data_workspace(d), stream, 2);
 }
 static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const float* w, const float* bias, const float* addend,
-                                  float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream) {
+                                  float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream, int mode) {
     int32_t rc = check_desc(d);
     if (rc) return rc;
-    SGX_CHECK_ARG(dy && w && dx, "conv bwd_data: null pointer");
+    SGX_CHECK_ARG((mode == 1 || (dy && dx)) && (mode == 2 || w), "conv bwd_data: null pointer");
     SGX_CHECK_ARG(d->K % 4 == 0 && d->y_ld_pix % 4 == 0, "conv bwd_data: K and dy pixel stride must be multiples of 4");
     if (ws_bytes < sgx_conv2d_bwd_data_workspace(d) || !ws) SGX_FAIL(SGX_ERR_WORKSPACE, "conv bwd_data: workspace too small");
     const int s = d->stride;
@@ -665,6 +674,7 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
             p.w_bytes = (long)d->C * p.w_ld_n * 4;
             p.act = SGX_ACT_NONE; p.accumulate = accumulate;
             if (T == 0) {
+                if (mode == 1) continue;
                 // no filter tap reaches this parity class (e.g. 1x1 stride 2): nothing to add when accumulating
                 if (accumulate && !addend && !bias) continue;
                 long n = (long)p.M * (p.Nout / 4);
@@ -673,14 +683,18 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
                 SGX_CHECK_LAUNCH("dgrad_fill");
                 continue;
             }
-            long n = (long)d->C * T * d->K;
-            int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-            SGX_LAUNCH(wtrans_kernel, dim3(grid), dim3(256), 0, stream, w, wt, d->K, d->C, d->R * d->S, T, taps);
-            SGX_CHECK_LAUNCH("wtrans");
-            TileCfg t = igemm_tile(p);
-            TileCfg m = pick_tile(p.M, p.Nout);
-            rc = run_igemm(p, m.bm, t.bn, stream);
-            if (rc) return rc;
+            if (mode != 2) {
+                long n = (long)d->C * T * d->K;
+                int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+                SGX_LAUNCH(wtrans_kernel, dim3(grid), dim3(256), 0, stream, w, wt, d->K, d->C, d->R * d->S, T, taps);
+                SGX_CHECK_LAUNCH("wtrans");
+            }
+            if (mode != 1) {
+                TileCfg t = igemm_tile(p);
+                TileCfg m = pick_tile(p.M, p.Nout);
+                rc = run_igemm(p, m.bm, t.bn, stream);
+                if (rc) return rc;
+            }
             wt += (long)d->C * T * d->K;
         }
     return SGX_OK;
@@ -1029,7 +1043,7 @@ extern "C" int32_t sgx_convT2x2_fwd(int32_t N, int32_t H, int32_t W, int32_t C, 
                                     const float* wt, const float* bias, float* y, int64_t y_ld_pix, int64_t y_ld_img, void* ws,
                                     int64_t ws_bytes, void* stream) {
     sgx_conv_desc d = convT_adjoint_desc(N, H, W, C, K, x_ld_pix, x_ld_img, y_ld_pix, y_ld_img);
-    return conv_bwd_data_impl(&d, x, wt, bias, nullptr, y, 0, ws, ws_bytes, stream);
+    return conv_bwd_data_impl(&d, x, wt, bias, nullptr, y, 0, ws, ws_bytes, stream, 0);
 }
 extern "C" int32_t sgx_convT2x2_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const float* dy, int64_t dy_ld_pix,
                                          int64_t dy_ld_img, const float* wt, float* dx, int64_t dx_ld_pix, int64_t dx_ld_img, void* stream) {

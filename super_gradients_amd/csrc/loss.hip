@@ -122,20 +122,19 @@ __device__ __forceinline__ void softmax_expect(const float* d, int R1, float& e)
     }
     e = acc / s;
 }
+// One thread per (anchor, side): a wave reads 64 consecutive (R+1)-float rows (contiguous memory) and writes 64 consecutive box
+// coordinates; the per-side arithmetic is unchanged.
 __global__ void decode_kernel(int B, int L, int R1, const float* distri, const float* points_grid, const float* strides, float mul_stride,
                               float* boxes) {
-    long n = (long)B * L;
+    long n = (long)B * L * 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        int l = (int)(i % L);
-        const float* d = distri + i * 4 * R1;
-        float e[4];
-        for (int k = 0; k < 4; ++k) softmax_expect(d + k * R1, R1, e[k]);
-        float px = points_grid[2 * l], py = points_grid[2 * l + 1];
-        float s = mul_stride != 0.f ? strides[l] : 1.f;
-        boxes[i * 4 + 0] = (px - e[0]) * s;
-        boxes[i * 4 + 1] = (py - e[1]) * s;
-        boxes[i * 4 + 2] = (px + e[2]) * s;
-        boxes[i * 4 + 3] = (py + e[3]) * s;
+        const int k = (int)(i & 3);
+        const int l = (int)((i >> 2) % L);
+        float e;
+        softmax_expect(distri + i * R1, R1, e);
+        const float pc = points_grid[2 * l + (k & 1)];
+        const float s = mul_stride != 0.f ? strides[l] : 1.f;
+        boxes[i] = (k < 2 ? pc - e : pc + e) * s;
     }
 }
 __global__ void sigmoid_kernel(const float* x, float* y, long n) {
@@ -144,8 +143,8 @@ __global__ void sigmoid_kernel(const float* x, float* y, long n) {
 extern "C" int32_t sgx_dfl_decode(int32_t B, int32_t L, int32_t C, int32_t reg_max, const float* logits, const float* distri,
                                   const float* points_grid, const float* strides, float* boxes, float* scores, void* stream) {
     SGX_CHECK_ARG(distri && points_grid && strides && boxes, "dfl_decode: null pointer");
-    long n = (long)B * L, blocks = (n + 255) / 256;
-    SGX_LAUNCH(decode_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, stream, B, L, reg_max + 1, distri, points_grid,
+    long n = (long)B * L, blocks = (4 * n + 255) / 256;
+    SGX_LAUNCH(decode_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, stream, B, L, reg_max + 1, distri, points_grid,
                strides, 1.f, boxes);
     SGX_CHECK_LAUNCH("dfl_decode");
     if (scores) {
@@ -596,18 +595,14 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(const float* partials, i
 
 // decode from PIXEL anchor points: grid point = point / stride (ppyolo_loss.py:803-804)
 __global__ void decode_px_kernel(int B, int L, int R1, const float* distri, const float* points, const float* strides, float* boxes) {
-    long n = (long)B * L;
+    long n = (long)B * L * 4;  // one thread per (anchor, side), see decode_kernel
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        int l = (int)(i % L);
-        const float* dd = distri + i * 4 * R1;
-        float e[4];
-        for (int k = 0; k < 4; ++k) softmax_expect(dd + k * R1, R1, e[k]);
-        float s = strides[l];
-        float px = points[2 * l] / s, py = points[2 * l + 1] / s;
-        boxes[i * 4 + 0] = px - e[0];
-        boxes[i * 4 + 1] = py - e[1];
-        boxes[i * 4 + 2] = px + e[2];
-        boxes[i * 4 + 3] = py + e[3];
+        const int k = (int)(i & 3);
+        const int l = (int)((i >> 2) % L);
+        float e;
+        softmax_expect(distri + i * R1, R1, e);
+        const float pc = points[2 * l + (k & 1)] / strides[l];
+        boxes[i] = k < 2 ? pc - e : pc + e;
     }
 }
 
@@ -637,7 +632,7 @@ extern "C" int32_t sgx_ppyoloe_loss_fwd(const sgx_loss_desc* d, const float* log
     SGX_MEMSET_ASYNC(w.maxi, 0, (long)d->B * (d->nmax > 0 ? d->nmax : 1) * 4, st);
     long blocks = (BL + 255) / 256;
     // 1. decode pred boxes (grid units)
-    SGX_LAUNCH(decode_px_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, stream, d->B, d->L, d->reg_max + 1, distri, points,
+    SGX_LAUNCH(decode_px_kernel, dim3((unsigned)(4 * blocks > 16384 ? 16384 : 4 * blocks)), dim3(256), 0, stream, d->B, d->L, d->reg_max + 1, distri, points,
                strides, w.pbox);
     SGX_CHECK_LAUNCH("decode_px");
     if (d->nmax > 0) {

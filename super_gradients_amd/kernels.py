@@ -123,6 +123,37 @@ def conv2d_bwd_data(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, accu
     return out
 
 
+def conv2d_wt_buffer(w, device):
+    """Persistent buffer for the pre-transposed weights of a conv (see conv2d_transpose_weights)."""
+    K, C, R, S = w.shape
+    return torch.empty(K * C * R * S + 64, device=device, dtype=torch.float32)
+
+
+def _wt_desc(w, stride, pad):
+    # the transpose depends only on (K, C, R, S, stride, pad); spatial sizes are placeholders that satisfy the descriptor checks
+    K, C, R, S = w.shape
+    h = max(R, stride) + 2
+    x = torch.empty(0, device=w.device).new_empty((1, h, h, C))
+    return conv_desc(x, K, R, S, stride, pad)
+
+
+def conv2d_transpose_weights(w, wt, stride=1, pad=0):
+    d = _wt_desc(w, stride, pad)
+    check(lib().sgx_conv2d_transpose_weights(ctypes.byref(d), ptr(w), ptr(wt), wt.numel() * 4, stream()), "sgx_conv2d_transpose_weights")
+
+
+def conv2d_bwd_data_wt(dy, w, wt, x_shape, stride=1, pad=0, addend=None, out=None, accumulate=False):
+    """conv2d_bwd_data with weights already transposed into `wt` by conv2d_transpose_weights (same stride / pad)."""
+    K, C, R, S = w.shape
+    if out is None:
+        out = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+    d = conv_desc(out, K, R, S, stride, pad, dy)
+    if addend is not None and nhwc_strides(addend) != nhwc_strides(out):
+        raise _lib.SgxError("bwd_data addend must share dx's strides")
+    check(lib().sgx_conv2d_bwd_data_wt(ctypes.byref(d), ptr(dy), ptr(wt), ptr(addend), ptr(out), int(accumulate), stream()), "sgx_conv2d_bwd_data_wt")
+    return out
+
+
 def conv2d_bwd_weight(x, dy, dw, dbias=None, stride=1, pad=0):
     """dw (logical [K,C,R,S], OHWI memory) += grad; dbias += column sums."""
     K, C, R, S = dw.shape

@@ -163,11 +163,31 @@ class SgxNetwork(nn.Module):
         import os
 
         self.side_stream = torch.cuda.Stream(device=device) if (device.type == "cuda" and os.environ.get("SGX_SIDE_STREAM", "1") != "0") else None
+        # The data gradient wants the weights transposed per parity class; they are fixed between forward and backward, so all of
+        # them are transposed on a third stream underneath the forward pass (one tiny launch per layer, off the critical path).
+        self.aux_stream = torch.cuda.Stream(device=device) if self.side_stream is not None else None
+        self._wt_valid = False
         for m in self.modules():
             if isinstance(m, SgxBlock):
                 object.__setattr__(m, "_net", self)  # plain attribute: must not register the network as a child module
                 m.on_materialize()
+        self._dgrad_convs = [m for m in self.modules() if hasattr(m, "transpose_weights")]
         return self
+
+    def prefetch_dgrad_weights(self):
+        aux = getattr(self, "aux_stream", None)
+        if aux is None:
+            return
+        aux.wait_stream(torch.cuda.current_stream())  # after the optimizer step that produced the current weights
+        with torch.cuda.stream(aux):
+            for m in self._dgrad_convs:
+                m.transpose_weights()
+        self._wt_valid = True
+
+    def join_aux(self):
+        aux = getattr(self, "aux_stream", None)
+        if aux is not None and self._wt_valid:
+            torch.cuda.current_stream().wait_stream(aux)
 
     def _apply(self, fn, recurse=True):
         if self._materialized:
@@ -251,6 +271,7 @@ class NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, anchor):
         ctx.net = net
+        net.prefetch_dgrad_weights()
         flat = tuple(net._fwd(x))
         ctx.mark_non_differentiable(*[t for t, d in zip(flat, net._differentiable_outputs(len(flat))) if not d])
         return flat
@@ -258,7 +279,9 @@ class NetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         net = ctx.net
+        net.join_aux()
         net._bwd(*grads)
+        net._wt_valid = False
         net.join_side()
         hook = getattr(net, "_post_backward_hook", None)
         if hook is not None:

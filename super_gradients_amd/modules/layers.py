@@ -62,6 +62,10 @@ class ConvLayer(SgxBlock):
         slots = {s.param: s for s in self._net.slots}
         s = slots[self.weight]
         self._w, self._gw = s.kernel_view, s.grad_kernel_view
+        self._wt = K.conv2d_wt_buffer(self._w, self._w.device) if self._net.aux_stream is not None else None
+
+    def transpose_weights(self):
+        K.conv2d_transpose_weights(self._w, self._wt, stride=self.stride, pad=self.padding)
 
     def conv(self, x, out=None, act=None, addend=None, stats=False):
         return K.conv2d_fwd(x, self._w, bias=self.bias, addend=addend, out=out, act=act, stride=self.stride, pad=self.padding, stat_partials=stats)
@@ -71,6 +75,8 @@ class ConvLayer(SgxBlock):
                                                         pad=self.padding), x, dy)
 
     def dgrad(self, dy, x_shape, out=None, accumulate=False, addend=None):
+        if self._wt is not None and self._net._wt_valid:  # transposed under the forward pass (engine.prefetch_dgrad_weights)
+            return K.conv2d_bwd_data_wt(dy, self._w, self._wt, x_shape, stride=self.stride, pad=self.padding, addend=addend, out=out, accumulate=accumulate)
         return K.conv2d_bwd_data(dy, self._w, x_shape, stride=self.stride, pad=self.padding, addend=addend, out=out, accumulate=accumulate)
 
 

@@ -107,6 +107,11 @@ def test_conv_bwd(backend, idx):
     dyd = to_nhwc(dy, backend)
     dx = K.conv2d_bwd_data(dyd, wd, tuple(xd.shape), stride=s, pad=p)
     assert_close(to_nchw_cpu(dx), x.grad, TOL, f"dgrad {shape}")
+    # weights transposed ahead of time (what the engine does under the forward pass): identical result
+    wtb = K.conv2d_wt_buffer(wd, backend)
+    K.conv2d_transpose_weights(wd, wtb, stride=s, pad=p)
+    dx3 = K.conv2d_bwd_data_wt(dyd, wd, wtb, tuple(xd.shape), stride=s, pad=p)
+    assert torch.equal(dx3.cpu(), dx.cpu()), f"dgrad with pre-transposed weights {shape}"
     # accumulate + addend form
     add = torch.randn(x.shape, generator=torch.Generator().manual_seed(3))
     dx2 = to_nhwc(torch.ones_like(x.detach()), backend)
