@@ -165,7 +165,7 @@ class SgxNetwork(nn.Module):
         self.side_stream = torch.cuda.Stream(device=device) if (device.type == "cuda" and os.environ.get("SGX_SIDE_STREAM", "1") != "0") else None
         # The data gradient wants the weights transposed per parity class; they are fixed between forward and backward, so all of
         # them are transposed on a third stream underneath the forward pass (one tiny launch per layer, off the critical path).
-        self.aux_stream = torch.cuda.Stream(device=device) if self.side_stream is not None else None
+        self.aux_stream = torch.cuda.Stream(device=device) if (self.side_stream is not None and os.environ.get("SGX_AUX_STREAM", "1") != "0") else None
         self._wt_valid = False
         for m in self.modules():
             if isinstance(m, SgxBlock):
