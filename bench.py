@@ -78,6 +78,108 @@ def cpu_baseline(model, size, seconds_budget=25.0):
                       f"{threads} threads of {cores} host cores"}
 
 
+def nms_leg(device, iters=100, warmup=10):
+    """BASELINE.json's second metric: NMS boxes/s.  SURVEY 8(d) config-5 style input: B=32 images, L=8400 anchors, 80 classes, scores
+    ~ Beta(0.5,0.5)^4 and boxes clustered around 30 centres so that every image has >= 1000 candidates above the recipe's
+    thresholds (score 0.01, top-k 1000, IoU 0.7, max 300, class-agnostic).  boxes/s = candidates entering NMS (after threshold +
+    top-k, summed over the batch) / device time of the whole post-prediction call, HIP-event timed.  CPU beside it: the C
+    restatement of torchvision's kernel (oracle/nms.c, single thread, as torchvision's CPU kernel is) on the same candidates."""
+    import numpy as np
+    import torch
+
+    from oracle import nms as onms
+    from super_gradients_amd import kernels as K
+
+    B, L, C = 32, 8400, 80
+    g = np.random.RandomState(0)
+    cen = g.uniform(96, 544, (B, 30, 2))
+    which = g.randint(0, 30, (B, L))
+    c = np.take_along_axis(cen, which[..., None].repeat(2, -1), 1) + g.normal(0, 8, (B, L, 2))
+    wh = g.uniform(20, 160, (B, L, 2))
+    boxes = torch.from_numpy(np.concatenate([c - wh / 2, c + wh / 2], -1).astype(np.float32)).to(device)
+    scores = torch.from_numpy((g.beta(0.5, 0.5, (B, L, C)) ** 4).astype(np.float32)).to(device)
+    args = (0.01, 0.7, 1000, 300)
+
+    def run():
+        return K.nms(boxes, scores, *args, multi_label=True, class_mode=0)
+
+    for _ in range(warmup):
+        out = run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        out = run()
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    ncand = int(torch.clamp(out[3], max=1000).sum())
+    kept = int(out[1].sum())
+    # CPU: the NMS proper on the same top-k candidates of 4 images (bounded sample)
+    t0 = time.perf_counter()
+    n_cpu = 0
+    for b in range(4):
+        sc, bx = scores[b].cpu(), boxes[b].cpu()
+        i, j = (sc > 0.01).nonzero(as_tuple=False).T
+        conf = sc[i, j]
+        top = torch.topk(conf, 1000).indices
+        onms.nms(bx[i][top], conf[top], 0.7)
+        n_cpu += 1000
+    cpu_s = time.perf_counter() - t0
+    return {"value": round(ncand / (ms * 1e-3), 1), "unit": "boxes/s", "ms_per_batch": round(ms, 4), "candidates": ncand, "kept": kept, "batch": B,
+            "config": "B=32 L=8400 C=80 multi-label, score>0.01, top-k 1000, IoU 0.7, max 300, class-agnostic",
+            "cpu_baseline": {"value": round(n_cpu / cpu_s, 1), "unit": "boxes/s", "cores": 1, "kind": "port",
+                             "sample": "4 images x 1000 candidates: threshold + top-k (ATen) + oracle/nms.c"}}
+
+
+def measured_traffic():
+    """HBM bytes per igemm launch from the committed rocprofv3 PMC passes of this same command (profiles/igemm_traffic.json,
+    written by tools/pmc_traffic.py from the FETCH_SIZE / WRITE_SIZE passes, with MI355X_MICROARCH.md's gfx950 correction)."""
+    f = os.path.join(ROOT, "profiles", "igemm_traffic.json")
+    if not os.path.exists(f):
+        return None, None
+    d = json.load(open(f))
+    return d.get("bytes_per_launch"), d.get("source")
+
+
+def resnet50_main(args):
+    """BASELINE.json configs[1]: ResNet-50, synthetic 224x224, bs 64, forward + backward only (no optimizer), 1 GPU."""
+    import torch
+
+    from super_gradients_amd.training import models
+    from super_gradients_amd.training.losses import CrossEntropyLoss
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(42)
+    net = models.get("resnet50", num_classes=1000).materialize(dev).train()
+    x = torch.randn(64, 3, 224, 224, device=dev)
+    y = torch.randint(0, 1000, (64,), device=dev)
+    crit = CrossEntropyLoss()
+
+    def step():
+        loss = crit(net(x), y)
+        loss.backward()
+        net.zero_grad()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    value = 64 * args.steps / dt
+    print(json.dumps({"metric": "images/sec ResNet-50 224x224 fwd+bwd", "value": round(value, 2), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+                      "config": {"workload": "ResNet-50 synthetic ImageNet-shape 224x224, bs=64, forward+backward only, random-init weights",
+                                 "final_loss": round(float(loss), 5)},
+                      "roofline": {"bound": "mfma", "achieved": round(value * 24.54 / 1e3, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(value * 24.54 / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                                   "note": "whole-step figure: images/s x 24.54 GFLOP (SURVEY 8d) / peak"}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,7 +190,13 @@ def main():
     ap.add_argument("--model", default="s", choices=["s", "m", "l"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ema", action="store_true")
+    ap.add_argument("--no-nms", action="store_true")
+    ap.add_argument("--workload", default="yolo_nas", choices=["yolo_nas", "resnet50"])
     args = ap.parse_args()
+    if args.workload == "resnet50":
+        if args.gpus != 1:
+            raise RuntimeError("the ResNet-50 workload (BASELINE.json configs[1]) is single-GPU")
+        return resnet50_main(args)
 
     import torch
     import torch.distributed as dist
@@ -144,6 +252,7 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    ig_bytes = K.prof_bytes(0)
     ig_ms, ig_fl, ig_n = K.prof_summary(0)
     wg_ms, wg_fl, wg_n = K.prof_summary(1)
     K.prof_enable(False)
@@ -166,6 +275,7 @@ def main():
         ig_tf = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         wg_tf = wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
         per_gpu = value / world
+        traffic, traffic_src = measured_traffic()
         rec = {
             "metric": f"images/sec/node YOLO-NAS-{args.model.upper()} {args.size}x{args.size} train-step",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -176,7 +286,8 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data gradient, v_mfma_f32_32x32x2_f32)",
                          "achieved": round(ig_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": None, "launches_per_step": ig_n // max(args.steps, 1), "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
+                         "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(ig_bytes / max(ig_n, 1)), "launches_per_step": ig_n // max(args.steps, 1), "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
                          "gflop_per_launch": round(ig_fl / max(ig_n, 1) / 1e9, 3), "kernel_ms_per_step": round(ig_ms / args.steps, 3),
                          "wgrad": {"achieved": round(wg_tf, 2), "frac": round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4), "launches_per_step": wg_n // max(args.steps, 1),
                                    "kernel_ms_per_step": round(wg_ms / args.steps, 3)},
@@ -184,6 +295,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(args.model, args.size)
+        if not args.no_nms and world == 1:
+            rec["nms"] = nms_leg(device)
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()

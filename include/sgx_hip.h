@@ -45,6 +45,8 @@ const char* sgx_last_error(void);
  * sgx_prof_summary synchronises on the recorded events and returns the sums since the last sgx_prof_enable().      */
 int32_t sgx_prof_enable(int32_t on);
 int32_t sgx_prof_summary(int32_t cls, double* ms, double* flops, int64_t* launches);
+/* algorithmic HBM bytes of the same launches: every input element, weight and output element moved once (fp32)           */
+int32_t sgx_prof_bytes(int32_t cls, double* bytes);
 
 /* Measurement aid (tools/conv_tune.py): force the conv tile shapes (0 = built-in heuristic).  Not thread-safe; never set by the product. */
 int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk, int32_t wgrad_bj, int32_t wgrad_split_target);

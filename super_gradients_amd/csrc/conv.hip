@@ -30,7 +30,7 @@
 namespace {
 struct ProfRec {
     hipEvent_t a, b;
-    double flops;
+    double flops, bytes;
     int cls;
 };
 std::mutex g_prof_mu;
@@ -51,12 +51,13 @@ struct ProfScope {
     bool on;
     ProfRec r;
     hipStream_t st;
-    ProfScope(int cls, double flops, void* stream) : on(false), st((hipStream_t)stream) {
+    ProfScope(int cls, double flops, double bytes, void* stream) : on(false), st((hipStream_t)stream) {
         std::lock_guard<std::mutex> g(g_prof_mu);
         if (!g_prof_on) return;
         on = true;
         r.cls = cls;
         r.flops = flops;
+        r.bytes = bytes;
         r.a = prof_event();
         r.b = prof_event();
         (void)hipEventRecord(r.a, st);
@@ -97,8 +98,20 @@ extern "C" int32_t sgx_prof_summary(int32_t cls, double* ms, double* flops, int6
     if (launches) *launches = n;
     return SGX_OK;
 }
-#define SGX_PROF(cls, flops, stream) ProfScope prof_scope__((cls), (flops), (stream))
+extern "C" int32_t sgx_prof_bytes(int32_t cls, double* bytes) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    double b = 0.0;
+    for (auto& r : g_prof_recs)
+        if (r.cls == cls) b += r.bytes;
+    if (bytes) *bytes = b;
+    return SGX_OK;
+}
+#define SGX_PROF(cls, flops, bytes, stream) ProfScope prof_scope__((cls), (flops), (bytes), (stream))
 #else
+extern "C" int32_t sgx_prof_bytes(int32_t, double* bytes) {
+    if (bytes) *bytes = 0;
+    return SGX_OK;
+}
 extern "C" int32_t sgx_prof_enable(int32_t) { return SGX_OK; }
 extern "C" int32_t sgx_prof_summary(int32_t, double* ms, double* flops, int64_t* launches) {
     if (ms) *ms = 0;
@@ -106,7 +119,7 @@ extern "C" int32_t sgx_prof_summary(int32_t, double* ms, double* flops, int64_t*
     if (launches) *launches = 0;
     return SGX_OK;
 }
-#define SGX_PROF(cls, flops, stream)
+#define SGX_PROF(cls, flops, bytes, stream)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -502,7 +515,9 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         static const int prio = getenv("SGX_IGEMM_PRIO") ? atoi(getenv("SGX_IGEMM_PRIO")) : 0;
         p.prio = prio;
     }
-    SGX_PROF(0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * (double)T, stream);
+    // algorithmic bytes: every input element, weight and output element once (fp32)
+    SGX_PROF(0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * (double)T,
+             4.0 * ((double)p.M / ((double)p.Ha * p.Wa) * p.Hin * p.Win * p.C + (double)p.Nout * p.C * T + (double)p.M * p.Nout), stream);
     const bool flat = p.C < IG_BK && T > 1;
     if (flat) {
         if (bn > 64) bn = 64;  // the flat variants exist for the narrow tiles only (stem layers have few output channels)
@@ -982,7 +997,8 @@ extern "C" int32_t sgx_conv2d_bwd_weight(const sgx_conv_desc* d, const float* x,
     long nblk = (long)pl.ksplit * pl.kt_tiles * pl.jt_tiles;
     dim3 grid((unsigned)nblk);
     {
-    SGX_PROF(1, 2.0 * (double)p.M * (double)d->K * (double)p.J, stream);
+    SGX_PROF(1, 2.0 * (double)p.M * (double)d->K * (double)p.J,
+             4.0 * ((double)d->N * d->H * d->W * d->C + (double)p.M * d->K + (double)d->K * p.J), stream);
     bool launched = false;
 #define WG_CASE(BK_, BJ_, WK_, WC_)                                                                                  \
     if (!launched && pl.bnk == BK_ && pl.bj == BJ_) {                                                                \

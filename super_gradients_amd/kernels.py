@@ -487,3 +487,10 @@ def prof_summary(cls: int):
     ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     check(lib().sgx_prof_summary(cls, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "sgx_prof_summary")
     return ms.value, fl.value, n.value
+
+
+def prof_bytes(cls: int) -> float:
+    """Algorithmic HBM bytes (inputs + weights + outputs once, fp32) of the launches prof_summary(cls) covers."""
+    b = ctypes.c_double()
+    check(lib().sgx_prof_bytes(cls, ctypes.byref(b)), "sgx_prof_bytes")
+    return b.value

@@ -163,9 +163,10 @@ class SgxNetwork(nn.Module):
         import os
 
         self.side_stream = torch.cuda.Stream(device=device) if (device.type == "cuda" and os.environ.get("SGX_SIDE_STREAM", "1") != "0") else None
-        # The data gradient wants the weights transposed per parity class; they are fixed between forward and backward, so all of
-        # them are transposed on a third stream underneath the forward pass (one tiny launch per layer, off the critical path).
-        self.aux_stream = torch.cuda.Stream(device=device) if (self.side_stream is not None and os.environ.get("SGX_AUX_STREAM", "1") != "0") else None
+        # Optional (SGX_AUX_STREAM=1): transpose all data-gradient weights on a third stream underneath the forward pass instead of
+        # per call.  Measured neutral-to-negative on YOLO-NAS-S (r1p: 528.7 vs 533.3 images/s): the per-call transposes already hide
+        # under the side-stream weight gradients, so it stays off by default.
+        self.aux_stream = torch.cuda.Stream(device=device) if (self.side_stream is not None and os.environ.get("SGX_AUX_STREAM", "0") == "1") else None
         self._wt_valid = False
         for m in self.modules():
             if isinstance(m, SgxBlock):
