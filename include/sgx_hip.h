@@ -50,6 +50,7 @@ int32_t sgx_prof_bytes(int32_t cls, double* bytes);
 
 /* Measurement aid (tools/conv_tune.py): force the conv tile shapes (0 = built-in heuristic).  Not thread-safe; never set by the product. */
 int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk, int32_t wgrad_bj, int32_t wgrad_split_target);
+int32_t sgx_debug_set_variant(int32_t wave_layout_variant);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution (implicit GEMM on fp32 MFMA, v_mfma_f32_32x32x2_f32).

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "sgx_prof_enable": (_i32, [_i32]),
     "sgx_prof_summary": (_i32, [_i32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "sgx_debug_set_tiles": (_i32, [_i32] * 5),
+    "sgx_debug_set_variant": (_i32, [_i32]),
     "sgx_prof_bytes": (_i32, [_i32, POINTER(ctypes.c_double)]),
     "sgx_conv2d_fwd": (_i32, [_CD, _P, _P, _P, _P, _P, _i32, _P, _P]),
     "sgx_conv2d_fwd_stat_blocks": (_i32, [_CD]),

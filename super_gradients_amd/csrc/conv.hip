@@ -166,10 +166,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     constexpr int AJ = (BM + RPP - 1) / RPP, BJ = (BN + RPP - 1) / RPP;
     static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "bad tile");
     static_assert(NTH >= BM && NTH >= BN, "epilogue helpers need one thread per tile row/col");
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * IG_LD];
+    constexpr int SLABS = 2 * (BM + BN) * IG_LD, STAGE = WM * WN * 32 * 32;  // operand slabs; epilogue staging patches (reuse the slabs)
+    __shared__ __attribute__((aligned(16))) float smem[SLABS > STAGE ? SLABS : STAGE];
     float* const As = smem;
     float* const Bs = smem + 2 * BM * IG_LD;
-    static_assert(2 * (BM + BN) * IG_LD >= WM * WN * 32 * 32, "epilogue staging tiles do not fit in the operand slabs");
     __shared__ long long rowoff[BM];
     __shared__ float red[2 * WM * BN];
 
@@ -464,7 +464,11 @@ struct TileCfg {
     int bm, bn;
 };
 // measurement aid (tools/conv_tune.py): force tile shapes / split target; 0 = heuristic
-static int g_ovr_bm = 0, g_ovr_bn = 0, g_ovr_wk = 0, g_ovr_wj = 0, g_ovr_split = 0;
+static int g_ovr_bm = 0, g_ovr_bn = 0, g_ovr_wk = 0, g_ovr_wj = 0, g_ovr_split = 0, g_ovr_var = 0;
+extern "C" int32_t sgx_debug_set_variant(int32_t v) {
+    g_ovr_var = v;
+    return SGX_OK;
+}
 extern "C" int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk, int32_t wgrad_bj, int32_t wgrad_split_target) {
     g_ovr_bm = bm; g_ovr_bn = bn; g_ovr_wk = wgrad_bnk; g_ovr_wj = wgrad_bj; g_ovr_split = wgrad_split_target;
     return SGX_OK;
@@ -526,7 +530,11 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, true>(p, stream);
         else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true>(p, stream);
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no flat tile %dx%d", bm, bn);
-    } else if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false>(p, stream);
+    } else if (g_ovr_var == 1 && bm == 64 && bn == 64) launch_igemm<64, 64, 1, 2, false>(p, stream);   // 2 waves x (64x32)
+    else if (g_ovr_var == 2 && bm == 128 && bn == 64) launch_igemm<128, 64, 4, 2, false>(p, stream);   // 8 waves x (32x32)
+    else if (g_ovr_var == 3 && bm == 128 && bn == 128) launch_igemm<128, 128, 4, 2, false>(p, stream); // 8 waves x (32x64)
+    else if (g_ovr_var == 4 && bm == 64 && bn == 128) launch_igemm<64, 128, 2, 4, false>(p, stream);   // 8 waves x (32x32)
+    else if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false>(p, stream);
     else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false>(p, stream);
     else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false>(p, stream);
     else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false>(p, stream);

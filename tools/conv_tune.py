@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--wgrad", action="store_true", help="also search the weight-gradient tiles")
     args = ap.parse_args()
     import torch
 
@@ -60,7 +61,14 @@ def main():
                     t = timeit(fn)
                     if t < best:
                         best, best_cfg = t, f"bm={bm} bn={bn}"
-        else:
+            for var, (bm, bn) in ((1, (64, 64)), (2, (128, 64)), (3, (128, 128)), (4, (64, 128))):  # wave-layout variants
+                lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                lib().sgx_debug_set_variant(var)
+                t = timeit(fn)
+                lib().sgx_debug_set_variant(0)
+                if t < best:
+                    best, best_cfg = t, f"bm={bm} bn={bn} variant={var}"
+        elif args.wgrad:
             for bnk in (32, 64, 96, 128):
                 for bj in (32, 64, 96, 128):
                     for split in (2048, 4096, 8192):
