@@ -17,7 +17,6 @@
 // decomposed into s*s output-parity classes, each a dense stride-1 problem over the dY grid with its
 // own tap subset (no multiply-by-zero work).  Reference call sites: see include/sgx_hip.h.
 #include "sgx_common.h"
-#include <type_traits>
 
 #define SGX_MAX_TAPS 64
 
@@ -167,14 +166,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     constexpr int AJ = (BM + RPP - 1) / RPP, BJ = (BN + RPP - 1) / RPP;
     static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "bad tile");
     static_assert(NTH >= BM && NTH >= BN, "epilogue helpers need one thread per tile row/col");
-    // operand slabs are sized to whole staging passes (AJ*RPP >= BM rows, BJ*RPP >= BN rows) so that every lane stores
-    // unconditionally: no exec-masked branches between the loads and their LDS stores, which is what lets hipcc emit counted
-    // s_waitcnt vmcnt(N) (wait for the older stage only) instead of vmcnt(0)
-    constexpr int RA = AJ * RPP, RB = BJ * RPP;
-    constexpr int SLABS = 2 * (RA + RB) * IG_LD, STAGE = WM * WN * 32 * 32;  // epilogue staging patches reuse the slabs
+    constexpr int SLABS = 2 * (BM + BN) * IG_LD, STAGE = WM * WN * 32 * 32;  // operand slabs; epilogue staging patches (reuse the slabs)
     __shared__ __attribute__((aligned(16))) float smem[SLABS > STAGE ? SLABS : STAGE];
     float* const As = smem;
-    float* const Bs = smem + 2 * RA * IG_LD;
+    float* const Bs = smem + 2 * BM * IG_LD;
     __shared__ long long rowoff[BM];
     __shared__ float red[2 * WM * BN];
 
@@ -253,40 +248,35 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 
     // scalar slab state of the NEXT slab to load (non-FLAT): tap row, tap column, channel chunk
     int s_ti = 0, s_tj = 0, s_ck = 0, s_kt = 0;
-    // TWO register stages: the loads of slab kt+2 are issued while slab kt is multiplied and slab kt+1 (loaded one iteration ago)
-    // waits in registers for its LDS slot - a global load has two full MFMA blocks to land, so a workgroup no longer depends on
-    // co-resident workgroups to hide HBM/L2 latency (r1n: the 64x64 tile won on occupancy alone).
-    float4 ra[2][AJ], rb[2][BJ];
-    auto load_tile = [&](auto slot_c, bool live) {  // live == false: past the last slab, every lane reads out of bounds (zeros)
-        constexpr int SL = decltype(slot_c)::value;
+    float4 ra[AJ], rb[BJ];
+    auto load_tile = [&]() {
         if (FLAT) {
             const int kk = s_kt * IG_BK + chunk4;  // flattened (tap, c) index of this lane's chunk
             const int t = kk / p.C;
             const int c = kk - t * p.C;
             const int ti = t / p.Tw, tj = t - ti * p.Tw;
-            const bool kok = live && t < T;
+            const bool kok = t < T;
             const int tapoff = ti * rowstep + tj * pixstep + c * 4;
             const int tb = kok ? t : 0;
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 const bool ok = kok && ((amask[j] >> tb) & 1ull);
-                ra[SL][j] = sgx_buf_ld4(bufA, ok ? (unsigned)(aoff[j] + tapoff) : SGX_BUF_OOB);
+                ra[j] = sgx_buf_ld4(bufA, ok ? (unsigned)(aoff[j] + tapoff) : SGX_BUF_OOB);
             }
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) rb[SL][j] = sgx_buf_ld4(bufB, (kok && bok[j]) ? (unsigned)(boff[j] + kk * 4) : SGX_BUF_OOB);
+            for (int j = 0; j < BJ; ++j) rb[j] = sgx_buf_ld4(bufB, (kok && bok[j]) ? (unsigned)(boff[j] + kk * 4) : SGX_BUF_OOB);
         } else {
             const int tbit = s_ti * p.Tw + s_tj;
             const int tapoff = s_ti * rowstep + s_tj * pixstep + s_ck * (IG_BK * 4);
             const int woff = (tbit * p.C + s_ck * IG_BK) * 4;
-            const bool cok = live && s_ck * IG_BK + chunk4 < p.C;
-            const int tb2 = tbit & 63;
+            const bool cok = s_ck * IG_BK + chunk4 < p.C;
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
-                const bool ok = cok && ((amask[j] >> tb2) & 1ull);
-                ra[SL][j] = sgx_buf_ld4(bufA, ok ? (unsigned)(aoff[j] + tapoff) : SGX_BUF_OOB);
+                const bool ok = cok && ((amask[j] >> tbit) & 1ull);
+                ra[j] = sgx_buf_ld4(bufA, ok ? (unsigned)(aoff[j] + tapoff) : SGX_BUF_OOB);
             }
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) rb[SL][j] = sgx_buf_ld4(bufB, (cok && bok[j]) ? (unsigned)(boff[j] + woff) : SGX_BUF_OOB);
+            for (int j = 0; j < BJ; ++j) rb[j] = sgx_buf_ld4(bufB, (cok && bok[j]) ? (unsigned)(boff[j] + woff) : SGX_BUF_OOB);
             if (++s_ck == cpt) {
                 s_ck = 0;
                 if (++s_tj == p.Tw) {
@@ -297,17 +287,16 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         }
         ++s_kt;
     };
-    auto store_tile = [&](auto slot_c, int buf) {
-        constexpr int SL = decltype(slot_c)::value;
+    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int row = lrow + RPP * j;
-            sgx_st4(&As[buf * RA * IG_LD + row * IG_LD + chunk4], ra[SL][j]);
+            if (row < BM) sgx_st4(&As[buf * BM * IG_LD + row * IG_LD + chunk4], ra[j]);
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int row = lrow + RPP * j;
-            sgx_st4(&Bs[buf * RB * IG_LD + row * IG_LD + chunk4], rb[SL][j]);
+            if (row < BN) sgx_st4(&Bs[buf * BN * IG_LD + row * IG_LD + chunk4], rb[j]);
         }
     };
 
@@ -319,29 +308,28 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    load_tile(S0{}, nkt > 0);
-    store_tile(S0{}, 0);
-    load_tile(S0{}, nkt > 1);  // slab 1 waits in stage 0 while slab 0 is multiplied
+    if (nkt > 0) {
+        load_tile();
+        store_tile(0);
+    }
     __syncthreads();
 
     const int frow = lane & 31, fk = (lane >> 5) * 8;
-    // iteration kt: LDS buffer kt&1 holds slab kt, register stage kt&1 holds slab kt+1, slab kt+2 is loaded into stage (kt&1)^1
-    auto iteration = [&](int kt, auto cur_c, auto nxt_c) {
+    for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        load_tile(nxt_c, kt + 2 < nkt);  // unconditional (dead slabs read zeros): keeps the loop body free of branches
+        if (kt + 1 < nkt) load_tile();  // global loads in flight under the MFMA block
+
         float af[TM][8], bf[TN][8];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const float* s = &As[buf * RA * IG_LD + (wm * TM * 32 + i * 32 + frow) * IG_LD + fk];
+            const float* s = &As[buf * BM * IG_LD + (wm * TM * 32 + i * 32 + frow) * IG_LD + fk];
             float4 v0 = sgx_ld4(s), v1 = sgx_ld4(s + 4);
             af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
             af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float* s = &Bs[buf * RB * IG_LD + (wn * TN * 32 + j * 32 + frow) * IG_LD + fk];
+            const float* s = &Bs[buf * BN * IG_LD + (wn * TN * 32 + j * 32 + frow) * IG_LD + fk];
             float4 v0 = sgx_ld4(s), v1 = sgx_ld4(s + 4);
             bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
             bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
@@ -360,12 +348,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         if (p.prio) __builtin_amdgcn_s_setprio(0);
 #endif
 
-        store_tile(cur_c, buf ^ 1);  // after the last slab this writes zeros nobody reads
+        if (kt + 1 < nkt) store_tile(buf ^ 1);
         __syncthreads();
-    };
-    for (int kt = 0; kt < nkt; kt += 2) {
-        iteration(kt, S0{}, S1{});
-        if (kt + 1 < nkt) iteration(kt + 1, S1{}, S0{});
     }
 
     // ---- epilogue: bias + addend + accumulate + activation, optional BN partial statistics --------------------------
