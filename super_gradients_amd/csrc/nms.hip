@@ -12,7 +12,7 @@
 #include "sgx_common.h"
 
 #define NMS_THREADS 1024
-#define NMS_MAXK 1024
+#define NMS_MAXK_LIMIT 4096  // largest instantiated top-k capacity (LDS: 37 B per candidate + 8 KB histogram <= 160 KB)
 #define NMS_IDXBITS 22
 #define NMS_HBINS 2048
 
@@ -45,6 +45,7 @@ __device__ __forceinline__ u64 nms_key(float score, long e) {
     return ((u64)__float_as_uint(score) << NMS_IDXBITS) | (u64)(((1u << NMS_IDXBITS) - 1u) - (unsigned)e);
 }
 
+template <int NMS_MAXK>
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const float* boxes, const float* scores, float* out, int* out_count,
                                                           int* out_index, int* num_candidates) {
     __shared__ int hist[NMS_HBINS];
@@ -140,41 +141,44 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
     __syncthreads();
     for (int size = 2; size <= NMS_MAXK; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            int i = tid;
-            int j = i ^ stride;
-            if (j > i) {
-                u64 a = keys[i], c = keys[j];
-                bool desc = (i & size) == 0;
-                if (desc ? (a < c) : (a > c)) {
-                    keys[i] = c;
-                    keys[j] = a;
+            for (int i = tid; i < NMS_MAXK; i += NMS_THREADS) {
+                int j = i ^ stride;
+                if (j > i) {
+                    u64 a = keys[i], c = keys[j];
+                    bool desc = (i & size) == 0;
+                    if (desc ? (a < c) : (a > c)) {
+                        keys[i] = c;
+                        keys[j] = a;
+                    }
                 }
             }
             __syncthreads();
         }
     }
-    // ---- load boxes / classes of the n survivors ----
+    // ---- load boxes / classes of the n survivors (candidate t is owned by thread t % NMS_THREADS) ----
     if (tid == 0) s_maxc = -INFINITY;
     __syncthreads();
     float mymax = -INFINITY;
-    if (tid < n) {
-        u64 k = keys[tid];
-        long e = (long)(((1u << NMS_IDXBITS) - 1u) - (unsigned)(k & ((1u << NMS_IDXBITS) - 1u)));
-        long anchor = d.multi_label ? e / d.C : e;
-        int c;
-        if (d.multi_label) c = (int)(e % d.C);
-        else {
-            float s;
-            nms_candidate(d, sc, e, s, c);
+    for (int t = tid; t < NMS_MAXK; t += NMS_THREADS) {
+        if (t < n) {
+            u64 k = keys[t];
+            long e = (long)(((1u << NMS_IDXBITS) - 1u) - (unsigned)(k & ((1u << NMS_IDXBITS) - 1u)));
+            long anchor = d.multi_label ? e / d.C : e;
+            int c;
+            if (d.multi_label) c = (int)(e % d.C);
+            else {
+                float s;
+                nms_candidate(d, sc, e, s, c);
+            }
+            cls_s[t] = c;
+            for (int q = 0; q < 4; ++q) {
+                float v = bxs[anchor * 4 + q];
+                bx[t][q] = v;
+                mymax = fmaxf(mymax, v);
+            }
         }
-        cls_s[tid] = c;
-        for (int q = 0; q < 4; ++q) {
-            float v = bxs[anchor * 4 + q];
-            bx[tid][q] = v;
-            mymax = fmaxf(mymax, v);
-        }
+        sup[t] = 0;
     }
-    sup[tid] = 0;
     // class_mode 3 = torchvision's own CPU dispatch (ops/boxes.py batched_nms): coordinate trick while boxes.numel() <= 4000
     const int class_mode = d.class_mode == 3 ? (4 * n > 4000 ? 2 : 1) : d.class_mode;
     if (class_mode == 1) {
@@ -189,35 +193,43 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
         }
         __syncthreads();
     }
-    float nb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (tid < n) {
-        float offv = 0.f;
-        if (class_mode == 1) offv = (float)cls_s[tid] * (s_maxc + 1.f);
-        for (int q = 0; q < 4; ++q) nb[q] = bx[tid][q] + offv;
-        area[tid] = (nb[2] - nb[0]) * (nb[3] - nb[1]);
-    }
     __syncthreads();
-    // keep original boxes for output; nb[] (offset boxes) stay in registers of thread j = tid
+    // boxes as the suppression test sees them: original coordinates (+ the class offset in mode 1), recomputed from LDS where needed
+    const float offscale = class_mode == 1 ? s_maxc + 1.f : 0.f;
+    auto nbox = [&](int t, float* o) {
+        const float offv = class_mode == 1 ? (float)cls_s[t] * offscale : 0.f;
+        for (int q = 0; q < 4; ++q) o[q] = bx[t][q] + offv;
+    };
+    for (int t = tid; t < n; t += NMS_THREADS) {
+        float nb[4];
+        nbox(t, nb);
+        area[t] = (nb[2] - nb[0]) * (nb[3] - nb[1]);
+    }
     if (tid == 0) s_kept = 0;
     __syncthreads();
-    // ---- greedy scan: one barrier per kept box ----
-    // To test (i, j) every thread needs box i: broadcast through LDS (offset form).
+    // ---- greedy scan: one barrier pair per kept box; box i is broadcast through LDS (offset form) ----
     for (int i = 0; i < n; ++i) {
         if (sup[i]) continue;  // uniform: flags only change before a barrier
-        if (tid == i) {
+        if (tid == 0) {
+            float nb[4];
+            nbox(i, nb);
             cur[0] = nb[0]; cur[1] = nb[1]; cur[2] = nb[2]; cur[3] = nb[3]; cur[4] = area[i];
             keep_list[s_kept] = i;
             s_kept = s_kept + 1;
         }
         __syncthreads();
-        if (tid > i && tid < n && !sup[tid] && (class_mode != 2 || cls_s[tid] == cls_s[i])) {
-            float xx1 = fmaxf(cur[0], nb[0]), yy1 = fmaxf(cur[1], nb[1]);
-            float xx2 = fminf(cur[2], nb[2]), yy2 = fminf(cur[3], nb[3]);
-            float w = xx2 - xx1; w = w < 0.f ? 0.f : w;
-            float h = yy2 - yy1; h = h < 0.f ? 0.f : h;
-            float inter = w * h;
-            float ovr = inter / (cur[4] + area[tid] - inter);
-            if (ovr > d.iou_threshold) sup[tid] = 1;
+        for (int t = tid; t < n; t += NMS_THREADS) {
+            if (t > i && !sup[t] && (class_mode != 2 || cls_s[t] == cls_s[i])) {
+                float nb[4];
+                nbox(t, nb);
+                float xx1 = fmaxf(cur[0], nb[0]), yy1 = fmaxf(cur[1], nb[1]);
+                float xx2 = fminf(cur[2], nb[2]), yy2 = fminf(cur[3], nb[3]);
+                float w = xx2 - xx1; w = w < 0.f ? 0.f : w;
+                float h = yy2 - yy1; h = h < 0.f ? 0.f : h;
+                float inter = w * h;
+                float ovr = inter / (cur[4] + area[t] - inter);
+                if (ovr > d.iou_threshold) sup[t] = 1;
+            }
         }
         __syncthreads();
         if (s_kept >= d.max_predictions) break;  // uniform
@@ -251,12 +263,15 @@ extern "C" int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const floa
     (void)ws_bytes;
     SGX_CHECK_ARG(d && boxes && scores && out && out_count, "nms: null pointer");
     SGX_CHECK_ARG(d->B > 0 && d->L > 0 && d->C > 0, "nms: bad dims");
-    SGX_CHECK_ARG(d->nms_top_k > 0 && d->nms_top_k <= NMS_MAXK, "nms: nms_top_k=%d unsupported (max %d)", d->nms_top_k, NMS_MAXK);
-    SGX_CHECK_ARG(d->max_predictions > 0 && d->max_predictions <= NMS_MAXK, "nms: bad max_predictions");
+    SGX_CHECK_ARG(d->nms_top_k > 0 && d->nms_top_k <= NMS_MAXK_LIMIT, "nms: nms_top_k=%d unsupported (max %d)", d->nms_top_k, NMS_MAXK_LIMIT);
+    SGX_CHECK_ARG(d->max_predictions > 0 && d->max_predictions <= NMS_MAXK_LIMIT, "nms: bad max_predictions");
     SGX_CHECK_ARG((long)d->L * (d->multi_label ? d->C : 1) <= (1L << NMS_IDXBITS), "nms: too many candidates for the %d-bit index field", NMS_IDXBITS);
     SGX_CHECK_ARG(d->class_mode >= 0 && d->class_mode <= 3, "nms: bad class_mode");
     SGX_CHECK_ARG(d->score_threshold >= 0.f, "nms: negative score threshold unsupported (keys assume non-negative scores)");
-    SGX_LAUNCH(nms_kernel, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates);
+    const int need = d->nms_top_k > d->max_predictions ? d->nms_top_k : d->max_predictions;
+    if (need <= 1024) SGX_LAUNCH(nms_kernel<1024>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates);
+    else if (need <= 2048) SGX_LAUNCH(nms_kernel<2048>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates);
+    else SGX_LAUNCH(nms_kernel<4096>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates);
     SGX_CHECK_LAUNCH("nms");
     return SGX_OK;
 }
