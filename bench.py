@@ -210,6 +210,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a HIP GPU (the product has no CPU path)")
+    if os.environ.get("SGX_WGRAD_SPLIT"):  # experiment switch: weight-gradient split target (waves), see csrc/conv.hip wgrad_plan
+        from super_gradients_amd._lib import lib
+
+        lib().sgx_debug_set_tiles(0, 0, 0, 0, int(os.environ["SGX_WGRAD_SPLIT"]))
     rank, world, device = setup_device_from_env()
     if world != args.gpus:
         raise RuntimeError(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run --nproc-per-node {args.gpus}")
