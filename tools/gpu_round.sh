@@ -28,7 +28,7 @@ if has convbench; then
   echo "convbench rc=$?" >> "$OUT/conv_bench.log"
   tail -4 "$OUT/conv_bench.log"
 fi
-PROF_CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline"
+PROF_CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-nms"
 if has stats; then
   cd /tmp
   timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o bench -- bash -c "cd $REPO && $PROF_CMD" > "$OUT/stats.log" 2>&1
@@ -40,7 +40,7 @@ if has stats; then
   find "$OUT/stats" -name "*kernel_trace.csv" -size +8M -delete
 fi
 if has pmc; then
-  PMC_CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+  PMC_CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-nms"
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
     i=$((i+1))
@@ -50,8 +50,10 @@ if has pmc; then
     cd "$REPO"
     python tools/prof_summary.py pmc "$OUT/pmc$i" > "$OUT/pmc${i}_summary.txt" 2>&1
     head -12 "$OUT/pmc${i}_summary.txt"
-    find "$OUT/pmc$i" -name "*.csv" -size +8M -delete
   done
+  python tools/pmc_traffic.py "$OUT/pmc1" "$OUT/pmc2" "$OUT/igemm_traffic.json" > "$OUT/pmc_traffic.log" 2>&1
+  cat "$OUT/pmc_traffic.log" | head -5
+  for i in 1 2 3; do find "$OUT/pmc$i" -name "*.csv" -size +8M -delete; done
 fi
 if has tests; then
   timeout 600 python -m pytest tests -m gpu -x -q --durations=15 > "$OUT/pytest_gpu.log" 2>&1
