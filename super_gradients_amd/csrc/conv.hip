@@ -150,7 +150,6 @@ struct IgemmParams {
     long a_bytes, w_bytes; // extents for the buffer descriptors
     int act, accumulate;
     int vec;                  // 1: Nout, output strides and pointers allow 16-byte epilogue accesses
-    int prio;                 // experiment switch (SGX_IGEMM_PRIO): raise the wave priority around the MFMA block
     int mt, nt, nblk, chunk;  // tile counts and XCD chunk
     int stat_nblk;
 };
@@ -334,9 +333,6 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
             bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
         }
-#ifndef SGX_EMU
-        if (p.prio) __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
@@ -344,9 +340,6 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
-#ifndef SGX_EMU
-        if (p.prio) __builtin_amdgcn_s_setprio(0);
-#endif
 
         if (kt + 1 < nkt) store_tile(buf ^ 1);
         __syncthreads();
@@ -515,10 +508,6 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
              ((uintptr_t)p.bias % 16) == 0)
                 ? 1
                 : 0;
-    {
-        static const int prio = getenv("SGX_IGEMM_PRIO") ? atoi(getenv("SGX_IGEMM_PRIO")) : 0;
-        p.prio = prio;
-    }
     // algorithmic bytes: every input element, weight and output element once (fp32)
     SGX_PROF(0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * (double)T,
              4.0 * ((double)p.M / ((double)p.Ha * p.Wa) * p.Hin * p.Win * p.C + (double)p.Nout * p.C * T + (double)p.M * p.Nout), stream);

@@ -218,6 +218,16 @@ class SgxNetwork(nn.Module):
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
 
+    def prep_model_for_conversion(self, input_size=None, **kwargs):
+        """Reference: CustomizableDetector.prep_model_for_conversion (customizable_detector.py:106-118) - every sub-module that
+        knows how to re-parameterise itself does so (QARepVGGBlock: branches [+ post-BN] -> one 3x3 conv); eval forward then runs
+        the deployment form."""
+        self.materialize()
+        for m in self.modules():
+            if m is not self and hasattr(m, "prep_model_for_conversion"):
+                m.prep_model_for_conversion(input_size, **kwargs)
+        return self
+
     def zero_grad(self, set_to_none: bool = False):
         if self._materialized:
             from .. import kernels as K

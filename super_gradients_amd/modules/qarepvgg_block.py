@@ -48,8 +48,11 @@ class QARepVGGBlock(SgxBlock):
         self.branch_1x1 = ConvLayer(in_channels, out_channels, 1, stride, 0, bias=True)
         self.use_residual_connection = bool(use_residual_connection and in_channels == out_channels and stride == 1)
         self.post_bn = BatchNorm(out_channels)
-        # reference placeholder (requires_grad=True there, never used in training mode): state_dict compatibility only
+        # reference placeholder (requires_grad=True there, never used in training mode): state_dict compatibility; it receives
+        # the fused kernel / bias in partial_fusion() / full_fusion() exactly as in the reference
         self.rbr_reparam = nn.Conv2d(in_channels, out_channels, 3, stride, 1, bias=True)
+        self.partially_fused = self.fully_fused = False
+        self._fused_w = self._fused_b = None
 
     def on_materialize(self):
         pass
@@ -58,6 +61,9 @@ class QARepVGGBlock(SgxBlock):
         c3, bn3, c1, pbn = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1, self.post_bn
         res = x if self.use_residual_connection else None
         if self.training:
+            if self.partially_fused or self.fully_fused:
+                raise RuntimeError("a fused QARepVGGBlock is inference-only on the HIP path (the reference's fused block trains a single conv; "
+                                   "re-parameterised training is outside the hot path)")
             # the two branches read the same x and are independent: the 1x1 branch runs on the side stream beside the 3x3 one
             t1 = torch.empty(K.conv_out_shape(x, self.out_channels, 1, 1, self.stride, 0), device=x.device, dtype=torch.float32)
             self._net.fork_side(lambda: c1.conv(x, out=t1), x, t1)
@@ -70,12 +76,81 @@ class QARepVGGBlock(SgxBlock):
             y = K.affine_act(s, scp, shp, act=self.act, out=out)
             self._ctx = (x, t3, s, sc3, sh3, m3, i3, scp, shp, mp, ip)
             return y
+        if self.fully_fused:      # deployment form: ONE 3x3 convolution with fused bias + activation
+            return K.conv2d_fwd(x, self._fused_w, bias=self._fused_b, out=out, act=self.act, stride=self.stride, pad=1)
+        if self.partially_fused:  # branches fused, post_bn kept
+            t = K.conv2d_fwd(x, self._fused_w, bias=self._fused_b, stride=self.stride, pad=1)
+            scp, shp, _, _ = pbn.scale_shift(None, 0, False)
+            return K.affine_act(t, scp, shp, act=self.act, out=out if out is not None else t)
         t3 = c3.conv(x)
         sc3, sh3, _, _ = bn3.scale_shift(None, 0, False)
         t1 = c1.conv(x)
         s = K.affine_act(t3, sc3, sh3, r1=t1, a1=self.alpha, r2=res, a2=1.0, out=t1)
         scp, shp, _, _ = pbn.scale_shift(None, 0, False)
         return K.affine_act(s, scp, shp, act=self.act, out=out if out is not None else s)
+
+    # ---- re-parameterisation (reference: qarepvgg_block.py:206-321) -------------------------------------------------------
+    @staticmethod
+    def _fuse_bn_tensor(kernel, bias, running_mean, running_var, gamma, beta, eps):
+        std = torch.sqrt(running_var + eps)
+        a = gamma / std
+        return kernel * a.reshape(-1, 1, 1, 1), bias * a + (beta - gamma * running_mean / std)
+
+    def _get_equivalent_kernel_bias_for_branches(self):
+        """3x3 (with its BN folded) + alpha * zero-padded 1x1 (+ bias) + identity, as one 3x3 kernel / bias."""
+        bn3 = self.branch_3x3.bn
+        w3 = self.branch_3x3.conv.weight.detach()
+        k3, b3 = self._fuse_bn_tensor(w3, 0.0, bn3.running_mean, bn3.running_var, bn3.weight.detach(), bn3.bias.detach(), bn3.eps)
+        k1 = torch.nn.functional.pad(self.branch_1x1.weight.detach(), [1, 1, 1, 1])
+        k = k3 + self.alpha * k1
+        if self.use_residual_connection:
+            cin = self.in_channels
+            ident = torch.zeros(cin, cin, 3, 3, device=k.device, dtype=k.dtype)
+            ident[torch.arange(cin), torch.arange(cin), 1, 1] = 1.0
+            k = k + ident
+        return k, b3 + self.alpha * self.branch_1x1.bias.detach()
+
+    def _install_fused(self, kernel, bias):
+        self.rbr_reparam.weight.data = kernel.to(self.rbr_reparam.weight.device if not getattr(self, "_net", None) else kernel.device).contiguous()
+        self.rbr_reparam.bias.data = bias.contiguous()
+        # physical form for the kernels: OHWI with the channel axis padded to 4 floats like every other conv weight
+        k, c = kernel.shape[:2]
+        cp = (c + 3) // 4 * 4
+        w = torch.zeros(k, 3, 3, cp, device=kernel.device, dtype=torch.float32)
+        w[..., :c] = kernel.permute(0, 2, 3, 1)
+        self._fused_w = w.permute(0, 3, 1, 2)
+        self._fused_b = bias.contiguous().float()
+
+    def partial_fusion(self):
+        """Fuse the branches into one kernel, keep post_bn (reference :281-307).  Unlike the reference the branch modules are kept
+        (the arenas own their storage); eval-mode forward switches to the fused kernel."""
+        if self.partially_fused:
+            return
+        if self.fully_fused:
+            raise NotImplementedError("QARepVGGBlock can't be converted to partially fused from fully fused")
+        self._install_fused(*self._get_equivalent_kernel_bias_for_branches())
+        self.partially_fused, self.fully_fused = True, False
+
+    def full_fusion(self):
+        """Fuse everything into conv + bias + activation (reference :253-279); the block becomes inference-only."""
+        if self.fully_fused:
+            return
+        if not self.partially_fused:
+            self.partial_fusion()
+        pbn = self.post_bn
+        k, b = self._fuse_bn_tensor(self.rbr_reparam.weight.detach(), self.rbr_reparam.bias.detach(), pbn.running_mean, pbn.running_var, pbn.weight.detach(),
+                                    pbn.bias.detach(), pbn.eps)
+        self._install_fused(k, b)
+        self.partially_fused, self.fully_fused = False, True
+
+    def fuse_block_residual_branches(self):
+        self.partial_fusion()
+
+    def prep_model_for_conversion(self, input_size=None, full_fusion: bool = False, **kwargs):
+        if full_fusion:
+            self.full_fusion()
+        else:
+            self.partial_fusion()
 
     def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
         c3, bn3, c1, pbn = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1, self.post_bn

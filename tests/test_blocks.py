@@ -133,3 +133,48 @@ def test_resnet_block(backend, kind, stride):
         ref, blk = BottleneckBlock(cin_eff, planes, stride, 4), Bottleneck(cin_eff, planes, stride, 4)
     x = torch.randn(n, cin_eff, hw, hw, generator=torch.Generator().manual_seed(0))
     _check(ref, blk, x, backend)
+
+
+@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("stride,cout", [(1, None), (2, 2)])
+def test_qarepvgg_fusion(backend, full, stride, cout):
+    """Re-parameterisation (reference qarepvgg_block.py:206-321; test pattern of tests/unit_tests/repvgg_unit_test.py:43-113): the fused
+    3x3 kernel / bias equal the reference's algebra, and the deployment-form eval forward equals the branch-form eval forward."""
+    from oracle import ref_shim
+    from super_gradients_amd.modules.layers import BatchNorm
+    from super_gradients_amd.modules.qarepvgg_block import QARepVGGBlock
+
+    n, c, hw = _shape(backend, (2, 64, 20), (1, 8, 6))
+    co = c if cout is None else c * cout
+    blk = QARepVGGBlock(c, co, stride=stride)
+    g = torch.Generator().manual_seed(3)
+    for m in blk.modules():
+        if isinstance(m, BatchNorm):
+            m.eps = 1e-3
+            m.weight.data.uniform_(0.5, 1.5, generator=g)
+            m.bias.data.normal_(0, 0.2, generator=g)
+            m.running_mean.normal_(0, 0.3, generator=g)
+            m.running_var.uniform_(0.5, 1.5, generator=g)
+    net = _wrap(blk, backend)
+    net.eval()
+    x = torch.randn(n, c, hw, hw, generator=g)
+    y_branches = to_nchw_cpu(blk.fwd(to_nhwc(x, backend)))
+    blk.prep_model_for_conversion(full_fusion=full)
+    y_fused = to_nchw_cpu(blk.fwd(to_nhwc(x, backend)))
+    assert_close(y_fused, y_branches, 2e-5, "fused eval forward vs branch eval forward")
+    if ref_shim.available():
+        ref_shim.install()
+        from super_gradients.modules.qarepvgg_block import QARepVGGBlock as Ref
+
+        ref = Ref(c, co, stride=stride, use_residual_connection=(stride == 1 and co == c))
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.eps = 1e-3
+        sd = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+        branch_sd = {k: v for k, v in sd.items() if not k.startswith("rbr_reparam")}
+        ref.load_state_dict(branch_sd, strict=False)
+        ref.eval()
+        (ref.full_fusion if full else ref.partial_fusion)()
+        assert_close(blk.rbr_reparam.weight.detach().cpu(), ref.rbr_reparam.weight.detach(), 1e-6, "fused kernel vs reference")
+        assert_close(blk.rbr_reparam.bias.detach().cpu(), ref.rbr_reparam.bias.detach(), 1e-6, "fused bias vs reference")
+        assert_close(y_fused, ref(x).detach(), 2e-5, "fused forward vs reference fused forward")

@@ -214,3 +214,75 @@ def test_yolo_nas_eval_and_nms(gpu_device):
                                    multi_label_per_box=True, class_agnostic_nms=True)
     for a, b in zip(res, ref_res):
         assert torch.equal(a.cpu(), b)
+
+
+@pytest.mark.gpu
+def test_yolo_nas_deployment_form(gpu_device):
+    """prep_model_for_conversion(full_fusion=True) (customizable_detector.py:106-118, qarepvgg_block.py:253-321): every QARepVGGBlock
+    collapses to one 3x3 conv + bias + ReLU; eval outputs are unchanged within fp32 round-off, against the branch form and the oracle."""
+    ref, net = _build_pair("s", 80, gpu_device)
+    g = torch.Generator().manual_seed(4)
+    for m in ref.modules():  # non-trivial running statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1, generator=g)
+            m.running_var.uniform_(0.8, 1.2, generator=g)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    ref.eval()
+    net.materialize(gpu_device).eval()
+    x = torch.rand(2, 3, 320, 320, generator=g)
+    with torch.no_grad():
+        (bx_r, sc_r), (lg_r, ds_r, *_r) = ref(x)
+        (bx0, sc0), (lg0, ds0, *_r0) = net(x.to(gpu_device))
+        net.prep_model_for_conversion(input_size=(320, 320), full_fusion=True)
+        (bx1, sc1), (lg1, ds1, *_r1) = net(x.to(gpu_device))
+    from super_gradients_amd.modules.qarepvgg_block import QARepVGGBlock
+
+    assert all(m.fully_fused for m in net.modules() if isinstance(m, QARepVGGBlock))
+    for a, b, r, name in ((lg1, lg0, lg_r, "logits"), (ds1, ds0, ds_r, "distri"), (bx1, bx0, bx_r, "boxes"), (sc1, sc0, sc_r, "scores")):
+        assert_close(a.cpu(), b.cpu(), 1e-4, f"deployment form vs branch form: {name}")
+        assert_close(a.cpu(), r, 2e-4, f"deployment form vs oracle: {name}")
+
+
+@pytest.mark.gpu
+def test_trainer_yolo_nas_recipe_shape(gpu_device, tmp_path):
+    """The YOLO-NAS recipe's optimisation settings in miniature through Trainer.train(): AdamW lr 2e-4 wd 1e-5 with zero weight decay on
+    bias/BN, linear batch warm-up + cosine, EMA (threshold decay), PPYoloELoss(TAL) - loss trajectory against the same loop on the oracle."""
+    from oracle.ppyolo_loss import PPYoloELossOracle
+    from super_gradients_amd.training import Trainer
+    from super_gradients_amd.training.losses import PPYoloELoss
+    from super_gradients_amd.training.utils.callbacks import CosineLRScheduler
+    import numpy as np
+
+    ref, net = _build_pair("s", 80, gpu_device)
+    n, bs = 3, 4
+    loader = []
+    for i in range(n):
+        g = torch.Generator().manual_seed(20 + i)
+        loader.append((torch.rand(bs, 3, 160, 160, generator=g), synthetic_targets(bs, seed=30 + i, kmax=4, size=160)))
+    tp = dict(max_epochs=1, lr_mode="CosineLRScheduler", initial_lr=2e-4, loss=PPYoloELoss(num_classes=80, use_static_assigner=False), optimizer="AdamW",
+              optimizer_params=dict(weight_decay=1e-5), zero_weight_decay_on_bias_and_bn=True, warmup_mode="LinearBatchLRWarmup", lr_warmup_steps=2,
+              warmup_initial_lr=1e-6, cosine_final_lr_ratio=0.1, ema=True, ema_params=dict(decay=0.9997, decay_type="threshold"), silent_mode=True,
+              save_model=False)
+    res = Trainer("yolo_nas_mini", ckpt_root_dir=str(tmp_path)).train(net, tp, loader)
+    decay = [p for k, p in ref.named_parameters() if p.dim() > 1]
+    no_decay = [p for k, p in ref.named_parameters() if p.dim() <= 1]
+    o = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay}], lr=2e-4, weight_decay=1e-5)
+    crit = PPYoloELossOracle(80, use_static_assigner=False)
+    ref.train()
+    tot = torch.zeros(4)
+    for b, (x, t) in enumerate(loader):
+        if b < 2:
+            for pg in o.param_groups:
+                pg["lr"] = float(np.linspace(1e-6, 2e-4, 2)[b])
+        loss, items = crit(ref(x), t)
+        loss.backward()
+        o.step()
+        o.zero_grad()
+        if b >= 2:
+            for pg in o.param_groups:
+                pg["lr"] = float(CosineLRScheduler.compute_learning_rate(max(0, b - 2), n - 2, 2e-4, 0.1))
+        tot += items * bs
+    tot /= n * bs
+    got = res[0]["train"]
+    for i, name in enumerate(["loss_cls", "loss_iou", "loss_dfl", "loss"]):
+        assert abs(got[name] - float(tot[i])) <= 1e-3 * abs(float(tot[i])), (name, got[name], float(tot[i]))

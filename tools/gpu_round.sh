@@ -19,10 +19,6 @@ if has bench; then
   echo "bench rc=$?" >> "$OUT/bench.err"
   cat "$OUT/bench.log"; tail -3 "$OUT/bench.err"
 fi
-if has convbench_prio; then
-  SGX_IGEMM_PRIO=1 timeout 400 python tools/conv_bench.py --out "$OUT/conv_bench_prio.txt" > "$OUT/conv_bench_prio.log" 2>&1
-  tail -4 "$OUT/conv_bench_prio.log"
-fi
 if has convbench; then
   timeout 400 python tools/conv_bench.py --out "$OUT/conv_bench.txt" > "$OUT/conv_bench.log" 2>&1
   echo "convbench rc=$?" >> "$OUT/conv_bench.log"
