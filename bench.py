@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ema", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="synchronised BatchNorm across ranks (recipe setting; off in the reference's own benchmark)")
     ap.add_argument("--workload", default="yolo_nas", choices=["yolo_nas", "resnet50"])
     args = ap.parse_args()
     if args.workload == "resnet50":
@@ -222,6 +223,8 @@ def main():
     net = models.get(f"yolo_nas_{args.model}", num_classes=80)
     net.materialize(device)
     net.train()
+    if args.sync_bn:
+        net.set_sync_bn(True)
     reducer = GradientAllReducer(net, net.gradient_buckets())
     reducer.broadcast_parameters(0)
     crit = PPYoloELoss(num_classes=80, use_static_assigner=False)

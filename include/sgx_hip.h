@@ -137,6 +137,16 @@ int32_t sgx_channel_stats_partial(const float* x, int64_t M, int32_t C, int64_t 
 int32_t sgx_bn_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma,
                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                         float* save_mean, float* save_invstd, float* scale, float* shift, void* ws, int64_t ws_bytes, void* stream);
+/* Synchronised BatchNorm across data-parallel ranks (reference: nn.SyncBatchNorm conversion at sg_trainer.py:1344-1350, recipe
+ * `sync_bn: True`): the per-channel sums leave as fp64 [2][C] (sum, sum of squares / sum g, sum g*(x-mean)), the host all-reduces
+ * them over RCCL, and the *_sums forms finish with the GLOBAL sums and element count.                               */
+int32_t sgx_bn_reduce_sums(const float* partials, int32_t nblk, int32_t C, double* sums, void* ws, int64_t ws_bytes, void* stream);
+int32_t sgx_bn_finalize_sums(const double* sums, int64_t M, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                             float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale, float* shift,
+                             void* stream);
+/* dgamma / dbeta accumulate THIS rank's sums (the gradient exchange adds the others); dx coefficients use the global ones.    */
+int32_t sgx_bn_bwd_finalize_sums(const double* local_sums, const double* global_sums, int64_t M_total, int32_t C, const float* gamma,
+                                 const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream);
 /* eval-mode BatchNorm folded to an affine map from the running statistics.                          */
 int32_t sgx_bn_eval_scale_shift(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                                 const float* running_var, float eps, float* scale, float* shift, void* stream);

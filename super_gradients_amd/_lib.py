@@ -77,6 +77,9 @@ PROTOTYPES = {
     "sgx_reduce_workspace": (_i64, [_i32, _i32]),
     "sgx_colsum_workspace": (_i64, [_i64, _i32]),
     "sgx_bn_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
+    "sgx_bn_reduce_sums": (_i32, [_P, _i32, _i32, _P, _P, _i64, _P]),
+    "sgx_bn_finalize_sums": (_i32, [_P, _i64, _i32, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P, _P]),
+    "sgx_bn_bwd_finalize_sums": (_i32, [_P, _P, _i64, _i32, _P, _P, _P, _P, _P, _P, _P]),
     "sgx_bn_eval_scale_shift": (_i32, [_i32, _P, _P, _P, _P, _f, _P, _P, _P]),
     "sgx_affine_act_fwd": (_i32, [_P, _i64, _P, _P, _P, _i64, _f, _P, _P, _i64, _f, _P, _i64, _i64, _i32, _i32, _P, _P]),
     "sgx_bn_bwd_reduce": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _i64, _i32, _i32, _P, _P]),
@@ -158,7 +161,7 @@ def ptr(t):
         return None
     if not t.is_cuda and not _TEST_HOST_MODE:
         raise SgxError("libsgx_hip kernels need tensors on the HIP device (got a CPU tensor); there is no CPU fallback")
-    if t.dtype not in (torch.float32, torch.int32, torch.int64, torch.uint8):
+    if t.dtype not in (torch.float32, torch.float64, torch.int32, torch.int64, torch.uint8):
         raise SgxError(f"unsupported dtype {t.dtype}")
     return t.data_ptr()
 

@@ -228,6 +228,33 @@ extern "C" int32_t sgx_bn_finalize(const float* partials, int32_t nblk, int64_t 
     return SGX_OK;
 }
 
+// ---- cross-rank (synchronised) BatchNorm: the per-channel sums leave the library as fp64 [planes][C] so that the host can
+// all-reduce them over RCCL (ONE small collective per BN layer and direction), then come back for the finalisation.
+__global__ void colsum_f64_kernel(ColSrc src, int planes, int C, double* out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    for (int p = 0; p < planes; ++p) out[(long)p * C + c] = colsrc_sum(src, p, C, c);
+}
+extern "C" int32_t sgx_bn_reduce_sums(const float* partials, int32_t nblk, int32_t C, double* sums, void* ws, int64_t ws_bytes, void* stream) {
+    SGX_CHECK_ARG(partials && sums && nblk > 0, "bn_reduce_sums: bad args");
+    ColSrc src;
+    int32_t rc = col_prereduce<2>(partials, nblk, C, ws, ws_bytes, stream, &src);
+    if (rc) return rc;
+    SGX_LAUNCH(colsum_f64_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, src, 2, C, sums);
+    SGX_CHECK_LAUNCH("bn_reduce_sums");
+    return SGX_OK;
+}
+extern "C" int32_t sgx_bn_finalize_sums(const double* sums, int64_t M, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                                        float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale, float* shift,
+                                        void* stream) {
+    SGX_CHECK_ARG(sums && scale && shift && M > 0, "bn_finalize_sums: bad args");
+    ColSrc src{nullptr, sums, 1};
+    SGX_LAUNCH(bn_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, src, (long)M, C, gamma, beta, eps, momentum, running_mean, running_var,
+               save_mean, save_invstd, scale, shift);
+    SGX_CHECK_LAUNCH("bn_finalize_sums");
+    return SGX_OK;
+}
+
 __global__ void bn_eval_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -315,15 +342,18 @@ extern "C" int32_t sgx_bn_bwd_reduce(const float* dy, int64_t dy_ld, const float
     return run_sweep<BnBwdReduceF, 2>(f, M, C, partials, stream, "bn_bwd_reduce");
 }
 
-__global__ void bn_bwd_finalize_kernel(ColSrc src, long M, int C, const float* gamma, const float* save_mean,
+// src: the sums that define dx (all ranks' when BatchNorm is synchronised); loc: this rank's own sums, which is what dgamma / dbeta
+// accumulate (the data-parallel gradient exchange adds the other ranks' later) - loc.n == 0 means "same as src"
+__global__ void bn_bwd_finalize_kernel(ColSrc src, ColSrc loc, long M, int C, const float* gamma, const float* save_mean,
                                        const float* save_invstd, float* dgamma, float* dbeta, float* coef) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double sg = colsrc_sum(src, 0, C, c), sgx = colsrc_sum(src, 1, C, c);
     double mean = save_mean[c], invstd = save_invstd[c], g = gamma ? (double)gamma[c] : 1.0;
-    double sgxhat = invstd * sgx;  // sgx is already centred: sum g*(x - mean)
+    const double lsg = loc.n ? colsrc_sum(loc, 0, C, c) : sg, lsgx = loc.n ? colsrc_sum(loc, 1, C, c) : sgx;
+    double sgxhat = invstd * lsgx;  // sgx is already centred: sum g*(x - mean)
     if (dgamma) dgamma[c] += (float)sgxhat;
-    if (dbeta) dbeta[c] += (float)sg;
+    if (dbeta) dbeta[c] += (float)lsg;
     // dx = c1 * ((g - mg) - (x - mean) * k): differences first, then the scale - the order ATen's CPU kernel uses, so a
     // nearly constant upstream gradient does not lose its small remainder to cancellation between large products
     coef[c] = (float)(g * invstd);
@@ -338,9 +368,17 @@ extern "C" int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int6
     ColSrc src;
     int32_t rc = col_prereduce<2>(partials, nblk, C, ws, ws_bytes, stream, &src);
     if (rc) return rc;
-    SGX_LAUNCH(bn_bwd_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, src, (long)M, C, gamma, save_mean, save_invstd,
-               dgamma, dbeta, coef);
+    SGX_LAUNCH(bn_bwd_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, src, ColSrc{nullptr, nullptr, 0}, (long)M, C, gamma, save_mean,
+               save_invstd, dgamma, dbeta, coef);
     SGX_CHECK_LAUNCH("bn_bwd_finalize");
+    return SGX_OK;
+}
+extern "C" int32_t sgx_bn_bwd_finalize_sums(const double* local_sums, const double* global_sums, int64_t M_total, int32_t C, const float* gamma,
+                                            const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
+    SGX_CHECK_ARG(local_sums && global_sums && save_mean && save_invstd && coef && M_total > 0, "bn_bwd_finalize_sums: bad args");
+    SGX_LAUNCH(bn_bwd_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, ColSrc{nullptr, global_sums, 1}, ColSrc{nullptr, local_sums, 1},
+               (long)M_total, C, gamma, save_mean, save_invstd, dgamma, dbeta, coef);
+    SGX_CHECK_LAUNCH("bn_bwd_finalize_sums");
     return SGX_OK;
 }
 

@@ -251,6 +251,27 @@ def bn_finalize(parts, M, gamma, beta, eps, momentum, running_mean, running_var)
     return st[0], st[1], st[2], st[3]
 
 
+def _allreduce_sums(sums):
+    import torch.distributed as dist
+
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    return dist.get_world_size()
+
+
+def bn_finalize_sync(parts, M, gamma, beta, eps, momentum, running_mean, running_var):
+    """bn_finalize with the statistics summed over all data-parallel ranks (equal per-rank element counts, as DistributedSampler
+    guarantees): one 2*C fp64 all-reduce."""
+    C = parts.shape[2]
+    ws = WORKSPACE.get(lib().sgx_reduce_workspace(parts.shape[1], C), parts.device)
+    sums = torch.empty(2, C, device=parts.device, dtype=torch.float64)
+    check(lib().sgx_bn_reduce_sums(ptr(parts), parts.shape[1], C, ptr(sums), ptr(ws), ws.numel(), stream()), "sgx_bn_reduce_sums")
+    world = _allreduce_sums(sums)
+    st = torch.empty(4, C, device=parts.device, dtype=torch.float32)
+    check(lib().sgx_bn_finalize_sums(ptr(sums), M * world, C, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean), ptr(running_var), ptr(st[2]),
+                                     ptr(st[3]), ptr(st[0]), ptr(st[1]), stream()), "sgx_bn_finalize_sums")
+    return st[0], st[1], st[2], st[3]
+
+
 def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps):
     C = running_mean.numel()
     st = torch.empty(2, C, device=running_mean.device, dtype=torch.float32)
@@ -273,7 +294,7 @@ def affine_act(x, scale=None, shift=None, r1=None, a1=1.0, a1_dev=None, r2=None,
     return (out, parts) if want_stats else out
 
 
-def bn_bwd(dy, x, scale, shift, gamma, save_mean, save_invstd, dgamma, dbeta, act=None, dx_out=None, want_g=False):
+def bn_bwd(dy, x, scale, shift, gamma, save_mean, save_invstd, dgamma, dbeta, act=None, dx_out=None, want_g=False, sync=False):
     """Full BN(+activation) backward: returns dx (and the masked upstream gradient g if want_g).
     dgamma/dbeta (views into the gradient arena) are accumulated in place."""
     M, ld = rows(x)
@@ -284,8 +305,16 @@ def bn_bwd(dy, x, scale, shift, gamma, save_mean, save_invstd, dgamma, dbeta, ac
     check(lib().sgx_bn_bwd_reduce(ptr(dy), dl, ptr(x), ld, ptr(scale), ptr(shift), ptr(save_mean), M, C, a, ptr(parts), stream()), "sgx_bn_bwd_reduce")
     coef = torch.empty(4, C, device=x.device, dtype=torch.float32)
     ws = WORKSPACE.get(lib().sgx_reduce_workspace(parts.shape[1], C), x.device)
-    check(lib().sgx_bn_bwd_finalize(ptr(parts), parts.shape[1], M, C, ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(dgamma), ptr(dbeta), ptr(coef),
-                                    ptr(ws), ws.numel(), stream()), "sgx_bn_bwd_finalize")
+    if sync:
+        local = torch.empty(2, C, device=x.device, dtype=torch.float64)
+        check(lib().sgx_bn_reduce_sums(ptr(parts), parts.shape[1], C, ptr(local), ptr(ws), ws.numel(), stream()), "sgx_bn_reduce_sums")
+        glob = local.clone()
+        world = _allreduce_sums(glob)
+        check(lib().sgx_bn_bwd_finalize_sums(ptr(local), ptr(glob), M * world, C, ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(dgamma), ptr(dbeta),
+                                             ptr(coef), stream()), "sgx_bn_bwd_finalize_sums")
+    else:
+        check(lib().sgx_bn_bwd_finalize(ptr(parts), parts.shape[1], M, C, ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(dgamma), ptr(dbeta),
+                                        ptr(coef), ptr(ws), ws.numel(), stream()), "sgx_bn_bwd_finalize")
     dx = dx_out if dx_out is not None else torch.empty(x.shape, device=x.device, dtype=torch.float32)
     g = torch.empty(x.shape, device=x.device, dtype=torch.float32) if want_g else None
     check(lib().sgx_bn_bwd_apply(ptr(dy), dl, ptr(x), ld, ptr(scale), ptr(shift), ptr(coef), ptr(dx), rows(dx)[1], ptr(g), rows(g)[1] if want_g else 0,

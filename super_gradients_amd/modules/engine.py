@@ -218,6 +218,16 @@ class SgxNetwork(nn.Module):
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
 
+    def set_sync_bn(self, enabled: bool = True):
+        """nn.SyncBatchNorm.convert_sync_batchnorm for this network (reference: sg_trainer.py:1344-1350, recipe `sync_bn: True`):
+        every BatchNorm computes its training statistics - and their gradients - over all data-parallel ranks."""
+        from .layers import BatchNorm
+
+        for m in self.modules():
+            if isinstance(m, BatchNorm):
+                m.sync = bool(enabled)
+        return self
+
     def prep_model_for_conversion(self, input_size=None, **kwargs):
         """Reference: CustomizableDetector.prep_model_for_conversion (customizable_detector.py:106-118) - every sub-module that
         knows how to re-parameterise itself does so (QARepVGGBlock: branches [+ post-BN] -> one 3x3 conv); eval forward then runs

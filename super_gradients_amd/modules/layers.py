@@ -92,19 +92,26 @@ class BatchNorm(SgxBlock):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.sync = False  # SgxNetwork.set_sync_bn: statistics over all data-parallel ranks (nn.SyncBatchNorm semantics)
 
     def on_materialize(self):
         pass
 
+    def _synced(self):
+        return self.sync and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+
     def scale_shift(self, parts, M, training):
         """-> (scale, shift, save_mean, save_invstd); eval mode folds the running statistics."""
         if training:
+            if self._synced():
+                return K.bn_finalize_sync(parts, M, self.weight, self.bias, self.eps, self.momentum, self.running_mean, self.running_var)
             return K.bn_finalize(parts, M, self.weight, self.bias, self.eps, self.momentum, self.running_mean, self.running_var)
         sc, sh = K.bn_eval_scale_shift(self.weight, self.bias, self.running_mean, self.running_var, self.eps)
         return sc, sh, None, None
 
     def backward(self, dy, t, scale, shift, mean, invstd, act, dx_out=None, want_g=False):
-        return K.bn_bwd(dy, t, scale, shift, self.weight, mean, invstd, self.weight.grad, self.bias.grad, act=act, dx_out=dx_out, want_g=want_g)
+        return K.bn_bwd(dy, t, scale, shift, self.weight, mean, invstd, self.weight.grad, self.bias.grad, act=act, dx_out=dx_out, want_g=want_g,
+                        sync=self._synced())
 
 
 class ConvTranspose2x2(SgxBlock):

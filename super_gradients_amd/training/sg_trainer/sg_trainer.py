@@ -9,6 +9,7 @@ What runs per batch is identical in order to the reference (callbacks -> forward
 zero_grad -> EMA -> callbacks); what differs is what the calls cost: the network is one autograd node over libsgx_hip kernels,
 optimizer / zero_grad / EMA are one launch each over the arenas, the gradient all-reduce is a handful of RCCL calls overlapped
 with backward, and nothing in the loop synchronises with the host except the once-per-epoch read-back of the averaged loss.
+`sync_bn: True` synchronises BatchNorm statistics across ranks (SgxNetwork.set_sync_bn).
 Out of the hot path and not provided: sg_loggers / tensorboard, dataset statistics, torch.compile, QAT, remote
 checkpoints, model averaging; DetectionMetrics matching is SURVEY 8(f)-2 (next).
 """
@@ -140,8 +141,6 @@ class Trainer:
         merged.update(given)
         if merged["mixed_precision"]:
             warnings.warn("mixed_precision=True is accepted for recipe compatibility; the MI355X path computes in fp32 (parity mode)")
-        if merged["sync_bn"]:
-            raise NotImplementedError("sync_bn is SURVEY 8(f)-4 (next); the reference's own benchmark runs with it off")
         return HpmStruct(**merged)
 
     def _build_loss(self, tp):
@@ -200,6 +199,8 @@ class Trainer:
         if world > 1:
             self.reducer = dtu.GradientAllReducer(self.net, self.net.gradient_buckets())
             self.reducer.broadcast_parameters(0)
+            if tp.sync_bn:
+                self.net.set_sync_bn(True)
         self.criterion = self._build_loss(tp)
         if isinstance(self.criterion, nn.Module):
             self.criterion.to(device)

@@ -79,6 +79,28 @@ def _worker(rank, world, port, outdir):
     out["items"], out["g_logits"] = items.clone(), logits.grad.clone()
     loc = K.ppyoloe_loss_fwd(preds[0], preds[1], preds[2], preds[3], preds[5], t, preds[4], False, True, (1.0, 2.5, 0.5))
     out["local_sums"], out["local_g_logits"] = loc["sums"].clone(), loc["g_logits"].clone()
+    # ---- synchronised BatchNorm: two ranks x half a batch == one process x the whole batch ----------------------------------
+    ref, snet = _tiny_models(dev)  # identical weights on both ranks (seeded inside)
+    snet.materialize(dev).train()
+    snet.set_sync_bn(True)
+    sred = GradientAllReducer(snet, snet.gradient_buckets())
+    gfull = torch.Generator().manual_seed(77)
+    xfull, wfull = torch.randn(8, 4, 8, 8, generator=gfull), torch.randn(8, 6, generator=gfull)
+    xs, ws_ = xfull[rank * 4:(rank + 1) * 4], wfull[rank * 4:(rank + 1) * 4]
+    snet.zero_grad()
+    ys = snet(xs)
+    (ys * ws_).sum().backward()
+    out["sync_y"], out["sync_grad"] = ys.detach().clone(), snet.g_arena.buf.clone()
+    out["sync_running"] = snet.b_arena.buf.clone()
+    if rank == 0:
+        ref.train()
+        yf = ref(xfull)
+        (yf * wfull).sum().backward()
+        out["full_y"] = yf.detach().clone()
+        out["full_grads"] = {k: p.grad.clone() for k, p in ref.named_parameters()}
+        out["full_buffers"] = {k: b.clone() for k, b in ref.named_buffers()}
+        out["slot_layout"] = [(s.name, s.start, s.numel, tuple(s.param.shape)) for s in snet.slots]
+        out["buffer_state"] = {k: v.detach().clone() for k, v in snet.state_dict().items() if "running" in k}
     torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -106,3 +128,22 @@ def test_world_size_2_gloo(tmp_path):
         assert torch.allclose(r[i]["items"][:3], items, rtol=2e-5), (r[i]["items"], items)
         assert abs(float(r[i]["items"][3]) - float(items.sum())) <= 2e-5 * float(items.sum())
         assert torch.allclose(r[i]["g_logits"], r[i]["local_g_logits"] / norm, rtol=2e-5, atol=1e-8)
+    # synchronised BatchNorm: outputs equal the full-batch run's halves; all-reduced gradients equal the full-batch gradients; the running
+    # statistics are the full-batch ones on both ranks
+    for i in range(world):
+        assert torch.allclose(r[i]["sync_y"], r[0]["full_y"][i * 4:(i + 1) * 4], rtol=1e-4, atol=1e-5), f"rank {i} sync-BN forward"
+    assert torch.allclose(r[0]["sync_grad"], r[1]["sync_grad"], rtol=1e-6, atol=1e-7)
+    for name, start, numel, shape in r[0]["slot_layout"]:
+        g = r[0]["sync_grad"][start:start + numel]
+        ref = r[0]["full_grads"][name]
+        if len(shape) == 4:  # conv weight: arena holds OHWI with C padded to 4
+            K_, C_, R_, S_ = shape
+            cp = (C_ + 3) // 4 * 4
+            g = g.view(K_, R_, S_, cp)[..., :C_].permute(0, 3, 1, 2)
+        else:
+            g = g.view(shape)
+        e = float((g - ref).abs().max()) / max(float(ref.abs().max()), 1e-3)
+        assert e <= 2e-4, f"sync-BN gradient of {name}: {e:.2e}"
+    for k, v in r[0]["buffer_state"].items():
+        assert torch.allclose(v, r[0]["full_buffers"][k], rtol=1e-5, atol=1e-6), k
+    assert torch.equal(r[0]["sync_running"], r[1]["sync_running"])
