@@ -270,6 +270,20 @@ int64_t sgx_nms_workspace(const sgx_nms_desc* d);
 int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const float* scores, float* out, int32_t* out_count,
                 int32_t* out_index, int32_t* num_candidates, void* ws, int64_t ws_bytes, void* stream);
 
+/* Validation metrics: match NMS rows to ground truth per image and IoU threshold (training/utils/detection_utils.py:1120-1290,
+ * IoUMatching :880-1005, get_top_k_idx_per_cls :1342-1358).  preds [B][P][6] = x1,y1,x2,y2,score,class with pred_count[B] valid rows
+ * (the layout sgx_nms writes); targets / crowd targets flat [T,6] = (img, class, cx, cy, w, h) indexed per image as by
+ * sgx_targets_index; thresholds[nthr].  Outputs uint8 [B][P][nthr]: matched (true positive) and ignore (outside the per-class
+ * top_k, or matched to a crowd target).                                                                                     */
+typedef struct sgx_match_desc {
+    int32_t B, P, nthr, top_k;
+    int32_t H, W, denormalize;  /* image size for clipping; denormalize: targets are in [0,1] and get multiplied by W / H */
+    int32_t nmax, cmax;         /* padded target / crowd-target slots per image                                             */
+} sgx_match_desc;
+int32_t sgx_detection_match(const sgx_match_desc* d, const float* preds, const int32_t* pred_count, const float* targets,
+                            const int32_t* gt_count, const int32_t* gt_index, const float* crowd, const int32_t* crowd_count,
+                            const int32_t* crowd_index, const float* thresholds, uint8_t* matched, uint8_t* ignore, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Classification loss (training/losses/label_smoothing_cross_entropy_loss.py:86-111, mean reduction).
  * ------------------------------------------------------------------------------------------- */

@@ -14,6 +14,9 @@ Fixtures (all inputs are regenerated from seeds by oracle/golden_util.py; only r
   ppyoloe_loss.pt      reference PPYoloELoss on random head outputs: {ATSS,TAL} x {varifocal,focal} x {batched,
                        sequential}, with the reference unit test's own fixed target tensor and with a seeded target set
                        that contains an empty image, plus the all-empty case: loss, items, d loss / d logits, d loss / d distri.
+  detection_metrics.pt reference compute_detection_matching (IoUMatching, crowd targets, per-class top-k, normalised targets) and
+                       compute_detection_metrics (training/utils/detection_utils.py:880-1580) on the seeded cases of
+                       tests/test_detection_metrics.py: matched / ignore flags per image, AP / precision / recall / F1 / best thresholds.
   post_prediction.pt   reference PPYoloEPostPredictionCallback.forward (post_prediction_callback.py:42-123) with
                        torchvision.ops.boxes.{nms,batched_nms} bound to oracle/nms.py (torchvision is not installed and
                        not vendored: the NMS arithmetic itself stays "parity unpinned", the code around it is pinned).
@@ -173,6 +176,20 @@ def make_post_prediction_fixture():
     return out
 
 
+def make_detection_metrics_fixture():
+    import importlib
+
+    T = importlib.import_module("tests.test_detection_metrics")
+    recs = []
+    for case in T.CASES:
+        preds, t, c, size = T._case(case["seed"], normalized=case["normalized"], crowd=case.get("crowd", True))
+        out, flat, met = T._reference(preds, t, c, size, case["top_k"], case["normalized"])
+        recs.append(dict(case=case, matched=[o[0].clone() for o in out], ignore=[o[1].clone() for o in out], scores=flat[2].clone(), pred_cls=flat[3].clone(),
+                         target_cls=flat[4].clone(), ap=met[0].clone(), precision=met[1].clone(), recall=met[2].clone(), f1=met[3].clone(),
+                         best_score_threshold=met[5].clone(), best_per_class=met[6].clone()))
+    return recs
+
+
 def main():
     if not ref_shim.available():
         raise SystemExit("reference tree not found: make_golden.py runs in the build container only")
@@ -188,6 +205,8 @@ def main():
         print(name, "CE", float(fx["loss"]), "fp64", float(fx["loss_f64"]))
     torch.save(make_loss_fixture(), os.path.join(G.GOLDEN_DIR, "ppyoloe_loss.pt"))
     torch.save(make_post_prediction_fixture(), os.path.join(G.GOLDEN_DIR, "post_prediction.pt"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.save(make_detection_metrics_fixture(), os.path.join(G.GOLDEN_DIR, "detection_metrics.pt"))
     for f in sorted(os.listdir(G.GOLDEN_DIR)):
         print(f, os.path.getsize(os.path.join(G.GOLDEN_DIR, f)) // 1024, "KiB")
 

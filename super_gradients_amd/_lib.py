@@ -45,6 +45,10 @@ class NmsDesc(ctypes.Structure):
     ]
 
 
+class MatchDesc(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in ("B", "P", "nthr", "top_k", "H", "W", "denormalize", "nmax", "cmax")]
+
+
 _P = c_void_p
 _i32, _i64, _f = c_int32, c_int64, c_float
 _CD, _LD, _ND = POINTER(ConvDesc), POINTER(LossDesc), POINTER(NmsDesc)
@@ -102,6 +106,7 @@ PROTOTYPES = {
     "sgx_scale_by_device_scalar": (_i32, [_P, _P, _P, _P, _i64, _P]),
     "sgx_nms_workspace": (_i64, [_ND]),
     "sgx_nms": (_i32, [_ND, _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
+    "sgx_detection_match": (_i32, [POINTER(MatchDesc)] + [_P] * 12),
     "sgx_softmax_ce_fwd_bwd": (_i32, [_i32, _i32, _P, _P, _f, _P, _P, _P]),
     "sgx_adamw_step": (_i32, [_P, _P, _P, _P, _i64, _f, _f, _f, _f, _i32, _P, _P, _i32, _P, _P]),
     "sgx_sgd_step": (_i32, [_P, _P, _P, _i64, _f, _f, _f, _i32, _i32, _P, _P, _i32, _P]),

@@ -275,3 +275,168 @@ extern "C" int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const floa
     SGX_CHECK_LAUNCH("nms");
     return SGX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Detection matching for the validation metrics (mAP): predictions (NMS rows) vs ground truth, per image and IoU threshold.
+// Replaces compute_detection_matching / compute_img_detection_matching / IoUMatching.compute_targets / compute_crowd_targets /
+// get_top_k_idx_per_cls (training/utils/detection_utils.py:1120-1290, 880-1005, 1342-1358), which the reference runs as a Python
+// loop over images with a Python loop over candidate (prediction, target) pairs inside.
+// One workgroup per image.  Per IoU threshold j the reference's rule reduces to an independent greedy pass: predictions in
+// (score desc, index asc) order, restricted to the top_k of their class; each takes the free same-class target of highest IoU
+// (first index among equals: stable descending sort) and is a true positive iff that IoU > thr[j] (and > thr[0], the reference's
+// candidate filter).  Crowd targets: a used prediction is ignored at threshold j iff its best same-class IoA (intersection over
+// detection area) > thr[j]; predictions outside the per-class top_k are ignored at every threshold.
+// Arithmetic order follows box_iou / crowd_ioa (:257-276, :797-810) and cxcywh2xyxy (:725-736); compiled with -ffp-contract=off.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MATCH_THREADS 256
+__device__ __forceinline__ float match_iou(const float* p, const float* t) {
+    const float area1 = (p[2] - p[0]) * (p[3] - p[1]);
+    const float area2 = (t[2] - t[0]) * (t[3] - t[1]);
+    float w = fminf(p[2], t[2]) - fmaxf(p[0], t[0]);
+    float h = fminf(p[3], t[3]) - fmaxf(p[1], t[1]);
+    w = w < 0.f ? 0.f : w;
+    h = h < 0.f ? 0.f : h;
+    const float inter = w * h;
+    return inter / (area1 + area2 - inter);
+}
+__device__ __forceinline__ void match_load_target(const float* t, int denorm, float W, float H, float* box, float* cls) {
+    // row = (img, cls, cx, cy, w, h);  y1 = cy - h*0.5; x1 = cx - w*0.5; y2 = h + y1; x2 = w + x1  (then optional de-normalisation)
+    *cls = t[1];
+    const float y1 = t[3] - t[5] * 0.5f, x1 = t[2] - t[4] * 0.5f;
+    float b[4] = {x1, y1, t[4] + x1, t[5] + y1};
+    if (denorm) {
+        b[0] *= W; b[2] *= W; b[1] *= H; b[3] *= H;
+    }
+    box[0] = b[0]; box[1] = b[1]; box[2] = b[2]; box[3] = b[3];
+}
+__global__ __launch_bounds__(MATCH_THREADS) void match_kernel(sgx_match_desc d, const float* preds, const int* pred_count, const float* targets,
+                                                              const int* gt_count, const int* gt_index, const float* crowd, const int* crowd_count,
+                                                              const int* crowd_index, const float* thr, unsigned char* matched,
+                                                              unsigned char* ignore) {
+    SGX_DYN_SMEM(float, sm);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int P = d.P, nthr = d.nthr;
+    int n = pred_count[b];
+    n = n < P ? n : P;
+    const int nt = d.nmax > 0 ? min(gt_count[b], d.nmax) : 0;
+    const int nc = d.cmax > 0 ? min(crowd_count[b], d.cmax) : 0;
+    float* pbox = sm;                        // [P][4]
+    float* pscore = pbox + (size_t)P * 4;    // [P]
+    float* pcls = pscore + P;                // [P]
+    float* tbox = pcls + P;                  // [nmax][4]
+    float* tcls = tbox + (size_t)d.nmax * 4; // [nmax]
+    float* cbox = tcls + d.nmax;             // [cmax][4]
+    float* ccls = cbox + (size_t)d.cmax * 4; // [cmax]
+    int* order = (int*)(ccls + d.cmax);      // [P]
+    unsigned char* used = (unsigned char*)(order + P);      // [P]
+    unsigned char* tmat = used + P;                          // [nthr][nmax]
+    const float Wf = (float)d.W, Hf = (float)d.H;
+    const bool clip = nt > 0 || nc > 0;  // the reference clips the predictions only when there is something to match (:1262-1264)
+    for (int i = tid; i < n; i += MATCH_THREADS) {
+        const float* r = preds + ((size_t)b * P + i) * 6;
+        float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+        if (clip) {
+            x1 = fminf(fmaxf(x1, 0.f), Wf); x2 = fminf(fmaxf(x2, 0.f), Wf);
+            y1 = fminf(fmaxf(y1, 0.f), Hf); y2 = fminf(fmaxf(y2, 0.f), Hf);
+        }
+        pbox[i * 4 + 0] = x1; pbox[i * 4 + 1] = y1; pbox[i * 4 + 2] = x2; pbox[i * 4 + 3] = y2;
+        pscore[i] = r[4];
+        pcls[i] = r[5];
+    }
+    for (int t = tid; t < nt; t += MATCH_THREADS) match_load_target(targets + (size_t)gt_index[(size_t)b * d.nmax + t] * 6, d.denormalize, Wf, Hf, tbox + t * 4, tcls + t);
+    for (int t = tid; t < nc; t += MATCH_THREADS) match_load_target(crowd + (size_t)crowd_index[(size_t)b * d.cmax + t] * 6, d.denormalize, Wf, Hf, cbox + t * 4, ccls + t);
+    for (int i = tid; i < nthr * d.nmax; i += MATCH_THREADS) tmat[i] = 0;
+    __syncthreads();
+    // global order (score desc, index asc) and membership in the per-class top_k
+    for (int i = tid; i < n; i += MATCH_THREADS) {
+        const float s = pscore[i], c = pcls[i];
+        int grank = 0, crank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float sj = pscore[j];
+            const bool before = sj > s || (sj == s && j < i);
+            grank += before ? 1 : 0;
+            crank += (before && pcls[j] == c) ? 1 : 0;
+        }
+        order[grank] = i;
+        used[i] = (crank < d.top_k && s != 0.f) ? 1 : 0;  // zero scores drop out of the reference's nonzero() selection
+    }
+    __syncthreads();
+    // one greedy pass per threshold
+    if (tid < nthr) {
+        const int j = tid;
+        const float tj = thr[j], t0 = thr[0];
+        unsigned char* free_t = tmat + (size_t)j * d.nmax;
+        for (int r = 0; r < n; ++r) {
+            const int i = order[r];
+            unsigned char m = 0;
+            if (used[i] && nt > 0) {
+                float best = -1.f;
+                int bi = -1;
+                const float c = pcls[i];
+                for (int t = 0; t < nt; ++t) {
+                    if (tcls[t] != c || free_t[t]) continue;
+                    const float v = match_iou(pbox + i * 4, tbox + t * 4);
+                    if (v > best) {
+                        best = v;
+                        bi = t;
+                    }
+                }
+                if (bi >= 0 && best > t0 && best > tj) {
+                    free_t[bi] = 1;
+                    m = 1;
+                }
+            }
+            matched[((size_t)b * P + i) * nthr + j] = m;
+        }
+    }
+    // crowd targets and the top_k rule -> ignore flags
+    for (int i = tid; i < n; i += MATCH_THREADS) {
+        float best = 0.f;
+        bool any = false;
+        if (used[i] && nc > 0) {
+            const float* pb = pbox + i * 4;
+            const float det_area = (pb[2] - pb[0]) * (pb[3] - pb[1]);
+            for (int t = 0; t < nc; ++t) {
+                float v = 0.f;
+                if (ccls[t] == pcls[i]) {
+                    float w = fminf(pb[2], cbox[t * 4 + 2]) - fmaxf(pb[0], cbox[t * 4 + 0]);
+                    float h = fminf(pb[3], cbox[t * 4 + 3]) - fmaxf(pb[1], cbox[t * 4 + 1]);
+                    w = w < 0.f ? 0.f : w;
+                    h = h < 0.f ? 0.f : h;
+                    v = (w * h) / det_area;
+                }
+                if (!any || v > best) best = v;
+                any = true;
+            }
+        }
+        for (int j = 0; j < nthr; ++j) ignore[((size_t)b * P + i) * nthr + j] = (!used[i] || (any && best > thr[j])) ? 1 : 0;
+    }
+    for (int i = n + tid; i < P; i += MATCH_THREADS)
+        for (int j = 0; j < nthr; ++j) {
+            matched[((size_t)b * P + i) * nthr + j] = 0;
+            ignore[((size_t)b * P + i) * nthr + j] = 1;
+        }
+}
+static size_t match_smem(const sgx_match_desc* d) {
+    return ((size_t)d->P * 6 + (size_t)d->nmax * 5 + (size_t)d->cmax * 5) * 4 + (size_t)d->P * 4 + (size_t)d->P + (size_t)d->nthr * d->nmax + 64;
+}
+extern "C" int32_t sgx_detection_match(const sgx_match_desc* d, const float* preds, const int32_t* pred_count, const float* targets,
+                                       const int32_t* gt_count, const int32_t* gt_index, const float* crowd, const int32_t* crowd_count,
+                                       const int32_t* crowd_index, const float* thresholds, uint8_t* matched, uint8_t* ignore, void* stream) {
+    SGX_CHECK_ARG(d && preds && pred_count && thresholds && matched && ignore, "detection_match: null pointer");
+    SGX_CHECK_ARG(d->B > 0 && d->P > 0 && d->nthr > 0 && d->nthr <= MATCH_THREADS && d->top_k > 0, "detection_match: bad dims");
+    SGX_CHECK_ARG(d->nmax == 0 || (targets && gt_count && gt_index), "detection_match: null targets");
+    SGX_CHECK_ARG(d->cmax == 0 || (crowd && crowd_count && crowd_index), "detection_match: null crowd targets");
+    const size_t smem = match_smem(d);
+    if (smem > 160 * 1024) SGX_FAIL(SGX_ERR_UNSUPPORTED, "detection_match: %zu bytes of LDS needed (P=%d, targets %d, crowd %d)", smem, d->P, d->nmax, d->cmax);
+#ifndef SGX_EMU
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) SGX_FAIL(SGX_ERR_HIP, "detection_match: cannot reserve %zu bytes of LDS: %s", smem, hipGetErrorString(e));
+    }
+#endif
+    SGX_LAUNCH(match_kernel, dim3(d->B), dim3(MATCH_THREADS), smem, stream, *d, preds, pred_count, targets, gt_count, gt_index, crowd, crowd_count,
+               crowd_index, thresholds, matched, ignore);
+    SGX_CHECK_LAUNCH("detection_match");
+    return SGX_OK;
+}

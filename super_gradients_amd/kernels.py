@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, LossDesc, NmsDesc, check, lib, ptr, stream
+from ._lib import ConvDesc, LossDesc, MatchDesc, NmsDesc, check, lib, ptr, stream
 
 ACT = {None: 0, "none": 0, "relu": 1, "silu": 2}
 
@@ -480,6 +480,35 @@ def nms(boxes, scores, score_threshold, iou_threshold, nms_top_k, max_prediction
     check(lib().sgx_nms(ctypes.byref(d), ptr(boxes.contiguous().float()), ptr(scores.contiguous().float()), ptr(out), ptr(cnt), ptr(idx), ptr(ncand), None, 0,
                         stream()), "sgx_nms")
     return out, cnt, idx, ncand
+
+
+def _index_targets(t, B):
+    """flat [T,6] targets -> (contiguous float tensor or None, gt_count[B], gt_index[B][nmax], nmax) on t's device."""
+    T = int(t.shape[0])
+    dev = t.device
+    cnt = torch.zeros(B, device=dev, dtype=torch.int32)
+    if T == 0:
+        return None, cnt, None, 0
+    t = t.contiguous().float()
+    idx = torch.empty(B, T, device=dev, dtype=torch.int32)
+    ovf = torch.empty(1, device=dev, dtype=torch.int32)
+    check(lib().sgx_targets_index(ptr(t), T, B, T, ptr(cnt), ptr(idx), ptr(ovf), stream()), "sgx_targets_index")
+    return t, cnt, idx, T
+
+
+def detection_match(rows, counts, targets, crowd_targets, thresholds, height, width, top_k, denormalize):
+    """rows [B,P,6] + counts [B] (the NMS output layout), targets / crowd_targets flat [T,6] -> (matched, ignore) uint8 [B,P,nthr]."""
+    B, P, _ = rows.shape
+    dev = rows.device
+    thr = thresholds.to(dev).float().contiguous()
+    t, tc, ti, nmax = _index_targets(targets.to(dev), B)
+    c, cc, ci, cmax = _index_targets(crowd_targets.to(dev), B)
+    d = MatchDesc(B, P, int(thr.numel()), int(top_k), int(height), int(width), int(bool(denormalize)), nmax, cmax)
+    matched = torch.empty(B, P, thr.numel(), device=dev, dtype=torch.uint8)
+    ignore = torch.empty(B, P, thr.numel(), device=dev, dtype=torch.uint8)
+    check(lib().sgx_detection_match(ctypes.byref(d), ptr(rows.contiguous().float()), ptr(counts.contiguous().int()), ptr(t), ptr(tc), ptr(ti), ptr(c), ptr(cc),
+                                    ptr(ci), ptr(thr), ptr(matched), ptr(ignore), stream()), "sgx_detection_match")
+    return matched, ignore
 
 
 def softmax_ce(logits, labels, smoothing=0.0):

@@ -1,2 +1,2 @@
-from . import losses, models  # noqa: F401
+from . import losses, metrics, models  # noqa: F401
 from .sg_trainer import Trainer  # noqa: F401

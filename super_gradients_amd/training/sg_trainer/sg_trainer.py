@@ -64,6 +64,22 @@ class AverageMeter:
         return tuple((self.sum / max(self.n, 1)).tolist())
 
 
+def _update_metric(m, outputs, targets, inputs, extras):
+    """Classification metrics take (preds, target); detection metrics also need the image batch (for H, W) and optional crowd targets
+    (metrics/detection_metrics.py:166-200)."""
+    from ..metrics.detection_metrics import DetectionMetrics
+
+    if isinstance(m, DetectionMetrics):
+        m.update(outputs, targets, device=str(inputs.device), inputs=inputs, crowd_targets=(extras or {}).get("crowd_targets"))
+    else:
+        m.update(outputs.detach() if torch.is_tensor(outputs) else outputs, targets)
+
+
+def _metric_results(m):
+    r = m.compute()
+    return dict(r) if isinstance(r, dict) else {type(m).__name__: r}
+
+
 def unpack_batch_items(batch_items):
     if len(batch_items) == 2:
         return batch_items[0], batch_items[1], {}
@@ -229,7 +245,8 @@ class Trainer:
             context.update_context(epoch=epoch)
             train_items = self._train_epoch(context, handler, train_loader, n_train, train_metrics, world)
             row = {"epoch": epoch, "lr": float(self.optimizer.param_groups[0]["lr"]), "train": dict(zip(self.loss_logging_items_names, train_items))}
-            row["train"].update({type(m).__name__: m.compute() for m in train_metrics})
+            for m in train_metrics:
+                row["train"].update(_metric_results(m))
             if valid_loader is not None and (epoch + 1) % tp.run_validation_freq == 0:
                 row["valid"] = self._validate_epoch(context, handler, valid_loader, valid_metrics)
                 self._track_best(context, handler, row, epoch)
@@ -269,7 +286,7 @@ class Trainer:
             handler.on_train_batch_loss_end(context)
             meter.update(items, int(inputs.shape[0]))
             for m in train_metrics:
-                m.update(outputs.detach() if torch.is_tensor(outputs) else outputs, targets)
+                _update_metric(m, outputs, targets, inputs, extras)
             loss.backward()
             handler.on_train_batch_backward_end(context)
             global_step = batch_idx + 1 + len(train_loader) * context.epoch
@@ -335,7 +352,7 @@ class Trainer:
                 items = loss[1] if isinstance(loss, tuple) else loss.reshape(1)
                 meter.update(items, int(inputs.shape[0]))
                 for m in metrics:
-                    m.update(outputs, targets)
+                    _update_metric(m, outputs, targets, inputs, extras)
                 context.update_context(preds=outputs, loss_log_items=items)
                 handler.on_validation_batch_end(context)
 
@@ -346,7 +363,8 @@ class Trainer:
             run(self.net)
         self.net.train()
         out = dict(zip(self.loss_logging_items_names or [], meter.average))
-        out.update({type(m).__name__: m.compute() for m in metrics})
+        for m in metrics:
+            out.update(_metric_results(m))
         context.update_context(metrics_dict=out)
         handler.on_validation_loader_end(context)
         return out

@@ -263,7 +263,12 @@ def test_trainer_yolo_nas_recipe_shape(gpu_device, tmp_path):
               optimizer_params=dict(weight_decay=1e-5), zero_weight_decay_on_bias_and_bn=True, warmup_mode="LinearBatchLRWarmup", lr_warmup_steps=2,
               warmup_initial_lr=1e-6, cosine_final_lr_ratio=0.1, ema=True, ema_params=dict(decay=0.9997, decay_type="threshold"), silent_mode=True,
               save_model=False)
-    res = Trainer("yolo_nas_mini", ckpt_root_dir=str(tmp_path)).train(net, tp, loader)
+    from super_gradients_amd.training.metrics import DetectionMetrics_050
+
+    cb = net.get_post_prediction_callback(conf=0.01, iou=0.7, nms_top_k=1000, max_predictions=300, multi_label_per_box=True, class_agnostic_nms=False)
+    tp.update(valid_metrics_list=[DetectionMetrics_050(num_cls=80, post_prediction_callback=cb, normalize_targets=True)], metric_to_watch="mAP@0.50")
+    res = Trainer("yolo_nas_mini", ckpt_root_dir=str(tmp_path)).train(net, tp, loader, valid_loader=loader[:2])
+    assert 0.0 <= res[0]["valid"]["mAP@0.50"] <= 1.0 and "Recall@0.50" in res[0]["valid"] and "loss" in res[0]["valid"]
     decay = [p for k, p in ref.named_parameters() if p.dim() > 1]
     no_decay = [p for k, p in ref.named_parameters() if p.dim() <= 1]
     o = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay}], lr=2e-4, weight_decay=1e-5)
