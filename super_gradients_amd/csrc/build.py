@@ -47,7 +47,7 @@ def build(force=False, verbose=True):
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
     if force or procs or _stale(OUT, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", OUT] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -32,7 +32,8 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError(f"emu compile failed on {src}")
     if force or procs or not os.path.exists(OUT):
-        subprocess.check_call([CXX, "-shared", "-fPIC", "-pthread", "-o", OUT] + objs)
+        # -Bsymbolic: the emulation library's own sgx_* references must never bind to a product library loaded earlier in the process
+        subprocess.check_call([CXX, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-o", OUT] + objs)
     return OUT
 
 

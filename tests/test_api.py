@@ -1,0 +1,140 @@
+"""The Python drop-in boundary: factory / registry / models.get() contracts and error behaviour, the C-ABI symbol table,
+the "no CPU fallback" rule.  Host logic only - runs everywhere."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    """Every function include/sgx_hip.h declares is exported by the built library and has a ctypes prototype (and vice versa)."""
+    from super_gradients_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "sgx_hip.h")).read()
+    declared = set(re.findall(r"\b(sgx_[a-zA-Z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.PROTOTYPES), f"header vs binding: {sorted(declared ^ set(_lib.PROTOTYPES))}"
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libsgx_hip.so not built")
+    cdll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(cdll, name), f"{name} declared in the header but not exported"
+    assert cdll.sgx_version() >= 1
+
+
+def test_no_cpu_fallback():
+    from super_gradients_amd import _lib
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd.training import models
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    _lib._TEST_HOST_MODE = False
+    with pytest.raises(_lib.SgxError):
+        _lib.ptr(torch.zeros(8))  # a CPU tensor reaching a kernel wrapper is rejected before any library call
+    net = models.get("yolo_nas_s", num_classes=3)
+    with pytest.raises(Exception):
+        net(torch.zeros(1, 3, 64, 64))  # no device to materialize on / CPU batch rejected
+
+
+def test_models_get_contract():
+    """model_factory.py:88-92,137-138,179-183: unknown names, missing num_classes, _sg_model_name; state_dict layout of the reference."""
+    from super_gradients_amd.common.factories import UnknownTypeException
+    from super_gradients_amd.training import models
+
+    with pytest.raises(UnknownTypeException):
+        models.get("yolo_nas_xxl", num_classes=80)
+    with pytest.raises(ValueError):
+        models.get("yolo_nas_s")
+    with pytest.raises(ValueError):
+        models.get(123, num_classes=80)
+    net = models.get("yolo_nas_s", num_classes=17)
+    assert models.get_model_name(net) == "yolo_nas_s" and net.num_classes == 17
+    sd = net.state_dict()
+    assert len(sd) == 921 and sum(1 for _ in net.parameters()) == 534
+    assert sd["heads.head1.cls_pred.weight"].shape[0] == 17 and "backbone.stem.conv.rbr_reparam.weight" in sd
+    assert net.get_input_shape_steps() == (32, 32)
+    for name in ("resnet18", "resnet50", "resnet18_cifar", "yolo_nas_m", "yolo_nas_l"):
+        assert models.get(name, num_classes=10) is not None
+
+
+def test_registry_and_factory_semantics():
+    """registry.py:36-41 (re-registering a different class raises), base_factory.py:37-72 (str / single-entry mapping / passthrough, fuzzy names)."""
+    from super_gradients_amd.common.factories import BaseFactory, DetectionModulesFactory, UnknownTypeException
+    from super_gradients_amd.common.registry import Registry
+
+    reg = Registry()
+
+    @reg.register("Thing", deprecated_name="thing_old")
+    class Thing:
+        def __init__(self, a=1):
+            self.a = a
+
+    reg.register("Thing")(Thing)  # same class again: fine
+    with pytest.raises(Exception):
+        reg.register("Thing")(type("Other", (), {}))
+    f = BaseFactory(reg)
+    assert f.get("Thing").a == 1 and f.get({"Thing": {"a": 5}}).a == 5 and f.get("thing").a == 1  # fuzzy name match
+    with pytest.warns(DeprecationWarning):
+        f.get("thing_old")
+    obj = object()
+    assert f.get(obj) is obj
+    with pytest.raises(UnknownTypeException):
+        f.get("Nope")
+    with pytest.raises(RuntimeError):
+        f.get({"Thing": {}, "Other": {}})
+    assert DetectionModulesFactory.insert_module_param({"X": {"a": 1}}, "in_channels", 3) == {"X": {"a": 1, "in_channels": 3}}
+    assert DetectionModulesFactory.insert_module_param("X", "in_channels", 3) == {"X": {"in_channels": 3}}
+
+
+def test_loss_and_callback_protocols():
+    """PPYoloELoss component_names / constructor (ppyolo_loss.py:643-653,990-992); keyword-only callback constructor (post_prediction_callback.py:13-40)."""
+    from super_gradients_amd.training.losses import PPYoloELoss
+    from super_gradients_amd.training.models.detection_models.pp_yolo_e.post_prediction_callback import PPYoloEPostPredictionCallback
+
+    crit = PPYoloELoss(num_classes=80)
+    assert crit.component_names == ["loss_cls", "loss_iou", "loss_dfl", "loss"] and crit.use_static_assigner is True
+    with pytest.warns(DeprecationWarning):
+        PPYoloELoss(num_classes=80, reg_max=16)
+    with pytest.raises(TypeError):
+        PPYoloEPostPredictionCallback(0.1, 0.6, 1000, 300)  # positional arguments are rejected like in the reference
+    cb = PPYoloEPostPredictionCallback(score_threshold=0.1, nms_threshold=0.6, nms_top_k=1000, max_predictions=300)
+    assert cb.multi_label_per_box is True and cb.class_agnostic_nms is False
+
+
+def test_trainer_resume(backend, tmp_path):
+    """Checkpoint round trip: train 1 epoch, resume for a second one == training 2 epochs in one go (weights, optimizer state, EMA, LR)."""
+    from super_gradients_amd.training import Trainer
+    from super_gradients_amd.training.losses import CrossEntropyLoss
+    from test_trainer import _loader, _tiny_models
+
+    loader = _loader(3, 4, 1)
+
+    def params(epochs, **kw):
+        return dict(max_epochs=epochs, lr_mode="StepLRScheduler", lr_updates=[1], lr_decay_factor=0.5, initial_lr=0.05, loss=CrossEntropyLoss(), optimizer="SGD",
+                    optimizer_params=dict(momentum=0.9, weight_decay=1e-3), ema=True, ema_params=dict(decay=0.9, decay_type="constant"), silent_mode=True, **kw)
+
+    _, net_a = _tiny_models(backend)
+    Trainer("a", ckpt_root_dir=str(tmp_path)).train(net_a, params(2), loader)
+    _, net_b = _tiny_models(backend)
+    Trainer("b", ckpt_root_dir=str(tmp_path)).train(net_b, params(1), loader)
+    _, net_c = _tiny_models(backend)
+    tp = params(2, resume_path=os.path.join(str(tmp_path), "b", "ckpt_latest.pth"))
+    # the schedule must see max_epochs=2 from the start for both runs: re-train "b" with max_epochs=2 but stop after epoch 0 via a callback
+    from super_gradients_amd.training.utils.callbacks import Callback
+
+    class StopAfterFirst(Callback):
+        def on_train_loader_end(self, context):
+            context.stop_training = True
+
+    _, net_b = _tiny_models(backend)
+    Trainer("b2", ckpt_root_dir=str(tmp_path)).train(net_b, params(2, phase_callbacks=[StopAfterFirst()]), loader)
+    tp["resume_path"] = os.path.join(str(tmp_path), "b2", "ckpt_latest.pth")
+    tr = Trainer("c", ckpt_root_dir=str(tmp_path))
+    tr.train(net_c, tp, loader)
+    for (k, va), vc in zip(net_a.state_dict().items(), net_c.state_dict().values()):
+        if va.dtype.is_floating_point:
+            assert torch.allclose(va.cpu(), vc.cpu(), rtol=1e-5, atol=1e-6), k
