@@ -111,7 +111,7 @@ def test_trainer_resume(backend, tmp_path):
     from super_gradients_amd.training.losses import CrossEntropyLoss
     from test_trainer import _loader, _tiny_models
 
-    loader = _loader(3, 4, 1)
+    loader = _loader(2, 2, 1)
 
     def params(epochs, **kw):
         return dict(max_epochs=epochs, lr_mode="StepLRScheduler", lr_updates=[1], lr_decay_factor=0.5, initial_lr=0.05, loss=CrossEntropyLoss(), optimizer="SGD",

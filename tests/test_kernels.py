@@ -417,11 +417,12 @@ def test_nms_large_topk(backend):
     """nms_top_k above 1024 (the 2048 / 4096-candidate instantiations): several candidates per thread in the sort and the scan."""
     from oracle import nms as onms
 
-    B, L, C, topk, maxp = _sizes(backend, (2, 8400, 80, 3000, 1200), (1, 700, 4, 1500, 1100))
+    B, L, C, topk, maxp = _sizes(backend, (2, 8400, 80, 3000, 1200), (1, 500, 4, 1500, 1100))
     boxes, scores = _nms_case(B, L, C, seed=9, clusters=40)
     kw = dict(score_threshold=0.02, nms_threshold=0.6, nms_top_k=topk, max_predictions=maxp, multi_label_per_box=True)
-    for class_mode, ref in ((0, onms.post_prediction(boxes, scores, class_agnostic_nms=True, **kw)),
-                            (3, onms.post_prediction(boxes, scores, class_agnostic_nms=False, **kw))):
+    modes = ((0, True), (3, False)) if backend.type == "cuda" else ((3, False),)  # host emulation: one mode (1024 OS threads per launch)
+    for class_mode, agnostic in modes:
+        ref = onms.post_prediction(boxes, scores, class_agnostic_nms=agnostic, **kw)
         out, cnt, idx, ncand = K.nms(boxes.to(backend), scores.to(backend), 0.02, 0.6, topk, maxp, multi_label=True, class_mode=class_mode)
         assert int(ncand.max()) > 1024, "case must exceed the 1024-candidate kernel"
         for b in range(B):

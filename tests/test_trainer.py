@@ -80,7 +80,7 @@ def test_trainer_matches_torch_loop(backend, tmp_path, opt):
     from super_gradients_amd.training.utils.callbacks import CosineLRScheduler
 
     ref, net = _tiny_models(backend)
-    n, epochs, bs = 3, 2, 4
+    n, epochs, bs = (3, 2, 4) if backend.type == "cuda" else (2, 2, 2)  # host emulation: keep the CPU suite short
     loader = _loader(n, bs, 1)
     initial_lr, warm_steps, warm_lr, ratio = 0.05, 2, 1e-3, 0.1
     oparams = dict(momentum=0.9, weight_decay=1e-2) if opt == "SGD" else dict(weight_decay=1e-2, betas=(0.9, 0.99))
