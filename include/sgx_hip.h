@@ -182,6 +182,17 @@ int32_t sgx_axpy(const float* x, int64_t x_ld, float a, const float* a_dev, floa
 /* g = dy where y > 0, else 0: backward of a ReLU applied after a residual add (classification_models/resnet.py:43-50,72-84). */
 int32_t sgx_relu_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, float* g, int64_t g_ld, int64_t M, int32_t C,
                      void* stream);
+/* RepVGGBlock training forward (modules/repvgg_block.py:98-107: act(bn3(conv3x3 x) + bn1(conv1x1 x))) and the post-activation
+ * residuals around it (csp_resnet.py:43-49 `x + y`, pp_yolo_head.py:205 `stem_cls(feat) + feat`) as ONE sweep:
+ *   y = act(s1[c]*x1 + t1[c] [+ s2[c]*x2 + t2[c]]) [+ r]        x2 / r may be NULL.                                          */
+int32_t sgx_dual_affine_act_fwd(const float* x1, int64_t x1_ld, const float* s1, const float* t1, const float* x2, int64_t x2_ld,
+                                const float* s2, const float* t2, const float* r, int64_t r_ld, float* y, int64_t y_ld, int64_t M,
+                                int32_t C, int32_t act, void* stream);
+/* its backward through the activation: g = dy * act'(s1*x1 + t1 [+ s2*x2 + t2]) - the upstream gradient both BatchNorm backward
+ * passes (sgx_bn_bwd_*, act = none) then consume.                                                                            */
+int32_t sgx_dual_affine_act_bwd(const float* dy, int64_t dy_ld, const float* x1, int64_t x1_ld, const float* s1, const float* t1,
+                                const float* x2, int64_t x2_ld, const float* s2, const float* t2, float* g, int64_t g_ld, int64_t M,
+                                int32_t C, int32_t act, void* stream);
 /* per-channel column sum: out[c] (+)= sum_rows x[row][c]  (conv bias gradients).                     */
 /* rows_per_img/ld_img: rows are grouped in images of rows_per_img rows, image i starts at x + i*ld_img
  * (pass rows_per_img = M, ld_img = 0 for a plain [M,C] matrix).  ws: sgx_colsum_workspace(M, C) bytes.  */
@@ -206,6 +217,33 @@ int32_t sgx_avgpool_fwd(int32_t N, int32_t HW, int32_t C, const float* x, int64_
                         float* y, void* stream);
 int32_t sgx_avgpool_bwd(int32_t N, int32_t HW, int32_t C, const float* dy, float* dx, int64_t dx_ld_pix,
                         int64_t dx_ld_img, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Squeeze-excitation gates and nearest up-sampling of PP-YOLOE:
+ *   EffectiveSEBlock.forward  modules/se_blocks.py:39-42     x * hardsigmoid(project(mean_hw(x)))
+ *   ESEAttn.forward           pp_yolo_e/pp_yolo_head.py:90-92  conv(feat * sigmoid(fc(avg_feat)))
+ *   F.interpolate(scale_factor=2, mode="nearest")  pp_yolo_e/pan.py:170
+ * ------------------------------------------------------------------------------------------- */
+#define SGX_GATE_NONE 0        /* f(p) = p (plain per-image channel scale) */
+#define SGX_GATE_HARDSIGMOID 1 /* f(p) = min(max(p/6 + 1/2, 0), 1); f' = 1/6 on -3 < p < 3 (ATen) */
+#define SGX_GATE_SIGMOID 2
+/* Per-image column reduction, deterministic two-stage (fp32 chunk partials, fp64 finalize in fixed order):
+ *   out[n][c] = scale * f'(pre[n][c]) * sum_p u[n][p][c] * v[n][p][c]      v NULL -> 1 ; pre NULL -> no f' factor.
+ * mean over H*W: u = x, scale = 1/HW.  Gate gradient: u = dy, v = x, pre = the gate's pre-activation.                          */
+int64_t sgx_image_colsum_workspace(int32_t N, int32_t HW, int32_t C);
+int32_t sgx_image_colsum(int32_t N, int32_t HW, int32_t C, const float* u, int64_t u_ld_pix, int64_t u_ld_img, const float* v,
+                         int64_t v_ld_pix, int64_t v_ld_img, float scale, const float* pre, int32_t gate, float* out, void* ws,
+                         int64_t ws_bytes, void* stream);
+/* y[n][p][c] (+)= x[n][p][c] * f(pre[n][c]) + bias_scale * bias[n][c]     bias NULL -> 0.  Forward of both gates; with
+ * x = dy and bias = d(mean) it is also their backward to the gated tensor.  In-place (y == x) is allowed when !accumulate.      */
+int32_t sgx_channel_gate(int32_t N, int32_t HW, int32_t C, const float* x, int64_t x_ld_pix, int64_t x_ld_img, const float* pre,
+                         int32_t gate, const float* bias, float bias_scale, float* y, int64_t y_ld_pix, int64_t y_ld_img,
+                         int32_t accumulate, void* stream);
+/* nearest-neighbour x2: y[n][2h+i][2w+j][c] = x[n][h][w][c]; backward dx (+)= the sum of the four.                                */
+int32_t sgx_upsample2x_fwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* x, int64_t x_ld_pix, int64_t x_ld_img, float* y,
+                           int64_t y_ld_pix, int64_t y_ld_img, void* stream);
+int32_t sgx_upsample2x_bwd(int32_t N, int32_t H, int32_t W, int32_t C, const float* dy, int64_t dy_ld_pix, int64_t dy_ld_img,
+                           float* dx, int64_t dx_ld_pix, int64_t dx_ld_img, int32_t accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Detection head decode, PPYoloELoss (assigner + VFL/GIoU/DFL with hand-written backward), NMS.

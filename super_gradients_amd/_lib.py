@@ -98,6 +98,13 @@ PROTOTYPES = {
     "sgx_maxpool_bwd": (_i32, [_i32] * 7 + [_P, _P, _i64, _i64, _P, _i64, _i64, _i32, _P]),
     "sgx_avgpool_fwd": (_i32, [_i32] * 3 + [_P, _i64, _i64, _P, _P]),
     "sgx_avgpool_bwd": (_i32, [_i32] * 3 + [_P, _P, _i64, _i64, _P]),
+    "sgx_dual_affine_act_fwd": (_i32, [_P, _i64, _P, _P, _P, _i64, _P, _P, _P, _i64, _P, _i64, _i64, _i32, _i32, _P]),
+    "sgx_dual_affine_act_bwd": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _i64, _P, _P, _P, _i64, _i64, _i32, _i32, _P]),
+    "sgx_image_colsum_workspace": (_i64, [_i32] * 3),
+    "sgx_image_colsum": (_i32, [_i32] * 3 + [_P, _i64, _i64, _P, _i64, _i64, _f, _P, _i32, _P, _P, _i64, _P]),
+    "sgx_channel_gate": (_i32, [_i32] * 3 + [_P, _i64, _i64, _P, _i32, _P, _f, _P, _i64, _i64, _i32, _P]),
+    "sgx_upsample2x_fwd": (_i32, [_i32] * 4 + [_P, _i64, _i64, _P, _i64, _i64, _P]),
+    "sgx_upsample2x_bwd": (_i32, [_i32] * 4 + [_P, _i64, _i64, _P, _i64, _i64, _i32, _P]),
     "sgx_dfl_decode": (_i32, [_i32] * 4 + [_P] * 6 + [_P]),
     "sgx_targets_index": (_i32, [_P, _i32, _i32, _i32, _P, _P, _P, _P]),
     "sgx_ppyoloe_loss_workspace": (_i64, [_LD]),

@@ -493,6 +493,71 @@ extern "C" int32_t sgx_relu_bwd(const float* dy, int64_t dy_ld, const float* y, 
     return run_sweep<ReluBwdF, 0>(f, M, C, nullptr, stream, "relu_bwd");
 }
 
+// RepVGG-style two-branch BatchNorm sum + activation (+ post-activation residual) in one sweep, and the gradient through the
+// activation (the pre-activation is recomputed from the two saved conv outputs; nothing else is stored).
+struct DualAffineF {
+    const float* x1; long x1_ld; const float* s1; const float* t1;
+    const float* x2; long x2_ld; const float* s2; const float* t2;
+    const float* r; long r_ld; float* y; long y_ld; int act;
+    struct In { float4 a, b, u; };
+    __device__ In load(long row, int c) const {
+        In in;
+        in.a = sgx_ld4(x1 + row * x1_ld + c);
+        in.b = x2 ? sgx_ld4(x2 + row * x2_ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        in.u = r ? sgx_ld4(r + row * r_ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        return in;
+    }
+    __device__ float4 pre(int c, const float4& a, const float4& b) const {
+        float4 s = sgx_ld4(s1 + c), t = sgx_ld4(t1 + c);
+        float4 v = make_float4(s.x * a.x + t.x, s.y * a.y + t.y, s.z * a.z + t.z, s.w * a.w + t.w);
+        if (x2) {
+            float4 p = sgx_ld4(s2 + c), q = sgx_ld4(t2 + c);
+            v.x += p.x * b.x + q.x; v.y += p.y * b.y + q.y; v.z += p.z * b.z + q.z; v.w += p.w * b.w + q.w;
+        }
+        return v;
+    }
+    __device__ void apply(long row, int c, const In& in, float4& q0, float4& q1) const {
+        (void)q0; (void)q1;
+        float4 v = pre(c, in.a, in.b);
+        float4 o = make_float4(sgx_act(v.x, act), sgx_act(v.y, act), sgx_act(v.z, act), sgx_act(v.w, act));
+        if (r) { o.x += in.u.x; o.y += in.u.y; o.z += in.u.z; o.w += in.u.w; }
+        sgx_st4(y + row * y_ld + c, o);
+    }
+};
+extern "C" int32_t sgx_dual_affine_act_fwd(const float* x1, int64_t x1_ld, const float* s1, const float* t1, const float* x2, int64_t x2_ld,
+                                           const float* s2, const float* t2, const float* r, int64_t r_ld, float* y, int64_t y_ld, int64_t M,
+                                           int32_t C, int32_t act, void* stream) {
+    SGX_CHECK_ARG(x1 && s1 && t1 && y, "dual_affine_act_fwd: null pointer");
+    SGX_CHECK_ARG(!x2 || (s2 && t2), "dual_affine_act_fwd: second branch needs scale and shift");
+    DualAffineF f{x1, x1_ld, s1, t1, x2, x2_ld, s2, t2, r, r_ld, y, y_ld, act};
+    return run_sweep<DualAffineF, 0>(f, M, C, nullptr, stream, "dual_affine_act_fwd");
+}
+struct DualAffineBwdF {
+    DualAffineF p; const float* dy; long dy_ld; float* g; long g_ld;
+    struct In { float4 a, b, d; };
+    __device__ In load(long row, int c) const {
+        In in;
+        in.a = sgx_ld4(p.x1 + row * p.x1_ld + c);
+        in.b = p.x2 ? sgx_ld4(p.x2 + row * p.x2_ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        in.d = sgx_ld4(dy + row * dy_ld + c);
+        return in;
+    }
+    __device__ void apply(long row, int c, const In& in, float4& q0, float4& q1) const {
+        (void)q0; (void)q1;
+        float4 v = p.pre(c, in.a, in.b);
+        sgx_st4(g + row * g_ld + c, make_float4(in.d.x * sgx_act_grad(v.x, p.act), in.d.y * sgx_act_grad(v.y, p.act),
+                                                 in.d.z * sgx_act_grad(v.z, p.act), in.d.w * sgx_act_grad(v.w, p.act)));
+    }
+};
+extern "C" int32_t sgx_dual_affine_act_bwd(const float* dy, int64_t dy_ld, const float* x1, int64_t x1_ld, const float* s1, const float* t1,
+                                           const float* x2, int64_t x2_ld, const float* s2, const float* t2, float* g, int64_t g_ld, int64_t M,
+                                           int32_t C, int32_t act, void* stream) {
+    SGX_CHECK_ARG(dy && x1 && s1 && t1 && g, "dual_affine_act_bwd: null pointer");
+    SGX_CHECK_ARG(!x2 || (s2 && t2), "dual_affine_act_bwd: second branch needs scale and shift");
+    DualAffineBwdF f{DualAffineF{x1, x1_ld, s1, t1, x2, x2_ld, s2, t2, nullptr, 0, nullptr, 0, act}, dy, dy_ld, g, g_ld};
+    return run_sweep<DualAffineBwdF, 0>(f, M, C, nullptr, stream, "dual_affine_act_bwd");
+}
+
 struct ColsumF {
     const float* x; long ld; long rows_per_img; long ld_img;
     struct In { float4 v; };

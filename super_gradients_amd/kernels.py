@@ -349,6 +349,77 @@ def relu_bwd(dy, y, out=None):
     return out
 
 
+def dual_affine_act(x1, s1, t1, x2=None, s2=None, t2=None, post_add=None, act=None, out=None):
+    """y = act(s1*x1 + t1 [+ s2*x2 + t2]) [+ post_add]   (RepVGG two-branch BatchNorm sum; post-activation residual)."""
+    M, ld1 = rows(x1)
+    C = x1.shape[3]
+    if out is None:
+        out = torch.empty(x1.shape, device=x1.device, dtype=torch.float32)
+    check(lib().sgx_dual_affine_act_fwd(ptr(x1), ld1, ptr(s1), ptr(t1), ptr(x2), rows(x2)[1] if x2 is not None else 0, ptr(s2), ptr(t2), ptr(post_add),
+                                        rows(post_add)[1] if post_add is not None else 0, ptr(out), rows(out)[1], M, C, ACT[act], stream()),
+          "sgx_dual_affine_act_fwd")
+    return out
+
+
+def dual_affine_act_bwd(dy, x1, s1, t1, x2=None, s2=None, t2=None, act=None, out=None):
+    """g = dy * act'(s1*x1 + t1 [+ s2*x2 + t2])."""
+    M, ld1 = rows(x1)
+    C = x1.shape[3]
+    if out is None:
+        out = torch.empty(x1.shape, device=x1.device, dtype=torch.float32)
+    check(lib().sgx_dual_affine_act_bwd(ptr(dy), rows(dy)[1], ptr(x1), ld1, ptr(s1), ptr(t1), ptr(x2), rows(x2)[1] if x2 is not None else 0, ptr(s2), ptr(t2),
+                                        ptr(out), rows(out)[1], M, C, ACT[act], stream()), "sgx_dual_affine_act_bwd")
+    return out
+
+
+GATE = {None: 0, "none": 0, "hardsigmoid": 1, "sigmoid": 2}
+
+
+def image_colsum(u, v=None, scale=1.0, pre=None, gate=None):
+    """out[n,c] = scale * f'(pre[n,c]) * sum_pixels u*v   ([N,C]; v / pre optional)."""
+    n, h, w, c = u.shape
+    ul, ui = nhwc_strides(u)
+    vl, vi = nhwc_strides(v) if v is not None else (0, 0)
+    out = torch.empty(n, c, device=u.device, dtype=torch.float32)
+    ws = WORKSPACE.get(lib().sgx_image_colsum_workspace(n, h * w, c), u.device)
+    check(lib().sgx_image_colsum(n, h * w, c, ptr(u), ul, ui, ptr(v), vl, vi, float(scale), ptr(pre), GATE[gate], ptr(out), ptr(ws), ws.numel(), stream()),
+          "sgx_image_colsum")
+    return out
+
+
+def channel_gate(x, pre, gate, bias=None, bias_scale=1.0, out=None, accumulate=False):
+    """y (+)= x * f(pre[n,c]) + bias_scale * bias[n,c]."""
+    n, h, w, c = x.shape
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    xl, xi = nhwc_strides(x)
+    yl, yi = nhwc_strides(out)
+    check(lib().sgx_channel_gate(n, h * w, c, ptr(x), xl, xi, ptr(pre), GATE[gate], ptr(bias), float(bias_scale), ptr(out), yl, yi, int(accumulate), stream()),
+          "sgx_channel_gate")
+    return out
+
+
+def upsample2x_fwd(x, out=None):
+    n, h, w, c = x.shape
+    if out is None:
+        out = torch.empty(n, 2 * h, 2 * w, c, device=x.device, dtype=torch.float32)
+    xl, xi = nhwc_strides(x)
+    yl, yi = nhwc_strides(out)
+    check(lib().sgx_upsample2x_fwd(n, h, w, c, ptr(x), xl, xi, ptr(out), yl, yi, stream()), "sgx_upsample2x_fwd")
+    return out
+
+
+def upsample2x_bwd(dy, out=None, accumulate=False):
+    n, h2, w2, c = dy.shape
+    h, w = h2 // 2, w2 // 2
+    if out is None:
+        out = torch.empty(n, h, w, c, device=dy.device, dtype=torch.float32)
+    dl, di = nhwc_strides(dy)
+    xl, xi = nhwc_strides(out)
+    check(lib().sgx_upsample2x_bwd(n, h, w, c, ptr(dy), dl, di, ptr(out), xl, xi, int(accumulate), stream()), "sgx_upsample2x_bwd")
+    return out
+
+
 def colsum(x, out, accumulate=True):
     ld_pix, ld_img = nhwc_strides(x)
     n, h, w, C = x.shape

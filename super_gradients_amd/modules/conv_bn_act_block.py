@@ -25,17 +25,24 @@ class _ConvBN(SgxBlock):
     def on_materialize(self):
         pass
 
-    def fwd(self, x, out=None):
+    def fwd(self, x, out=None, post_add=None):
+        """post_add: tensor added AFTER the activation (pp_yolo_head.py:205 `stem_cls(feat, avg_feat) + feat`); its gradient is the
+        caller's (dy reaches it unchanged)."""
         conv, bn = self._parts()
         if self.training:
             t, parts = conv.conv(x, stats=True)
             M = t.shape[0] * t.shape[1] * t.shape[2]
             scale, shift, mean, invstd = bn.scale_shift(parts, M, True)
-            y = K.affine_act(t, scale, shift, act=self.act, out=out)
+            if post_add is None:
+                y = K.affine_act(t, scale, shift, act=self.act, out=out)
+            else:
+                y = K.dual_affine_act(t, scale, shift, post_add=post_add, act=self.act, out=out)
             self._ctx = (x, t, scale, shift, mean, invstd)
             return y
         t = conv.conv(x)
         scale, shift, _, _ = bn.scale_shift(None, 0, False)
+        if post_add is not None:
+            return K.dual_affine_act(t, scale, shift, post_add=post_add, act=self.act, out=out if out is not None else t)
         return K.affine_act(t, scale, shift, act=self.act, out=out if out is not None else t)
 
     def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):

@@ -30,12 +30,30 @@ def _yolo_nas(spec):
     return dict(in_channels=3, backbone=backbone, neck=neck, heads=heads, bn_eps=1e-3, bn_momentum=0.03, inplace_act=True)
 
 
+# PP-YOLOE (recipes/arch_params/ppyoloe_arch_params.yaml + ppyoloe_{s,m,l,x}_arch_params.yaml): (depth_mult, width_mult)
+_PPYOLOE = {"ppyoloe_s_arch_params": (0.33, 0.50), "ppyoloe_m_arch_params": (0.67, 0.75), "ppyoloe_l_arch_params": (1.0, 1.0),
+            "ppyoloe_x_arch_params": (1.33, 1.25)}
+
+
+def _ppyoloe(mults):
+    depth, width = mults
+    return dict(depth_mult=depth, width_mult=width, num_classes=80,
+                backbone=dict(layers=[3, 6, 6, 3], channels=[64, 128, 256, 512, 1024], activation="silu", return_idx=[1, 2, 3], use_large_stem=True,
+                              use_alpha=False, pretrained_weights=None),
+                neck=dict(in_channels=[256, 512, 1024], out_channels=[768, 384, 192], activation="silu", block_num=3, stage_num=1, spp=True),
+                head=dict(in_channels=[768, 384, 192], activation="silu", fpn_strides=[32, 16, 8], grid_cell_scale=5.0, grid_cell_offset=0.5, reg_max=16,
+                          eval_size=None))
+
+
 def get_arch_params(config_name: str, overriding_params: dict = None, recipes_dir_path=None) -> dict:
     from ..utils.utils import recursive_override
 
-    if config_name not in _YOLO_NAS:
-        raise ValueError(f"unknown arch params '{config_name}' (available: {sorted(_YOLO_NAS)})")
-    cfg = _yolo_nas(_YOLO_NAS[config_name])
+    if config_name in _PPYOLOE:
+        cfg = _ppyoloe(_PPYOLOE[config_name])
+    elif config_name in _YOLO_NAS:
+        cfg = _yolo_nas(_YOLO_NAS[config_name])
+    else:
+        raise ValueError(f"unknown arch params '{config_name}' (available: {sorted(list(_YOLO_NAS) + list(_PPYOLOE))})")
     if overriding_params:
         cfg = copy.deepcopy(cfg)
         recursive_override(cfg, dict(overriding_params))

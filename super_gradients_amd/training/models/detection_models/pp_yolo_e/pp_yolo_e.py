@@ -1,0 +1,128 @@
+"""PPYoloE / PPYoloE_S / _M / _L / _X on the HIP kernels (reference: pp_yolo_e/pp_yolo_e.py:95-439).
+
+CSPResNetBackbone -> PPYoloECSPPAN -> PPYOLOEHead as ONE autograd node (modules/engine.py:SgxNetwork): training returns the
+reference's raw 6-tuple (cls_logits [B,L,C], reg_distri [B,L,68], anchors, anchor_points, num_anchors_list, stride_tensor), eval
+returns ((pred_bboxes, pred_scores), raw) - exactly what PPYoloELoss / PPYoloEPostPredictionCallback consume.
+"""
+import copy
+from typing import Tuple
+
+import torch
+
+from ..... import kernels as K
+from .....common.registry import register_model
+from .....modules.engine import SgxNetwork
+from ....utils.utils import HpmStruct
+from ...arch_params_factory import get_arch_params
+from ..csp_resnet import CSPResNetBackbone
+from .pan import PPYoloECSPPAN
+from .post_prediction_callback import PPYoloEPostPredictionCallback
+from .pp_yolo_head import PPYOLOEHead
+
+
+class PPYoloE(SgxNetwork):
+    def __init__(self, arch_params):
+        super().__init__()
+        if isinstance(arch_params, HpmStruct):
+            arch_params = arch_params.to_dict()
+        arch_params = copy.deepcopy(dict(arch_params))
+        self.backbone = CSPResNetBackbone(**arch_params["backbone"], depth_mult=arch_params["depth_mult"], width_mult=arch_params["width_mult"])
+        self.neck = PPYoloECSPPAN(**arch_params["neck"], depth_mult=arch_params["depth_mult"], width_mult=arch_params["width_mult"])
+        self.head = PPYOLOEHead(**arch_params["head"], width_mult=arch_params["width_mult"], num_classes=arch_params["num_classes"])
+        self.in_channels = 3
+        self._default_nms_iou, self._default_nms_conf, self._default_nms_top_k = 0.7, 0.5, 1024
+        self._default_max_predictions, self._default_multi_label_per_box, self._default_class_agnostic_nms = 300, True, False
+
+    def get_post_prediction_callback(self, *, conf: float, iou: float, nms_top_k: int, max_predictions: int, multi_label_per_box: bool,
+                                     class_agnostic_nms: bool) -> PPYoloEPostPredictionCallback:
+        return PPYoloEPostPredictionCallback(score_threshold=conf, nms_threshold=iou, nms_top_k=nms_top_k, max_predictions=max_predictions,
+                                             multi_label_per_box=multi_label_per_box, class_agnostic_nms=class_agnostic_nms)
+
+    def get_input_shape_steps(self) -> Tuple[int, int]:
+        return 32, 32
+
+    def get_minimum_input_shape_size(self) -> Tuple[int, int]:
+        return 32, 32
+
+    def get_input_channels(self) -> int:
+        return self.backbone.get_input_channels()
+
+    def get_finetune_lr_dict(self, lr: float):
+        return {"head": lr, "default": 0}
+
+    @property
+    def num_classes(self):
+        return self.head.num_classes
+
+    def prep_model_for_conversion(self, input_size=None, **kwargs):
+        """RepVGG blocks -> single 3x3 convs, anchors cached for `input_size` (reference :358-377)."""
+        if input_size is not None:
+            self.head.cache_anchors(input_size[-2:])
+        return super().prep_model_for_conversion(input_size, **kwargs)
+
+    # ---- SgxNetwork protocol -------------------------------------------------------------------------------------
+    def _fwd(self, x):
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected an NCHW batch with {self.in_channels} channels, got {tuple(x.shape)}")
+        xh = K.nchw_to_nhwc(x.float())
+        boxes, scores, logits, distri, anchors, pts, counts, strides = self.head.fwd(self.neck.fwd(self.backbone.fwd(xh)))
+        self._aux = (anchors, pts, list(counts), strides)
+        self._out_shapes = (tuple(logits.shape), tuple(distri.shape))
+        return (logits, distri) if boxes is None else (boxes, scores, logits, distri)
+
+    def _differentiable_outputs(self, n):
+        return [True, True] if n == 2 else [False, False, True, True]
+
+    def _pack(self, flat):
+        anchors, pts, counts, strides = self._aux
+        if len(flat) == 2:
+            return flat[0], flat[1], anchors, pts, list(counts), strides
+        boxes, scores, logits, distri = flat
+        return (boxes, scores), (logits, distri, anchors, pts, list(counts), strides)
+
+    def _bwd(self, d_logits, d_distri):
+        dev = self._device
+        like_l, like_d = self._out_shapes
+        if d_logits is None:
+            d_logits = torch.zeros(like_l, device=dev)
+        if d_distri is None:
+            d_distri = torch.zeros(like_d, device=dev)
+        ready = getattr(self, "_grad_ready", None) or (lambda prefix: None)
+        dps = self.head.bwd(d_logits.contiguous(), d_distri.contiguous())
+        ready("head.")
+        dcs = self.neck.bwd(*dps)
+        ready("neck.")
+        self.backbone.bwd(dcs, on_layer_done=lambda layer: ready(f"backbone.{layer}."))
+
+    def gradient_buckets(self):
+        """Arena ranges in backward-completion order (training/utils/distributed_training_utils.GradientAllReducer)."""
+        return ["backbone.stem."] + [f"backbone.stages.{i}." for i in range(len(self.backbone.stages))] + ["neck.", "head."]
+
+
+def _variant(default_name):
+    def init(self, arch_params=None):
+        if isinstance(arch_params, HpmStruct):
+            arch_params = arch_params.to_dict()
+        PPYoloE.__init__(self, get_arch_params(default_name, overriding_params=dict(arch_params or {})))
+
+    return init
+
+
+@register_model("ppyoloe_s")
+class PPYoloE_S(PPYoloE):
+    __init__ = _variant("ppyoloe_s_arch_params")
+
+
+@register_model("ppyoloe_m")
+class PPYoloE_M(PPYoloE):
+    __init__ = _variant("ppyoloe_m_arch_params")
+
+
+@register_model("ppyoloe_l")
+class PPYoloE_L(PPYoloE):
+    __init__ = _variant("ppyoloe_l_arch_params")
+
+
+@register_model("ppyoloe_x")
+class PPYoloE_X(PPYoloE):
+    __init__ = _variant("ppyoloe_x_arch_params")

@@ -429,3 +429,74 @@ def test_nms_large_topk(backend):
             n = int(cnt[b])
             assert n == ref[b].shape[0], f"mode {class_mode} image {b}: kept {n} vs oracle {ref[b].shape[0]}"
             assert torch.equal(out[b, :n].cpu(), ref[b]), f"mode {class_mode} image {b}: rows differ"
+
+
+# --------------------------------------------------------------------------------------------- PP-YOLOE pieces
+@pytest.mark.parametrize("act", ["silu", "relu", None])
+def test_dual_affine_act(backend, act):
+    """RepVGG two-branch BN sum + activation (+ post-activation residual), and the gradient through the activation."""
+    n, h, w, c = _sizes(backend, (3, 37, 29, 96), (2, 5, 3, 8))
+    g = torch.Generator().manual_seed(11)
+    x1, x2, r, dy = (torch.randn(n, c, h, w, generator=g) for _ in range(4))
+    s1, t1, s2, t2 = (torch.randn(c, generator=g) for _ in range(4))
+    f = {"silu": F.silu, "relu": F.relu, None: lambda v: v}[act]
+    v = lambda t: t.view(1, c, 1, 1)  # noqa: E731
+    pre = (x1 * v(s1) + v(t1) + x2 * v(s2) + v(t2)).requires_grad_(True)
+    ref = f(pre) + r
+    (gref,) = torch.autograd.grad(ref, pre, dy)
+    d = lambda t: t.to(backend)  # noqa: E731
+    out = empty_nhwc(n, h, w, c, backend, ld_pix=c + 8, c_off=4)
+    K.dual_affine_act(to_nhwc(x1, backend, ld_pix=c + 4), d(s1), d(t1), to_nhwc(x2, backend), d(s2), d(t2), post_add=to_nhwc(r, backend), act=act, out=out)
+    assert_close(to_nchw_cpu(out), ref.detach(), TOL, f"dual_affine_act {act}")
+    gg = K.dual_affine_act_bwd(to_nhwc(dy, backend), to_nhwc(x1, backend), d(s1), d(t1), to_nhwc(x2, backend, ld_pix=c + 12, c_off=8), d(s2), d(t2), act=act)
+    assert_close(to_nchw_cpu(gg), gref, TOL, f"dual_affine_act_bwd {act}")
+    # single branch + post-activation residual (pp_yolo_head.py:205)
+    ref1 = f(x1 * v(s1) + v(t1)) + r
+    y1 = K.dual_affine_act(to_nhwc(x1, backend), d(s1), d(t1), post_add=to_nhwc(r, backend), act=act)
+    assert_close(to_nchw_cpu(y1), ref1, TOL, f"single affine + post add {act}")
+
+
+@pytest.mark.parametrize("gate", ["hardsigmoid", "sigmoid"])
+def test_se_gate(backend, gate):
+    """mean over H*W, x * f(pre), and both gradients (EffectiveSEBlock se_blocks.py:39-42, ESEAttn pp_yolo_head.py:90-92)."""
+    n, h, w, c = _sizes(backend, (3, 45, 37, 192), (2, 6, 5, 8))   # 1665 pixels: several 512-pixel chunks on the GPU
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(n, c, h, w, generator=g).requires_grad_(True)
+    pre = (torch.randn(n, c, generator=g) * 3).requires_grad_(True)
+    dy = torch.randn(n, c, h, w, generator=g)
+    f = {"hardsigmoid": F.hardsigmoid, "sigmoid": torch.sigmoid}[gate]
+    y = x * f(pre).view(n, c, 1, 1)
+    gx, gpre = torch.autograd.grad(y, (x, pre), dy)
+    xd, dyd, pd = to_nhwc(x.detach(), backend, ld_pix=c + 4), to_nhwc(dy, backend), pre.detach().to(backend)
+    mean = K.image_colsum(xd, scale=1.0 / (h * w))
+    assert_close(mean.cpu(), x.detach().mean((2, 3)), TOL, "image mean")
+    yd = K.channel_gate(xd, pd, gate)
+    assert_close(to_nchw_cpu(yd), y.detach(), TOL, f"gate fwd {gate}")
+    dpre = K.image_colsum(dyd, v=xd, pre=pd, gate=gate)
+    assert_close(dpre.cpu(), gpre, 5e-5, f"gate dpre {gate}")
+    bias = torch.randn(n, c, generator=g)
+    base = torch.randn(n, c, h, w, generator=g)
+    acc = to_nhwc(base, backend, ld_pix=c + 8, c_off=4)
+    K.channel_gate(dyd, pd, gate, bias=bias.to(backend), bias_scale=0.25, out=acc, accumulate=True)
+    assert_close(to_nchw_cpu(acc), base + gx + 0.25 * bias.view(n, c, 1, 1), TOL, f"gate bwd (accumulate + bias) {gate}")
+    inplace = to_nhwc(dy, backend)
+    K.channel_gate(inplace, pd, gate, out=inplace)
+    assert_close(to_nchw_cpu(inplace), gx, TOL, f"gate in place {gate}")
+
+
+def test_upsample2x(backend):
+    n, h, w, c = _sizes(backend, (2, 20, 24, 96), (2, 3, 4, 8))
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(n, c, h, w, generator=g).requires_grad_(True)
+    ref = F.interpolate(x, scale_factor=2, mode="nearest")
+    dy = torch.randn(ref.shape, generator=g)
+    (gx,) = torch.autograd.grad(ref, x, dy)
+    out = empty_nhwc(n, 2 * h, 2 * w, c, backend, ld_pix=c + 8)
+    K.upsample2x_fwd(to_nhwc(x.detach(), backend, ld_pix=c + 4, c_off=4), out=out)
+    assert torch.equal(to_nchw_cpu(out), ref.detach()), "nearest up-sampling is a copy: bit-exact"
+    dx = K.upsample2x_bwd(to_nhwc(dy, backend, ld_pix=c + 4))
+    assert_close(to_nchw_cpu(dx), gx, 1e-6, "upsample bwd")
+    base = torch.randn(n, c, h, w, generator=g)
+    acc = to_nhwc(base, backend)
+    K.upsample2x_bwd(to_nhwc(dy, backend), out=acc, accumulate=True)
+    assert_close(to_nchw_cpu(acc), base + gx, 1e-6, "upsample bwd accumulate")
