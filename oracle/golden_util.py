@@ -33,7 +33,7 @@ def deterministic_fill(module: torch.nn.Module, seed: int = 0) -> None:
             v = torch.empty(t.shape).uniform_(0.5, 1.5, generator=g)
         elif leaf == "alpha":
             v = 1.0 + torch.randn(t.shape, generator=g) * 0.1
-        elif name.endswith("cls_pred.bias"):
+        elif name.endswith("cls_pred.bias") or (".pred_cls." in name and leaf == "bias"):
             # the detection prior the reference initialises with (dfl_heads.py:98-100, -log((1-0.01)/0.01)): keeps the
             # classification loss - and with it the conditioning of the loss gradient - in its realistic regime
             v = -math.log(99.0) + torch.randn(t.shape, generator=g) * 0.1

@@ -8,6 +8,9 @@ Fixtures (all inputs are regenerated from seeds by oracle/golden_util.py; only r
                        deterministic_fill weights, train-mode forward on a seeded image batch: decoded boxes / scores,
                        raw logits / distribution logits, anchors, points, strides; reference PPYoloELoss (TAL and ATSS)
                        loss items; per-parameter gradient L2 norms and sums of the TAL loss; BN running-stat checksums.
+  ppyoloe_s.pt         reference PPYoloE-S (pp_yolo_e/pp_yolo_e.py:95, csp_resnet.py, pan.py, pp_yolo_head.py), deterministic_fill weights:
+                       train-mode raw outputs (fp32 + the same modules in fp64), PPYoloELoss (TAL / ATSS) items, per-parameter gradient
+                       norms (fp32 / fp64), BN running-stat checksums, eval-mode decoded boxes / scores and raw outputs.
   resnet18_cifar.pt, resnet50.pt   reference CifarResNet / ResNet (classification_models/resnet.py) with deterministic_fill
                        weights, train-mode forward on a seeded batch: logits, mean cross-entropy, per-parameter gradient norms
                        (fp32 and the same modules in fp64), BN running-stat checksums.
@@ -108,6 +111,55 @@ def make_model_fixture(variant):
     return fx
 
 
+def make_ppyoloe_fixture(variant="s", batch=2, size=128):
+    """Reference PPYoloE (CSPResNet + CSPPAN + PPYOLOEHead): train-mode raw 6-tuple, PPYoloELoss items, gradient norms (fp32 / fp64),
+    BN running-stat checksums, eval-mode decoded + raw outputs."""
+    import copy
+
+    torch.manual_seed(0)
+    net = ref_shim.build_reference_ppyoloe(variant, num_classes=80)
+    G.deterministic_fill(net, seed=1)
+    net.train()
+    x = G.seeded_input(batch, 3, size, seed=2)
+    targets = G.detection_targets(batch, size, seed=3, kmax=3, empty_last=False)
+    net64 = copy.deepcopy(net).double()
+    out = net(x)
+    logits, distri, anchors, points, counts, strides = out
+    fx = dict(variant=variant, batch=batch, size=size, state_keys=list(net.state_dict().keys()),
+              state_shapes=[tuple(v.shape) for v in net.state_dict().values()], logits=logits.detach().clone(), distri=distri.detach().clone(),
+              anchors=anchors.clone(), points=points.clone(), counts=list(counts), strides=strides.clone(), targets=targets)
+    net64_eval = copy.deepcopy(net64)
+    out64 = net64(x.double())
+    fx.update(logits_f64=out64[0].detach().clone(), distri_f64=out64[1].detach().clone())
+    torch.set_default_dtype(torch.float64)
+    try:
+        loss64, _ = ref_shim.reference_ppyolo_loss(num_classes=80, use_static_assigner=False)(out64, targets.double())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    loss64.backward()
+    fx["grad_norms_f64"] = torch.tensor([float(p.grad.norm()) for n, p in net64.named_parameters()], dtype=torch.float64)
+    for static in (False, True):
+        loss, items = ref_shim.reference_ppyolo_loss(num_classes=80, use_static_assigner=static)(out, targets)
+        fx["loss_items_atss" if static else "loss_items_tal"] = items.detach().clone()
+        if not static:
+            loss.backward(retain_graph=True)
+            fx["grad_names"] = [n for n, p in net.named_parameters()]
+            fx["grad_norms"] = torch.tensor([float(p.grad.double().norm()) for p in net.parameters()], dtype=torch.float64)
+    fx["bn_running_checksum"] = {k: float(v.double().sum()) for k, v in net.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+    # eval on the seeded running statistics (a fresh copy: the training forward above updated them); fp64 twin for the three-way bar
+    ev = ref_shim.build_reference_ppyoloe(variant, num_classes=80)
+    G.deterministic_fill(ev, seed=1)
+    ev.eval()
+    ev64 = copy.deepcopy(ev).double()
+    with torch.no_grad():
+        (eb, es), (el, ed, *_r) = ev(x)
+        (eb64, es64), (el64, ed64, *_r) = ev64(x.double())
+    fx.update(eval_boxes=eb.clone(), eval_scores=es.clone(), eval_logits=el.clone(), eval_distri=ed.clone(), eval_logits_f64=el64.clone(),
+              eval_distri_f64=ed64.clone(), eval_boxes_f64=eb64.clone())
+    del net64_eval
+    return fx
+
+
 RESNET_CASES = {"resnet18_cifar": dict(cls="ResNet18Cifar", batch=8, size=32, classes=10), "resnet50": dict(cls="ResNet50", batch=4, size=64, classes=100)}
 
 
@@ -195,10 +247,17 @@ def main():
         raise SystemExit("reference tree not found: make_golden.py runs in the build container only")
     os.makedirs(G.GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(8)
-    for v in MODEL_CASES:
+    only = set(sys.argv[1:])   # e.g. `python oracle/make_golden.py ppyoloe_s` regenerates just that fixture
+    for v in ([] if only else MODEL_CASES):
         fx = make_model_fixture(v)
         torch.save(fx, os.path.join(G.GOLDEN_DIR, f"yolo_nas_{v}.pt"))
         print(v, "loss items TAL", fx["loss_items_tal"].tolist(), "ATSS", fx["loss_items_atss"].tolist())
+    if not only or "ppyoloe_s" in only:
+        fx = make_ppyoloe_fixture("s")
+        torch.save(fx, os.path.join(G.GOLDEN_DIR, "ppyoloe_s.pt"))
+        print("ppyoloe_s loss items TAL", fx["loss_items_tal"].tolist(), "ATSS", fx["loss_items_atss"].tolist())
+    if only:
+        return
     for name in RESNET_CASES:
         fx = make_resnet_fixture(name)
         torch.save(fx, os.path.join(G.GOLDEN_DIR, f"{name}.pt"))

@@ -230,6 +230,24 @@ def build_reference_yolo_nas(variant: str = "s", num_classes: int = 80, in_chann
     )
 
 
+def build_reference_ppyoloe(variant: str = "s", num_classes: int = 80):
+    """The reference's own PPYoloE (pp_yolo_e/pp_yolo_e.py:95-111) from its arch YAMLs (recipes/arch_params/ppyoloe_*.yaml), bypassing hydra."""
+    import yaml
+
+    install()
+    from super_gradients.training.models.detection_models.pp_yolo_e.pp_yolo_e import PPYoloE
+
+    d = os.path.join(REF_SRC, "super_gradients", "recipes", "arch_params")
+    with open(os.path.join(d, "ppyoloe_arch_params.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    with open(os.path.join(d, f"ppyoloe_{variant}_arch_params.yaml")) as f:
+        var = yaml.safe_load(f)
+    cfg["depth_mult"], cfg["width_mult"] = var["depth_mult"], var["width_mult"]
+    cfg["num_classes"] = num_classes
+    cfg["backbone"]["pretrained_weights"] = None   # no network here
+    return PPYoloE(cfg)
+
+
 def reference_ppyolo_loss(**kw):
     install()
     from super_gradients.training.losses.ppyolo_loss import PPYoloELoss

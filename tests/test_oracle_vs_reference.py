@@ -293,3 +293,128 @@ def test_reference_unit_test_batched_equals_sequential_on_product(backend):
             assert abs(float(ours[0]) - float(ref[0])) < 0.5e-4 * max(1.0, abs(float(ref[0])))
             for i in range(4):
                 assert abs(float(ours[1][i]) - float(ref[1][i])) < 0.5e-4 * max(1.0, abs(float(ref[1][i])))
+
+
+# ------------------------------------------------------------------------------------------------ PP-YOLOE
+def test_oracle_ppyoloe_golden():
+    """oracle/pp_yolo_e.py against tests/golden/ppyoloe_s.pt (outputs of the reference's own PPYoloE source files)."""
+    from oracle.pp_yolo_e import PPYoloE
+    from oracle.ppyolo_loss import PPYoloELossOracle
+
+    fx = _load("ppyoloe_s.pt")
+    net = PPYoloE("s", num_classes=80)
+    sd = net.state_dict()
+    assert list(sd.keys()) == fx["state_keys"], "state_dict keys / order differ from the reference"
+    assert [tuple(v.shape) for v in sd.values()] == fx["state_shapes"]
+    G.deterministic_fill(net, seed=1)
+    import copy
+
+    ev = copy.deepcopy(net).eval()
+    net.train()
+    x = G.seeded_input(fx["batch"], 3, fx["size"], seed=2)
+    out = net(x)
+    logits, distri, anchors, points, counts, strides = out
+    assert torch.equal(anchors, fx["anchors"]) and torch.equal(points, fx["points"]) and torch.equal(strides, fx["strides"]) and list(counts) == fx["counts"]
+    _close(logits, fx["logits"], 2e-5, "logits")
+    _close(distri, fx["distri"], 2e-5, "distri")
+    for static, key in ((False, "loss_items_tal"), (True, "loss_items_atss")):
+        loss, items = PPYoloELossOracle(80, use_static_assigner=static)(out, fx["targets"])
+        _close(items, fx[key], 2e-5, key)
+        if not static:
+            loss.backward()
+            assert [n for n, _ in net.named_parameters()] == fx["grad_names"]
+            norms = torch.tensor([float(p.grad.double().norm()) for p in net.parameters()], dtype=torch.float64)
+            big = fx["grad_norms"] > 1e-3 * fx["grad_norms"].max()
+            assert float(((norms - fx["grad_norms"]).abs() / fx["grad_norms"].clamp_min(1e-30))[big].max()) < 5e-3
+    for k, v in fx["bn_running_checksum"].items():
+        assert abs(float(net.state_dict()[k].double().sum()) - v) <= 2e-5 * max(abs(v), 1.0), k
+    with torch.no_grad():
+        (eb, es), (el, ed, *_r) = ev(x)
+    for name, t in (("eval_boxes", eb), ("eval_scores", es), ("eval_logits", el), ("eval_distri", ed)):
+        _close(t, fx[name], 2e-5, name)
+
+
+@pytest.mark.gpu
+def test_product_ppyoloe_golden(gpu_device):
+    """The HIP PP-YOLOE-S against the reference's own outputs (fixture), three-way with the reference's fp64 run where fp32 round-off
+    through the training-mode BatchNorms exceeds 1e-4 on its own."""
+    from super_gradients_amd.training import models
+    from super_gradients_amd.training.losses import PPYoloELoss
+
+    fx = _load("ppyoloe_s.pt")
+    tol = 1e-4
+
+    def build():
+        net = models.get("ppyoloe_s", num_classes=80)
+        sd = net.state_dict()
+        assert list(sd.keys()) == fx["state_keys"] and [tuple(v.shape) for v in sd.values()] == fx["state_shapes"]
+        G.deterministic_fill(net, seed=1)
+        return net.materialize(gpu_device)
+
+    def three_way(name, t):
+        e_pair = rel_err(t.cpu(), fx[name])
+        e_hip, e_cpu = rel_err(t.cpu().double(), fx[name + "_f64"]), rel_err(fx[name].double(), fx[name + "_f64"])
+        assert e_pair <= tol or e_hip <= max(tol, 2.0 * e_cpu), f"{name}: hip-ref32 {e_pair:.2e}, hip-ref64 {e_hip:.2e}, ref32-ref64 {e_cpu:.2e}"
+
+    x = G.seeded_input(fx["batch"], 3, fx["size"], seed=2).to(gpu_device)
+    ev = build().eval()
+    with torch.no_grad():
+        (eb, es), (el, ed, *_r) = ev(x)
+    for name, t in (("eval_logits", el), ("eval_distri", ed), ("eval_boxes", eb)):
+        three_way(name, t)
+    net = build().train()
+    out = net(x)
+    logits, distri, anchors, points, counts, strides = out
+    assert torch.equal(anchors.cpu(), fx["anchors"]) and torch.equal(points.cpu(), fx["points"]) and torch.equal(strides.cpu(), fx["strides"])
+    three_way("logits", logits)
+    three_way("distri", distri)
+    for static, key in ((True, "loss_items_atss"), (False, "loss_items_tal")):
+        loss, items = PPYoloELoss(80, use_static_assigner=static)(out, fx["targets"].to(gpu_device))
+        _close(items.cpu(), fx[key], tol, key)
+    loss.backward()  # TAL
+    params = dict(net.named_parameters())
+    norms = torch.tensor([float(params[n].grad.double().norm()) for n in fx["grad_names"]], dtype=torch.float64)
+    t64 = fx["grad_norms_f64"]
+    big = fx["grad_norms"] > 1e-3 * fx["grad_norms"].max()
+    e_hip = ((norms - t64).abs() / t64.clamp_min(1e-30))[big]
+    e_ref = ((fx["grad_norms"] - t64).abs() / t64.clamp_min(1e-30))[big]
+    msg = (f"gradient norms vs fp64: hip worst {float(e_hip.max()):.2e} mean {float(e_hip.mean()):.2e}; "
+           f"reference fp32 worst {float(e_ref.max()):.2e} mean {float(e_ref.mean()):.2e}")
+    assert float(e_hip.max()) <= max(5e-3, 3.0 * float(e_ref.max())) and float(e_hip.mean()) <= max(1e-3, 3.0 * float(e_ref.mean())), msg
+    print(f"[ppyoloe_s] {msg}")
+    for k, v in fx["bn_running_checksum"].items():
+        assert abs(float(net.state_dict()[k].double().sum()) - v) <= 1e-4 * max(abs(v), 1.0), k
+
+
+@live
+@pytest.mark.parametrize("variant", ["s", "m"])
+def test_oracle_ppyoloe_live(variant):
+    """oracle/pp_yolo_e.py against the reference's PPYoloE executed here: same state_dict, bit-exact training forward, gradients."""
+    from oracle.pp_yolo_e import PPYoloE
+
+    torch.manual_seed(10)
+    ref = ref_shim.build_reference_ppyoloe(variant, num_classes=80)
+    G.deterministic_fill(ref, seed=3)
+    net = PPYoloE(variant, num_classes=80)
+    assert list(net.state_dict().keys()) == list(ref.state_dict().keys())
+    net.load_state_dict(ref.state_dict(), strict=True)
+    ref.train(), net.train()
+    x = G.seeded_input(2, 3, 96, seed=11)
+    o_ref, o = ref(x), net(x)
+    for i in (0, 1, 2, 3, 5):
+        assert torch.equal(o[i], o_ref[i]), f"{variant}: output {i} differs"
+    assert list(o[4]) == list(o_ref[4])
+    g = torch.Generator().manual_seed(12)
+    up = [torch.randn(o[0].shape, generator=g), torch.randn(o[1].shape, generator=g)]
+    torch.autograd.backward([o_ref[0], o_ref[1]], up)
+    torch.autograd.backward([o[0], o[1]], up)
+    rp = dict(ref.named_parameters())
+    for n, p in net.named_parameters():
+        e = float((p.grad - rp[n].grad).norm()) / max(float(rp[n].grad.norm()), 1e-12)
+        assert e < 1e-5, f"{n}: grad rel L2 {e:.2e}"
+    ref.eval(), net.eval()
+    with torch.no_grad():
+        (b_r, s_r), raw_r = ref(x)
+        (b, s), raw = net(x)
+    _close(b, b_r, 2e-6, "eval boxes")
+    assert torch.equal(s, s_r) and torch.equal(raw[0], raw_r[0]) and torch.equal(raw[1], raw_r[1])
