@@ -50,6 +50,12 @@ int32_t sgx_prof_bytes(int32_t cls, double* bytes);
 
 /* Measurement aid (tools/conv_tune.py): force the conv tile shapes (0 = built-in heuristic).  Not thread-safe; never set by the product. */
 int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk, int32_t wgrad_bj, int32_t wgrad_split_target);
+/* Arithmetic of the forward / data-gradient GEMMs.  0 (default): fp32 matrix pipe, exact fp32 FMA chains.  1: "bf16x3" - every fp32
+ * operand is split into three bf16 pieces (24 mantissa bits) and the six significant cross products run on the bf16 matrix pipe with
+ * fp32 accumulation: fp32-accurate results (dropped terms <= 2^-24 of a product) at 2.7x fewer matrix-pipe cycles.  2: per problem -
+ * bf16x3 where the reduction depth (taps x channels) is >= 192, fp32 MFMA for shallow ones.  Process-wide.                           */
+int32_t sgx_conv_set_math(int32_t mode);
+int32_t sgx_conv_get_math(void);
 int32_t sgx_debug_set_variant(int32_t wave_layout_variant);
 
 /* ---------------------------------------------------------------------------------------------

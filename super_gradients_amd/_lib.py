@@ -61,6 +61,8 @@ PROTOTYPES = {
     "sgx_prof_summary": (_i32, [_i32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "sgx_debug_set_tiles": (_i32, [_i32] * 5),
     "sgx_debug_set_variant": (_i32, [_i32]),
+    "sgx_conv_set_math": (_i32, [_i32]),
+    "sgx_conv_get_math": (_i32, []),
     "sgx_prof_bytes": (_i32, [_i32, POINTER(ctypes.c_double)]),
     "sgx_conv2d_fwd": (_i32, [_CD, _P, _P, _P, _P, _P, _i32, _P, _P]),
     "sgx_conv2d_fwd_stat_blocks": (_i32, [_CD]),
@@ -154,6 +156,11 @@ def lib():
             )
         _LIB = bind(ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL))
         _check_single_runtime()
+        mode = os.environ.get("SGX_CONV_MATH")   # "fp32" | "bf16x3" | "auto" (kernels.set_conv_math); unset = the library default
+        if mode:
+            if mode not in ("fp32", "bf16x3", "auto"):
+                raise RuntimeError(f"SGX_CONV_MATH={mode!r}: expected 'fp32', 'bf16x3' or 'auto'")
+            _LIB.sgx_conv_set_math({"fp32": 0, "bf16x3": 1, "auto": 2}[mode])
     return _LIB
 
 

@@ -156,8 +156,88 @@ struct IgemmParams {
 
 #define IG_BK 16
 #define IG_LD 20
+// ---- "bf16x3" arithmetic (MATH = 1): fp32 operands split into three bf16 pieces (round-to-nearest, each residual exact in fp32), products hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi on the bf16 matrix pipe
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate): the dropped terms are <= 2^-24 of the product, i.e. the result carries fp32
+// accuracy, while six 32-cycle bf16 MFMAs replace eight 64-cycle fp32 ones per 16-deep slab (2.7x fewer matrix-pipe cycles).
+// The split happens ONCE per element, when a slab is staged from registers into LDS: three bf16 planes of [rows][16 bf16 = 8 dwords],
+// no padding; the two 16-byte halves of a row are swapped on rows with bit 3 set (IG_SWZ), which makes the 16-byte fragment reads of
+// 16 consecutive rows hit 16 distinct 4-bank groups (conflict-free) at 2/3 of the LDS a padded pitch would need.
+#define IG_LDP 8
+#define IG_SWZ(row, dw) ((dw) ^ ((((row) >> 3) & 1) << 2))
+__device__ __forceinline__ unsigned sgx_f2u(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+__device__ __forceinline__ float sgx_u2f(unsigned u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// (bf16(b) << 16) | bf16(a), round-to-nearest-even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned sgx_pack_bf16(float a, float b) {
+#ifdef SGX_EMU
+    const unsigned ua = sgx_f2u(a), ub = sgx_f2u(b);
+    const unsigned ra = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16, rb = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
+    return (ra & 0xffffu) | (rb << 16);
+#else
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+#endif
+}
+// x = hi + mid + lo with every piece rounded to nearest: |x - (hi + mid + lo)| <= 2^-27 |x|, the residuals are exact in fp32, and the
+// pieces carry mixed signs, so the cross terms the six-product scheme drops (mid*lo, lo*mid, lo*lo: <= 2^-26 of a product) are unbiased.
+// (A truncating split is one instruction cheaper per pair but leaves every dropped term with the sign of the product: measured as a
+// 2x larger end-to-end error than the fp32 matrix pipe on the YOLO-NAS-M golden fixture.)
+__device__ __forceinline__ void sgx_split3(const float4& v, uint2& h, uint2& m, uint2& l) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned hp[2], mp[2], lp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        hp[i] = sgx_pack_bf16(a, b);
+        const float ra = a - sgx_u2f(hp[i] << 16), rb = b - sgx_u2f(hp[i] & 0xffff0000u);
+        mp[i] = sgx_pack_bf16(ra, rb);
+        const float sa = ra - sgx_u2f(mp[i] << 16), sb = rb - sgx_u2f(mp[i] & 0xffff0000u);
+        lp[i] = sgx_pack_bf16(sa, sb);
+    }
+    h = make_uint2(hp[0], hp[1]);
+    m = make_uint2(mp[0], mp[1]);
+    l = make_uint2(lp[0], lp[1]);
+}
+#ifdef SGX_EMU
+// host emulation of v_mfma_f32_32x32x16_bf16: lane l holds A[row l%32][k = 8*(l/32) .. +7] and B[k = 8*(l/32) .. +7][col l%32]
+static inline sgx_f32x16 sgx_mfma_bf16(const uint4& a, const uint4& b, sgx_f32x16 c) {
+    uint64_t u[4];
+    memcpy(&u[0], &a, 16);
+    memcpy(&u[2], &b, 16);
+    auto x = sgx_emu::xchg_put(u, 4);
+    const int l = sgx_emu::t_lane;
+    const int col = l & 31;
+    sgx_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = d[r];
+        for (int half = 0; half < 2; ++half) {
+            unsigned short av[8], bv[8];
+            memcpy(av, &x.w->xbuf[x.buf][row + 32 * half][0], 16);
+            memcpy(bv, &x.w->xbuf[x.buf][col + 32 * half][2], 16);
+            for (int k = 0; k < 8; ++k) acc = fmaf(sgx_u2f((unsigned)av[k] << 16), sgx_u2f((unsigned)bv[k] << 16), acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+#else
+typedef __bf16 sgx_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ sgx_f32x16 sgx_mfma_bf16(const uint4& a, const uint4& b, sgx_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sgx_bf16x8, a), __builtin_bit_cast(sgx_bf16x8, b), c, 0, 0, 0);
+}
+#endif
 
-template <int BM, int BN, int WM, int WN, bool FLAT>
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     constexpr int NTH = WM * WN * 64;   // threads per workgroup
     constexpr int RPP = NTH / 4;        // slab rows staged per pass (4 threads x 16 B per 16-float row)
@@ -165,10 +245,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     constexpr int AJ = (BM + RPP - 1) / RPP, BJ = (BN + RPP - 1) / RPP;
     static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "bad tile");
     static_assert(NTH >= BM && NTH >= BN, "epilogue helpers need one thread per tile row/col");
-    constexpr int SLABS = 2 * (BM + BN) * IG_LD, STAGE = WM * WN * 32 * 32;  // operand slabs; epilogue staging patches (reuse the slabs)
+    constexpr int ROWW = MATH == 1 ? 3 * IG_LDP : IG_LD;                       // dwords of LDS per slab row (all planes)
+    constexpr int SLABS = 2 * (BM + BN) * ROWW, STAGE = WM * WN * 32 * 32;   // operand slabs; epilogue staging patches (reuse the slabs)
     __shared__ __attribute__((aligned(16))) float smem[SLABS > STAGE ? SLABS : STAGE];
     float* const As = smem;
-    float* const Bs = smem + 2 * BM * IG_LD;
+    float* const Bs = smem + 2 * BM * ROWW;
     __shared__ long long rowoff[BM];
     __shared__ float red[2 * WM * BN];
 
@@ -248,7 +329,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     // scalar slab state of the NEXT slab to load (non-FLAT): tap row, tap column, channel chunk
     int s_ti = 0, s_tj = 0, s_ck = 0, s_kt = 0;
     float4 ra[AJ], rb[BJ];
-    auto load_tile = [&]() {
+    auto load_tile_to = [&](float4* ra, float4* rb) {
         if (FLAT) {
             const int kk = s_kt * IG_BK + chunk4;  // flattened (tap, c) index of this lane's chunk
             const int t = kk / p.C;
@@ -286,7 +367,35 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         }
         ++s_kt;
     };
-    auto store_tile = [&](int buf) {
+    auto load_tile = [&]() { load_tile_to(ra, rb); };
+    auto store_tile_from = [&](int buf, const float4* ra, const float4* rb) {
+        if (MATH == 1) {  // planes [buf][hi|mid|lo][row][IG_LDP dwords]; this lane's 4 k-values are 2 dwords of a row
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const int row = lrow + RPP * j;
+                if (row < BM) {
+                    uint2 h, m, l;
+                    sgx_split3(ra[j], h, m, l);
+                    unsigned* d = reinterpret_cast<unsigned*>(As) + (buf * 3 * BM + row) * IG_LDP + IG_SWZ(row, chunk4 >> 1);
+                    *reinterpret_cast<uint2*>(d) = h;
+                    *reinterpret_cast<uint2*>(d + BM * IG_LDP) = m;
+                    *reinterpret_cast<uint2*>(d + 2 * BM * IG_LDP) = l;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int row = lrow + RPP * j;
+                if (row < BN) {
+                    uint2 h, m, l;
+                    sgx_split3(rb[j], h, m, l);
+                    unsigned* d = reinterpret_cast<unsigned*>(Bs) + (buf * 3 * BN + row) * IG_LDP + IG_SWZ(row, chunk4 >> 1);
+                    *reinterpret_cast<uint2*>(d) = h;
+                    *reinterpret_cast<uint2*>(d + BN * IG_LDP) = m;
+                    *reinterpret_cast<uint2*>(d + 2 * BN * IG_LDP) = l;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int row = lrow + RPP * j;
@@ -298,6 +407,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             if (row < BN) sgx_st4(&Bs[buf * BN * IG_LD + row * IG_LD + chunk4], rb[j]);
         }
     };
+    auto store_tile = [&](int buf) { store_tile_from(buf, ra, rb); };
 
     sgx_f32x16 acc[TM][TN];
 #pragma unroll
@@ -307,6 +417,19 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // bf16x3: the five correction products (<= 2^-8 of the leading one) get their own accumulator, so that their fp32 additions round
+    // at 2^-8 of the result's magnitude; the leading hi*hi products are exact and add into `acc` once per 16-deep slab - fewer
+    // roundings at full magnitude than the fp32 matrix pipe's eight per slab.  The two are summed once, before the epilogue.
+    sgx_f32x16 acc2[MATH == 1 ? TM : 1][MATH == 1 ? TN : 1];
+    if (MATH == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[MATH == 1 ? i : 0][MATH == 1 ? j : 0][r] = 0.f;
+    }
+
     if (nkt > 0) {
         load_tile();
         store_tile(0);
@@ -314,10 +437,61 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     __syncthreads();
 
     const int frow = lane & 31, fk = (lane >> 5) * 8;
+    // bf16x3 fragment reads + the six cross-product MFMAs of one slab (smallest terms first)
+    auto compute_bf3 = [&](int buf) {
+        uint4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const unsigned* s = reinterpret_cast<const unsigned*>(As) + (buf * 3 * BM + wm * TM * 32 + i * 32 + frow) * IG_LDP + IG_SWZ(frow, (lane >> 5) * 4);
+            ah[i] = *reinterpret_cast<const uint4*>(s);
+            am[i] = *reinterpret_cast<const uint4*>(s + BM * IG_LDP);
+            al[i] = *reinterpret_cast<const uint4*>(s + 2 * BM * IG_LDP);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const unsigned* s = reinterpret_cast<const unsigned*>(Bs) + (buf * 3 * BN + wn * TN * 32 + j * 32 + frow) * IG_LDP + IG_SWZ(frow, (lane >> 5) * 4);
+            bh[j] = *reinterpret_cast<const uint4*>(s);
+            bm[j] = *reinterpret_cast<const uint4*>(s + BN * IG_LDP);
+            bl[j] = *reinterpret_cast<const uint4*>(s + 2 * BN * IG_LDP);
+        }
+        // smallest terms first; the six products of one (i, j) are interleaved across the tile's accumulators
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc2[i][j] = sgx_mfma_bf16(al[i], bh[j], acc2[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc2[i][j] = sgx_mfma_bf16(ah[i], bl[j], acc2[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc2[i][j] = sgx_mfma_bf16(am[i], bm[j], acc2[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc2[i][j] = sgx_mfma_bf16(am[i], bh[j], acc2[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc2[i][j] = sgx_mfma_bf16(ah[i], bm[j], acc2[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = sgx_mfma_bf16(ah[i], bh[j], acc[i][j]);
+    };
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) load_tile();  // global loads in flight under the MFMA block
 
+        if (MATH == 1) {
+            // (a second register stage - slabs fetched two iterations ahead, counted vmcnt - was measured: no gain, r1z/r1z2;
+            // this path is bound by LDS traffic and the per-slab barrier, not by global-load latency)
+            compute_bf3(buf);
+            if (kt + 1 < nkt) store_tile(buf ^ 1);
+            __syncthreads();
+            continue;
+        }
         float af[TM][8], bf[TN][8];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -345,6 +519,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         __syncthreads();
     }
 
+    if (MATH == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[MATH == 1 ? i : 0][MATH == 1 ? j : 0][r];
+    }
     // ---- epilogue: bias + addend + accumulate + activation, optional BN partial statistics --------------------------
     // The MFMA accumulator layout gives a lane ONE column and 16 scattered rows (4-byte stores, 128-byte runs).  Each wave
     // therefore transposes its 32x32 sub-tiles through a private 4 KB LDS patch (the operand slabs are free now) so that
@@ -458,6 +640,19 @@ struct TileCfg {
 };
 // measurement aid (tools/conv_tune.py): force tile shapes / split target; 0 = heuristic
 static int g_ovr_bm = 0, g_ovr_bn = 0, g_ovr_wk = 0, g_ovr_wj = 0, g_ovr_split = 0, g_ovr_var = 0;
+// arithmetic of the forward / data-gradient GEMMs: 0 = fp32 MFMA (exact fp32 FMA chains), 1 = bf16x3 split (see IG_LDP above)
+static int g_conv_math = 0;
+extern "C" int32_t sgx_conv_set_math(int32_t mode) {
+    SGX_CHECK_ARG(mode >= 0 && mode <= 2, "conv math mode %d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = per problem)", mode);
+    g_conv_math = mode;
+    return SGX_OK;
+}
+extern "C" int32_t sgx_conv_get_math(void) { return g_conv_math; }
+// Mode 2 picks per GEMM: the split arithmetic pays for its extra staging work (VALU split, 1.5x LDS bytes) only when the reduction
+// is deep enough to be matrix-pipe bound.  Measured on all YOLO-NAS-S problems (profiles/r1y_conv_bench_bf16x3.txt vs r1n): bf16x3
+// wins from a depth (taps x channels) of ~192 (1.2-1.3x on the 3x3 layers), loses 5-30 % on shallow 1x1 layers.
+#define SGX_BF3_MIN_DEPTH 192
+static int conv_math_for(int taps, int C) { return g_conv_math == 2 ? ((long)taps * C >= SGX_BF3_MIN_DEPTH ? 1 : 0) : g_conv_math; }
 extern "C" int32_t sgx_debug_set_variant(int32_t v) {
     g_ovr_var = v;
     return SGX_OK;
@@ -467,10 +662,14 @@ extern "C" int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk
     return SGX_OK;
 }
 static TileCfg pick_tile_heuristic(long M, int N);
-static TileCfg pick_tile(long M, int N) {
+static TileCfg pick_tile(long M, int N, int math) {
     TileCfg t = pick_tile_heuristic(M, N);
     if (g_ovr_bm) t.bm = g_ovr_bm;
     if (g_ovr_bn) t.bn = g_ovr_bn;
+    if (math == 1) {  // three bf16 planes per slab: the two largest tiles do not fit 64 KB of LDS
+        if (t.bm == 128 && t.bn == 128) t.bn = 64;
+        if (t.bm == 128 && t.bn == 96) t.bm = 64;
+    }
     return t;
 }
 static TileCfg pick_tile_heuristic(long M, int N) {
@@ -485,14 +684,14 @@ static TileCfg pick_tile_heuristic(long M, int N) {
     return TileCfg{M >= 16384 ? 128 : 64, 32};
 }
 
-template <int BM, int BN, int WM, int WN, bool FLAT>
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0>
 static void launch_igemm(IgemmParams& p, void* stream) {
     p.mt = sgx_cdiv(p.M, BM);
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
     p.chunk = sgx_cdiv(p.nblk, 8);
     int grid = p.chunk * 8;
-    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
+    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
 }
 
 static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
@@ -512,7 +711,21 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
     SGX_PROF(0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * (double)T,
              4.0 * ((double)p.M / ((double)p.Ha * p.Wa) * p.Hin * p.Win * p.C + (double)p.Nout * p.C * T + (double)p.M * p.Nout), stream);
     const bool flat = p.C < IG_BK && T > 1;
-    if (flat) {
+    if (conv_math_for(T, p.C) == 1) {
+        if (flat && bn > 64) bn = 64;
+        if (flat && bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, true, 1>(p, stream);
+        else if (flat && bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, true, 1>(p, stream);
+        else if (flat && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, true, 1>(p, stream);
+        else if (flat && bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true, 1>(p, stream);
+        else if (flat) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (bf16x3): no flat tile %dx%d", bm, bn);
+        else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, 1>(p, stream);
+        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 1>(p, stream);
+        else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2, false, 1>(p, stream);
+        else if (bm == 64 && bn == 96) launch_igemm<64, 96, 2, 1, false, 1>(p, stream);
+        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 1>(p, stream);
+        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, 1>(p, stream);
+        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (bf16x3): no tile %dx%d", bm, bn);
+    } else if (flat) {
         if (bn > 64) bn = 64;  // the flat variants exist for the narrow tiles only (stem layers have few output channels)
         if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, true>(p, stream);
         else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, true>(p, stream);
@@ -536,7 +749,7 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
     return SGX_OK;
 }
 static TileCfg igemm_tile(const IgemmParams& p) {
-    TileCfg t = pick_tile(p.M, p.Nout);
+    TileCfg t = pick_tile(p.M, p.Nout, conv_math_for(p.Th * p.Tw, p.C));
     if (p.C < IG_BK && p.Th * p.Tw > 1 && t.bn > 64) t.bn = 64;
     return t;
 }
@@ -559,7 +772,7 @@ static long view_bytes(int N, int H, int W, int C, long ld_pix, long ld_img) {
 
 extern "C" int32_t sgx_conv2d_fwd_stat_blocks(const sgx_conv_desc* d) {
     long M = (long)d->N * d->Ho * d->Wo;
-    TileCfg t = pick_tile(M, d->K);
+    TileCfg t = pick_tile(M, d->K, conv_math_for(d->R * d->S, d->C));
     return sgx_cdiv(M, t.bm);
 }
 
@@ -580,7 +793,7 @@ extern "C" int32_t sgx_conv2d_fwd(const sgx_conv_desc* d, const float* x, const 
     p.a_bytes = view_bytes(d->N, d->H, d->W, d->C, d->x_ld_pix, d->x_ld_img);
     p.w_bytes = (long)d->K * p.w_ld_n * 4;
     p.act = act; p.accumulate = 0;
-    TileCfg t = pick_tile(p.M, p.Nout);  // the statistics rows follow the M tile: keep it in step with sgx_conv2d_fwd_stat_blocks
+    TileCfg t = pick_tile(p.M, p.Nout, conv_math_for(p.Th * p.Tw, p.C));  // the statistics rows follow the M tile: keep it in step with sgx_conv2d_fwd_stat_blocks
     p.stat_nblk = sgx_cdiv(p.M, t.bm);
     TileCfg u = igemm_tile(p);
     return run_igemm(p, t.bm, u.bn, stream);
@@ -703,7 +916,7 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
             }
             if (mode != 1) {
                 TileCfg t = igemm_tile(p);
-                TileCfg m = pick_tile(p.M, p.Nout);
+                TileCfg m = pick_tile(p.M, p.Nout, conv_math_for(p.Th * p.Tw, p.C));
                 rc = run_igemm(p, m.bm, t.bn, stream);
                 if (rc) return rc;
             }

@@ -606,6 +606,21 @@ def ema_update(ema, p, decay):
     check(lib().sgx_ema_update(ptr(ema), ptr(p), ema.numel(), float(decay), stream()), "sgx_ema_update")
 
 
+# --------------------------------------------------------------------------------------------- conv arithmetic
+CONV_MATH = {"fp32": 0, "bf16x3": 1, "auto": 2}
+
+
+def set_conv_math(mode: str):
+    """"fp32": fp32 matrix pipe (exact fp32 FMA chains).  "bf16x3": fp32 operands split into three bf16 pieces, six cross products on the
+    bf16 matrix pipe with fp32 accumulation - fp32-accurate, 2.7x fewer matrix-pipe cycles.  "auto": bf16x3 for reductions of depth
+    (taps x channels) >= 192, fp32 MFMA for shallow ones (include/sgx_hip.h: sgx_conv_set_math)."""
+    check(lib().sgx_conv_set_math(CONV_MATH[mode]), "sgx_conv_set_math")
+
+
+def get_conv_math() -> str:
+    return {v: k for k, v in CONV_MATH.items()}[lib().sgx_conv_get_math()]
+
+
 # --------------------------------------------------------------------------------------------- measurement aid
 def prof_enable(on: bool):
     check(lib().sgx_prof_enable(int(on)), "sgx_prof_enable")

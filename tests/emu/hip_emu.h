@@ -68,6 +68,14 @@ struct int2 {
     int x, y;
 };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+struct alignas(8) uint2 {
+    unsigned x, y;
+};
+struct alignas(16) uint4 {
+    unsigned x, y, z, w;
+};
+static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
 static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 static inline int2 make_int2(int a, int b) { return int2{a, b}; }
 

@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from util import assert_close, empty_nhwc, to_nchw_cpu, to_nhwc
+from util import assert_close, empty_nhwc, rel_err, to_nchw_cpu, to_nhwc
 
 from super_gradients_amd import kernels as K
 
@@ -123,6 +123,50 @@ def test_conv_bwd(backend, idx):
     K.conv2d_bwd_weight(xd, dyd, dw, db, stride=s, pad=p)
     assert_close(dw.cpu(), wt.grad + 0.5, TOL, f"wgrad {shape}")
     assert_close(db.cpu(), b.grad, TOL, f"dbias {shape}")
+
+
+@pytest.mark.parametrize("idx", range(max(len(CONV_GPU), len(CONV_EMU))))
+def test_conv_bf16x3(backend, idx):
+    """The bf16x3 arithmetic of the forward / data-gradient GEMMs (sgx_conv_set_math(1)): fp32 operands split into three bf16 pieces,
+    six cross products on the bf16 matrix pipe, fp32 accumulate - held to the SAME tolerance as the fp32-MFMA path."""
+    shapes = _sizes(backend, CONV_GPU, CONV_EMU)
+    if idx >= len(shapes):
+        pytest.skip("no such case")
+    shape = shapes[idx]
+    n, h, w, c, k, r, s, p = shape
+    x, wt, b = _conv_case(shape)
+    x.requires_grad_(True)
+    y = F.conv2d(x, wt, b, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+    y.backward(dy)
+    add = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
+    K.set_conv_math("bf16x3")
+    try:
+        assert K.get_conv_math() == "bf16x3"
+        xd = to_nhwc(x.detach(), backend, ld_pix=c + 8, c_off=4)
+        wd = K.to_ohwi(wt.to(backend))
+        yd = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s, pad=p)
+        assert_close(to_nchw_cpu(yd), y.detach(), TOL, f"bf16x3 conv fwd {shape}")
+        # the error of the split arithmetic itself, against the fp64 truth: no worse than the fp32 matrix pipe's (same inputs, same
+        # summation order inside a slab), i.e. the split is NOT a precision trade
+        y64 = F.conv2d(x.detach().double(), wt.double(), b.double(), stride=s, padding=p)
+        K.set_conv_math("fp32")
+        y32 = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s, pad=p)
+        K.set_conv_math("bf16x3")
+        e_bf3, e_f32 = rel_err(to_nchw_cpu(yd).double(), y64), rel_err(to_nchw_cpu(y32).double(), y64)
+        assert e_bf3 <= 1.5 * e_f32 + 5e-8, f"bf16x3 error vs fp64 {e_bf3:.2e}, fp32 MFMA {e_f32:.2e}"
+        if k % 4 == 0:
+            out = empty_nhwc(n, y.shape[2], y.shape[3], k, backend, ld_pix=k + 12, c_off=8)
+            y2, parts = K.conv2d_fwd(xd, wd, bias=b.to(backend), addend=to_nhwc(add, backend, ld_pix=k + 12, c_off=8), out=out, act="relu", stride=s, pad=p,
+                                     stat_partials=True)
+            pre = y.detach() + add
+            assert_close(to_nchw_cpu(y2), F.relu(pre), TOL, f"bf16x3 conv fwd fused {shape}")
+            assert_close(parts[0].sum(0).cpu() / (pre.numel() // k), pre.mean((0, 2, 3)), 1e-4, "stat sum")
+            dx = K.conv2d_bwd_data(to_nhwc(dy, backend), wd, (n, h, w, c), stride=s, pad=p)
+            assert_close(to_nchw_cpu(dx), x.grad, TOL, f"bf16x3 dgrad {shape}")
+    finally:
+        K.set_conv_math("fp32")
+    assert K.get_conv_math() == "fp32"
 
 
 def test_conv_transpose(backend):
