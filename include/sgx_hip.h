@@ -124,6 +124,13 @@ int32_t sgx_convT2x2_bwd_weight(int32_t N, int32_t H, int32_t W, int32_t C, int3
 int32_t sgx_nchw_to_nhwc(int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cpad, const float* x, float* y, void* stream);
 int32_t sgx_nhwc_to_nchw(int32_t N, int32_t C, int32_t H, int32_t W, const float* x, int64_t x_ld_pix, int64_t x_ld_img,
                          float* y, void* stream);
+/* Device side of the input pipeline: the uint8 HWC images the dataset yields, stacked [N,H,W,C], become the
+ * standardized fp32 NHWC batch (channels zero-padded to Cpad) the first convolution reads - replacing, on the host, DetectionStandardize
+ * (transforms.py:490-510: image / max_value), the optional (x - mean) / std normalisation, DetectionCollateFN's stack + moveaxis + float()
+ * (collate_fn/detection_collate_fn.py:27-32) and this library's own nchw_to_nhwc.  y = (x / max_value - mean[c]) / std[c]; mean/std NULL:
+ * y = x / max_value (a true division: bit-identical to the reference's numpy arithmetic for every uint8 value).                         */
+int32_t sgx_standardize_u8_hwc(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cpad, const uint8_t* x, float max_value,
+                               const float* mean, const float* std, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm (training mode) and the fused elementwise stages around it.

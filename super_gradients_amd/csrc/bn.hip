@@ -663,3 +663,36 @@ extern "C" int32_t sgx_nhwc_to_nchw(int32_t N, int32_t C, int32_t H, int32_t W, 
     SGX_CHECK_LAUNCH("nhwc_to_nchw");
     return SGX_OK;
 }
+
+// uint8 HWC batch -> standardized fp32 NHWC (channels padded to Cpad): one thread per pixel, 16-byte stores.
+__global__ void standardize_u8_kernel(long npix, int C, int Cpad, const uint8_t* x, float max_value, const float* mean, const float* stdv, float* y) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        const uint8_t* px = x + i * C;
+        float* py = y + i * Cpad;
+        for (int c0 = 0; c0 < Cpad; c0 += 4) {
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = c0 + t;
+                float f = 0.f;
+                if (c < C) {
+                    f = (float)px[c] / max_value;
+                    if (mean) f = (f - mean[c]) / stdv[c];
+                }
+                v[t] = f;
+            }
+            sgx_st4(py + c0, make_float4(v[0], v[1], v[2], v[3]));
+        }
+    }
+}
+extern "C" int32_t sgx_standardize_u8_hwc(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cpad, const uint8_t* x, float max_value,
+                                          const float* mean, const float* stdv, float* y, void* stream) {
+    SGX_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && Cpad >= C && Cpad % 4 == 0, "standardize_u8: bad args (C=%d Cpad=%d)", C, Cpad);
+    SGX_CHECK_ARG(max_value > 0.f && ((mean == nullptr) == (stdv == nullptr)), "standardize_u8: max_value > 0, mean and std go together");
+    const long npix = (long)N * H * W;
+    const long blocks = (npix + 255) / 256;
+    SGX_LAUNCH(standardize_u8_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, stream, npix, C, Cpad, x, max_value, mean,
+               stdv, y);
+    SGX_CHECK_LAUNCH("standardize_u8");
+    return SGX_OK;
+}

@@ -220,6 +220,33 @@ def nchw_to_nhwc(x, cpad=None):
     return y
 
 
+def standardize_u8(x_u8, max_value=255.0, mean=None, std=None, cpad=None):
+    """uint8 [N,H,W,C] (the dataset's HWC images, stacked) -> fp32 NHWC [N,H,W,Cpad]: (x / max_value - mean) / std, zero pad channels."""
+    n, h, w, c = x_u8.shape
+    if x_u8.dtype != torch.uint8:
+        raise _lib.SgxError(f"standardize_u8 needs a uint8 batch, got {x_u8.dtype}")
+    cpad = cpad or ((c + 3) // 4) * 4
+    x_u8 = x_u8.contiguous()
+    y = torch.empty(n, h, w, cpad, device=x_u8.device, dtype=torch.float32)
+    check(lib().sgx_standardize_u8_hwc(n, h, w, c, cpad, ptr(x_u8), float(max_value), ptr(mean), ptr(std), ptr(y), stream()), "sgx_standardize_u8_hwc")
+    return y
+
+
+def nhwc_as_nchw_view(y, channels):
+    """Logical NCHW [N,C,H,W] view of an NHWC buffer (what model(x) receives from DeviceDetectionCollateFN): no copy."""
+    return y.permute(0, 3, 1, 2)[:, :channels]
+
+
+def input_to_nhwc(x):
+    """The NHWC fp32 (channels padded to 4) tensor the first convolution reads, from whatever the loader delivered: a logical NCHW
+    view of an NHWC buffer (nhwc_as_nchw_view: used as is, zero copies) or a plain NCHW batch (one re-layout kernel)."""
+    n, c, h, w = x.shape
+    cp = ((c + 3) // 4) * 4
+    if x.dtype == torch.float32 and x.stride() == (h * w * cp, 1, w * cp, cp) and x.storage_offset() % 4 == 0:
+        return torch.as_strided(x, (n, h, w, cp), (h * w * cp, w * cp, cp, 1), x.storage_offset())
+    return nchw_to_nhwc(x.float())
+
+
 def nhwc_to_nchw(x):
     n, h, w, c = x.shape
     ld_pix, ld_img = nhwc_strides(x)

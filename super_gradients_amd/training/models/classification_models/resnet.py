@@ -187,7 +187,7 @@ class _ResNetBase(SgxNetwork):
     def _fwd(self, x):
         if x.dim() != 4 or x.shape[1] != self.conv1.in_channels:
             raise ValueError(f"expected an NCHW batch with {self.conv1.in_channels} channels, got {tuple(x.shape)}")
-        a = self._stem_fwd(K.nchw_to_nhwc(x.float()))
+        a = self._stem_fwd(K.input_to_nhwc(x))
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer.blocks():
                 a = blk.fwd(a)

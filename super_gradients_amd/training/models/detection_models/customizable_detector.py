@@ -43,7 +43,7 @@ class CustomizableDetector(SgxNetwork):
     def _fwd(self, x):
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise ValueError(f"expected an NCHW batch with {self.in_channels} channels, got {tuple(x.shape)}")
-        xh = K.nchw_to_nhwc(x.float())
+        xh = K.input_to_nhwc(x)
         feats = self.backbone.fwd(xh)
         p = self.neck.fwd(feats)
         boxes, scores, logits, distri, anchors, pts, counts, strides = self.heads.fwd(p)

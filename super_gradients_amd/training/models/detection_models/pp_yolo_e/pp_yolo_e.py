@@ -64,7 +64,7 @@ class PPYoloE(SgxNetwork):
     def _fwd(self, x):
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise ValueError(f"expected an NCHW batch with {self.in_channels} channels, got {tuple(x.shape)}")
-        xh = K.nchw_to_nhwc(x.float())
+        xh = K.input_to_nhwc(x)
         boxes, scores, logits, distri, anchors, pts, counts, strides = self.head.fwd(self.neck.fwd(self.backbone.fwd(xh)))
         self._aux = (anchors, pts, list(counts), strides)
         self._out_shapes = (tuple(logits.shape), tuple(distri.shape))

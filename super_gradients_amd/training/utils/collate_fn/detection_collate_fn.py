@@ -1,0 +1,71 @@
+"""Detection batch collation (reference: training/utils/collate_fn/detection_collate_fn.py:10-49) and its MI355X form.
+
+DetectionCollateFN        the reference's host-side semantics: items (image, targets[Ni,5]) -> (images [N,C,H,W] float32,
+                          targets [sum Ni, 6] with the batch index prepended).
+DeviceDetectionCollateFN  the same contract with the pixel work moved to the GPU: the dataset's uint8 HWC images are
+                          stacked as they are (a quarter of the fp32 bytes over PCIe), and ONE kernel (sgx_standardize_u8_hwc) produces the
+                          standardized fp32 NHWC batch the first convolution reads - replacing DetectionStandardize / normalisation on the
+                          host, the collate's moveaxis + float(), and the model's own NCHW->NHWC re-layout.  The returned image tensor is a
+                          logical [N,C,H,W] view of that buffer, so `model(images)` is unchanged (models detect the layout: zero copies).
+"""
+from typing import List, Tuple, Union
+
+import numpy as np
+import torch
+
+from .... import kernels as K
+
+
+class DetectionCollateFN:
+    def __init__(self):
+        self.expected_item_names = ("image", "targets")
+
+    def __call__(self, data) -> Tuple[torch.Tensor, torch.Tensor]:
+        try:
+            images_batch, labels_batch = list(zip(*data))
+        except (ValueError, TypeError):
+            raise ValueError(f"DetectionCollateFN expects items {self.expected_item_names}, got {type(data[0])}")
+        return self._format_images(images_batch), self._format_targets(labels_batch)
+
+    @staticmethod
+    def _format_images(images_batch: List[Union[torch.Tensor, np.ndarray]]) -> torch.Tensor:
+        stack = torch.stack([torch.as_tensor(img) for img in images_batch], 0)
+        if stack.shape[3] == 3:
+            stack = torch.moveaxis(stack, -1, 1).float()
+        return stack
+
+    @staticmethod
+    def _format_targets(labels_batch: List[Union[torch.Tensor, np.ndarray]]) -> torch.Tensor:
+        out = []
+        for i, labels in enumerate(labels_batch):
+            labels = torch.as_tensor(labels)
+            out.append(torch.cat((labels.new_ones((labels.shape[0], 1)) * i, labels), dim=-1))
+        return torch.cat(out, 0)
+
+
+class DeviceDetectionCollateFN(DetectionCollateFN):
+    """Items: (uint8 HWC image, targets [Ni,5]).  max_value / mean / std: the standardisation the reference recipe applies on the host
+    (YOLO-NAS: DetectionStandardize(max_value=255); ImageNet-style models: / 255 then (x - mean) / std)."""
+
+    def __init__(self, device="cuda", max_value: float = 255.0, mean=None, std=None):
+        super().__init__()
+        self.device = torch.device(device)
+        self.max_value = float(max_value)
+        if (mean is None) != (std is None):
+            raise ValueError("mean and std go together")
+        self._mean = None if mean is None else torch.as_tensor(mean, dtype=torch.float32)
+        self._std = None if std is None else torch.as_tensor(std, dtype=torch.float32)
+
+    def __call__(self, data) -> Tuple[torch.Tensor, torch.Tensor]:
+        try:
+            images_batch, labels_batch = list(zip(*data))
+        except (ValueError, TypeError):
+            raise ValueError(f"DeviceDetectionCollateFN expects items {self.expected_item_names}, got {type(data[0])}")
+        stack = torch.stack([torch.as_tensor(img) for img in images_batch], 0)
+        if stack.dtype != torch.uint8 or stack.dim() != 4:
+            raise ValueError(f"DeviceDetectionCollateFN expects uint8 HWC images (the dataset's native form), got {stack.dtype} {tuple(stack.shape)}")
+        c = stack.shape[3]
+        mean = None if self._mean is None else self._mean.to(self.device)
+        std = None if self._std is None else self._std.to(self.device)
+        y = K.standardize_u8(stack.to(self.device, non_blocking=True), self.max_value, mean, std)
+        return K.nhwc_as_nchw_view(y, c), self._format_targets(labels_batch).float().to(self.device, non_blocking=True)

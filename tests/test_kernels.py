@@ -544,3 +544,30 @@ def test_upsample2x(backend):
     acc = to_nhwc(base, backend)
     K.upsample2x_bwd(to_nhwc(dy, backend), out=acc, accumulate=True)
     assert_close(to_nchw_cpu(acc), base + gx, 1e-6, "upsample bwd accumulate")
+
+
+def test_standardize_u8_and_device_collate(backend):
+    """Device side of the input pipeline: uint8 HWC -> standardized NHWC fp32, bit-identical to the reference's host
+    arithmetic (DetectionStandardize: numpy image / 255 -> float32) for EVERY uint8 value; the collate's view is consumed zero-copy."""
+    from super_gradients_amd.training.utils.collate_fn import DetectionCollateFN, DeviceDetectionCollateFN
+
+    allv = torch.arange(256, dtype=torch.uint8).reshape(1, 16, 16, 1).repeat(1, 1, 1, 3)
+    y = K.standardize_u8(allv.to(backend))
+    ref = torch.from_numpy((allv.numpy() / 255.0).astype(np.float32))
+    assert torch.equal(y[..., :3].cpu(), ref) and float(y[..., 3].abs().max()) == 0.0
+    g = torch.Generator().manual_seed(5)
+    n, h, w = _sizes(backend, (4, 96, 80), (2, 6, 5))
+    items = [(torch.randint(0, 256, (h, w, 3), dtype=torch.uint8, generator=g).numpy(), np.random.RandomState(i).rand(i + 1, 5).astype(np.float32))
+             for i in range(n)]
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    x_dev, t_dev = DeviceDetectionCollateFN(device=backend, mean=mean, std=std)(items)
+    host = [((img / 255.0).astype(np.float32), t) for img, t in items]   # DetectionStandardize on the host ...
+    x_ref, t_ref = DetectionCollateFN()(host)                            # ... then the reference collate
+    x_ref = (x_ref - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    assert tuple(x_dev.shape) == tuple(x_ref.shape) == (n, 3, h, w)
+    assert_close(x_dev.cpu(), x_ref, 1e-6, "device collate images")
+    assert torch.equal(t_dev.cpu(), t_ref) and t_ref.shape == (sum(i + 1 for i in range(n)), 6)
+    nhwc = K.input_to_nhwc(x_dev)
+    assert nhwc.data_ptr() == x_dev.data_ptr() and tuple(nhwc.shape) == (n, h, w, 4), "the model entrance must reuse the collated buffer"
+    plain = K.input_to_nhwc(x_ref.to(backend))   # a plain NCHW batch takes the re-layout kernel
+    assert torch.equal(plain.cpu(), nhwc.cpu()) or rel_err(plain.cpu(), nhwc.cpu()) < 1e-6
