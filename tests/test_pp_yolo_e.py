@@ -239,3 +239,22 @@ def test_trainer_ppyoloe_recipe_shape(gpu_device, tmp_path):
     got = res[0]["train"]
     for i, name in enumerate(["loss_cls", "loss_iou", "loss_dfl", "loss"]):
         assert abs(got[name] - float(tot[i])) <= 1e-3 * abs(float(tot[i])), (name, got[name], float(tot[i]))
+
+
+def test_ppyoloe_gradient_buckets_tile_the_arena(backend):
+    """Data-parallel exchange of PP-YOLOE (bench.py --workload ppyoloe --gpus N): the bucket prefixes the backward announces
+    (head -> neck -> backbone stages -> stem) must tile the gradient arena exactly; GradientAllReducer refuses anything else."""
+    from super_gradients_amd.training import models
+    from super_gradients_amd.training.utils.distributed_training_utils import GradientAllReducer
+
+    for v in ("s", "m"):
+        net = models.get(f"ppyoloe_{v}", num_classes=80).materialize(backend)
+        red = GradientAllReducer(net, net.gradient_buckets())
+        assert set(red.ranges) == set(net.gradient_buckets())
+        spans = sorted(red.ranges.values())
+        assert spans[0][0] == 0 and spans[-1][1] == net.g_arena.size and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        # every live parameter's gradient view lies inside the bucket its name announces
+        for s in net.slots:
+            pref = next(p for p in red.ranges if s.name.startswith(p))
+            a, b = red.ranges[pref]
+            assert a <= s.start and s.start + s.numel <= b, s.name
