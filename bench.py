@@ -196,6 +196,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ema", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the 3 extra untimed steps that time the conv kernels without the side stream")
     ap.add_argument("--sync-bn", action="store_true", help="synchronised BatchNorm across ranks (recipe setting; off in the reference's own benchmark)")
     ap.add_argument("--workload", default="yolo_nas", choices=["yolo_nas", "resnet50", "ppyoloe"],
                     help="yolo_nas = BASELINE.json's headline config; resnet50 = configs[1]; ppyoloe = SURVEY 8f-1 (same loss / step, CSPResNet model)")
@@ -276,7 +277,7 @@ def main():
     fence()
     side, net.side_stream = getattr(net, "side_stream", None), None
     K.prof_enable(True)
-    for _ in range(3):
+    for _ in range(0 if args.no_exclusive else 3):
         step()
     fence()
     ex_ms, ex_fl, ex_n = K.prof_summary(0)
