@@ -192,7 +192,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--model", default="s", choices=["s", "m", "l"])
+    ap.add_argument("--model", default="s", choices=["s", "m", "l", "x"], help="x: PP-YOLOE only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ema", action="store_true")
     ap.add_argument("--no-nms", action="store_true")

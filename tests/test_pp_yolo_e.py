@@ -258,3 +258,33 @@ def test_ppyoloe_gradient_buckets_tile_the_arena(backend):
             pref = next(p for p in red.ranges if s.name.startswith(p))
             a, b = red.ranges[pref]
             assert a <= s.start and s.start + s.numel <= b, s.name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ppyoloe_s", "ppyoloe_x"])
+def test_reference_unit_test_from_name_and_from_cls(gpu_device, name):
+    """The reference's own unit test transplanted (tests/unit_tests/ppyoloe_unit_test.py:11-39): build by name and by class with
+    arch_params={}, eval forward of a NON-square 640x480 batch; here additionally held to the oracle's outputs."""
+    from oracle import golden_util as G
+    from oracle.pp_yolo_e import PPYoloE as Oracle
+    from super_gradients_amd.training import models
+    from super_gradients_amd.training.models import PPYoloE_S, PPYoloE_X
+
+    x = torch.randn(1, 3, 640, 480, generator=torch.Generator().manual_seed(0))
+    by_name = models.get(name, num_classes=80).eval()
+    by_cls = {"ppyoloe_s": PPYoloE_S, "ppyoloe_x": PPYoloE_X}[name](arch_params={}).eval()
+    ref = Oracle(name[-1], num_classes=80).eval()
+    G.deterministic_fill(ref, seed=2)
+    with torch.no_grad():
+        (bx_r, sc_r), raw_r = ref(x)
+    for net in (by_name, by_cls):
+        assert list(net.state_dict().keys()) == list(ref.state_dict().keys())
+        net.load_state_dict(ref.state_dict(), strict=True)
+        net.materialize(gpu_device)
+        with torch.no_grad():
+            out = net(x.to(gpu_device))
+        assert out is not None
+        (bx, sc), raw = out
+        assert list(raw[4]) == list(raw_r[4]) == [20 * 15, 40 * 30, 80 * 60]
+        assert_close(raw[0].cpu(), raw_r[0], 1e-4, f"{name} logits (640x480)")
+        assert_close(bx.cpu(), bx_r, 1e-4, f"{name} boxes (640x480)")
