@@ -312,8 +312,10 @@ def main():
             "dtype": "fp32", "data": "synthetic",
             "config": {"workload": f"{family}-{args.model.upper()} synthetic COCO {args.size}x{args.size}, bs={args.batch}/GPU, PPYoloELoss(TAL)+AdamW"
                                    + ("" if args.no_ema else "+EMA") + ", random-init weights",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data gradient, v_mfma_f32_32x32x2_f32)",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
+                       "conv_math": K.get_conv_math()},  # "fp32" = fp32 matrix pipe (default); SGX_CONV_MATH=auto|bf16x3 opts into the split arithmetic
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data gradient, "
+                                                    + ("v_mfma_f32_32x32x2_f32)" if K.get_conv_math() == "fp32" else "v_mfma_f32_32x32x16_bf16 x6 / v_mfma_f32_32x32x2_f32 per problem)"),
                          "achieved": round(ig_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(ig_bytes / max(ig_n, 1)), "launches_per_step": ig_n // max(args.steps, 1), "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
