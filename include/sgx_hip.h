@@ -96,6 +96,19 @@ int32_t sgx_conv2d_bwd_data(const sgx_conv_desc* d, const float* dy, const float
 int32_t sgx_conv2d_transpose_weights(const sgx_conv_desc* d, const float* w, float* wt, int64_t wt_bytes, void* stream);
 int32_t sgx_conv2d_bwd_data_wt(const sgx_conv_desc* d, const float* dy, const float* wt, const float* addend, float* dx,
                                int32_t accumulate, void* stream);
+/* All of a network's data-gradient weight transposes as ONE launch per step instead of one per convolution and parity class
+ * (YOLO-NAS-S: 165 launches of ~10 us): sgx_conv2d_transpose_jobs appends the jobs of convolution d (weights w -> buffer wt of
+ * sgx_conv2d_bwd_data_workspace(d) bytes; pointers must stay valid - they are arena views) to a HOST array; the caller uploads the
+ * array once and runs it with sgx_wtrans_batch before each backward pass.                                                        */
+typedef struct sgx_wtrans_job {
+    const float* w;      /* [K][RS][C]                                     */
+    float* wt;           /* [C][T][K] of this parity class                  */
+    int32_t K, C, RS, T; /* T taps of the class, listed in taps[]            */
+    uint8_t taps[64];
+} sgx_wtrans_job;
+int32_t sgx_conv2d_transpose_jobs(const sgx_conv_desc* d, const float* w, float* wt, int64_t wt_bytes, sgx_wtrans_job* jobs,
+                                  int32_t max_jobs, int32_t* njobs);
+int32_t sgx_wtrans_batch(const sgx_wtrans_job* jobs_dev, int32_t njobs, void* stream);
 
 /* dw[k][r][s][c] += sum_pixels dy * x   (accumulates into dw: callers zero the gradient arena once per
  * optimizer step).  dbias[k] += sum dy if dbias != NULL.  ws: sgx_conv2d_bwd_weight_workspace(d).  */

@@ -38,6 +38,10 @@ class LossDesc(ctypes.Structure):
     ]
 
 
+class WtransJob(ctypes.Structure):  # == sgx_wtrans_job
+    _fields_ = [("w", ctypes.c_void_p), ("wt", ctypes.c_void_p), ("K", c_int32), ("C", c_int32), ("RS", c_int32), ("T", c_int32), ("taps", ctypes.c_uint8 * 64)]
+
+
 class NmsDesc(ctypes.Structure):
     _fields_ = [
         ("B", c_int32), ("L", c_int32), ("C", c_int32), ("multi_label", c_int32), ("class_mode", c_int32),
@@ -70,6 +74,8 @@ PROTOTYPES = {
     "sgx_conv2d_bwd_data": (_i32, [_CD, _P, _P, _P, _P, _i32, _P, _i64, _P]),
     "sgx_conv2d_transpose_weights": (_i32, [_CD, _P, _P, _i64, _P]),
     "sgx_conv2d_bwd_data_wt": (_i32, [_CD, _P, _P, _P, _P, _i32, _P]),
+    "sgx_conv2d_transpose_jobs": (_i32, [_CD, _P, _P, _i64, POINTER(WtransJob), _i32, POINTER(c_int32)]),
+    "sgx_wtrans_batch": (_i32, [_P, _i32, _P]),
     "sgx_conv2d_bwd_weight_workspace": (_i64, [_CD]),
     "sgx_conv2d_bwd_weight": (_i32, [_CD, _P, _P, _P, _P, _P, _i64, _P]),
     "sgx_convT2x2_workspace": (_i64, [_i32] * 5),

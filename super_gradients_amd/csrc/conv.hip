@@ -858,6 +858,44 @@ extern "C" int32_t sgx_conv2d_bwd_data_wt(const sgx_conv_desc* d, const float* d
                                           int32_t accumulate, void* stream) {
     return conv_bwd_data_impl(d, dy, nullptr, nullptr, addend, dx, accumulate, const_cast<float*>(wt), sgx_conv2d_bwd_data_workspace(d), stream, 2);
 }
+// batched form of wtrans_kernel: blockIdx.y = job, blockIdx.x strides over the job's elements
+__global__ void wtrans_batch_kernel(const sgx_wtrans_job* jobs) {
+    __shared__ sgx_wtrans_job job;
+    if (threadIdx.x == 0) job = jobs[blockIdx.y];
+    __syncthreads();
+    const long n = (long)job.C * job.T * job.K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int k = (int)(i % job.K);
+        long r = i / job.K;
+        int t = (int)(r % job.T);
+        int c = (int)(r / job.T);
+        job.wt[i] = job.w[((long)k * job.RS + job.taps[t]) * job.C + c];
+    }
+}
+extern "C" int32_t sgx_wtrans_batch(const sgx_wtrans_job* jobs_dev, int32_t njobs, void* stream) {
+    SGX_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 65535, "wtrans_batch: bad args (njobs=%d)", njobs);
+    SGX_LAUNCH(wtrans_batch_kernel, dim3(32, (unsigned)njobs), dim3(256), 0, stream, jobs_dev);
+    SGX_CHECK_LAUNCH("wtrans_batch");
+    return SGX_OK;
+}
+// mode 3 of conv_bwd_data_impl records the transposes instead of launching them
+struct WtransRecorder {
+    sgx_wtrans_job* jobs;
+    int max, n;
+};
+static thread_local WtransRecorder* g_wt_rec = nullptr;
+extern "C" int32_t sgx_conv2d_transpose_jobs(const sgx_conv_desc* d, const float* w, float* wt, int64_t wt_bytes, sgx_wtrans_job* jobs,
+                                             int32_t max_jobs, int32_t* njobs) {
+    SGX_CHECK_ARG(jobs && njobs && max_jobs > 0, "transpose_jobs: null pointer");
+    WtransRecorder rec{jobs, max_jobs, 0};
+    g_wt_rec = &rec;
+    int32_t rc = conv_bwd_data_impl(d, nullptr, w, nullptr, nullptr, nullptr, 0, wt, wt_bytes, nullptr, 1);
+    g_wt_rec = nullptr;
+    if (rc) return rc;
+    if (rec.n > max_jobs) SGX_FAIL(SGX_ERR_BAD_ARG, "transpose_jobs: %d jobs, room for %d", rec.n, max_jobs);
+    *njobs = rec.n;
+    return SGX_OK;
+}
 static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const float* w, const float* bias, const float* addend,
                                   float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream, int mode) {
     int32_t rc = check_desc(d);
@@ -908,7 +946,15 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
                 SGX_CHECK_LAUNCH("dgrad_fill");
                 continue;
             }
-            if (mode != 2) {
+            if (mode == 1 && g_wt_rec) {
+                if (g_wt_rec->n < g_wt_rec->max) {
+                    sgx_wtrans_job& j = g_wt_rec->jobs[g_wt_rec->n];
+                    memset(&j, 0, sizeof(j));
+                    j.w = w; j.wt = wt; j.K = d->K; j.C = d->C; j.RS = d->R * d->S; j.T = T;
+                    memcpy(j.taps, taps.idx, sizeof(taps.idx) < sizeof(j.taps) ? sizeof(taps.idx) : sizeof(j.taps));
+                }
+                ++g_wt_rec->n;
+            } else if (mode != 2) {
                 long n = (long)d->C * T * d->K;
                 int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
                 SGX_LAUNCH(wtrans_kernel, dim3(grid), dim3(256), 0, stream, w, wt, d->K, d->C, d->R * d->S, T, taps);

@@ -142,6 +142,20 @@ def conv2d_transpose_weights(w, wt, stride=1, pad=0):
     check(lib().sgx_conv2d_transpose_weights(ctypes.byref(d), ptr(w), ptr(wt), wt.numel() * 4, stream()), "sgx_conv2d_transpose_weights")
 
 
+def conv2d_transpose_jobs(w, wt, stride=1, pad=0) -> bytes:
+    """The transposes conv2d_transpose_weights(w, wt, stride, pad) would launch, as packed sgx_wtrans_job records (host bytes)."""
+    d = _wt_desc(w, stride, pad)
+    jobs = (_lib.WtransJob * 16)()
+    n = ctypes.c_int32()
+    check(lib().sgx_conv2d_transpose_jobs(ctypes.byref(d), ptr(w), ptr(wt), wt.numel() * 4, jobs, 16, ctypes.byref(n)), "sgx_conv2d_transpose_jobs")
+    return bytes(jobs)[: n.value * ctypes.sizeof(_lib.WtransJob)]
+
+
+def wtrans_batch(jobs_dev, njobs):
+    """Run a table of transposes (uint8 tensor on the device holding njobs sgx_wtrans_job records) as one launch."""
+    check(lib().sgx_wtrans_batch(ptr(jobs_dev), int(njobs), stream()), "sgx_wtrans_batch")
+
+
 def conv2d_bwd_data_wt(dy, w, wt, x_shape, stride=1, pad=0, addend=None, out=None, accumulate=False):
     """conv2d_bwd_data with weights already transposed into `wt` by conv2d_transpose_weights (same stride / pad)."""
     K, C, R, S = w.shape

@@ -62,7 +62,7 @@ class ConvLayer(SgxBlock):
         slots = {s.param: s for s in self._net.slots}
         s = slots[self.weight]
         self._w, self._gw = s.kernel_view, s.grad_kernel_view
-        self._wt = K.conv2d_wt_buffer(self._w, self._w.device) if self._net.aux_stream is not None else None
+        self._wt = K.conv2d_wt_buffer(self._w, self._w.device) if (self._net.aux_stream is not None or self._net.wt_batch) else None
 
     def transpose_weights(self):
         K.conv2d_transpose_weights(self._w, self._wt, stride=self.stride, pad=self.padding)

@@ -571,3 +571,26 @@ def test_standardize_u8_and_device_collate(backend):
     assert nhwc.data_ptr() == x_dev.data_ptr() and tuple(nhwc.shape) == (n, h, w, 4), "the model entrance must reuse the collated buffer"
     plain = K.input_to_nhwc(x_ref.to(backend))   # a plain NCHW batch takes the re-layout kernel
     assert torch.equal(plain.cpu(), nhwc.cpu()) or rel_err(plain.cpu(), nhwc.cpu()) < 1e-6
+
+
+def test_wtrans_batch_equals_per_conv_transposes(backend):
+    """sgx_conv2d_transpose_jobs + ONE sgx_wtrans_batch launch == the per-convolution sgx_conv2d_transpose_weights launches (bit-exact),
+    over 1x1 / 3x3 / stride-2 / 7x7-stride-2 filters (1, 1, 4 and 4 output-parity classes)."""
+    import ctypes
+
+    from super_gradients_amd import _lib
+
+    cfgs = [(8, 4, 1, 1, 0), (12, 8, 3, 1, 1), (8, 8, 3, 2, 1), (4, 4, 7, 2, 3), (8, 12, 1, 2, 0)]   # (K, C, R, stride, pad)
+    g = torch.Generator().manual_seed(3)
+    ws, singles, batched, table = [], [], [], b""
+    for k, c, r, s, p in cfgs:
+        w = K.to_ohwi(torch.randn(k, c, r, r, generator=g).to(backend))
+        a, b = K.conv2d_wt_buffer(w, backend).fill_(-1.0), K.conv2d_wt_buffer(w, backend).fill_(-1.0)
+        K.conv2d_transpose_weights(w, a, stride=s, pad=p)
+        table += K.conv2d_transpose_jobs(w, b, stride=s, pad=p)
+        ws.append(w), singles.append(a), batched.append(b)
+    n = len(table) // ctypes.sizeof(_lib.WtransJob)
+    assert n == 1 + 1 + 4 + 4 + 1   # a 1x1 stride-2 filter reaches one parity class only
+    K.wtrans_batch(torch.frombuffer(bytearray(table), dtype=torch.uint8).to(backend), n)
+    for (k, c, r, s, p), a, b in zip(cfgs, singles, batched):
+        assert torch.equal(a.cpu(), b.cpu()), f"batched transpose differs for K={k} C={c} R={r} s={s}"

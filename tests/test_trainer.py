@@ -229,3 +229,30 @@ def test_trainer_resnet18_cifar_recipe_shape(gpu_device, tmp_path):
     sd = net.state_dict()
     worst = max(float((sd[k].cpu() - v).norm() / v.norm().clamp_min(1e-6)) for k, v in ref.state_dict().items() if v.dtype.is_floating_point and v.dim() > 1)
     assert worst <= 2e-2, f"weights after 4 SGD steps differ by {worst:.2e} (relative L2, worst tensor)"
+
+
+def test_batched_weight_transposes_do_not_change_the_step(backend, monkeypatch):
+    """SGX_WT_BATCH=1 (all data-gradient weight transposes as one launch per step): outputs and every gradient are bit-identical to
+    the per-convolution path, over two optimizer steps (the transposed copies must follow the updated weights)."""
+    from super_gradients_amd.training.utils.optimizers import ArenaSGD
+
+    x = torch.randn(4, 4, 8, 8, generator=torch.Generator().manual_seed(1))
+    up = torch.randn(4, 6, generator=torch.Generator().manual_seed(2))
+    results = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SGX_WT_BATCH", mode)
+        _, net = _tiny_models(backend)
+        net.materialize(backend).train()
+        assert net.wt_batch == (mode == "1") and (net._wt_njobs == 1 + 4 if mode == "1" else net._wt_jobs is None)
+        opt = ArenaSGD(net, lr=0.1, momentum=0.9)
+        outs = []
+        for _ in range(2):
+            y = net(x.to(backend))
+            y.backward(up.to(backend))
+            net.join_side()
+            outs.append((y.detach().cpu().clone(), net.g_arena.buf.cpu().clone()))
+            opt.step()
+            opt.zero_grad()
+        results.append(outs)
+    for (y0, g0), (y1, g1) in zip(*results):
+        assert torch.equal(y0, y1) and torch.equal(g0, g1)
