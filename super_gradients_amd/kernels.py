@@ -37,10 +37,15 @@ WORKSPACE = _Workspace()
 
 # --------------------------------------------------------------------------------------------- layout helpers
 def nhwc_strides(t: torch.Tensor) -> Tuple[int, int]:
-    if t.dim() != 4 or t.stride(3) != 1 or (t.shape[1] > 1 and t.stride(1) != t.shape[2] * t.stride(2)):
+    if t.dim() != 4 or (t.shape[3] > 1 and t.stride(3) != 1):
         raise _lib.SgxError(f"tensor is not an NHWC view with contiguous channels: shape {tuple(t.shape)} strides {t.stride()}")
-    ld_pix = t.stride(2)
-    return ld_pix, (t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2] * ld_pix)  # strides of size-1 dims carry no information
+    n, h, w, c = t.shape
+    # strides of size-1 dims carry no information (torch leaves arbitrary values there, e.g. after permute on a 1x1 map): derive the
+    # pixel stride from the first dimension that has one
+    ld_pix = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else c)
+    if w > 1 and h > 1 and t.stride(1) != w * ld_pix:
+        raise _lib.SgxError(f"tensor is not an NHWC view with contiguous channels: shape {tuple(t.shape)} strides {t.stride()}")
+    return ld_pix, (t.stride(0) if n > 1 else h * w * ld_pix)
 
 
 def rows(t: torch.Tensor) -> Tuple[int, int]:

@@ -103,6 +103,8 @@ class BatchNorm(SgxBlock):
     def scale_shift(self, parts, M, training):
         """-> (scale, shift, save_mean, save_invstd); eval mode folds the running statistics."""
         if training:
+            if M <= 1:  # F.batch_norm's own check (torch/nn/functional.py: _verify_batch_size): the unbiased variance divides by M - 1
+                raise ValueError(f"Expected more than 1 value per channel when training, got {M} value(s) per channel ({self.num_features} channels)")
             if self._synced():
                 return K.bn_finalize_sync(parts, M, self.weight, self.bias, self.eps, self.momentum, self.running_mean, self.running_var)
             return K.bn_finalize(parts, M, self.weight, self.bias, self.eps, self.momentum, self.running_mean, self.running_var)

@@ -231,3 +231,21 @@ def test_ppyoloe_csp_stage(backend, nblk, spp):
         pytest.skip("host emulation: the 1-block and 2-block forms cover the wiring")
     x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
     _check(O(c, co, nblk, nn.SiLU, spp), CSPStage(c, co, nblk, "silu", spp), x, backend)
+
+
+def test_batchnorm_single_value_per_channel_raises(backend):
+    """Training-mode BatchNorm over ONE value per channel: the reference raises (F.batch_norm: 'Expected more than 1 value per channel
+    when training'); so does the HIP path, instead of writing inf/NaN into the running variance.  Eval mode is fine."""
+    from super_gradients_amd.modules import Conv
+
+    blk = Conv(8, 8, 1, 1, "relu")
+    net = _wrap(blk, backend)
+    x = to_nhwc(torch.randn(1, 8, 1, 1), backend)
+    net.train()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        blk.fwd(x)
+    ref = nn.Sequential(nn.Conv2d(8, 8, 1, bias=False), nn.BatchNorm2d(8)).train()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        ref(torch.randn(1, 8, 1, 1))
+    net.eval()
+    assert torch.isfinite(blk.fwd(x).cpu()).all()
