@@ -42,7 +42,8 @@ static LossWs carve(const sgx_loss_desc* d, void* ws) {
     w.aiou = (float*)(p + off); off += align_up(BL * 4);
     w.maxm = (unsigned*)(p + off); off += align_up(Bn * 4);
     w.maxi = (unsigned*)(p + off); off += align_up(Bn * 4);
-    long nblk = (BL + LOSS_THREADS - 1) / LOSS_THREADS + ((long)d->B * d->L * d->C / 4 + LOSS_THREADS - 1) / LOSS_THREADS;
+    const long cls_items = (long)d->B * d->L * (d->C % 4 == 0 ? d->C / 4 : d->C);  // float4 groups, or single classes when C % 4 != 0
+    long nblk = (BL + LOSS_THREADS - 1) / LOSS_THREADS + (cls_items + LOSS_THREADS - 1) / LOSS_THREADS;
     w.partials = (float*)(p + off); off += align_up((nblk + 8) * 4 * 4);
     w.bytes = off;
     return w;
@@ -578,6 +579,34 @@ __global__ __launch_bounds__(LOSS_THREADS) void cls_loss_kernel(sgx_loss_desc d,
     }
 }
 
+// class counts that are not a multiple of 4 (fine-tuning on custom datasets): one thread per (anchor, class), 4-byte accesses
+__global__ __launch_bounds__(LOSS_THREADS) void cls_loss_scalar_kernel(sgx_loss_desc d, const float* logits, const int* assigned_label,
+                                                                       const float* assigned_score, float* g_logits, float* partials) {
+    __shared__ float red[LOSS_THREADS];
+    const long n = (long)d.B * d.L * d.C;
+    const long i = (long)blockIdx.x * LOSS_THREADS + threadIdx.x;
+    float acc = 0.f;
+    if (i < n) {
+        const long a = i / d.C;
+        const int c = (int)(i - a * d.C);
+        const bool is_lab = c == assigned_label[a];
+        float ls, gr;
+        cls_elem(logits[i], is_lab ? assigned_score[a] : 0.f, is_lab, d.use_varifocal, d.use_static_assigner, ls, gr);
+        acc = ls;
+        g_logits[i] = gr * d.w_cls;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int wdt = LOSS_THREADS / 2; wdt > 0; wdt >>= 1) {
+        if ((int)threadIdx.x < wdt) red[threadIdx.x] += red[threadIdx.x + wdt];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float* o = partials + (long)blockIdx.x * 4;
+        o[0] = red[0]; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void loss_sums_kernel(const float* partials, int nblk, float* sums) {
     __shared__ double red[4][256];
     double s[4] = {0, 0, 0, 0};
@@ -613,7 +642,7 @@ extern "C" int32_t sgx_ppyoloe_loss_fwd(const sgx_loss_desc* d, const float* log
     SGX_CHECK_ARG(d && logits && distri && anchors && points && strides && sums && assigned_label && assigned_box && assigned_score &&
                       g_logits && g_distri && gt_count,
                   "ppyoloe_loss: null pointer");
-    SGX_CHECK_ARG(d->B > 0 && d->L > 0 && d->C > 0 && d->C % 4 == 0 && d->reg_max > 0 && d->reg_max < 64, "ppyoloe_loss: bad dims");
+    SGX_CHECK_ARG(d->B > 0 && d->L > 0 && d->C > 0 && d->reg_max > 0 && d->reg_max < 64, "ppyoloe_loss: bad dims");
     SGX_CHECK_ARG(d->nmax == 0 || (targets && gt_index), "ppyoloe_loss: null targets");
     SGX_CHECK_ARG((long)d->L * 4 <= 160 * 1024 - 4096, "ppyoloe_loss: L=%d does not fit the LDS metric buffer", d->L);
     if (!ws || ws_bytes < sgx_ppyoloe_loss_workspace(d)) SGX_FAIL(SGX_ERR_WORKSPACE, "ppyoloe_loss: workspace too small");
@@ -651,9 +680,14 @@ extern "C" int32_t sgx_ppyoloe_loss_fwd(const sgx_loss_desc* d, const float* log
     SGX_LAUNCH(box_loss_kernel, dim3(nb_box), dim3(LOSS_THREADS), 0, stream, *d, distri, points, strides, targets, gt_index, w, assigned_label,
                assigned_box, assigned_score, g_distri, w.partials);
     SGX_CHECK_LAUNCH("box_loss");
-    const int nb_cls = (int)((BL * (d->C / 4) + LOSS_THREADS - 1) / LOSS_THREADS);
-    SGX_LAUNCH(cls_loss_kernel, dim3(nb_cls), dim3(LOSS_THREADS), 0, stream, *d, logits, (const int*)assigned_label, (const float*)assigned_score,
-               g_logits, w.partials + (long)nb_box * 4);
+    const bool vec_cls = d->C % 4 == 0;
+    const int nb_cls = (int)((BL * (vec_cls ? d->C / 4 : d->C) + LOSS_THREADS - 1) / LOSS_THREADS);
+    if (vec_cls)
+        SGX_LAUNCH(cls_loss_kernel, dim3(nb_cls), dim3(LOSS_THREADS), 0, stream, *d, logits, (const int*)assigned_label,
+                   (const float*)assigned_score, g_logits, w.partials + (long)nb_box * 4);
+    else
+        SGX_LAUNCH(cls_loss_scalar_kernel, dim3(nb_cls), dim3(LOSS_THREADS), 0, stream, *d, logits, (const int*)assigned_label,
+                   (const float*)assigned_score, g_logits, w.partials + (long)nb_box * 4);
     SGX_CHECK_LAUNCH("cls_loss");
     SGX_LAUNCH(loss_sums_kernel, dim3(1), dim3(256), 0, stream, (const float*)w.partials, nb_box + nb_cls, sums);
     SGX_CHECK_LAUNCH("loss_sums");

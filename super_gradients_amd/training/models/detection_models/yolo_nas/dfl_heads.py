@@ -36,7 +36,12 @@ class _Seq1(nn.Module):
 
 
 class _PredConv(ConvLayer):
-    """nn.Conv2d(inter, n_out, 1) with bias; writes into a row range of the level-concatenated prediction buffer."""
+    """nn.Conv2d(inter, n_out, k) with bias; writes into a row range of the level-concatenated prediction buffer.
+
+    n_out is the class count for the classification branch - any number, not only multiples of 4 (fine-tuning on custom datasets:
+    the reference's own unit test builds YOLO-NAS with 17 classes, tests/unit_tests/yolo_nas_tests.py:13-18).  The forward conv kernel
+    has a scalar epilogue for that; the backward kernels read dy in 16-byte groups, so for n_out % 4 != 0 the gradient is computed
+    against zero-padded copies (dy, weights) and the first n_out rows of the padded weight gradient are added into the arena."""
 
     def fwd(self, x, out=None):
         self._x = x if self.training else None
@@ -44,8 +49,32 @@ class _PredConv(ConvLayer):
 
     def bwd(self, dy, need_dx=True, **kw):
         x, self._x = self._x, None
-        self.wgrad(x, dy)
-        return self.dgrad(dy, tuple(x.shape), **kw) if need_dx else None
+        if self.out_channels % 4 == 0:
+            self.wgrad(x, dy)
+            return self.dgrad(dy, tuple(x.shape), **kw) if need_dx else None
+        k, kp, r, dev = self.out_channels, (self.out_channels + 3) // 4 * 4, self.kernel_size, dy.device
+        cp = self._w.shape[1]
+        dyp = torch.zeros(*dy.shape[:3], kp, device=dev, dtype=torch.float32)
+        dyp[..., :k].copy_(dy)
+
+        def rows(t, n):   # [K,C,R,S] logical / OHWI memory -> [1,1,n,R*S*C] view of its first n filters
+            return t.permute(0, 2, 3, 1).reshape(1, 1, t.shape[0], -1)[:, :, :n]
+
+        def weight_gradient():
+            gw = K.ohwi_empty(kp, cp, r, r, dev)
+            gw.zero_()
+            gb = torch.zeros(kp, device=dev, dtype=torch.float32)
+            K.conv2d_bwd_weight(x, dyp, gw, gb, stride=self.stride, pad=self.padding)
+            K.axpy(rows(gw, k), out=rows(self._gw, k), accumulate=True)
+            self.bias.grad.add_(gb[:k])
+
+        self._net.fork_side(weight_gradient, x, dyp)
+        if not need_dx:
+            return None
+        wp = K.ohwi_empty(kp, cp, r, r, dev)
+        wp.zero_()
+        wp[:k].copy_(self._w)
+        return K.conv2d_bwd_data(dyp, wp, tuple(x.shape), stride=self.stride, pad=self.padding, **kw)
 
 
 @register_detection_module()
