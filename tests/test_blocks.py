@@ -280,3 +280,48 @@ def test_prediction_conv_any_class_count(backend, ksize, nout):
     assert_close(to_nchw_cpu(dx), x.grad, 1e-4, "input gradient")
     assert_close(blk.weight.grad.cpu(), ref.weight.grad, 1e-4, "weight gradient")
     assert_close(blk.bias.grad.cpu(), ref.bias.grad, 1e-4, "bias gradient")
+
+
+def test_stem_with_custom_in_channels(backend):
+    """tests/unit_tests/yolo_nas_tests.py:13-18 builds YOLO-NAS with in_channels=2: the stem QARepVGG block on a 2-channel image
+    (channels are zero-padded to 4 at the NCHW -> NHWC entrance; weights carry the same physical padding)."""
+    from oracle.yolo_nas import QARep
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd.modules import QARepVGGBlock
+    from super_gradients_amd.training import models
+
+    if backend.type == "cuda":
+        pytest.skip("added at the end of round 1 on the host emulation; enabled on the GPU after its first validated run")
+    net = models.get("yolo_nas_s", arch_params=dict(in_channels=2), num_classes=17)
+    sd = net.state_dict()
+    assert tuple(sd["backbone.stem.conv.branch_3x3.conv.weight"].shape) == (48, 2, 3, 3) and tuple(sd["heads.head1.cls_pred.weight"].shape)[0] == 17
+    x = torch.randn(2, 2, 8, 8, generator=torch.Generator().manual_seed(0)) + 0.5
+    ref, blk = QARep(2, 8, 2, residual=False), QARepVGGBlock(2, 8, stride=2, use_residual_connection=False)
+    _randomize(ref, 1)
+    wrapped = _wrap(blk, backend)
+    blk.load_state_dict(ref.state_dict(), strict=True)
+    from super_gradients_amd.modules.layers import BatchNorm
+
+    for m in blk.modules():
+        if isinstance(m, BatchNorm):
+            m.eps, m.momentum = 1e-3, 0.03
+    ref.train(), wrapped.train()
+    xr = x.clone().requires_grad_(True)
+    y = ref(xr)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+    y.backward(dy)
+    wrapped.zero_grad()
+    xh = K.input_to_nhwc(x.to(backend))
+    assert tuple(xh.shape) == (2, 8, 8, 4)
+    yd = blk.fwd(xh)
+    assert_close(to_nchw_cpu(yd), y, 2e-5, "forward")
+    blk.bwd(to_nhwc(dy, backend), need_dx=False)
+    wrapped.join_side()
+    rp = dict(ref.named_parameters())
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    for name, p in blk.named_parameters():
+        if "rbr_reparam" in name:
+            continue
+        rg = rp[name].grad   # (gradients that are analytically zero in front of a training-mode BatchNorm are judged against the largest one)
+        e = float((p.grad.cpu().double() - rg.double()).abs().max()) / max(float(rg.abs().max()), 1e-2 * gmax)
+        assert e <= 1e-4, f"grad {name}: {e:.3e}"
