@@ -39,6 +39,26 @@ class CustomizableDetector(SgxNetwork):
                 m.eps = bn_eps if bn_eps else m.eps
                 m.momentum = bn_momentum if bn_momentum else m.momentum
 
+    def replace_head(self, new_num_classes: Optional[int] = None, new_head=None):
+        """customizable_detector.py:111-122 (the fine-tuning path: load the 80-class checkpoint, then ask for the new class count).
+        Heads that support it (NDFLHeads) only get new class-prediction convs, initialised from the statistics of the old ones.
+        Must happen before the model is materialised in the HBM arenas (i.e. before .materialize() / the first forward)."""
+        if new_num_classes is None and new_head is None:
+            raise ValueError("At least one of new_num_classes, new_head must be given to replace output layer.")
+        if self._materialized:
+            raise RuntimeError("replace_head must be called before the model is materialized in HBM (before the first forward)")
+        if new_head is not None:
+            self.heads = new_head
+        elif hasattr(self.heads, "replace_num_classes"):
+            from ....modules.head_replacement_utils import replace_num_classes_with_random_weights
+
+            self.heads.replace_num_classes(new_num_classes, replace_num_classes_with_random_weights)
+        else:
+            f = DetectionModulesFactory()
+            self.heads_params = f.insert_module_param(self.heads_params, "num_classes", new_num_classes)
+            self.heads = f.get(f.insert_module_param(self.heads_params, "in_channels", self.neck.out_channels))
+            self._initialize_weights(self.bn_eps, self.bn_momentum, self.inplace_act)
+
     # ---- SgxNetwork protocol -------------------------------------------------------------------------------------
     def _fwd(self, x):
         if x.dim() != 4 or x.shape[1] != self.in_channels:

@@ -54,6 +54,17 @@ class PPYoloE(SgxNetwork):
     def num_classes(self):
         return self.head.num_classes
 
+    def replace_head(self, new_num_classes=None, new_head=None):
+        """pp_yolo_e.py:379-385; before the model is materialised in the HBM arenas."""
+        if new_num_classes is None and new_head is None:
+            raise ValueError("At least one of new_num_classes, new_head must be given to replace output layer.")
+        if self._materialized:
+            raise RuntimeError("replace_head must be called before the model is materialized in HBM (before the first forward)")
+        if new_head is not None:
+            self.head = new_head
+        else:
+            self.head.replace_num_classes(new_num_classes)
+
     def prep_model_for_conversion(self, input_size=None, **kwargs):
         """RepVGG blocks -> single 3x3 convs, anchors cached for `input_size` (reference :358-377)."""
         if input_size is not None:

@@ -87,6 +87,14 @@ class PPYOLOEHead(BaseDetectionModule):
             torch.nn.init.constant_(reg_.weight, 0.0)
             torch.nn.init.constant_(reg_.bias, 1.0)
 
+    def replace_num_classes(self, num_classes: int):
+        """pp_yolo_head.py:167-177: new class-prediction convs, zero weights and the -log(99) prior bias."""
+        self.num_classes = num_classes
+        self.pred_cls = nn.ModuleList([_PredConv(c, num_classes, 3, 1, 1, bias=True) for c in self.in_channels])
+        for cls_ in self.pred_cls:
+            torch.nn.init.constant_(cls_.weight, 0.0)
+            torch.nn.init.constant_(cls_.bias, -math.log((1 - 0.01) / 0.01))
+
     def cache_anchors(self, input_size):
         self.eval_size = list(input_size)[-2:]
 

@@ -96,6 +96,11 @@ class YoloNASDFLHead(BaseDetectionModule):
         self.prior_prob = 1e-2
         nn.init.constant_(self.cls_pred.bias, -math.log((1 - self.prior_prob) / self.prior_prob))
 
+    def replace_num_classes(self, num_classes: int, compute_new_weights_fn):
+        """dfl_heads.py:77-79: only the class-prediction conv is replaced."""
+        self.cls_pred = compute_new_weights_fn(self.cls_pred, num_classes)
+        self.num_classes = num_classes
+
     @property
     def out_channels(self):
         return None
@@ -139,6 +144,12 @@ class NDFLHeads(BaseDetectionModule):
     @property
     def out_channels(self):
         return None
+
+    def replace_num_classes(self, num_classes: int, compute_new_weights_fn):
+        """dfl_heads.py:165-170"""
+        for i in range(self.num_heads):
+            getattr(self, f"head{i + 1}").replace_num_classes(num_classes, compute_new_weights_fn)
+        self.num_classes = num_classes
 
     def anchors_for(self, sizes, device):
         """generate_anchors_for_grid_cell (pp_yolo_head.py:21-76) + the grid-unit points of dfl_heads.py:251-282; cached."""

@@ -52,7 +52,7 @@ def get(model_name: str, arch_params: Optional[dict] = None, num_classes: Option
         sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
         net.load_state_dict(sd, strict=strict_load in (True, "on"))
     if checkpoint_num_classes != num_classes:
-        raise NotImplementedError("replace_head after loading a checkpoint with a different class count is not implemented on the HIP path")
+        net.replace_head(new_num_classes=num_classes)  # transfer learning (model_factory.py:250-251)
     if num_input_channels is not None and num_input_channels != net.get_input_channels():
         raise NotImplementedError("pass in_channels through arch_params instead of num_input_channels")
     return net

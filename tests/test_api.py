@@ -138,3 +138,38 @@ def test_trainer_resume(backend, tmp_path):
     for (k, va), vc in zip(net_a.state_dict().items(), net_c.state_dict().values()):
         if va.dtype.is_floating_point:
             assert torch.allclose(va.cpu(), vc.cpu(), rtol=1e-5, atol=1e-6), k
+
+
+def test_replace_head_transfer_learning(tmp_path):
+    """tests/unit_tests/replace_head_test.py:26-40 and model_factory.py:227-251: build with the checkpoint's class count, load it, then
+    replace_head(new_num_classes): YOLO-NAS swaps only the class-prediction convs (statistics-matched random weights), PP-YOLOE re-creates
+    pred_cls with zero weights and the prior bias; everything else keeps the loaded values; models.get(checkpoint_num_classes=...) does both."""
+    import math
+
+    from super_gradients_amd.training import models
+
+    src = models.get("yolo_nas_s", num_classes=80)
+    ckpt = str(tmp_path / "ckpt.pth")
+    torch.save({"net": src.state_dict()}, ckpt)
+    net = models.get("yolo_nas_s", num_classes=100, checkpoint_path=ckpt, checkpoint_num_classes=80, strict_load=True)
+    assert net.num_classes == 100
+    sd, ref = net.state_dict(), src.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k in sd:
+        if ".cls_pred." in k:
+            assert sd[k].shape[0] == 100
+        else:
+            assert torch.equal(sd[k], ref[k]), k
+    w_old, w_new = ref["heads.head1.cls_pred.weight"], sd["heads.head1.cls_pred.weight"]
+    assert abs(float(w_new.std()) - float(w_old.std())) < 0.2 * float(w_old.std())   # drawn with the old layer's statistics
+    with pytest.raises(ValueError):
+        net.replace_head()
+    pp = models.get("ppyoloe_s", num_classes=80)
+    pp.replace_head(new_num_classes=100)
+    assert pp.num_classes == 100
+    for i in range(3):
+        assert tuple(pp.head.pred_cls[i].weight.shape)[:1] == (100,) and float(pp.head.pred_cls[i].weight.abs().max()) == 0.0
+        assert torch.allclose(pp.head.pred_cls[i].bias.detach(), torch.full((100,), -math.log(99.0)))
+    rn = models.get("resnet18", num_classes=1000)
+    rn.replace_head(new_num_classes=10)
+    assert rn.linear.weight.shape[0] == 10
