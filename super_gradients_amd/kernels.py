@@ -42,7 +42,12 @@ def nhwc_strides(t: torch.Tensor) -> Tuple[int, int]:
     n, h, w, c = t.shape
     # strides of size-1 dims carry no information (torch leaves arbitrary values there, e.g. after permute on a 1x1 map): derive the
     # pixel stride from the first dimension that has one
-    ld_pix = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else c)
+    if w > 1:
+        ld_pix = t.stride(2)
+    elif h > 1:
+        ld_pix = t.stride(1)
+    else:  # a single pixel per image: keep a plausible recorded stride (a channel slice of a wider one-pixel buffer), else fall back to C
+        ld_pix = t.stride(2) if t.stride(2) >= c else (t.stride(1) if t.stride(1) >= c else c)
     if w > 1 and h > 1 and t.stride(1) != w * ld_pix:
         raise _lib.SgxError(f"tensor is not an NHWC view with contiguous channels: shape {tuple(t.shape)} strides {t.stride()}")
     return ld_pix, (t.stride(0) if n > 1 else h * w * ld_pix)
