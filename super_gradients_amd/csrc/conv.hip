@@ -666,10 +666,6 @@ static TileCfg pick_tile(long M, int N, int math) {
     TileCfg t = pick_tile_heuristic(M, N);
     if (g_ovr_bm) t.bm = g_ovr_bm;
     if (g_ovr_bn) t.bn = g_ovr_bn;
-    if (math == 1) {  // three bf16 planes per slab: the two largest tiles do not fit 64 KB of LDS
-        if (t.bm == 128 && t.bn == 128) t.bn = 64;
-        if (t.bm == 128 && t.bn == 96) t.bm = 64;
-    }
     return t;
 }
 static TileCfg pick_tile_heuristic(long M, int N) {
@@ -718,6 +714,8 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         else if (flat && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, true, 1>(p, stream);
         else if (flat && bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true, 1>(p, stream);
         else if (flat) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (bf16x3): no flat tile %dx%d", bm, bn);
+        else if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, 1>(p, stream);  // 52 KB of LDS with the unpadded planes
+        else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, 1>(p, stream);
         else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, 1>(p, stream);
         else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 1>(p, stream);
         else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2, false, 1>(p, stream);

@@ -748,3 +748,33 @@ def test_nms_degenerate_boxes(backend):
         n = int(cnt[0])
         assert n == ref[0].shape[0], f"multi={multi} mode={mode}: kept {n} vs oracle {ref[0].shape[0]}"
         assert torch.equal(out[0, :n].cpu(), ref[0]), f"multi={multi} mode={mode}: rows differ"
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+def test_conv_every_tile_shape(backend, math):
+    """Every instantiated (BM, BN) tile of the implicit-GEMM kernel, forced through the measurement override (sgx_debug_set_tiles), on
+    one forward + data-gradient problem with ragged edges in both tile dimensions - the heuristics only ever pick a few of them."""
+    from super_gradients_amd._lib import lib
+
+    if backend.type == "cuda":
+        pytest.skip("added at the end of round 1 on the host emulation; enabled on the GPU after its first validated run")
+    n, h, w, c, k, r, s, p = (1, 9, 8, 20, 100, 3, 1, 1)   # M = 72 pixels, N = 100 filters: partial tiles everywhere
+    x, wt, b = _conv_case((n, h, w, c, k, r, s, p))
+    x.requires_grad_(True)
+    y = F.conv2d(x, wt, b, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+    y.backward(dy)
+    xd, wd = to_nhwc(x.detach(), backend), K.to_ohwi(wt.to(backend))
+    K.set_conv_math(math)
+    try:
+        for bm in (64, 128):
+            for bn in (32, 64, 96, 128):
+                lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                yd, parts = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s, pad=p, stat_partials=True)
+                assert_close(to_nchw_cpu(yd), y.detach(), TOL, f"{math} fwd tile {bm}x{bn}")
+                assert_close(parts[0].sum(0).cpu() / (n * h * w), y.detach().mean((0, 2, 3)), 1e-4, f"{math} stats tile {bm}x{bn}")
+                dx = K.conv2d_bwd_data(to_nhwc(dy, backend), wd, (n, h, w, c), stride=s, pad=p)
+                assert_close(to_nchw_cpu(dx), x.grad, TOL, f"{math} dgrad tile {bm}x{bn}")
+    finally:
+        lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
+        K.set_conv_math("fp32")
