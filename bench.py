@@ -243,6 +243,8 @@ def main():
     state = {"step": 0}
 
     def step():
+        if world > 1:
+            reducer.broadcast_buffers(0)  # what DDP(broadcast_buffers=True), the reference's wrapping, does at every forward
         out = net(x)
         loss, _ = crit(out, targets)
         loss.backward()

@@ -280,6 +280,8 @@ class Trainer:
                 inputs, targets = tp.pre_prediction_callback(inputs, targets, batch_idx)
             context.update_context(batch_idx=batch_idx, inputs=inputs, target=targets, additional_batch_items=extras, **extras)
             handler.on_train_batch_start(context)
+            if self.reducer is not None and world > 1:
+                self.reducer.broadcast_buffers(0)  # DDP(broadcast_buffers=True) semantics
             outputs = self.net(inputs)
             loss, items = self._get_losses(outputs, targets)
             context.update_context(preds=outputs, loss_log_items=items, loss_logging_items_names=self.loss_logging_items_names)

@@ -109,6 +109,14 @@ class GradientAllReducer:
         self.pending = []
         self.issued = set()
 
+    def broadcast_buffers(self, src: int = 0):
+        """What DistributedDataParallel(broadcast_buffers=True) - the reference's wrapping (sg_trainer.py:1352-1357, torch default) - does
+        at the start of every training forward: BatchNorm running statistics and step counters of every rank are overwritten with rank
+        `src`'s.  Two small collectives over the buffer arenas."""
+        if self.world > 1:
+            dist.broadcast(self.net.b_arena.buf, src)
+            dist.broadcast(self.net.i_arena, src)
+
     def broadcast_parameters(self, src: int = 0):
         """DDP-constructor semantics: every rank starts from rank `src`'s parameters and buffers."""
         if self.world > 1:

@@ -92,6 +92,12 @@ def _worker(rank, world, port, outdir):
     (ys * ws_).sum().backward()
     out["sync_y"], out["sync_grad"] = ys.detach().clone(), snet.g_arena.buf.clone()
     out["sync_running"] = snet.b_arena.buf.clone()
+    # ---- DDP(broadcast_buffers=True): rank 0's BatchNorm statistics overwrite everyone's before a forward ----------------------------
+    net.b_arena.buf.add_(float(rank + 1))
+    net.i_arena.add_(rank + 5)
+    out["buffers_before"] = (net.b_arena.buf.clone(), net.i_arena.clone())
+    reducer.broadcast_buffers(0)
+    out["buffers_after"] = (net.b_arena.buf.clone(), net.i_arena.clone())
     if rank == 0:
         ref.train()
         yf = ref(xfull)
@@ -147,3 +153,7 @@ def test_world_size_2_gloo(tmp_path):
     for k, v in r[0]["buffer_state"].items():
         assert torch.allclose(v, r[0]["full_buffers"][k], rtol=1e-5, atol=1e-6), k
     assert torch.equal(r[0]["sync_running"], r[1]["sync_running"])
+    # DDP(broadcast_buffers=True): after the broadcast every rank holds what rank 0 held before it (float statistics and step counters)
+    assert not torch.equal(r[0]["buffers_before"][0], r[1]["buffers_before"][0])
+    for i in range(world):
+        assert torch.equal(r[i]["buffers_after"][0], r[0]["buffers_before"][0]) and torch.equal(r[i]["buffers_after"][1], r[0]["buffers_before"][1])
