@@ -168,6 +168,9 @@ def lib():
             if mode not in ("fp32", "bf16x3", "auto"):
                 raise RuntimeError(f"SGX_CONV_MATH={mode!r}: expected 'fp32', 'bf16x3' or 'auto'")
             _LIB.sgx_conv_set_math({"fp32": 0, "bf16x3": 1, "auto": 2}[mode])
+        var = os.environ.get("SGX_CONV_VARIANT")  # experiment switch of the conv kernels (sgx_debug_set_variant; 5 = 32-deep slabs)
+        if var:
+            _LIB.sgx_debug_set_variant(int(var))
     return _LIB
 
 

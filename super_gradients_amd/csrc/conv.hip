@@ -237,19 +237,28 @@ __device__ __forceinline__ sgx_f32x16 sgx_mfma_bf16(const uint4& a, const uint4&
 }
 #endif
 
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0>
+// KD = slab depth.  16: two LDS buffers, one barrier per slab (the round-1 loop).  32 (fp32 arithmetic, C % 32 == 0; experiment
+// switch sgx_debug_set_variant(5), see run_igemm): every global load instruction covers whole 128-byte lines (8 lanes x 16 B per slab
+// row instead of 4 x 16 B = half a line - MI355X's load path handles half-line "fragment-shaped" requests at about half the rate),
+// half the load instructions, address arithmetic and barriers per FLOP, and a register prefetch that is 16 MFMAs (1024 matrix-pipe
+// cycles) ahead instead of 8.  ONE LDS buffer (18 KB for 64x64: occupancy stays VGPR-bound) with a write-after-barrier hand-over.
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
+    static_assert(KD == 16 || (KD == 32 && MATH == 0 && !FLAT), "32-deep slabs: fp32 arithmetic, channel-chunked K axis only");
     constexpr int NTH = WM * WN * 64;   // threads per workgroup
-    constexpr int RPP = NTH / 4;        // slab rows staged per pass (4 threads x 16 B per 16-float row)
+    constexpr int CPR = KD / 4;         // threads per slab row (16 B each)
+    constexpr int RPP = NTH / CPR;      // slab rows staged per pass
+    constexpr int LD = KD + 4;          // fp32 LDS row pitch: 20 / 36 floats -> conflict-free ds_read_b128 over 16 consecutive rows
+    constexpr int NBUF = KD == 16 ? 2 : 1;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int AJ = (BM + RPP - 1) / RPP, BJ = (BN + RPP - 1) / RPP;
     static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "bad tile");
     static_assert(NTH >= BM && NTH >= BN, "epilogue helpers need one thread per tile row/col");
-    constexpr int ROWW = MATH == 1 ? 3 * IG_LDP : IG_LD;                       // dwords of LDS per slab row (all planes)
-    constexpr int SLABS = 2 * (BM + BN) * ROWW, STAGE = WM * WN * 32 * 32;   // operand slabs; epilogue staging patches (reuse the slabs)
+    constexpr int ROWW = MATH == 1 ? 3 * IG_LDP : LD;                          // dwords of LDS per slab row (all planes)
+    constexpr int SLABS = NBUF * (BM + BN) * ROWW, STAGE = WM * WN * 32 * 32;   // operand slabs; epilogue staging patches (reuse the slabs)
     __shared__ __attribute__((aligned(16))) float smem[SLABS > STAGE ? SLABS : STAGE];
     float* const As = smem;
-    float* const Bs = smem + 2 * BM * ROWW;
+    float* const Bs = smem + NBUF * BM * ROWW;
     __shared__ long long rowoff[BM];
     __shared__ float red[2 * WM * BN];
 
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     const sgx_buf bufA = sgx_make_buf(p.A + (long)img0 * p.a_ld_img, p.a_bytes - (long)img0 * p.a_ld_img * 4);
     const sgx_buf bufB = sgx_make_buf(p.Wt, p.w_bytes);
 
-    const int lrow = tid >> 2, chunk4 = (tid & 3) * 4;
+    const int lrow = tid / CPR, chunk4 = (tid % CPR) * 4;
     int aoff[AJ];
     unsigned long long amask[AJ];
 #pragma unroll
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         boff[j] = (int)(((long)n * p.w_ld_n + (FLAT ? 0 : chunk4)) * 4);
     }
 
-    const int cpt = (p.C + IG_BK - 1) / IG_BK;
+    const int cpt = (p.C + KD - 1) / KD;
     const int nkt = FLAT ? (T * p.C + IG_BK - 1) / IG_BK : T * cpt;
     const int pixstep = p.dstep * (int)p.a_ld_pix * 4;      // bytes per tap step along w
     const int rowstep = pixstep * p.Win;                     // bytes per tap step along h
@@ -347,9 +356,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             for (int j = 0; j < BJ; ++j) rb[j] = sgx_buf_ld4(bufB, (kok && bok[j]) ? (unsigned)(boff[j] + kk * 4) : SGX_BUF_OOB);
         } else {
             const int tbit = s_ti * p.Tw + s_tj;
-            const int tapoff = s_ti * rowstep + s_tj * pixstep + s_ck * (IG_BK * 4);
-            const int woff = (tbit * p.C + s_ck * IG_BK) * 4;
-            const bool cok = s_ck * IG_BK + chunk4 < p.C;
+            const int tapoff = s_ti * rowstep + s_tj * pixstep + s_ck * (KD * 4);
+            const int woff = (tbit * p.C + s_ck * KD) * 4;
+            const bool cok = s_ck * KD + chunk4 < p.C;
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 const bool ok = cok && ((amask[j] >> tbit) & 1ull);
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 const int row = lrow + RPP * j;
-                if (row < BM) {
+                if (BM % RPP == 0 || row < BM) {
                     uint2 h, m, l;
                     sgx_split3(ra[j], h, m, l);
                     unsigned* d = reinterpret_cast<unsigned*>(As) + (buf * 3 * BM + row) * IG_LDP + IG_SWZ(row, chunk4 >> 1);
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
                 const int row = lrow + RPP * j;
-                if (row < BN) {
+                if (BN % RPP == 0 || row < BN) {
                     uint2 h, m, l;
                     sgx_split3(rb[j], h, m, l);
                     unsigned* d = reinterpret_cast<unsigned*>(Bs) + (buf * 3 * BN + row) * IG_LDP + IG_SWZ(row, chunk4 >> 1);
@@ -399,12 +408,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int row = lrow + RPP * j;
-            if (row < BM) sgx_st4(&As[buf * BM * IG_LD + row * IG_LD + chunk4], ra[j]);
+            if (BM % RPP == 0 || row < BM) sgx_st4(&As[buf * BM * LD + row * LD + chunk4], ra[j]);
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int row = lrow + RPP * j;
-            if (row < BN) sgx_st4(&Bs[buf * BN * IG_LD + row * IG_LD + chunk4], rb[j]);
+            if (BN % RPP == 0 || row < BN) sgx_st4(&Bs[buf * BN * LD + row * LD + chunk4], rb[j]);
         }
     };
     auto store_tile = [&](int buf) { store_tile_from(buf, ra, rb); };
@@ -480,29 +489,19 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = sgx_mfma_bf16(ah[i], bh[j], acc[i][j]);
     };
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile();  // global loads in flight under the MFMA block
-
-        if (MATH == 1) {
-            // (a second register stage - slabs fetched two iterations ahead, counted vmcnt - was measured: no gain, r1z/r1z2;
-            // this path is bound by LDS traffic and the per-slab barrier, not by global-load latency)
-            compute_bf3(buf);
-            if (kt + 1 < nkt) store_tile(buf ^ 1);
-            __syncthreads();
-            continue;
-        }
+    // fp32 arithmetic: fragments of one 16-deep step (columns kofs .. kofs+15 of the slab) and its 8 x TM x TN MFMAs
+    auto compute_f32 = [&](int buf, int kofs) {
         float af[TM][8], bf[TN][8];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const float* s = &As[buf * BM * IG_LD + (wm * TM * 32 + i * 32 + frow) * IG_LD + fk];
+            const float* s = &As[buf * BM * LD + (wm * TM * 32 + i * 32 + frow) * LD + kofs + fk];
             float4 v0 = sgx_ld4(s), v1 = sgx_ld4(s + 4);
             af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
             af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float* s = &Bs[buf * BN * IG_LD + (wn * TN * 32 + j * 32 + frow) * IG_LD + fk];
+            const float* s = &Bs[buf * BN * LD + (wn * TN * 32 + j * 32 + frow) * LD + kofs + fk];
             float4 v0 = sgx_ld4(s), v1 = sgx_ld4(s + 4);
             bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
             bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
@@ -514,7 +513,32 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    };
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (KD == 32) {
+            // one LDS buffer: the next slab travels in registers under 16 x TM x TN MFMAs and is written after every wave has read this one
+            if (kt + 1 < nkt) load_tile();
+            compute_f32(0, 0);
+            compute_f32(0, 16);
+            __syncthreads();
+            if (kt + 1 < nkt) {
+                store_tile(0);
+                __syncthreads();
+            }
+            continue;
+        }
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile();  // global loads in flight under the MFMA block
 
+        if (MATH == 1) {
+            // (a second register stage - slabs fetched two iterations ahead, counted vmcnt - was measured: no gain, r1z/r1z2;
+            // this path is bound by LDS traffic and the per-slab barrier, not by global-load latency)
+            compute_bf3(buf);
+            if (kt + 1 < nkt) store_tile(buf ^ 1);
+            __syncthreads();
+            continue;
+        }
+        compute_f32(buf, 0);
         if (kt + 1 < nkt) store_tile(buf ^ 1);
         __syncthreads();
     }
@@ -680,14 +704,19 @@ static TileCfg pick_tile_heuristic(long M, int N) {
     return TileCfg{M >= 16384 ? 128 : 64, 32};
 }
 
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0>
+// 32-deep slabs are an experiment switch until their first measurement on the GPU: sgx_debug_set_variant(5) / SGX_CONV_VARIANT=5.
+// Eligible: fp32 arithmetic, channel-chunked K axis, C a multiple of 32 (a ragged last chunk would multiply zeros for up to half a slab).
+static bool igemm_deep_slabs(const IgemmParams& p) {
+    return g_ovr_var == 5 && conv_math_for(p.Th * p.Tw, p.C) == 0 && p.C % 32 == 0;
+}
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK>
 static void launch_igemm(IgemmParams& p, void* stream) {
     p.mt = sgx_cdiv(p.M, BM);
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
     p.chunk = sgx_cdiv(p.nblk, 8);
     int grid = p.chunk * 8;
-    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
+    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
 }
 
 static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
@@ -730,6 +759,16 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, true>(p, stream);
         else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true>(p, stream);
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no flat tile %dx%d", bm, bn);
+    } else if (igemm_deep_slabs(p)) {  // 32-deep slabs (see igemm_kernel): whole-line loads, one LDS buffer
+        if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, 0, 32>(p, stream);
+        else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, 0, 32>(p, stream);
+        else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, 0, 32>(p, stream);
+        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 0, 32>(p, stream);
+        else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2, false, 0, 32>(p, stream);
+        else if (bm == 64 && bn == 96) launch_igemm<64, 96, 2, 1, false, 0, 32>(p, stream);
+        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, 32>(p, stream);
+        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, 0, 32>(p, stream);
+        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (32-deep slabs): no tile %dx%d", bm, bn);
     } else if (g_ovr_var == 1 && bm == 64 && bn == 64) launch_igemm<64, 64, 1, 2, false>(p, stream);   // 2 waves x (64x32)
     else if (g_ovr_var == 2 && bm == 128 && bn == 64) launch_igemm<128, 64, 4, 2, false>(p, stream);   // 8 waves x (32x32)
     else if (g_ovr_var == 3 && bm == 128 && bn == 128) launch_igemm<128, 128, 4, 2, false>(p, stream); // 8 waves x (32x64)
