@@ -237,19 +237,21 @@ __device__ __forceinline__ sgx_f32x16 sgx_mfma_bf16(const uint4& a, const uint4&
 }
 #endif
 
-// KD = slab depth.  16: two LDS buffers, one barrier per slab (the round-1 loop).  32 (fp32 arithmetic, C % 32 == 0; experiment
-// switch sgx_debug_set_variant(5), see run_igemm): every global load instruction covers whole 128-byte lines (8 lanes x 16 B per slab
-// row instead of 4 x 16 B = half a line - MI355X's load path handles half-line "fragment-shaped" requests at about half the rate),
-// half the load instructions, address arithmetic and barriers per FLOP, and a register prefetch that is 16 MFMAs (1024 matrix-pipe
-// cycles) ahead instead of 8.  ONE LDS buffer (18 KB for 64x64: occupancy stays VGPR-bound) with a write-after-barrier hand-over.
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK>
+// KD = slab depth, NBUF = LDS buffers.  (16, 2): one barrier per slab (the round-1 loop).  KD = 32 (fp32 arithmetic, C % 32 == 0;
+// experiment switches sgx_debug_set_variant(5 | 6), see run_igemm): every global load instruction covers whole 128-byte lines (8 lanes
+// x 16 B per slab row instead of 4 x 16 B = half a line - MI355X's load path handles half-line "fragment-shaped" requests at about half
+// the rate), half the load instructions and address arithmetic per FLOP, and a register prefetch that is 16 MFMAs (1024 matrix-pipe
+// cycles) ahead instead of 8.  (32, 1): ONE LDS buffer (18 KB for 64x64: occupancy stays VGPR-bound, 7 workgroups per CU) with a
+// write-after-barrier hand-over - two barriers per slab, i.e. as many per FLOP as (16, 2).  (32, 2): two buffers (37 KB for 64x64:
+// 4 workgroups per CU), one barrier per slab - half the barriers per FLOP at lower occupancy.
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
-    static_assert(KD == 16 || (KD == 32 && MATH == 0 && !FLAT), "32-deep slabs: fp32 arithmetic, channel-chunked K axis only");
+    static_assert((KD == 16 && NBUF == 2) || (KD == 32 && MATH == 0 && !FLAT && (NBUF == 1 || NBUF == 2)),
+                  "32-deep slabs: fp32 arithmetic, channel-chunked K axis only");
     constexpr int NTH = WM * WN * 64;   // threads per workgroup
     constexpr int CPR = KD / 4;         // threads per slab row (16 B each)
     constexpr int RPP = NTH / CPR;      // slab rows staged per pass
     constexpr int LD = KD + 4;          // fp32 LDS row pitch: 20 / 36 floats -> conflict-free ds_read_b128 over 16 consecutive rows
-    constexpr int NBUF = KD == 16 ? 2 : 1;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int AJ = (BM + RPP - 1) / RPP, BJ = (BN + RPP - 1) / RPP;
     static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "bad tile");
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
     };
     for (int kt = 0; kt < nkt; ++kt) {
-        if (KD == 32) {
+        if (KD == 32 && NBUF == 1) {
             // one LDS buffer: the next slab travels in registers under 16 x TM x TN MFMAs and is written after every wave has read this one
             if (kt + 1 < nkt) load_tile();
             compute_f32(0, 0);
@@ -528,6 +530,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             continue;
         }
         const int buf = kt & 1;
+        if (KD == 32) {
+            if (kt + 1 < nkt) load_tile();
+            compute_f32(buf, 0);
+            compute_f32(buf, 16);
+            if (kt + 1 < nkt) store_tile(buf ^ 1);
+            __syncthreads();
+            continue;
+        }
         if (kt + 1 < nkt) load_tile();  // global loads in flight under the MFMA block
 
         if (MATH == 1) {
@@ -704,19 +714,20 @@ static TileCfg pick_tile_heuristic(long M, int N) {
     return TileCfg{M >= 16384 ? 128 : 64, 32};
 }
 
-// 32-deep slabs are an experiment switch until their first measurement on the GPU: sgx_debug_set_variant(5) / SGX_CONV_VARIANT=5.
-// Eligible: fp32 arithmetic, channel-chunked K axis, C a multiple of 32 (a ragged last chunk would multiply zeros for up to half a slab).
+// 32-deep slabs are an experiment switch until their first measurement on the GPU: sgx_debug_set_variant(5 | 6) / SGX_CONV_VARIANT
+// (5: one LDS buffer, 6: two).  Eligible: fp32 arithmetic, channel-chunked K axis, C a multiple of 32 (a ragged last chunk would
+// multiply zeros for up to half a slab).
 static bool igemm_deep_slabs(const IgemmParams& p) {
-    return g_ovr_var == 5 && conv_math_for(p.Th * p.Tw, p.C) == 0 && p.C % 32 == 0;
+    return (g_ovr_var == 5 || g_ovr_var == 6) && conv_math_for(p.Th * p.Tw, p.C) == 0 && p.C % 32 == 0;
 }
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK>
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2>
 static void launch_igemm(IgemmParams& p, void* stream) {
     p.mt = sgx_cdiv(p.M, BM);
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
     p.chunk = sgx_cdiv(p.nblk, 8);
     int grid = p.chunk * 8;
-    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
+    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
 }
 
 static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
@@ -759,16 +770,16 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, true>(p, stream);
         else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true>(p, stream);
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no flat tile %dx%d", bm, bn);
-    } else if (igemm_deep_slabs(p)) {  // 32-deep slabs (see igemm_kernel): whole-line loads, one LDS buffer
-        if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, 0, 32>(p, stream);
-        else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, 0, 32>(p, stream);
-        else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, 0, 32>(p, stream);
-        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 0, 32>(p, stream);
-        else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2, false, 0, 32>(p, stream);
-        else if (bm == 64 && bn == 96) launch_igemm<64, 96, 2, 1, false, 0, 32>(p, stream);
-        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, 32>(p, stream);
-        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, 0, 32>(p, stream);
-        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (32-deep slabs): no tile %dx%d", bm, bn);
+    } else if (igemm_deep_slabs(p)) {  // 32-deep slabs (see igemm_kernel): whole-line loads
+#define SGX_DEEP(BM_, BN_, WM_, WN_)                                                        \
+    if (bm == BM_ && bn == BN_) {                                                           \
+        if (g_ovr_var == 5) launch_igemm<BM_, BN_, WM_, WN_, false, 0, 32, 1>(p, stream);   \
+        else launch_igemm<BM_, BN_, WM_, WN_, false, 0, 32, 2>(p, stream);                  \
+    } else
+        SGX_DEEP(128, 128, 2, 2) SGX_DEEP(128, 96, 4, 1) SGX_DEEP(128, 64, 2, 2) SGX_DEEP(128, 32, 4, 1) SGX_DEEP(64, 128, 2, 2)
+        SGX_DEEP(64, 96, 2, 1) SGX_DEEP(64, 64, 2, 2) SGX_DEEP(64, 32, 2, 1)
+        SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (32-deep slabs): no tile %dx%d", bm, bn);
+#undef SGX_DEEP
     } else if (g_ovr_var == 1 && bm == 64 && bn == 64) launch_igemm<64, 64, 1, 2, false>(p, stream);   // 2 waves x (64x32)
     else if (g_ovr_var == 2 && bm == 128 && bn == 64) launch_igemm<128, 64, 4, 2, false>(p, stream);   // 8 waves x (32x32)
     else if (g_ovr_var == 3 && bm == 128 && bn == 128) launch_igemm<128, 128, 4, 2, false>(p, stream); // 8 waves x (32x64)

@@ -69,13 +69,14 @@ def main():
                 if t < best:
                     best, best_cfg = t, f"bm={bm} bn={bn} variant={var}"
             # 32-deep slabs (variant 5; eligible problems only: fp32 arithmetic, C % 32 == 0 - others run the default kernel again)
-            lib().sgx_debug_set_variant(5)
-            for bm in (0, 64, 128):
-                for bn in ((0,) if bm == 0 else (32, 64, 96, 128)):
-                    lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
-                    t = timeit(fn)
-                    if t < best:
-                        best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + " variant=5 (32-deep slabs)"
+            for var in (5, 6):  # one / two LDS buffers
+                lib().sgx_debug_set_variant(var)
+                for bm in (0, 64, 128):
+                    for bn in ((0,) if bm == 0 else (32, 64, 96, 128)):
+                        lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                        t = timeit(fn)
+                        if t < best:
+                            best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + f" variant={var} (32-deep slabs)"
             lib().sgx_debug_set_variant(0)
         elif args.wgrad:
             for bnk in (32, 64, 96, 128):
