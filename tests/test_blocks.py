@@ -4,7 +4,7 @@ import pytest
 import torch
 from torch import nn
 
-from util import assert_close, to_nchw_cpu, to_nhwc
+from util import assert_close, first_gpu_run_pending, to_nchw_cpu, to_nhwc
 
 
 class _Net(nn.Module):
@@ -257,8 +257,7 @@ def test_prediction_conv_any_class_count(backend, ksize, nout):
     of 4 (the reference's own test builds 17 classes, tests/unit_tests/yolo_nas_tests.py:13-18): forward, input / weight / bias gradient."""
     from super_gradients_amd.training.models.detection_models.yolo_nas.dfl_heads import _PredConv
 
-    if backend.type == "cuda":
-        pytest.skip("added at the end of round 1 on the host emulation; enabled on the GPU after its first validated run")
+    first_gpu_run_pending(backend)
     n, c, h, w = 2, 8, 5, 4
     g = torch.Generator().manual_seed(0)
     x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
@@ -290,8 +289,7 @@ def test_stem_with_custom_in_channels(backend):
     from super_gradients_amd.modules import QARepVGGBlock
     from super_gradients_amd.training import models
 
-    if backend.type == "cuda":
-        pytest.skip("added at the end of round 1 on the host emulation; enabled on the GPU after its first validated run")
+    first_gpu_run_pending(backend)
     net = models.get("yolo_nas_s", arch_params=dict(in_channels=2), num_classes=17)
     sd = net.state_dict()
     assert tuple(sd["backbone.stem.conv.branch_3x3.conv.weight"].shape) == (48, 2, 3, 3) and tuple(sd["heads.head1.cls_pred.weight"].shape)[0] == 17

@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from util import assert_close, empty_nhwc, rel_err, to_nchw_cpu, to_nhwc
+from util import assert_close, empty_nhwc, first_gpu_run_pending, rel_err, to_nchw_cpu, to_nhwc
 
 from super_gradients_amd import kernels as K
 
@@ -396,8 +396,7 @@ def test_ppyoloe_loss_any_class_count(backend, C):
     """Class counts that are not a multiple of 4 (scalar classification-loss kernel): same parity bar as the vector path."""
     from oracle.ppyolo_loss import PPYoloELossOracle
 
-    if backend.type == "cuda":
-        pytest.skip("added at the end of round 1 on the host emulation; enabled on the GPU after its first validated run")
+    first_gpu_run_pending(backend)
     B, hw = 2, [(12, 12), (6, 6), (3, 3)]
     logits, distri, anchors, pts, pts_grid, counts, strides, targets = _head_case(B, hw, C, seed=4)
     logits.requires_grad_(True)
@@ -652,8 +651,7 @@ def test_ppyoloe_assignment_adversarial(backend, kind):
     TAL and ATSS.  Zero logits make every anchor's class scores equal, so candidate ranking is decided by IoU ties and index order."""
     from oracle.ppyolo_loss import PPYoloELossOracle
 
-    if backend.type == "cuda":
-        pytest.skip("added at the end of round 1 on the host emulation; enabled on the GPU after its first validated run")
+    first_gpu_run_pending(backend)
     B, hw, C = 2, [(12, 12), (6, 6), (3, 3)], 8
     logits, distri, anchors, pts, pts_grid, counts, strides, _ = _head_case(B, hw, C, seed=5)
     logits = torch.zeros_like(logits) if kind in ("duplicates", "many") else logits
@@ -685,8 +683,7 @@ def test_atss_distance_tie_policy(backend):
     that everything away from the tie agrees with the oracle)."""
     from oracle.ppyolo_loss import PPYoloELossOracle
 
-    if backend.type == "cuda":
-        pytest.skip("added at the end of round 1 on the host emulation; enabled on the GPU after its first validated run")
+    first_gpu_run_pending(backend)
     B, hw, C = 1, [(12, 12), (6, 6), (3, 3)], 8
     logits, distri, anchors, pts, pts_grid, counts, strides, _ = _head_case(B, hw, C, seed=5)
     s = 96.0
@@ -725,8 +722,7 @@ def test_nms_degenerate_boxes(backend):
     (IoU exactly 1), boxes touching along an edge (IoU exactly 0), IoU exactly AT the threshold (kept: suppression is `>`), equal scores."""
     from oracle import nms as onms
 
-    if backend.type == "cuda":
-        pytest.skip("added at the end of round 1 on the host emulation; enabled on the GPU after its first validated run")
+    first_gpu_run_pending(backend)
     bx = torch.tensor([
         [10, 10, 50, 50], [10, 10, 50, 50],        # identical pair
         [50, 10, 90, 50],                           # touches the first along x = 50
@@ -757,8 +753,7 @@ def test_conv_deep_slabs(backend, case):
     16-deep slabs, so the results must be BIT-identical to the default kernel's, not just close."""
     from super_gradients_amd._lib import lib
 
-    if backend.type == "cuda":
-        pytest.skip("added at the end of round 1 on the host emulation; enabled on the GPU after its first validated run")
+    first_gpu_run_pending(backend)
     n, h, w, c, k, r, s, p = case
     x, wt, b = _conv_case(case)
     x.requires_grad_(True)
@@ -792,8 +787,7 @@ def test_conv_every_tile_shape(backend, math):
     one forward + data-gradient problem with ragged edges in both tile dimensions - the heuristics only ever pick a few of them."""
     from super_gradients_amd._lib import lib
 
-    if backend.type == "cuda":
-        pytest.skip("added at the end of round 1 on the host emulation; enabled on the GPU after its first validated run")
+    first_gpu_run_pending(backend)
     n, h, w, c, k, r, s, p = (1, 9, 8, 20, 100, 3, 1, 1)   # M = 72 pixels, N = 100 filters: partial tiles everywhere
     x, wt, b = _conv_case((n, h, w, c, k, r, s, p))
     x.requires_grad_(True)

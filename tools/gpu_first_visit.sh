@@ -1,0 +1,21 @@
+#!/bin/bash
+# First GPU visit of a round: (1) the tests that were written without GPU time (green on the host emulation only), non-fatally;
+# (2) A/B of the conv-kernel experiment switches on the train-step bench; (3) the per-problem tuner over every tile x variant.
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_first_visit.sh r2a'
+# Everything lands under gpurun_out/$TAG/; copy what is to be judged into profiles/.
+TAG=${1:-first}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+SGX_GPU_UNVALIDATED=1 timeout 400 python -m pytest tests/test_kernels.py tests/test_blocks.py -m gpu -q \
+  -k "any_class_count or assignment_adversarial or distance_tie_policy or nms_degenerate_boxes or conv_every_tile_shape or conv_deep_slabs or stem_with_custom_in_channels" \
+  > "$OUT/pytest_first_gpu_run.log" 2>&1
+echo "pytest rc=$?" >> "$OUT/pytest_first_gpu_run.log"; tail -4 "$OUT/pytest_first_gpu_run.log"
+for v in 0 5 6; do
+  SGX_CONV_VARIANT=$v timeout 200 python bench.py --no-nms --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/bench_variant$v.json" 2> "$OUT/bench_variant$v.err"
+  echo "variant $v rc=$?: $(python -c "import json,sys; r=json.loads(open('$OUT/bench_variant$v.json').read().strip().splitlines()[-1]); print(r['value'],'img/s', r['ms_per_step'],'ms; igemm', r['roofline']['achieved'], 'TF concurrent,', r['roofline']['exclusive']['achieved'], 'TF exclusive')" 2>&1 | tail -1)"
+done
+if [[ "${TUNE:-1}" == "1" ]]; then
+  timeout 700 python tools/conv_tune.py --out "$OUT/conv_tune_variants.txt" > "$OUT/conv_tune.log" 2>&1
+  echo "conv_tune rc=$?"; head -12 "$OUT/conv_tune_variants.txt"
+fi
