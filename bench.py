@@ -30,6 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 TRAIN_GFLOP_PER_IMG = {"s": 101.634, "m": 282.556, "l": 386.959}  # 3 x forward conv FLOPs @640^2
 PEAK_FP32_MFMA_TFLOPS = 157.3
+HBM_ACHIEVABLE_TBS = 6.3  # MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable
 
 
 def synthetic_batch(batch, size, seed, device):
@@ -272,6 +273,9 @@ def main():
     ig_bytes = K.prof_bytes(0)
     ig_ms, ig_fl, ig_n = K.prof_summary(0)
     wg_ms, wg_fl, wg_n = K.prof_summary(1)
+    # per-launch roofline time: max(FLOPs / MFMA peak, algorithmic bytes / achievable HBM rate) summed over the same launches
+    ig_bound_ms = K.prof_bound_ms(0, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
+    wg_bound_ms = K.prof_bound_ms(1, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
     K.prof_enable(False)
     # The per-launch figures above are taken while the weight-gradient kernels run concurrently on the side HIP stream (they share the
     # CUs, which is what makes the step faster but stretches every launch).  For the kernel's own efficiency: 3 extra, untimed steps
@@ -284,6 +288,7 @@ def main():
     fence()
     ex_ms, ex_fl, ex_n = K.prof_summary(0)
     exw_ms, exw_fl, exw_n = K.prof_summary(1)
+    ex_bound_ms = K.prof_bound_ms(0, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
     K.prof_enable(False)
     net.side_stream = side
     # host side of one step: enqueue time of a step with the device idle at the start (no sync inside)
@@ -322,6 +327,11 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(ig_bytes / max(ig_n, 1)), "launches_per_step": ig_n // max(args.steps, 1), "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
                          "gflop_per_launch": round(ig_fl / max(ig_n, 1) / 1e9, 3), "kernel_ms_per_step": round(ig_ms / args.steps, 3),
+                         # the launch mix against the bound that applies to EACH launch's shape (shallow 1x1 layers are nearer the HBM bound than the MFMA one)
+                         "per_launch_bound": {"bound_ms_per_step": round(ig_bound_ms / args.steps, 3), "frac": round(ig_bound_ms / ig_ms, 4) if ig_ms > 0 else None,
+                                              "exclusive_frac": round(ex_bound_ms / ex_ms, 4) if ex_ms > 0 else None,
+                                              "wgrad_frac": round(wg_bound_ms / wg_ms, 4) if wg_ms > 0 else None,
+                                              "note": f"sum over launches of max(FLOPs / {PEAK_FP32_MFMA_TFLOPS} TFLOP/s, algorithmic bytes / {HBM_ACHIEVABLE_TBS} TB/s) / measured kernel time"},
                          "exclusive": {"achieved": round(ex_fl / (ex_ms * 1e-3) / 1e12, 2) if ex_ms > 0 else None,
                                        "frac": round(ex_fl / (ex_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ex_ms > 0 else None,
                                        "wgrad_achieved": round(exw_fl / (exw_ms * 1e-3) / 1e12, 2) if exw_ms > 0 else None,

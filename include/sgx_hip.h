@@ -47,6 +47,9 @@ int32_t sgx_prof_enable(int32_t on);
 int32_t sgx_prof_summary(int32_t cls, double* ms, double* flops, int64_t* launches);
 /* algorithmic HBM bytes of the same launches: every input element, weight and output element moved once (fp32)           */
 int32_t sgx_prof_bytes(int32_t cls, double* bytes);
+/* roofline time of the same launches: sum over launches of max(FLOPs / peak_flops, bytes / hbm_bytes_per_s), in ms - the time a
+ * launch mix would take if every launch ran at whichever of the two bounds (matrix pipe, HBM) is the tighter one for ITS shape      */
+int32_t sgx_prof_bound_ms(int32_t cls, double peak_flops, double hbm_bytes_per_s, double* ms);
 
 /* Measurement aid (tools/conv_tune.py): force the conv tile shapes (0 = built-in heuristic).  Not thread-safe; never set by the product. */
 int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk, int32_t wgrad_bj, int32_t wgrad_split_target);

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "sgx_conv_set_math": (_i32, [_i32]),
     "sgx_conv_get_math": (_i32, []),
     "sgx_prof_bytes": (_i32, [_i32, POINTER(ctypes.c_double)]),
+    "sgx_prof_bound_ms": (_i32, [_i32, ctypes.c_double, ctypes.c_double, POINTER(ctypes.c_double)]),
     "sgx_conv2d_fwd": (_i32, [_CD, _P, _P, _P, _P, _P, _i32, _P, _P]),
     "sgx_conv2d_fwd_stat_blocks": (_i32, [_CD]),
     "sgx_conv2d_bwd_data_workspace": (_i64, [_CD]),

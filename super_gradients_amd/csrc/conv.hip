@@ -106,8 +106,21 @@ extern "C" int32_t sgx_prof_bytes(int32_t cls, double* bytes) {
     if (bytes) *bytes = b;
     return SGX_OK;
 }
+extern "C" int32_t sgx_prof_bound_ms(int32_t cls, double peak_flops, double hbm_bytes_per_s, double* ms) {
+    SGX_CHECK_ARG(peak_flops > 0 && hbm_bytes_per_s > 0 && ms, "prof_bound_ms: bad args");
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    double t = 0.0;
+    for (auto& r : g_prof_recs)
+        if (r.cls == cls) t += fmax(r.flops / peak_flops, r.bytes / hbm_bytes_per_s);
+    *ms = t * 1e3;
+    return SGX_OK;
+}
 #define SGX_PROF(cls, flops, bytes, stream) ProfScope prof_scope__((cls), (flops), (bytes), (stream))
 #else
+extern "C" int32_t sgx_prof_bound_ms(int32_t, double, double, double* ms) {
+    if (ms) *ms = 0;
+    return SGX_OK;
+}
 extern "C" int32_t sgx_prof_bytes(int32_t, double* bytes) {
     if (bytes) *bytes = 0;
     return SGX_OK;

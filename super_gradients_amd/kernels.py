@@ -689,3 +689,10 @@ def prof_bytes(cls: int) -> float:
     b = ctypes.c_double()
     check(lib().sgx_prof_bytes(cls, ctypes.byref(b)), "sgx_prof_bytes")
     return b.value
+
+
+def prof_bound_ms(cls: int, peak_flops: float, hbm_bytes_per_s: float) -> float:
+    """Roofline time (ms) of the launches prof_summary(cls) covers: sum of max(FLOPs / peak, algorithmic bytes / HBM rate) per launch."""
+    t = ctypes.c_double()
+    check(lib().sgx_prof_bound_ms(cls, float(peak_flops), float(hbm_bytes_per_s), ctypes.byref(t)), "sgx_prof_bound_ms")
+    return t.value
