@@ -207,8 +207,17 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
     }
     if (tid == 0) s_kept = 0;
     __syncthreads();
+    // An IoU never exceeds 1, so with a threshold >= 2 nothing can be suppressed and the scan degenerates to "the first max_predictions
+    // of the sorted candidates": the pre-NMS top-k of the decoding modules (kernels.decode_topk) takes this exit instead of n barrier pairs.
+    const bool no_suppression = d.iou_threshold >= 2.0f;
+    if (no_suppression) {
+        const int kn = n < d.max_predictions ? n : d.max_predictions;
+        for (int t = tid; t < kn; t += NMS_THREADS) keep_list[t] = t;
+        if (tid == 0) s_kept = kn;
+        __syncthreads();
+    }
     // ---- greedy scan: one barrier pair per kept box; box i is broadcast through LDS (offset form) ----
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < (no_suppression ? 0 : n); ++i) {
         if (sup[i]) continue;  // uniform: flags only change before a barrier
         if (tid == 0) {
             float nb[4];

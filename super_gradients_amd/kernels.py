@@ -604,6 +604,22 @@ def nms(boxes, scores, score_threshold, iou_threshold, nms_top_k, max_prediction
     return out, cnt, idx, ncand
 
 
+def decode_topk(boxes, scores, k: int):
+    """Pre-NMS top-k of the decoding modules (reference: yolo_nas_variants.py:53-72, pp_yolo_e.py:57-84): per image the k anchors with the
+    largest class confidence max_c scores[b, l, c], sorted by confidence descending (equal confidences: lower anchor index first - torch.topk
+    leaves that order unspecified), with their boxes and full score rows.  One launch of the post-prediction kernel in single-label mode
+    with no threshold and no suppression (its threshold -> exact radix select -> LDS sort stages), then a row gather.
+    -> (boxes [B, k, 4], scores [B, k, C], anchor index [B, k] int64).  Scores must be >= 0 (sigmoid outputs)."""
+    B, L, C = scores.shape
+    if not 0 < k <= L:
+        raise ValueError(f"decode_topk: k={k} must be in [1, {L}] (torch.topk raises likewise)")
+    out, cnt, idx, _ = nms(boxes, scores, 0.0, 2.0, k, k, multi_label=False, class_mode=0)
+    if int(cnt.min()) != k:
+        raise ValueError("decode_topk: negative or NaN class scores (the decoding modules expect sigmoid outputs)")
+    idx = idx.long()
+    return out[:, :, :4].contiguous(), torch.gather(scores, 1, idx[:, :, None].expand(B, k, C)), idx
+
+
 def _index_targets(t, B):
     """flat [T,6] targets -> (contiguous float tensor or None, gt_count[B], gt_index[B][nmax], nmax) on t's device."""
     T = int(t.shape[0])

@@ -20,6 +20,27 @@ from .post_prediction_callback import PPYoloEPostPredictionCallback
 from .pp_yolo_head import PPYOLOEHead
 
 
+class PPYoloEDecodingModule(torch.nn.Module):
+    """Pre-NMS decoding of the export / inference path (reference: pp_yolo_e.py:31-97): per image the `num_pre_nms_predictions` anchors
+    with the highest class confidence, sorted by confidence, with their boxes and score rows (kernels.decode_topk)."""
+
+    def __init__(self, num_pre_nms_predictions: int = 1000):
+        super().__init__()
+        self.num_pre_nms_predictions = num_pre_nms_predictions
+
+    def get_num_pre_nms_predictions(self) -> int:
+        return self.num_pre_nms_predictions
+
+    def infer_total_number_of_predictions(self, predictions) -> int:
+        pred_bboxes, _ = predictions[0]
+        return pred_bboxes.size(1)
+
+    def forward(self, inputs):
+        pred_bboxes, pred_scores = inputs[0]
+        boxes, scores, _ = K.decode_topk(pred_bboxes, pred_scores, self.num_pre_nms_predictions)
+        return boxes, scores
+
+
 class PPYoloE(SgxNetwork):
     def __init__(self, arch_params):
         super().__init__()
@@ -37,6 +58,9 @@ class PPYoloE(SgxNetwork):
                                      class_agnostic_nms: bool) -> PPYoloEPostPredictionCallback:
         return PPYoloEPostPredictionCallback(score_threshold=conf, nms_threshold=iou, nms_top_k=nms_top_k, max_predictions=max_predictions,
                                              multi_label_per_box=multi_label_per_box, class_agnostic_nms=class_agnostic_nms)
+
+    def get_decoding_module(self, num_pre_nms_predictions: int, **kwargs) -> PPYoloEDecodingModule:
+        return PPYoloEDecodingModule(num_pre_nms_predictions=num_pre_nms_predictions)
 
     def get_input_shape_steps(self) -> Tuple[int, int]:
         return 32, 32

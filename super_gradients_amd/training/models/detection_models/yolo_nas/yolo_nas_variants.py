@@ -1,11 +1,38 @@
 """YoloNAS / YoloNAS_S / _M / _L (reference: yolo_nas/yolo_nas_variants.py:75-212) on the HIP kernels."""
 import copy
-from typing import Tuple
+from typing import Any, Tuple
+
+import torch
+from torch import nn
+
+from ..... import kernels as K
 
 from .....common.registry import register_model
 from ....utils.utils import HpmStruct, get_param
 from ...arch_params_factory import get_arch_params
 from ..customizable_detector import CustomizableDetector
+
+
+class YoloNASDecodingModule(nn.Module):
+    """Pre-NMS decoding of the export / inference path (reference: yolo_nas_variants.py:25-72): keeps, per image, the
+    `num_pre_nms_predictions` anchors with the highest class confidence, sorted by confidence, with their boxes and score rows.
+    One launch of the post-prediction kernel (kernels.decode_topk) instead of max + topk + two flat gathers."""
+
+    def __init__(self, num_pre_nms_predictions: int = 1000):
+        super().__init__()
+        self.num_pre_nms_predictions = num_pre_nms_predictions
+
+    def infer_total_number_of_predictions(self, predictions: Any) -> int:
+        pred_bboxes, _ = predictions[0]
+        return pred_bboxes.size(1)
+
+    def get_num_pre_nms_predictions(self) -> int:
+        return self.num_pre_nms_predictions
+
+    def forward(self, inputs: Tuple[Tuple[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, ...]]):
+        pred_bboxes, pred_scores = inputs[0]
+        boxes, scores, _ = K.decode_topk(pred_bboxes, pred_scores, self.num_pre_nms_predictions)
+        return boxes, scores
 
 
 class YoloNAS(CustomizableDetector):
@@ -18,6 +45,9 @@ class YoloNAS(CustomizableDetector):
 
         return PPYoloEPostPredictionCallback(score_threshold=conf, nms_threshold=iou, nms_top_k=nms_top_k, max_predictions=max_predictions,
                                              multi_label_per_box=multi_label_per_box, class_agnostic_nms=class_agnostic_nms)
+
+    def get_decoding_module(self, num_pre_nms_predictions: int, **kwargs) -> YoloNASDecodingModule:
+        return YoloNASDecodingModule(num_pre_nms_predictions)
 
     def get_input_shape_steps(self) -> Tuple[int, int]:
         return 32, 32
