@@ -24,6 +24,8 @@ import os
 import sys
 import time
 
+# the GPU box's driver only supports dmabuf IPC: RCCL / cross-process tensor sharing fail without this (must be set before HIP initialises)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -214,6 +216,7 @@ def main():
     from super_gradients_amd.training import models
     from super_gradients_amd.training.losses import PPYoloELoss
     from super_gradients_amd.training.utils.distributed_training_utils import GradientAllReducer, setup_device_from_env
+    from super_gradients_amd.training.utils.distributed_training_utils import barrier as dist_barrier
     from super_gradients_amd.training.utils.ema import ModelEMA
     from super_gradients_amd.training.utils.optimizers import ArenaAdamW
 
@@ -257,8 +260,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        dist_barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -349,7 +351,7 @@ def main():
             rec["nms"] = nms_leg(device)
         print(json.dumps(rec), flush=True)
     if world > 1:
-        dist.barrier()
+        dist_barrier()
         dist.destroy_process_group()
 
 

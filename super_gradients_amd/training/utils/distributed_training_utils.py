@@ -48,6 +48,17 @@ def setup_device_from_env(backend: str = None) -> Tuple[int, int, torch.device]:
     return rank, world, device
 
 
+def barrier():
+    """dist.barrier() that names this process's GPU for the RCCL backend (without device_ids torch guesses the device from the rank and
+    warns that a wrong guess can hang); a no-op without a process group."""
+    if not is_distributed():
+        return
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier()
+
+
 def setup_device(multi_gpu=None, num_gpus: int = None, device: str = "cuda"):
     """Reference: training/utils/distributed_training_utils.py:229-286.  On the MI355X path the process model is fixed: one
     process per GPU, launched by `python -m torch.distributed.run` (env:// rendezvous); this call joins the process group

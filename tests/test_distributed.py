@@ -27,6 +27,7 @@ def _worker(rank, world, port, outdir):
 
     from super_gradients_amd import kernels as K
     from super_gradients_amd.training.losses import PPYoloELoss
+    from super_gradients_amd.training.utils import distributed_training_utils as DU
     from super_gradients_amd.training.utils.distributed_training_utils import GradientAllReducer, setup_device_from_env
     from super_gradients_amd.training.utils.optimizers import ArenaSGD
     from test_trainer import _tiny_models
@@ -108,7 +109,7 @@ def _worker(rank, world, port, outdir):
         out["slot_layout"] = [(s.name, s.start, s.numel, tuple(s.param.shape)) for s in snet.slots]
         out["buffer_state"] = {k: v.detach().clone() for k, v in snet.state_dict().items() if "running" in k}
     torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
-    dist.barrier()
+    DU.barrier()  # the helper bench.py fences with (names the GPU for RCCL, plain barrier for gloo)
     dist.destroy_process_group()
 
 
