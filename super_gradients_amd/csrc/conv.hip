@@ -259,8 +259,7 @@ __device__ __forceinline__ sgx_f32x16 sgx_mfma_bf16(const uint4& a, const uint4&
 // 4 workgroups per CU), one barrier per slab - half the barriers per FLOP at lower occupancy.
 template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
-    static_assert((KD == 16 && NBUF == 2) || (KD == 32 && MATH == 0 && !FLAT && (NBUF == 1 || NBUF == 2)),
-                  "32-deep slabs: fp32 arithmetic, channel-chunked K axis only");
+    static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && (NBUF == 1 || NBUF == 2)), "32-deep slabs: channel-chunked K axis only");
     constexpr int NTH = WM * WN * 64;   // threads per workgroup
     constexpr int CPR = KD / 4;         // threads per slab row (16 B each)
     constexpr int RPP = NTH / CPR;      // slab rows staged per pass
@@ -269,7 +268,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     constexpr int AJ = (BM + RPP - 1) / RPP, BJ = (BN + RPP - 1) / RPP;
     static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "bad tile");
     static_assert(NTH >= BM && NTH >= BN, "epilogue helpers need one thread per tile row/col");
-    constexpr int ROWW = MATH == 1 ? 3 * IG_LDP : LD;                          // dwords of LDS per slab row (all planes)
+    constexpr int LDPW = KD / 2;        // bf16x3: dwords per slab row and plane (KD bf16), unpadded
+    constexpr int ROWW = MATH == 1 ? 3 * LDPW : LD;                            // dwords of LDS per slab row (all planes)
+    // bf16x3 plane swizzle: 16-byte chunks of a row are permuted by row bits so that the fragment reads of 16 consecutive rows hit 16
+    // distinct 4-bank groups - 32-byte rows: halves swapped on rows with bit 3 set; 64-byte rows: chunk ^= row bits 2-3
+    auto swz = [](int row, int dw) { return KD == 16 ? IG_SWZ(row, dw) : (dw ^ (((row >> 2) & 3) << 2)); };
     constexpr int SLABS = NBUF * (BM + BN) * ROWW, STAGE = WM * WN * 32 * 32;   // operand slabs; epilogue staging patches (reuse the slabs)
     __shared__ __attribute__((aligned(16))) float smem[SLABS > STAGE ? SLABS : STAGE];
     float* const As = smem;
@@ -400,10 +403,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                 if (BM % RPP == 0 || row < BM) {
                     uint2 h, m, l;
                     sgx_split3(ra[j], h, m, l);
-                    unsigned* d = reinterpret_cast<unsigned*>(As) + (buf * 3 * BM + row) * IG_LDP + IG_SWZ(row, chunk4 >> 1);
+                    unsigned* d = reinterpret_cast<unsigned*>(As) + (buf * 3 * BM + row) * LDPW + swz(row, chunk4 >> 1);
                     *reinterpret_cast<uint2*>(d) = h;
-                    *reinterpret_cast<uint2*>(d + BM * IG_LDP) = m;
-                    *reinterpret_cast<uint2*>(d + 2 * BM * IG_LDP) = l;
+                    *reinterpret_cast<uint2*>(d + BM * LDPW) = m;
+                    *reinterpret_cast<uint2*>(d + 2 * BM * LDPW) = l;
                 }
             }
 #pragma unroll
@@ -412,10 +415,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                 if (BN % RPP == 0 || row < BN) {
                     uint2 h, m, l;
                     sgx_split3(rb[j], h, m, l);
-                    unsigned* d = reinterpret_cast<unsigned*>(Bs) + (buf * 3 * BN + row) * IG_LDP + IG_SWZ(row, chunk4 >> 1);
+                    unsigned* d = reinterpret_cast<unsigned*>(Bs) + (buf * 3 * BN + row) * LDPW + swz(row, chunk4 >> 1);
                     *reinterpret_cast<uint2*>(d) = h;
-                    *reinterpret_cast<uint2*>(d + BN * IG_LDP) = m;
-                    *reinterpret_cast<uint2*>(d + 2 * BN * IG_LDP) = l;
+                    *reinterpret_cast<uint2*>(d + BN * LDPW) = m;
+                    *reinterpret_cast<uint2*>(d + 2 * BN * LDPW) = l;
                 }
             }
             return;
@@ -462,21 +465,21 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 
     const int frow = lane & 31, fk = (lane >> 5) * 8;
     // bf16x3 fragment reads + the six cross-product MFMAs of one slab (smallest terms first)
-    auto compute_bf3 = [&](int buf) {
+    auto compute_bf3 = [&](int buf, int half) {  // half: which 16-deep step of the slab (0 for 16-deep slabs)
         uint4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const unsigned* s = reinterpret_cast<const unsigned*>(As) + (buf * 3 * BM + wm * TM * 32 + i * 32 + frow) * IG_LDP + IG_SWZ(frow, (lane >> 5) * 4);
+            const unsigned* s = reinterpret_cast<const unsigned*>(As) + (buf * 3 * BM + wm * TM * 32 + i * 32 + frow) * LDPW + swz(frow, half * 8 + (lane >> 5) * 4);
             ah[i] = *reinterpret_cast<const uint4*>(s);
-            am[i] = *reinterpret_cast<const uint4*>(s + BM * IG_LDP);
-            al[i] = *reinterpret_cast<const uint4*>(s + 2 * BM * IG_LDP);
+            am[i] = *reinterpret_cast<const uint4*>(s + BM * LDPW);
+            al[i] = *reinterpret_cast<const uint4*>(s + 2 * BM * LDPW);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const unsigned* s = reinterpret_cast<const unsigned*>(Bs) + (buf * 3 * BN + wn * TN * 32 + j * 32 + frow) * IG_LDP + IG_SWZ(frow, (lane >> 5) * 4);
+            const unsigned* s = reinterpret_cast<const unsigned*>(Bs) + (buf * 3 * BN + wn * TN * 32 + j * 32 + frow) * LDPW + swz(frow, half * 8 + (lane >> 5) * 4);
             bh[j] = *reinterpret_cast<const uint4*>(s);
-            bm[j] = *reinterpret_cast<const uint4*>(s + BN * IG_LDP);
-            bl[j] = *reinterpret_cast<const uint4*>(s + 2 * BN * IG_LDP);
+            bm[j] = *reinterpret_cast<const uint4*>(s + BN * LDPW);
+            bl[j] = *reinterpret_cast<const uint4*>(s + 2 * BN * LDPW);
         }
         // smallest terms first; the six products of one (i, j) are interleaved across the tile's accumulators
 #pragma unroll
@@ -533,8 +536,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         if (KD == 32 && NBUF == 1) {
             // one LDS buffer: the next slab travels in registers under 16 x TM x TN MFMAs and is written after every wave has read this one
             if (kt + 1 < nkt) load_tile();
-            compute_f32(0, 0);
-            compute_f32(0, 16);
+            if (MATH == 1) {
+                compute_bf3(0, 0);
+                compute_bf3(0, 1);
+            } else {
+                compute_f32(0, 0);
+                compute_f32(0, 16);
+            }
             __syncthreads();
             if (kt + 1 < nkt) {
                 store_tile(0);
@@ -545,8 +553,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         const int buf = kt & 1;
         if (KD == 32) {
             if (kt + 1 < nkt) load_tile();
-            compute_f32(buf, 0);
-            compute_f32(buf, 16);
+            if (MATH == 1) {
+                compute_bf3(buf, 0);
+                compute_bf3(buf, 1);
+            } else {
+                compute_f32(buf, 0);
+                compute_f32(buf, 16);
+            }
             if (kt + 1 < nkt) store_tile(buf ^ 1);
             __syncthreads();
             continue;
@@ -556,7 +569,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         if (MATH == 1) {
             // (a second register stage - slabs fetched two iterations ahead, counted vmcnt - was measured: no gain, r1z/r1z2;
             // this path is bound by LDS traffic and the per-slab barrier, not by global-load latency)
-            compute_bf3(buf);
+            compute_bf3(buf, 0);
             if (kt + 1 < nkt) store_tile(buf ^ 1);
             __syncthreads();
             continue;
@@ -728,11 +741,22 @@ static TileCfg pick_tile_heuristic(long M, int N) {
 }
 
 // 32-deep slabs are an experiment switch until their first measurement on the GPU: sgx_debug_set_variant(5 | 6) / SGX_CONV_VARIANT
-// (5: one LDS buffer, 6: two).  Eligible: fp32 arithmetic, channel-chunked K axis, C a multiple of 32 (a ragged last chunk would
-// multiply zeros for up to half a slab).
-static bool igemm_deep_slabs(const IgemmParams& p) {
-    return (g_ovr_var == 5 || g_ovr_var == 6) && conv_math_for(p.Th * p.Tw, p.C) == 0 && p.C % 32 == 0;
-}
+// (5: one LDS buffer, 6: two), for both arithmetic modes.  Eligible: channel-chunked K axis, C a multiple of 32 (a ragged last chunk
+// would multiply zeros for up to half a slab).
+static bool igemm_deep_slabs(const IgemmParams& p) { return (g_ovr_var == 5 || g_ovr_var == 6) && p.C % 32 == 0; }
+// dispatch over the eight non-flat tile shapes for one (MATH, KD, NBUF)
+#define SGX_IGEMM_TILES(MATH_, KD_, NBUF_)                                                                  \
+    do {                                                                                                    \
+        if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, MATH_, KD_, NBUF_>(p, stream);      \
+        else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, MATH_, KD_, NBUF_>(p, stream);   \
+        else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, MATH_, KD_, NBUF_>(p, stream);   \
+        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, MATH_, KD_, NBUF_>(p, stream);   \
+        else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2, false, MATH_, KD_, NBUF_>(p, stream);   \
+        else if (bm == 64 && bn == 96) launch_igemm<64, 96, 2, 1, false, MATH_, KD_, NBUF_>(p, stream);     \
+        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, MATH_, KD_, NBUF_>(p, stream);     \
+        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, MATH_, KD_, NBUF_>(p, stream);     \
+        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no tile %dx%d (math %d, %d-deep slabs)", bm, bn, MATH_, KD_); \
+    } while (0)
 template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2>
 static void launch_igemm(IgemmParams& p, void* stream) {
     p.mt = sgx_cdiv(p.M, BM);
@@ -767,7 +791,10 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         else if (flat && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, true, 1>(p, stream);
         else if (flat && bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true, 1>(p, stream);
         else if (flat) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (bf16x3): no flat tile %dx%d", bm, bn);
-        else if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, 1>(p, stream);  // 52 KB of LDS with the unpadded planes
+        else if (igemm_deep_slabs(p)) {
+            if (g_ovr_var == 5) SGX_IGEMM_TILES(1, 32, 1);
+            else SGX_IGEMM_TILES(1, 32, 2);
+        } else if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, 1>(p, stream);  // 52 KB of LDS with the unpadded planes
         else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, 1>(p, stream);
         else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, 1>(p, stream);
         else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 1>(p, stream);
@@ -784,15 +811,8 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true>(p, stream);
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no flat tile %dx%d", bm, bn);
     } else if (igemm_deep_slabs(p)) {  // 32-deep slabs (see igemm_kernel): whole-line loads
-#define SGX_DEEP(BM_, BN_, WM_, WN_)                                                        \
-    if (bm == BM_ && bn == BN_) {                                                           \
-        if (g_ovr_var == 5) launch_igemm<BM_, BN_, WM_, WN_, false, 0, 32, 1>(p, stream);   \
-        else launch_igemm<BM_, BN_, WM_, WN_, false, 0, 32, 2>(p, stream);                  \
-    } else
-        SGX_DEEP(128, 128, 2, 2) SGX_DEEP(128, 96, 4, 1) SGX_DEEP(128, 64, 2, 2) SGX_DEEP(128, 32, 4, 1) SGX_DEEP(64, 128, 2, 2)
-        SGX_DEEP(64, 96, 2, 1) SGX_DEEP(64, 64, 2, 2) SGX_DEEP(64, 32, 2, 1)
-        SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (32-deep slabs): no tile %dx%d", bm, bn);
-#undef SGX_DEEP
+        if (g_ovr_var == 5) SGX_IGEMM_TILES(0, 32, 1);
+        else SGX_IGEMM_TILES(0, 32, 2);
     } else if (g_ovr_var == 1 && bm == 64 && bn == 64) launch_igemm<64, 64, 1, 2, false>(p, stream);   // 2 waves x (64x32)
     else if (g_ovr_var == 2 && bm == 128 && bn == 64) launch_igemm<128, 64, 4, 2, false>(p, stream);   // 8 waves x (32x32)
     else if (g_ovr_var == 3 && bm == 128 && bn == 128) launch_igemm<128, 128, 4, 2, false>(p, stream); // 8 waves x (32x64)

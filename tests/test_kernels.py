@@ -747,7 +747,8 @@ def test_nms_degenerate_boxes(backend):
 
 
 @pytest.mark.parametrize("case", [(1, 9, 8, 64, 72, 3, 1, 1), (2, 7, 6, 32, 64, 3, 2, 1), (1, 5, 9, 96, 160, 1, 1, 0)])
-def test_conv_deep_slabs(backend, case):
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+def test_conv_deep_slabs(backend, case, math):
     """32-deep slabs (igemm_kernel<..., KD = 32>, experiment switches sgx_debug_set_variant(5 | 6): one / two LDS buffers): every tile shape on problems with ragged
     edges in both tile dimensions, 3x3 / stride-2 (parity-class data gradient) / 1x1.  The reduction runs in the same order as with
     16-deep slabs, so the results must be BIT-identical to the default kernel's, not just close."""
@@ -761,6 +762,7 @@ def test_conv_deep_slabs(backend, case):
     dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
     y.backward(dy)
     xd, wd, dyd = to_nhwc(x.detach(), backend), K.to_ohwi(wt.to(backend)), to_nhwc(dy, backend)
+    K.set_conv_math(math)
     try:
         tiles = [(bm, bn) for bm in (64, 128) for bn in (32, 64, 96, 128)] if r == 3 and s == 1 else [(64, 64), (128, 96)]
         for bm, bn in tiles:
@@ -779,6 +781,7 @@ def test_conv_deep_slabs(backend, case):
     finally:
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
         lib().sgx_debug_set_variant(0)
+        K.set_conv_math("fp32")
 
 
 @pytest.mark.parametrize("math", ["fp32", "bf16x3"])
