@@ -11,11 +11,18 @@ SGX_GPU_UNVALIDATED=1 timeout 400 python -m pytest tests/test_kernels.py tests/t
   -k "any_class_count or assignment_adversarial or distance_tie_policy or nms_degenerate_boxes or conv_every_tile_shape or conv_deep_slabs or stem_with_custom_in_channels or decod" \
   > "$OUT/pytest_first_gpu_run.log" 2>&1
 echo "pytest rc=$?" >> "$OUT/pytest_first_gpu_run.log"; tail -4 "$OUT/pytest_first_gpu_run.log"
-for v in 0 5 6; do
-  SGX_CONV_VARIANT=$v timeout 200 python bench.py --no-nms --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/bench_variant$v.json" 2> "$OUT/bench_variant$v.err"
-  echo "variant $v rc=$?: $(python -c "import json,sys; r=json.loads(open('$OUT/bench_variant$v.json').read().strip().splitlines()[-1]); print(r['value'],'img/s', r['ms_per_step'],'ms; igemm', r['roofline']['achieved'], 'TF concurrent,', r['roofline']['exclusive']['achieved'], 'TF exclusive')" 2>&1 | tail -1)"
+for m in fp32 auto; do
+  for v in 0 5 6; do
+    f="$OUT/bench_${m}_variant$v"
+    SGX_CONV_MATH=$m SGX_CONV_VARIANT=$v timeout 200 python bench.py --no-nms --no-cpu-baseline ${BENCH_ARGS:-} > "$f.json" 2> "$f.err"
+    echo "math $m variant $v rc=$?: $(python -c "import json,sys; r=json.loads(open('$f.json').read().strip().splitlines()[-1]); print(r['value'],'img/s', r['ms_per_step'],'ms; igemm', r['roofline']['achieved'], 'TF concurrent,', r['roofline']['exclusive']['achieved'], 'TF exclusive')" 2>&1 | tail -1)"
+  done
 done
 if [[ "${TUNE:-1}" == "1" ]]; then
   timeout 700 python tools/conv_tune.py --out "$OUT/conv_tune_variants.txt" > "$OUT/conv_tune.log" 2>&1
   echo "conv_tune rc=$?"; head -12 "$OUT/conv_tune_variants.txt"
+fi
+if [[ "${TUNE_BF3:-0}" == "1" ]]; then
+  SGX_CONV_MATH=bf16x3 timeout 700 python tools/conv_tune.py --out "$OUT/conv_tune_variants_bf16x3.txt" > "$OUT/conv_tune_bf16x3.log" 2>&1
+  echo "conv_tune bf16x3 rc=$?"; head -12 "$OUT/conv_tune_variants_bf16x3.txt"
 fi
