@@ -32,6 +32,8 @@ if has stats; then
   cd "$REPO"
   python tools/prof_summary.py stats "$OUT/stats" > "$OUT/kernel_stats_summary.txt" 2>&1
   head -40 "$OUT/kernel_stats_summary.txt"
+  python tools/prof_summary.py timeline "$OUT/stats" > "$OUT/kernel_timeline_summary.txt" 2>&1   # idle / overlap / per-queue gaps
+  head -12 "$OUT/kernel_timeline_summary.txt"
   # the raw per-dispatch trace is large; keep the stats csv only
   find "$OUT/stats" -name "*kernel_trace.csv" -size +8M -delete
 fi

@@ -3,6 +3,9 @@
     python tools/prof_summary.py stats <dir>    per-kernel calls / total / average / share (from *kernel_stats.csv, or
                                                 recomputed from *kernel_trace.csv) + register counts per kernel
     python tools/prof_summary.py pmc   <dir>    per-kernel sums of every collected counter (from *counter_collection.csv)
+    python tools/prof_summary.py timeline <dir> where the wall clock of the traced run goes (from *kernel_trace.csv): device idle time,
+                                                time with one / several kernels resident, per-queue busy time and gap histogram, the
+                                                largest idle gaps with their neighbours - answers "launch-gap bound or throughput bound?"
 """
 import collections
 import csv
@@ -76,5 +79,64 @@ def pmc(d):
     print(f"{'TOTAL':<92} {sum(len(s) for s in calls.values()):>7} {sum(dur.values()) / 1e6:>9.3f} " + " ".join(f"{tot[c]:>22.1f}" for c in names))
 
 
+def timeline(d, top=12):
+    ev = []
+    for f in find(d, "*kernel_trace.csv"):
+        for r in csv.DictReader(open(f, newline="")):
+            q = r.get("Queue_Id") or r.get("Stream_Id") or "?"
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), str(q), short(r["Kernel_Name"])))
+    if not ev:
+        print("# no *kernel_trace.csv under", d)
+        return
+    ev.sort()
+    t0, t1 = ev[0][0], max(e[1] for e in ev)
+    wall = t1 - t0
+    # sweep line over start/end points: time with 0 / 1 / >= 2 kernels resident
+    pts = sorted([(s, 1) for s, _, _, _ in ev] + [(e, -1) for _, e, _, _ in ev])
+    depth, last, by_depth = 0, t0, collections.Counter()
+    for t, dlt in pts:
+        by_depth[min(depth, 2)] += t - last
+        last, depth = t, depth + dlt
+    print(f"# source: kernel_trace csv(s) under {os.path.basename(d.rstrip('/'))}: {len(ev)} dispatches over {wall / 1e6:.3f} ms of wall clock")
+    print(f"device idle (no kernel resident) {by_depth[0] / 1e6:9.3f} ms  {100.0 * by_depth[0] / wall:5.1f} %")
+    print(f"exactly one kernel resident      {by_depth[1] / 1e6:9.3f} ms  {100.0 * by_depth[1] / wall:5.1f} %")
+    print(f"two or more kernels resident     {by_depth[2] / 1e6:9.3f} ms  {100.0 * by_depth[2] / wall:5.1f} %")
+    print(f"sum of kernel durations          {sum(e - s for s, e, _, _ in ev) / 1e6:9.3f} ms")
+    # per queue: busy time, gaps between consecutive dispatches of the queue
+    edges = [2e3, 5e3, 10e3, 50e3]
+    labels = ["<2us", "2-5us", "5-10us", "10-50us", ">50us"]
+    print(f"\n{'queue':<12} {'kernels':>8} {'busy_ms':>9} {'gap_ms':>9}  gaps: " + " ".join(f"{l:>8}" for l in labels))
+    byq = collections.defaultdict(list)
+    for e in ev:
+        byq[e[2]].append(e)
+    for q, es in sorted(byq.items(), key=lambda kv: -len(kv[1])):
+        busy = sum(e - s for s, e, _, _ in es)
+        hist, gap_total, prev_end = [0] * 5, 0, None
+        for s, e, _, _ in es:
+            if prev_end is not None and s > prev_end:
+                g = s - prev_end
+                gap_total += g
+                hist[sum(g >= x for x in edges)] += 1
+            prev_end = e if prev_end is None else max(prev_end, e)
+        print(f"{q:<12} {len(es):>8} {busy / 1e6:>9.3f} {gap_total / 1e6:>9.3f}        " + " ".join(f"{h:>8}" for h in hist))
+    # largest device-idle gaps with their neighbours
+    gaps, cur_end, cur_name = [], ev[0][1], ev[0][3]
+    for s, e, _, n in ev[1:]:
+        if s > cur_end:
+            gaps.append((s - cur_end, cur_name, n))
+        if e > cur_end:
+            cur_end, cur_name = e, n
+    print(f"\n{len(gaps)} device-idle gaps, {sum(g for g, _, _ in gaps) / 1e6:.3f} ms in total; the largest:")
+    for g, a, b in sorted(gaps, key=lambda t: -t[0])[:top]:
+        print(f"  {g / 1e3:9.1f} us  after {a[:60]:<60} before {b[:60]}")
+    # which kernels sit next to the idle time (sum of the gap that FOLLOWS each kernel class)
+    after = collections.Counter()
+    for g, a, _ in gaps:
+        after[a] += g
+    print("\nidle time by the kernel it follows:")
+    for n, g in after.most_common(top):
+        print(f"  {g / 1e6:9.3f} ms  {n[:90]}")
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "timeline": timeline}[sys.argv[1]](sys.argv[2])
