@@ -200,6 +200,11 @@ int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int64_t M, int3
 int32_t sgx_bn_bwd_apply(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale,
                          const float* shift, const float* coef, float* dx, int64_t dx_ld, float* g_out, int64_t g_ld,
                          int64_t M, int32_t C, int32_t act, void* stream);
+/* sgx_bn_bwd_apply fused with the sgx_bn_bwd_reduce (act = none) of the BatchNorm that consumes dx as its upstream gradient:
+ * next_partials [2][sgx_stats_blocks(M)][C] = what sgx_bn_bwd_reduce(dx, next_x, ..., next_mean) would write.  next_x must not alias dx. */
+int32_t sgx_bn_bwd_apply_reduce(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale, const float* shift,
+                                const float* coef, float* dx, int64_t dx_ld, int64_t M, int32_t C, int32_t act, const float* next_x,
+                                int64_t next_x_ld, const float* next_mean, float* next_partials, void* stream);
 /* z = a*x + y with a device-resident scalar a (yolo_stages.py:61-63) and its backward pieces:
  * sgx_dot_partial gives sum(x*dz) partials [nblk] for d a; finalize with sgx_sum_partials.          */
 int32_t sgx_dot_partial(const float* a, int64_t a_ld, const float* b, int64_t b_ld, int64_t M, int32_t C,

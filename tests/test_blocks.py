@@ -97,6 +97,31 @@ def test_qarepvgg_block(backend, stride, cout):
     _check(QARep(c, co, stride, residual=stride == 1), QARepVGGBlock(c, co, stride=stride, use_residual_connection=stride == 1), x, backend)
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+def test_qarepvgg_fused_bn_backward_reduce(backend, stride, monkeypatch):
+    """SGX_FUSE_BN_REDUCE (experiment switch): branch_3x3.bn's backward sums come out of post_bn's apply sweep (sgx_bn_bwd_apply_reduce)
+    instead of a sweep of their own.  Same row partition, same accumulation order: every gradient must be BIT-identical to the unfused
+    path, and the fused block still meets the parity bar against the oracle."""
+    from oracle.yolo_nas import QARep
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd.modules import QARepVGGBlock
+
+    first_gpu_run_pending(backend)
+    n, c, h, w = _shape(backend, (2, 64, 10, 10), (2, 8, 7, 5))
+    co = c * stride
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
+    res = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(K, "FUSE_BN_BWD_REDUCE", fuse)
+        torch.manual_seed(7)
+        ref, blk = QARep(c, co, stride, residual=stride == 1), QARepVGGBlock(c, co, stride=stride, use_residual_connection=stride == 1)
+        _check(ref, blk, x, backend)
+        res[fuse] = {k: v.grad.detach().cpu().clone() for k, v in blk.named_parameters() if v.grad is not None}
+    assert res[True].keys() == res[False].keys() and len(res[True]) >= 6
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), f"{k}: fused BN backward reduce changes the gradient"
+
+
 @pytest.mark.parametrize("concat", [False, True])
 def test_csp_layer(backend, concat):
     from oracle.yolo_nas import CSP, _qa
