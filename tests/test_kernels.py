@@ -746,7 +746,7 @@ def test_nms_degenerate_boxes(backend):
         assert torch.equal(out[0, :n].cpu(), ref[0]), f"multi={multi} mode={mode}: rows differ"
 
 
-@pytest.mark.parametrize("case", [(1, 9, 8, 64, 72, 3, 1, 1), (2, 7, 6, 32, 64, 3, 2, 1), (1, 5, 9, 96, 160, 1, 1, 0)])
+@pytest.mark.parametrize("case", [(1, 5, 4, 32, 40, 3, 1, 1), (1, 6, 6, 32, 32, 3, 2, 1), (1, 5, 9, 96, 40, 1, 1, 0)])
 @pytest.mark.parametrize("math", ["fp32", "bf16x3"])
 def test_conv_deep_slabs(backend, case, math):
     """32-deep slabs (igemm_kernel<..., KD = 32>, experiment switches sgx_debug_set_variant(5 | 6): one / two LDS buffers): every tile shape on problems with ragged
@@ -764,7 +764,8 @@ def test_conv_deep_slabs(backend, case, math):
     xd, wd, dyd = to_nhwc(x.detach(), backend), K.to_ohwi(wt.to(backend)), to_nhwc(dy, backend)
     K.set_conv_math(math)
     try:
-        tiles = [(bm, bn) for bm in (64, 128) for bn in (32, 64, 96, 128)] if r == 3 and s == 1 else [(64, 64), (128, 96)]
+        # (every instantiated tile compiles from the same template; tile plumbing itself is test_conv_every_tile_shape's job)
+        tiles = [(64, 64), (128, 32), (64, 96), (128, 128)] if r == 3 and s == 1 else [(64, 64)] if s == 2 else [(64, 32), (128, 96)]
         for bm, bn in tiles:
             lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
             res = {}
