@@ -66,8 +66,10 @@ class SeqConvBnRelu(nn.Module):  # reference `ConvBNReLU`: keys seq.conv.weight,
 
 
 class QARep(nn.Module):
-    def __init__(self, cin, cout, stride=1, residual=True):
+    def __init__(self, cin, cout, stride=1, residual=True, use_alpha=False):
         super().__init__()
+        # qarepvgg_block.py:130-136: learnable [1] multiplier of the 1x1 branch when use_alpha, else the float 1.0
+        self.alpha = nn.Parameter(torch.tensor([1.0]), requires_grad=True) if use_alpha else 1.0
         self.branch_3x3 = nn.Sequential()
         self.branch_3x3.add_module("conv", nn.Conv2d(cin, cout, 3, stride, 1, bias=False))
         self.branch_3x3.add_module("bn", nn.BatchNorm2d(cout))
@@ -77,7 +79,7 @@ class QARep(nn.Module):
         self.rbr_reparam = nn.Conv2d(cin, cout, 3, stride, 1, bias=True)  # unused placeholder (qarepvgg_block.py:166)
 
     def forward(self, x):
-        s = self.branch_3x3(x) + 1.0 * self.branch_1x1(x)
+        s = self.branch_3x3(x) + self.alpha * self.branch_1x1(x)
         if self.residual:
             s = s + x
         return F.relu(self.post_bn(s))

@@ -37,11 +37,10 @@ class QARepVGGBlock(SgxBlock):
             raise NotImplementedError("QARepVGGBlock on the HIP path: no SE block (YOLO-NAS uses none)")
         if not (build_residual_branches and use_1x1_bias and use_post_bn):
             raise NotImplementedError("QARepVGGBlock on the HIP path implements the training form (3 branches, 1x1 bias, post-BN)")
-        if use_alpha:
-            raise NotImplementedError("QARepVGGBlock(use_alpha=True) is not used by YOLO-NAS; alpha is the constant 1.0 here")
         self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
         self.act = act_name(activation_type)
-        self.alpha = 1.0
+        # reference :130-136: a learnable [1] multiplier of the 1x1 branch when use_alpha, else the float 1.0 (YOLO-NAS recipes: False)
+        self.alpha = nn.Parameter(torch.tensor([1.0]), requires_grad=True) if use_alpha else 1.0
         self.branch_3x3 = _Branch()
         self.branch_3x3.add_module("conv", ConvLayer(in_channels, out_channels, 3, stride, 1, bias=False))
         self.branch_3x3.add_module("bn", BatchNorm(out_channels))
@@ -57,9 +56,14 @@ class QARepVGGBlock(SgxBlock):
     def on_materialize(self):
         pass
 
+    def _alpha(self):
+        """-> (host float, device scalar or None) as the sweeps take it"""
+        return (1.0, self.alpha) if isinstance(self.alpha, torch.Tensor) else (float(self.alpha), None)
+
     def fwd(self, x, out=None):
         c3, bn3, c1, pbn = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1, self.post_bn
         res = x if self.use_residual_connection else None
+        a, a_dev = self._alpha()
         if self.training:
             if self.partially_fused or self.fully_fused:
                 raise RuntimeError("a fused QARepVGGBlock is inference-only on the HIP path (the reference's fused block trains a single conv; "
@@ -71,10 +75,11 @@ class QARepVGGBlock(SgxBlock):
             M = t3.shape[0] * t3.shape[1] * t3.shape[2]
             sc3, sh3, m3, i3 = bn3.scale_shift(parts, M, True)
             self._net.join_side()
-            s, parts_s = K.affine_act(t3, sc3, sh3, r1=t1, a1=self.alpha, r2=res, a2=1.0, out=t1, want_stats=True)  # s overwrites t1
+            # s overwrites t1 - unless alpha is learnable: its gradient is <ds, t1>, so the 1x1 branch output is kept
+            s, parts_s = K.affine_act(t3, sc3, sh3, r1=t1, a1=a, a1_dev=a_dev, r2=res, a2=1.0, out=t1 if a_dev is None else None, want_stats=True)
             scp, shp, mp, ip = pbn.scale_shift(parts_s, M, True)
             y = K.affine_act(s, scp, shp, act=self.act, out=out)
-            self._ctx = (x, t3, s, sc3, sh3, m3, i3, scp, shp, mp, ip)
+            self._ctx = (x, t3, s, sc3, sh3, m3, i3, scp, shp, mp, ip, t1 if a_dev is not None else None)
             return y
         if self.fully_fused:      # deployment form: ONE 3x3 convolution with fused bias + activation
             return K.conv2d_fwd(x, self._fused_w, bias=self._fused_b, out=out, act=self.act, stride=self.stride, pad=1)
@@ -85,7 +90,7 @@ class QARepVGGBlock(SgxBlock):
         t3 = c3.conv(x)
         sc3, sh3, _, _ = bn3.scale_shift(None, 0, False)
         t1 = c1.conv(x)
-        s = K.affine_act(t3, sc3, sh3, r1=t1, a1=self.alpha, r2=res, a2=1.0, out=t1)
+        s = K.affine_act(t3, sc3, sh3, r1=t1, a1=a, a1_dev=a_dev, r2=res, a2=1.0, out=t1)
         scp, shp, _, _ = pbn.scale_shift(None, 0, False)
         return K.affine_act(s, scp, shp, act=self.act, out=out if out is not None else s)
 
@@ -102,13 +107,14 @@ class QARepVGGBlock(SgxBlock):
         w3 = self.branch_3x3.conv.weight.detach()
         k3, b3 = self._fuse_bn_tensor(w3, 0.0, bn3.running_mean, bn3.running_var, bn3.weight.detach(), bn3.bias.detach(), bn3.eps)
         k1 = torch.nn.functional.pad(self.branch_1x1.weight.detach(), [1, 1, 1, 1])
-        k = k3 + self.alpha * k1
+        alpha = self.alpha.detach().to(k1.device) if isinstance(self.alpha, torch.Tensor) else self.alpha
+        k = k3 + alpha * k1
         if self.use_residual_connection:
             cin = self.in_channels
             ident = torch.zeros(cin, cin, 3, 3, device=k.device, dtype=k.dtype)
             ident[torch.arange(cin), torch.arange(cin), 1, 1] = 1.0
             k = k + ident
-        return k, b3 + self.alpha * self.branch_1x1.bias.detach()
+        return k, b3 + alpha * self.branch_1x1.bias.detach()
 
     def _install_fused(self, kernel, bias):
         self.rbr_reparam.weight.data = kernel.to(self.rbr_reparam.weight.device if not getattr(self, "_net", None) else kernel.device).contiguous()
@@ -154,12 +160,16 @@ class QARepVGGBlock(SgxBlock):
 
     def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
         c3, bn3, c1, pbn = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1, self.post_bn
-        (x, t3, s, sc3, sh3, m3, i3, scp, shp, mp, ip), self._ctx = self._ctx, None
+        (x, t3, s, sc3, sh3, m3, i3, scp, shp, mp, ip, t1), self._ctx = self._ctx, None
         if K.FUSE_BN_BWD_REDUCE:  # bn3's reduce sums come out of post_bn's apply sweep (one read of ds and t3 less)
             ds, parts3 = pbn.backward(dy, s, scp, shp, mp, ip, self.act, dx_out=s, next_reduce=(t3, m3))
         else:
             ds, parts3 = pbn.backward(dy, s, scp, shp, mp, ip, self.act, dx_out=s), None   # in place over s
-        c1.wgrad(x, ds)                                                         # alpha == 1.0
+        ds1 = ds                                                                # gradient of the 1x1 branch output: alpha * ds
+        if t1 is not None:                                                      # learnable alpha: d alpha = <ds, conv1x1(x) + b>
+            K.dot_sum(t1, ds, self.alpha.grad, accumulate=True)
+            ds1 = K.axpy(ds, a_dev=self.alpha, out=t1)                          # in place over t1
+        c1.wgrad(x, ds1)
         dt3 = bn3.backward(ds, t3, sc3, sh3, m3, i3, None, dx_out=t3, parts=parts3)   # in place over t3
         c3.wgrad(x, dt3)
         if not need_dx:
@@ -167,6 +177,6 @@ class QARepVGGBlock(SgxBlock):
         shape = tuple(x.shape)
         if self.use_residual_connection:
             dx = c3.dgrad(dt3, shape, out=dx_out, accumulate=accumulate, addend=ds)
-            return c1.dgrad(ds, shape, out=dx, accumulate=True, addend=addend)
+            return c1.dgrad(ds1, shape, out=dx, accumulate=True, addend=addend)
         dx = c3.dgrad(dt3, shape, out=dx_out, accumulate=accumulate, addend=addend)
-        return c1.dgrad(ds, shape, out=dx, accumulate=True)
+        return c1.dgrad(ds1, shape, out=dx, accumulate=True)

@@ -98,6 +98,58 @@ def test_qarepvgg_block(backend, stride, cout):
 
 
 @pytest.mark.parametrize("stride", [1, 2])
+def test_qarepvgg_block_learnable_alpha(backend, stride):
+    """QARepVGGBlock(use_alpha=True) (qarepvgg_block.py:130-136, 198-203): learnable multiplier of the 1x1 branch - forward, every
+    gradient incl. d alpha = <ds, conv1x1(x) + b>, running statistics; then the fused deployment form with that alpha folded in."""
+    from oracle.yolo_nas import QARep
+    from super_gradients_amd.modules import QARepVGGBlock
+
+    first_gpu_run_pending(backend)
+    n, c, h, w = _shape(backend, (2, 64, 10, 10), (2, 8, 6, 5))
+    co = c * stride
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
+    ref, blk = QARep(c, co, stride, residual=stride == 1, use_alpha=True), QARepVGGBlock(c, co, stride=stride, use_residual_connection=stride == 1, use_alpha=True)
+    ref.alpha.data.fill_(0.7)
+    _check(ref, blk, x, backend)
+    assert blk.alpha.grad is not None and float(blk.alpha.grad.abs().sum()) > 0
+    # deployment form: alpha enters the fused kernel and bias (qarepvgg_block.py:206-230)
+    ref.eval()
+    blk.eval()
+    with torch.no_grad():
+        want = ref(x)
+        blk.full_fusion()
+        got = blk.fwd(to_nhwc(x, backend))
+    assert_close(to_nchw_cpu(got), want, 1e-4, "fused forward with alpha")
+
+
+@pytest.mark.skipif(not __import__("oracle.ref_shim", fromlist=["x"]).available(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("stride", [1, 2])
+def test_oracle_qarepvgg_alpha_live(stride):
+    """oracle.QARep(use_alpha=True) against the reference's own QARepVGGBlock source executed through the import shim."""
+    from oracle import ref_shim
+    from oracle.yolo_nas import QARep
+
+    ref_shim.install()
+    from super_gradients.modules.qarepvgg_block import QARepVGGBlock as RefBlock
+
+    c, co = 8, 8 * stride
+    torch.manual_seed(3)
+    r = RefBlock(c, co, stride=stride, use_alpha=True, use_residual_connection=stride == 1).train()
+    o = QARep(c, co, stride, residual=stride == 1, use_alpha=True).train()
+    r.alpha.data.fill_(0.6)
+    missing = o.load_state_dict(r.state_dict(), strict=False)
+    assert not missing.missing_keys
+    x = torch.randn(2, c, 6, 5, generator=torch.Generator().manual_seed(1))
+    xr, xo = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    yr, yo = r(xr), o(xo)
+    assert torch.equal(yr, yo)
+    g = torch.randn(yr.shape, generator=torch.Generator().manual_seed(2))
+    yr.backward(g)
+    yo.backward(g)
+    assert torch.equal(xr.grad, xo.grad) and torch.equal(r.alpha.grad, o.alpha.grad)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
 def test_qarepvgg_fused_bn_backward_reduce(backend, stride, monkeypatch):
     """SGX_FUSE_BN_REDUCE (experiment switch): branch_3x3.bn's backward sums come out of post_bn's apply sweep (sgx_bn_bwd_apply_reduce)
     instead of a sweep of their own.  Same row partition, same accumulation order: every gradient must be BIT-identical to the unfused
