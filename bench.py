@@ -213,6 +213,7 @@ def main():
     import torch.distributed as dist
 
     from super_gradients_amd import kernels as K
+    from super_gradients_amd._lib import lib
     from super_gradients_amd.training import models
     from super_gradients_amd.training.losses import PPYoloELoss
     from super_gradients_amd.training.utils.distributed_training_utils import GradientAllReducer, setup_device_from_env
@@ -223,8 +224,6 @@ def main():
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a HIP GPU (the product has no CPU path)")
     if os.environ.get("SGX_WGRAD_SPLIT"):  # experiment switch: weight-gradient split target (waves), see csrc/conv.hip wgrad_plan
-        from super_gradients_amd._lib import lib
-
         lib().sgx_debug_set_tiles(0, 0, 0, 0, int(os.environ["SGX_WGRAD_SPLIT"]))
     rank, world, device = setup_device_from_env()
     if world != args.gpus:
@@ -322,7 +321,8 @@ def main():
             "config": {"workload": f"{family}-{args.model.upper()} synthetic COCO {args.size}x{args.size}, bs={args.batch}/GPU, PPYoloELoss(TAL)+AdamW"
                                    + ("" if args.no_ema else "+EMA") + ", random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
-                       "conv_math": K.get_conv_math(), "conv_variant": int(os.environ.get("SGX_CONV_VARIANT") or 0)},  # "fp32" = fp32 matrix pipe (default); SGX_CONV_MATH=auto|bf16x3 opts into the split arithmetic
+                       "conv_math": K.get_conv_math(), "conv_variant": int(os.environ.get("SGX_CONV_VARIANT") or 0),
+                       "conv_tuning_entries": int(lib().sgx_conv_tuning_size())},  # per-problem (tile, variant) table, tools/conv_tune.py --emit-table  # "fp32" = fp32 matrix pipe (default); SGX_CONV_MATH=auto|bf16x3 opts into the split arithmetic
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data gradient, "
                                                     + ("v_mfma_f32_32x32x2_f32)" if K.get_conv_math() == "fp32" else "v_mfma_f32_32x32x16_bf16 x6 / v_mfma_f32_32x32x2_f32 per problem)"),
                          "achieved": round(ig_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_tf / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -51,6 +51,13 @@ int32_t sgx_prof_bytes(int32_t cls, double* bytes);
  * launch mix would take if every launch ran at whichever of the two bounds (matrix pipe, HBM) is the tighter one for ITS shape      */
 int32_t sgx_prof_bound_ms(int32_t cls, double peak_flops, double hbm_bytes_per_s, double* ms);
 
+/* Per-problem tuning table: n entries of 12 int32 {kind (0 = forward, 1 = data gradient), N, H, W, C, K, R, stride, pad, BM, BN, variant}
+ * (BM / BN = 0: keep the heuristic's).  A convolution call whose descriptor matches an entry uses that tile / kernel variant instead of the
+ * built-in heuristic - what tools/conv_tune.py measured as the fastest for that problem on this chip; results are unchanged (every variant
+ * reduces in the same order).  Load before the first launch (not synchronised with running calls); n = 0 clears the table.             */
+int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n);
+int32_t sgx_conv_tuning_size(void);
+
 /* Measurement aid (tools/conv_tune.py): force the conv tile shapes (0 = built-in heuristic).  Not thread-safe; never set by the product. */
 int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk, int32_t wgrad_bj, int32_t wgrad_split_target);
 /* Arithmetic of the forward / data-gradient GEMMs.  0 (default): fp32 matrix pipe, exact fp32 FMA chains.  1: "bf16x3" - every fp32

@@ -65,6 +65,8 @@ PROTOTYPES = {
     "sgx_prof_summary": (_i32, [_i32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "sgx_debug_set_tiles": (_i32, [_i32] * 5),
     "sgx_debug_set_variant": (_i32, [_i32]),
+    "sgx_conv_tuning_load": (_i32, [POINTER(c_int32), _i32]),
+    "sgx_conv_tuning_size": (_i32, []),
     "sgx_conv_set_math": (_i32, [_i32]),
     "sgx_conv_get_math": (_i32, []),
     "sgx_prof_bytes": (_i32, [_i32, POINTER(ctypes.c_double)]),
@@ -173,7 +175,39 @@ def lib():
         var = os.environ.get("SGX_CONV_VARIANT")  # experiment switch of the conv kernels (sgx_debug_set_variant; 5 = 32-deep slabs)
         if var:
             _LIB.sgx_debug_set_variant(int(var))
+        # per-problem (tile, variant) table measured by tools/conv_tune.py --emit-table: SGX_CONV_TUNING=<json> ("" / "0" = none),
+        # default csrc/conv_tuning_gfx950.json when it has been committed
+        tune = os.environ.get("SGX_CONV_TUNING")
+        if tune is None and os.path.exists(DEFAULT_TUNING):
+            tune = DEFAULT_TUNING
+        if tune and tune != "0":
+            load_conv_tuning(tune, _LIB)
     return _LIB
+
+
+DEFAULT_TUNING = os.path.join(_HERE, "csrc", "conv_tuning_gfx950.json")
+TUNE_FIELDS = ("kind", "N", "H", "W", "C", "K", "R", "stride", "pad", "bm", "bn", "variant")
+
+
+def load_conv_tuning(path_or_entries, library=None) -> int:
+    """Install a per-problem tuning table (sgx_conv_tuning_load).  `path_or_entries`: a JSON file {"entries": [{kind: "fwd"|"dgrad", N, H, W,
+    C, K, R, stride, pad, bm, bn, variant}, ...]} as tools/conv_tune.py --emit-table writes it, or such a list; [] clears.  -> entries installed"""
+    import json
+
+    entries = path_or_entries
+    if isinstance(entries, str):
+        with open(entries) as f:
+            entries = json.load(f)["entries"]
+    flat = []
+    for e in entries:
+        flat += [{"fwd": 0, "dgrad": 1}[e["kind"]]] + [int(e[k]) for k in TUNE_FIELDS[1:]]
+    arr = (c_int32 * max(len(flat), 1))(*flat)
+    L = library if library is not None else lib()
+    rc = L.sgx_conv_tuning_load(arr, len(entries))
+    if rc != 0:
+        msg = L.sgx_last_error()
+        raise RuntimeError(f"sgx_conv_tuning_load failed with status {rc}: {msg.decode() if msg else ''}")
+    return len(entries)
 
 
 class SgxError(RuntimeError):

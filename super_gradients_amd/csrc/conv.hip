@@ -19,6 +19,8 @@
 #include "sgx_common.h"
 
 #define SGX_MAX_TAPS 64
+#include <array>
+#include <map>
 
 // ------------------------------------------------------------------------------------------------
 // Optional per-launch timing of the two MFMA kernel classes (bench.py's roofline leg): HIP events recorded on the
@@ -721,9 +723,48 @@ extern "C" int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk
     g_ovr_bm = bm; g_ovr_bn = bn; g_ovr_wk = wgrad_bnk; g_ovr_wj = wgrad_bj; g_ovr_split = wgrad_split_target;
     return SGX_OK;
 }
+// ---- per-problem tuning table (sgx_conv_tuning_load): what tools/conv_tune.py measured as the best (tile, variant) of a convolution
+// problem replaces the heuristic for exactly that problem.  Keyed at the API level - (kind, N, H, W, C, K, R, stride, pad) - so that every
+// launch of one call (the parity classes of a strided data gradient) uses the same entry, and sgx_conv2d_fwd_stat_blocks agrees with the
+// forward launch.  Load before the first launch; lookups are lock-free reads of an immutable map.
+struct TuneVal {
+    int bm, bn, var;
+};
+static std::map<std::array<int, 9>, TuneVal> g_tune;
+static thread_local const TuneVal* t_tune = nullptr;  // entry of the API call running on this thread
+struct TuneScope {
+    const TuneVal* prev;
+    TuneScope(int kind, const sgx_conv_desc* d) : prev(t_tune) {
+        t_tune = nullptr;
+        if (!g_tune.empty() && d) {
+            auto it = g_tune.find(std::array<int, 9>{kind, d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->pad});
+            if (it != g_tune.end()) t_tune = &it->second;
+        }
+    }
+    ~TuneScope() { t_tune = prev; }
+};
+extern "C" int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n) {
+    SGX_CHECK_ARG(n >= 0 && (n == 0 || entries), "conv_tuning_load: bad args");
+    std::map<std::array<int, 9>, TuneVal> m;
+    for (int i = 0; i < n; ++i) {
+        const int32_t* e = entries + 12 * i;
+        SGX_CHECK_ARG(e[0] == 0 || e[0] == 1, "conv_tuning_load: entry %d: kind %d (0 = forward, 1 = data gradient)", i, e[0]);
+        SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && (e[10] == 0 || e[10] == 32 || e[10] == 64 || e[10] == 96 || e[10] == 128) &&
+                          e[11] >= 0 && e[11] <= 6, "conv_tuning_load: entry %d: no kernel (tile %dx%d, variant %d)", i, e[9], e[10], e[11]);
+        m[std::array<int, 9>{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8]}] = TuneVal{e[9], e[10], e[11]};
+    }
+    g_tune.swap(m);
+    return SGX_OK;
+}
+extern "C" int32_t sgx_conv_tuning_size(void) { return (int32_t)g_tune.size(); }
+// the experiment switch wins over the table (measurements must see what they ask for)
+static int conv_variant() { return g_ovr_var ? g_ovr_var : (t_tune ? t_tune->var : 0); }
+
 static TileCfg pick_tile_heuristic(long M, int N);
 static TileCfg pick_tile(long M, int N, int math) {
     TileCfg t = pick_tile_heuristic(M, N);
+    if (t_tune && t_tune->bm) t.bm = t_tune->bm;
+    if (t_tune && t_tune->bn) t.bn = t_tune->bn;
     if (g_ovr_bm) t.bm = g_ovr_bm;
     if (g_ovr_bn) t.bn = g_ovr_bn;
     return t;
@@ -743,7 +784,7 @@ static TileCfg pick_tile_heuristic(long M, int N) {
 // 32-deep slabs are an experiment switch until their first measurement on the GPU: sgx_debug_set_variant(5 | 6) / SGX_CONV_VARIANT
 // (5: one LDS buffer, 6: two), for both arithmetic modes.  Eligible: channel-chunked K axis, C a multiple of 32 (a ragged last chunk
 // would multiply zeros for up to half a slab).
-static bool igemm_deep_slabs(const IgemmParams& p) { return (g_ovr_var == 5 || g_ovr_var == 6) && p.C % 32 == 0; }
+static bool igemm_deep_slabs(const IgemmParams& p) { return (conv_variant() == 5 || conv_variant() == 6) && p.C % 32 == 0; }
 // dispatch over the eight non-flat tile shapes for one (MATH, KD, NBUF)
 #define SGX_IGEMM_TILES(MATH_, KD_, NBUF_)                                                                  \
     do {                                                                                                    \
@@ -769,6 +810,7 @@ static void launch_igemm(IgemmParams& p, void* stream) {
 
 static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
     const int T = p.Th * p.Tw;
+    const int var = conv_variant();
     if (T > SGX_MAX_TAPS) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: more than %d taps", SGX_MAX_TAPS);
     if (p.w_bytes > SGX_BUF_MAX) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: weight tensor larger than 2 GiB");
     {
@@ -792,7 +834,7 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         else if (flat && bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true, 1>(p, stream);
         else if (flat) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (bf16x3): no flat tile %dx%d", bm, bn);
         else if (igemm_deep_slabs(p)) {
-            if (g_ovr_var == 5) SGX_IGEMM_TILES(1, 32, 1);
+            if (var == 5) SGX_IGEMM_TILES(1, 32, 1);
             else SGX_IGEMM_TILES(1, 32, 2);
         } else if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, 1>(p, stream);  // 52 KB of LDS with the unpadded planes
         else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, 1>(p, stream);
@@ -811,12 +853,12 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true>(p, stream);
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no flat tile %dx%d", bm, bn);
     } else if (igemm_deep_slabs(p)) {  // 32-deep slabs (see igemm_kernel): whole-line loads
-        if (g_ovr_var == 5) SGX_IGEMM_TILES(0, 32, 1);
+        if (var == 5) SGX_IGEMM_TILES(0, 32, 1);
         else SGX_IGEMM_TILES(0, 32, 2);
-    } else if (g_ovr_var == 1 && bm == 64 && bn == 64) launch_igemm<64, 64, 1, 2, false>(p, stream);   // 2 waves x (64x32)
-    else if (g_ovr_var == 2 && bm == 128 && bn == 64) launch_igemm<128, 64, 4, 2, false>(p, stream);   // 8 waves x (32x32)
-    else if (g_ovr_var == 3 && bm == 128 && bn == 128) launch_igemm<128, 128, 4, 2, false>(p, stream); // 8 waves x (32x64)
-    else if (g_ovr_var == 4 && bm == 64 && bn == 128) launch_igemm<64, 128, 2, 4, false>(p, stream);   // 8 waves x (32x32)
+    } else if (var == 1 && bm == 64 && bn == 64) launch_igemm<64, 64, 1, 2, false>(p, stream);   // 2 waves x (64x32)
+    else if (var == 2 && bm == 128 && bn == 64) launch_igemm<128, 64, 4, 2, false>(p, stream);   // 8 waves x (32x32)
+    else if (var == 3 && bm == 128 && bn == 128) launch_igemm<128, 128, 4, 2, false>(p, stream); // 8 waves x (32x64)
+    else if (var == 4 && bm == 64 && bn == 128) launch_igemm<64, 128, 2, 4, false>(p, stream);   // 8 waves x (32x32)
     else if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false>(p, stream);
     else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false>(p, stream);
     else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false>(p, stream);
@@ -852,6 +894,7 @@ static long view_bytes(int N, int H, int W, int C, long ld_pix, long ld_img) {
 }
 
 extern "C" int32_t sgx_conv2d_fwd_stat_blocks(const sgx_conv_desc* d) {
+    TuneScope tune(0, d);
     long M = (long)d->N * d->Ho * d->Wo;
     TileCfg t = pick_tile(M, d->K, conv_math_for(d->R * d->S, d->C));
     return sgx_cdiv(M, t.bm);
@@ -862,6 +905,7 @@ extern "C" int32_t sgx_conv2d_fwd(const sgx_conv_desc* d, const float* x, const 
     int32_t rc = check_desc(d);
     if (rc) return rc;
     SGX_CHECK_ARG(x && w && y, "conv fwd: null pointer");
+    TuneScope tune(0, d);
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = x; p.Wt = w; p.bias = bias; p.addend = addend; p.Y = y; p.stat_partials = stat_partials;
@@ -982,6 +1026,7 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
     int32_t rc = check_desc(d);
     if (rc) return rc;
     SGX_CHECK_ARG((mode == 1 || (dy && dx)) && (mode == 2 || w), "conv bwd_data: null pointer");
+    TuneScope tune(1, d);
     SGX_CHECK_ARG(d->K % 4 == 0 && d->y_ld_pix % 4 == 0, "conv bwd_data: K and dy pixel stride must be multiples of 4");
     if (ws_bytes < sgx_conv2d_bwd_data_workspace(d) || !ws) SGX_FAIL(SGX_ERR_WORKSPACE, "conv bwd_data: workspace too small");
     const int s = d->stride;

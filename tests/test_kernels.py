@@ -785,6 +785,38 @@ def test_conv_deep_slabs(backend, case, math):
         K.set_conv_math("fp32")
 
 
+def test_conv_tuning_table(backend):
+    """sgx_conv_tuning_load: a problem listed in the table runs with the listed tile / variant (results bit-identical to the heuristic's),
+    the forward statistics rows follow the table's M tile, other problems keep the heuristic, bad entries are rejected, [] clears."""
+    from super_gradients_amd._lib import lib, load_conv_tuning
+
+    first_gpu_run_pending(backend)
+    case = (1, 9, 8, 32, 40, 3, 1, 1)
+    n, h, w, c, k, r, s, p = case
+    x, wt, b = _conv_case(case)
+    xd, wd = to_nhwc(x, backend), K.to_ohwi(wt.to(backend))
+    dyd = to_nhwc(torch.randn(n, k, h, w, generator=torch.Generator().manual_seed(2)), backend)
+    y0, parts0 = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s, pad=p, stat_partials=True)
+    dx0 = K.conv2d_bwd_data(dyd, wd, (n, h, w, c), stride=s, pad=p)
+    key = dict(N=n, H=h, W=w, C=c, K=k, R=r, stride=s, pad=p)
+    try:
+        assert load_conv_tuning([dict(kind="fwd", bm=128, bn=32, variant=5, **key), dict(kind="dgrad", bm=64, bn=32, variant=6, **key)]) == 2
+        assert lib().sgx_conv_tuning_size() == 2
+        y1, parts1 = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s, pad=p, stat_partials=True)
+        dx1 = K.conv2d_bwd_data(dyd, wd, (n, h, w, c), stride=s, pad=p)
+        assert torch.equal(y1.cpu(), y0.cpu()) and torch.equal(dx1.cpu(), dx0.cpu())
+        assert parts1.shape[1] == 1 and parts0.shape[1] == 2, "statistics rows: one 128-row tile from the table vs two 64-row tiles (72 pixels)"
+        assert_close(parts1.sum(1).cpu(), parts0.sum(1).cpu(), 1e-5, "statistics")
+        # the table is consulted per problem: an impossible wave-layout entry fails for ITS problem only
+        load_conv_tuning([dict(kind="fwd", bm=128, bn=128, variant=2, **dict(key, K=k + 4))])
+        assert torch.equal(K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s, pad=p).cpu(), y0.cpu())
+        with pytest.raises(RuntimeError, match="no kernel"):
+            load_conv_tuning([dict(kind="fwd", bm=48, bn=32, variant=0, **key)])
+    finally:
+        load_conv_tuning([])
+    assert lib().sgx_conv_tuning_size() == 0
+
+
 @pytest.mark.parametrize("math", ["fp32", "bf16x3"])
 def test_conv_every_tile_shape(backend, math):
     """Every instantiated (BM, BN) tile of the implicit-GEMM kernel, forced through the measurement override (sgx_debug_set_tiles), on

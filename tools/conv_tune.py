@@ -21,16 +21,25 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--out", default=None)
     ap.add_argument("--wgrad", action="store_true", help="also search the weight-gradient tiles")
+    ap.add_argument("--emit-table", default=None, help="write the per-problem winners (forward / data gradient) as a tuning table for "
+                    "sgx_conv_tuning_load (super_gradients_amd/csrc/conv_tuning_gfx950.json is loaded by default when present)")
+    ap.add_argument("--min-gain", type=float, default=0.02, help="a winner enters the table only if it beats the heuristic by this fraction")
     args = ap.parse_args()
     import torch
 
     import conv_bench as CB
     from super_gradients_amd import kernels as K
-    from super_gradients_amd._lib import lib
+    from super_gradients_amd._lib import lib, load_conv_tuning
 
     os.environ["SGX_SIDE_STREAM"] = "0"
     dev = torch.device("cuda:0")
+    load_conv_tuning([])  # measure the built-in heuristic, not a previously committed table
     rec = CB.record_problems(args.model, args.batch, args.size, dev)
+    agg = {}  # (kind, N, H, W, C, K, R, stride, pad) -> {(bm, bn, variant): calls x us summed over the stride / option variants of the problem}
+
+    def note(key, calls, cfg, t):
+        d = agg.setdefault(tuple(key[:9]), {})
+        d[cfg] = d.get(cfg, 0.0) + calls * t
 
     def timeit(fn):
         try:
@@ -54,11 +63,13 @@ def main():
         base = timeit(fn)
         best, best_cfg = base, "heuristic"
         if kind in ("fwd", "dgrad"):
+            note(key, calls, (0, 0, 0), base)
             stats = kind == "fwd" and key[11:][3]
             for bm in (64, 128):
                 for bn in (32, 64, 96, 128):
                     lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
                     t = timeit(fn)
+                    note(key, calls, (bm, bn, 0), t)
                     if t < best:
                         best, best_cfg = t, f"bm={bm} bn={bn}"
             for var, (bm, bn) in ((1, (64, 64)), (2, (128, 64)), (3, (128, 128)), (4, (64, 128))):  # wave-layout variants
@@ -66,6 +77,7 @@ def main():
                 lib().sgx_debug_set_variant(var)
                 t = timeit(fn)
                 lib().sgx_debug_set_variant(0)
+                note(key, calls, (bm, bn, var), t)
                 if t < best:
                     best, best_cfg = t, f"bm={bm} bn={bn} variant={var}"
             # 32-deep slabs (variant 5; eligible problems only: fp32 arithmetic, C % 32 == 0 - others run the default kernel again)
@@ -75,6 +87,7 @@ def main():
                     for bn in ((0,) if bm == 0 else (32, 64, 96, 128)):
                         lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
                         t = timeit(fn)
+                        note(key, calls, (bm, bn, var), t)
                         if t < best:
                             best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + f" variant={var} (32-deep slabs)"
             lib().sgx_debug_set_variant(0)
@@ -95,6 +108,25 @@ def main():
     print(text)
     if args.out:
         open(args.out, "w").write(text + "\n")
+    if args.emit_table:
+        import json
+
+        entries, t_heur, t_tab = [], 0.0, 0.0
+        for pk, cfgs in agg.items():
+            cfg, t = min(cfgs.items(), key=lambda kv: kv[1])
+            heur = cfgs[(0, 0, 0)]
+            t_heur += heur
+            if t < (1.0 - args.min_gain) * heur:
+                kind, n, h, w, c, k_, r, stride, pad = pk
+                entries.append(dict(kind=kind, N=n, H=h, W=w, C=c, K=k_, R=r, stride=stride, pad=pad, bm=cfg[0], bn=cfg[1], variant=cfg[2],
+                                    us_heuristic=round(heur, 1), us_table=round(t, 1)))
+                t_tab += t
+            else:
+                t_tab += heur
+        meta = dict(model=f"yolo_nas_{args.model}", batch=args.batch, size=args.size, conv_math=K.get_conv_math(),
+                    ms_per_step_heuristic=round(t_heur / 1e3, 3), ms_per_step_table=round(t_tab / 1e3, 3), min_gain=args.min_gain)
+        json.dump(dict(meta=meta, entries=entries), open(args.emit_table, "w"), indent=1)
+        print(f"# tuning table: {len(entries)} of {len(agg)} forward / data-gradient problems, {meta['ms_per_step_heuristic']} -> {meta['ms_per_step_table']} ms/step -> {args.emit_table}")
 
 
 if __name__ == "__main__":
