@@ -52,7 +52,8 @@ int32_t sgx_prof_bytes(int32_t cls, double* bytes);
 int32_t sgx_prof_bound_ms(int32_t cls, double peak_flops, double hbm_bytes_per_s, double* ms);
 
 /* Per-problem tuning table: n entries of 12 int32 {kind (0 = forward, 1 = data gradient), N, H, W, C, K, R, stride, pad, BM, BN, variant}
- * (BM / BN = 0: keep the heuristic's).  A convolution call whose descriptor matches an entry uses that tile / kernel variant instead of the
+ * (BM / BN = 0: keep the heuristic's), or {2 = weight gradient, N, ..., pad, filter tile, (tap, channel) tile, split target in waves} - a
+ * different split regroups the pixel sum of dW (fp32 rounding level, deterministic for a given table).  A convolution call whose descriptor matches an entry uses that tile / kernel variant instead of the
  * built-in heuristic - what tools/conv_tune.py measured as the fastest for that problem on this chip; outputs are bit-identical (every tile / variant
  * reduces in the same order; only the statistic partial rows regroup with BM).  Load before the first launch (not synchronised with running calls); n = 0 clears the table.             */
 int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n);

@@ -200,7 +200,7 @@ def load_conv_tuning(path_or_entries, library=None) -> int:
             entries = json.load(f)["entries"]
     flat = []
     for e in entries:
-        flat += [{"fwd": 0, "dgrad": 1}[e["kind"]]] + [int(e[k]) for k in TUNE_FIELDS[1:]]
+        flat += [{"fwd": 0, "dgrad": 1, "wgrad": 2}[e["kind"]]] + [int(e[k]) for k in TUNE_FIELDS[1:]]  # wgrad: bm / bn / variant = filter tile / column tile / split target
     arr = (c_int32 * max(len(flat), 1))(*flat)
     L = library if library is not None else lib()
     rc = L.sgx_conv_tuning_load(arr, len(entries))

@@ -748,9 +748,15 @@ extern "C" int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n) {
     std::map<std::array<int, 9>, TuneVal> m;
     for (int i = 0; i < n; ++i) {
         const int32_t* e = entries + 12 * i;
-        SGX_CHECK_ARG(e[0] == 0 || e[0] == 1, "conv_tuning_load: entry %d: kind %d (0 = forward, 1 = data gradient)", i, e[0]);
-        SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && (e[10] == 0 || e[10] == 32 || e[10] == 64 || e[10] == 96 || e[10] == 128) &&
-                          e[11] >= 0 && e[11] <= 6, "conv_tuning_load: entry %d: no kernel (tile %dx%d, variant %d)", i, e[9], e[10], e[11]);
+        SGX_CHECK_ARG(e[0] >= 0 && e[0] <= 2, "conv_tuning_load: entry %d: kind %d (0 = forward, 1 = data gradient, 2 = weight gradient)", i, e[0]);
+        const bool wide = e[10] == 0 || e[10] == 32 || e[10] == 64 || e[10] == 96 || e[10] == 128;
+        if (e[0] == 2)  // weight gradient: filter tile, flattened (tap, channel) tile, split target (waves over the chip; 0 = heuristic)
+            SGX_CHECK_ARG((e[9] == 0 || e[9] == 32 || e[9] == 64 || e[9] == 96 || e[9] == 128) && wide && e[11] >= 0 &&
+                              (e[9] == 0) == (e[10] == 0),  // all 16 tiles of {32, 64, 96, 128}^2 are instantiated
+                          "conv_tuning_load: entry %d: no weight-gradient kernel (tile %dx%d, split target %d)", i, e[9], e[10], e[11]);
+        else
+            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && e[11] >= 0 && e[11] <= 6,
+                          "conv_tuning_load: entry %d: no kernel (tile %dx%d, variant %d)", i, e[9], e[10], e[11]);
         m[std::array<int, 9>{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8]}] = TuneVal{e[9], e[10], e[11]};
     }
     g_tune.swap(m);
@@ -1328,6 +1334,7 @@ static WgradPlan wgrad_plan(const sgx_conv_desc* d) {
     if (bnk == 96) bj = J >= 128 ? 128 : wg_tile(J);
     else if (bnk == 32) bj = J >= 128 ? 128 : wg_tile(J);
     else bj = J >= 64 ? 64 : wg_tile(J);
+    if (t_tune && t_tune->bm) bnk = t_tune->bm, bj = t_tune->bn;  // tuning table entry of this problem (kind 2)
     pl.bnk = g_ovr_wk ? g_ovr_wk : bnk;
     pl.bj = g_ovr_wj ? g_ovr_wj : bj;
     pl.waves = wg_waves(pl.bnk, pl.bj);
@@ -1335,7 +1342,8 @@ static WgradPlan wgrad_plan(const sgx_conv_desc* d) {
     pl.jt_tiles = sgx_cdiv(J, pl.bj);
     long M = (long)d->N * d->Ho * d->Wo;
     long tiles = (long)pl.kt_tiles * pl.jt_tiles;
-    long target = (g_ovr_split ? g_ovr_split : (pl.bnk == 64 && pl.bj == 64 ? 8192 : 4096)) / pl.waves;  // 4-8 waves per SIMD over the chip
+    const int tuned_split = t_tune ? t_tune->var : 0;
+    long target = (g_ovr_split ? g_ovr_split : tuned_split ? tuned_split : (pl.bnk == 64 && pl.bj == 64 ? 8192 : 4096)) / pl.waves;  // 4-8 waves per SIMD over the chip
     long ks = (target + tiles - 1) / tiles;
     long maxsplit = (M + 255) / 256;         // at least 256 pixels (16 slabs) per split
     if (ks > maxsplit) ks = maxsplit;
@@ -1353,6 +1361,7 @@ static WgradPlan wgrad_plan(const sgx_conv_desc* d) {
 }
 
 extern "C" int64_t sgx_conv2d_bwd_weight_workspace(const sgx_conv_desc* d) {
+    TuneScope tune(2, d);
     WgradPlan pl = wgrad_plan(d);
     int64_t slabs = (int64_t)pl.ksplit * d->K * d->R * d->S * d->C * sizeof(float);
     int64_t bias = sgx_colsum_workspace((int64_t)d->N * d->Ho * d->Wo, d->K);
@@ -1366,6 +1375,7 @@ extern "C" int32_t sgx_conv2d_bwd_weight(const sgx_conv_desc* d, const float* x,
     SGX_CHECK_ARG(x && dy && dw, "conv bwd_weight: null pointer");
     SGX_CHECK_ARG(d->K % 4 == 0 && d->y_ld_pix % 4 == 0, "conv bwd_weight: K and dy pixel stride must be multiples of 4");
     if (!ws || ws_bytes < sgx_conv2d_bwd_weight_workspace(d)) SGX_FAIL(SGX_ERR_WORKSPACE, "conv bwd_weight: workspace too small");
+    TuneScope tune(2, d);
     WgradPlan pl = wgrad_plan(d);
     WgradParams p;
     p.X = x; p.DY = dy; p.part = (float*)ws;

@@ -812,6 +812,13 @@ def test_conv_tuning_table(backend):
         assert torch.equal(K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s, pad=p).cpu(), y0.cpu())
         with pytest.raises(RuntimeError, match="no kernel"):
             load_conv_tuning([dict(kind="fwd", bm=48, bn=32, variant=0, **key)])
+        # weight gradient: filter tile x (tap, channel) tile x split target; a different split regroups the pixel sum (rounding level)
+        g0 = K.to_ohwi(torch.zeros_like(wt).to(backend))
+        K.conv2d_bwd_weight(xd, dyd, g0, None, stride=s, pad=p)
+        load_conv_tuning([dict(kind="wgrad", bm=32, bn=96, variant=2048, **key)])
+        g1 = K.to_ohwi(torch.zeros_like(wt).to(backend))
+        K.conv2d_bwd_weight(xd, dyd, g1, None, stride=s, pad=p)
+        assert_close(g1.cpu(), g0.cpu(), 1e-5, "weight gradient with a tuned tile / split")
     finally:
         load_conv_tuning([])
     assert lib().sgx_conv_tuning_size() == 0

@@ -92,11 +92,13 @@ def main():
                             best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + f" variant={var} (32-deep slabs)"
             lib().sgx_debug_set_variant(0)
         elif args.wgrad:
+            note(key, calls, (0, 0, 0), base)
             for bnk in (32, 64, 96, 128):
                 for bj in (32, 64, 96, 128):
                     for split in (2048, 4096, 8192):
                         lib().sgx_debug_set_tiles(0, 0, bnk, bj, split)
                         t = timeit(fn)
+                        note(key, calls, (bnk, bj, split), t)
                         if t < best:
                             best, best_cfg = t, f"bnk={bnk} bj={bj} split={split}"
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
@@ -126,7 +128,7 @@ def main():
         meta = dict(model=f"yolo_nas_{args.model}", batch=args.batch, size=args.size, conv_math=K.get_conv_math(),
                     ms_per_step_heuristic=round(t_heur / 1e3, 3), ms_per_step_table=round(t_tab / 1e3, 3), min_gain=args.min_gain)
         json.dump(dict(meta=meta, entries=entries), open(args.emit_table, "w"), indent=1)
-        print(f"# tuning table: {len(entries)} of {len(agg)} forward / data-gradient problems, {meta['ms_per_step_heuristic']} -> {meta['ms_per_step_table']} ms/step -> {args.emit_table}")
+        print(f"# tuning table: {len(entries)} of {len(agg)} problems, {meta['ms_per_step_heuristic']} -> {meta['ms_per_step_table']} ms/step -> {args.emit_table}")
 
 
 if __name__ == "__main__":

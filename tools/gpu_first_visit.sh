@@ -22,7 +22,7 @@ f="$OUT/bench_fused_bn_reduce"
 SGX_FUSE_BN_REDUCE=1 timeout 200 python bench.py --no-nms --no-cpu-baseline ${BENCH_ARGS:-} > "$f.json" 2> "$f.err"
 echo "SGX_FUSE_BN_REDUCE=1 rc=$?: $(python -c "import json; r=json.loads(open('$f.json').read().strip().splitlines()[-1]); print(r['value'],'img/s', r['ms_per_step'],'ms')" 2>&1 | tail -1)"
 if [[ "${TUNE:-1}" == "1" ]]; then
-  timeout 700 python tools/conv_tune.py --out "$OUT/conv_tune_variants.txt" --emit-table "$OUT/conv_tuning_gfx950.json" > "$OUT/conv_tune.log" 2>&1
+  timeout 900 python tools/conv_tune.py ${TUNE_ARGS:---wgrad} --out "$OUT/conv_tune_variants.txt" --emit-table "$OUT/conv_tuning_gfx950.json" > "$OUT/conv_tune.log" 2>&1
   echo "conv_tune rc=$?"; head -12 "$OUT/conv_tune_variants.txt"; tail -1 "$OUT/conv_tune.log"
   # the table's end-to-end effect (commit it as super_gradients_amd/csrc/conv_tuning_gfx950.json to make it the default)
   f="$OUT/bench_tuning_table"
