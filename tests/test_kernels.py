@@ -637,7 +637,7 @@ def _adversarial_targets(kind, size, C):
     elif kind == "tiny_and_outside":  # a box smaller than a stride-8 cell between anchor centres, and boxes sticking out of the image
         rows = [[0, 4, 12.0, 12.0, 3.0, 3.0], [0, 5, 2.0, s / 2, 40.0, 30.0], [1, 6, s - 3.0, s - 3.0, 30.0, 30.0], [1, 7, s / 2, s / 2, 2 * s, 2 * s]]
     elif kind == "many":           # more GTs than anchors of the coarsest level, on a regular lattice (equal distances / IoUs everywhere)
-        rows = [[b, (i * 5 + j) % C, (i + 0.5) * s / 5, (j + 0.5) * s / 5, s / 6, s / 6] for b in range(2) for i in range(5) for j in range(5)]
+        rows = [[b, (i * 4 + j) % C, (i + 0.5) * s / 4, (j + 0.5) * s / 4, s / 5, s / 5] for b in range(2) for i in range(4) for j in range(3 + b)]
     elif kind == "one_image_empty":
         rows = [[1, 0, s / 2, s / 2, s / 2, s / 3], [1, 0, s / 3, s / 2, s / 4, s / 3]]
     else:
@@ -831,7 +831,7 @@ def test_conv_every_tile_shape(backend, math):
     from super_gradients_amd._lib import lib
 
     first_gpu_run_pending(backend)
-    n, h, w, c, k, r, s, p = (1, 9, 8, 20, 100, 3, 1, 1)   # M = 72 pixels, N = 100 filters: partial tiles everywhere
+    n, h, w, c, k, r, s, p = (1, 9, 8, 20, 72, 3, 1, 1)   # M = 72 pixels, N = 72 filters: partial tiles everywhere
     x, wt, b = _conv_case((n, h, w, c, k, r, s, p))
     x.requires_grad_(True)
     y = F.conv2d(x, wt, b, stride=s, padding=p)
