@@ -213,6 +213,11 @@ int32_t sgx_bn_bwd_apply(const float* dy, int64_t dy_ld, const float* x, int64_t
 int32_t sgx_bn_bwd_apply_reduce(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale, const float* shift,
                                 const float* coef, float* dx, int64_t dx_ld, int64_t M, int32_t C, int32_t act, const float* next_x,
                                 int64_t next_x_ld, const float* next_mean, float* next_partials, void* stream);
+/* Experiment switch (first GPU measurement pending): the finalize stages above (sgx_bn_finalize, sgx_bn_bwd_finalize, sgx_bn_reduce_sums,
+ * sgx_colsum) as ONE cooperative launch (32 channels x 16 row lanes per workgroup fold the fp32 partial rows in fp64, fixed order) instead
+ * of a pre-reduction launch + a finalize launch, for up to 4096 partial rows.  Same sums up to fp64 regrouping.  Not thread-safe.   */
+int32_t sgx_bn_set_fused_finalize(int32_t on);
+int32_t sgx_bn_get_fused_finalize(void);
 /* z = a*x + y with a device-resident scalar a (yolo_stages.py:61-63) and its backward pieces:
  * sgx_dot_partial gives sum(x*dz) partials [nblk] for d a; finalize with sgx_sum_partials.          */
 int32_t sgx_dot_partial(const float* a, int64_t a_ld, const float* b, int64_t b_ld, int64_t M, int32_t C,

@@ -102,6 +102,8 @@ PROTOTYPES = {
     "sgx_bn_bwd_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
     "sgx_bn_bwd_apply": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _P, _i64, _P, _i64, _i64, _i32, _i32, _P]),
     "sgx_bn_bwd_apply_reduce": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _P, _i64, _i64, _i32, _i32, _P, _i64, _P, _P, _P]),
+    "sgx_bn_set_fused_finalize": (_i32, [_i32]),
+    "sgx_bn_get_fused_finalize": (_i32, []),
     "sgx_dot_partial": (_i32, [_P, _i64, _P, _i64, _i64, _i32, _P, _P]),
     "sgx_sum_partials": (_i32, [_P, _i32, _f, _P, _i32, _P]),
     "sgx_axpy": (_i32, [_P, _i64, _f, _P, _P, _i64, _i64, _i32, _i32, _P]),
@@ -175,6 +177,8 @@ def lib():
         var = os.environ.get("SGX_CONV_VARIANT")  # experiment switch of the conv kernels (sgx_debug_set_variant; 5 = 32-deep slabs)
         if var:
             _LIB.sgx_debug_set_variant(int(var))
+        if os.environ.get("SGX_FUSED_FINALIZE", "0") == "1":  # experiment switch: one-launch BatchNorm / column-sum finalize
+            _LIB.sgx_bn_set_fused_finalize(1)
         # per-problem (tile, variant) table measured by tools/conv_tune.py --emit-table: SGX_CONV_TUNING=<json> ("" / "0" = none),
         # default csrc/conv_tuning_gfx950.json when it has been committed
         tune = os.environ.get("SGX_CONV_TUNING")

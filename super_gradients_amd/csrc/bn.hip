@@ -130,8 +130,29 @@ extern "C" int32_t sgx_channel_stats_partial(const float* x, int64_t M, int32_t 
 struct ColSrc {  // what a finalize kernel sums over: either the fp32 partials or the fp64 slices
     const float* f;
     const double* d;
-    int n;  // rows per plane
+    int n;     // rows per plane
+    int coop;  // 1: the finalize kernel is launched with CO_CH x CO_RL threads per workgroup and folds the fp32 partial rows itself
 };
+// ---- one-launch finalize (experiment switch sgx_bn_set_fused_finalize, first GPU measurement pending): instead of a pre-reduction
+// launch + a finalize launch, the finalize kernel runs with 32 channels x 16 row lanes per workgroup; every lane folds its rows
+// (b = lane, lane + 16, ...) in fp64, the 16 lane sums meet in LDS and are added in lane order (deterministic, no atomics).  Worth it
+// while one workgroup can stream the partial rows of its 32 channels faster than a second launch costs: nblk <= CR_COOP_MAX.
+#define CO_CH 32
+#define CO_RL 16
+#define CR_COOP_MAX 4096
+static int g_fused_finalize = 0;
+extern "C" int32_t sgx_bn_set_fused_finalize(int32_t on) {
+    g_fused_finalize = on != 0;
+    return SGX_OK;
+}
+extern "C" int32_t sgx_bn_get_fused_finalize(void) { return g_fused_finalize; }
+static dim3 fin_grid(const ColSrc& s, int C) { return dim3(sgx_cdiv(C, s.coop ? CO_CH : 64)); }
+static dim3 fin_block(const ColSrc& s) { return dim3(s.coop ? CO_CH * CO_RL : 64); }
+// channel of this thread, whether it exists, whether this thread writes the channel's results
+#define SGX_FIN_THREAD(src, C)                                                                                            \
+    const int c = (src).coop ? blockIdx.x * CO_CH + (threadIdx.x % CO_CH) : blockIdx.x * blockDim.x + threadIdx.x;        \
+    const bool cok = c < (C);                                                                                            \
+    const bool writer = cok && (!(src).coop || threadIdx.x < CO_CH)
 __device__ __forceinline__ double colsrc_sum(const ColSrc& s, int plane, int C, int c) {
     double acc = 0.0;
     if (s.d) {
@@ -144,6 +165,25 @@ __device__ __forceinline__ double colsrc_sum(const ColSrc& s, int plane, int C, 
         for (int b = 0; b < s.n; ++b) acc += (double)p[(long)b * C];
     }
     return acc;
+}
+// column total of one plane; in coop mode EVERY thread of the workgroup must call it (barriers), all lanes return the total
+__device__ __forceinline__ double col_total(const ColSrc& s, int plane, int C, int c, bool cok) {
+    if (!s.coop) return cok ? colsrc_sum(s, plane, C, c) : 0.0;
+    __shared__ double red[CO_RL][CO_CH + 1];
+    const int cl = threadIdx.x % CO_CH, rl = threadIdx.x / CO_CH;
+    double acc = 0.0;
+    if (cok) {
+        const float* p = s.f + (long)plane * s.n * C + c;
+#pragma unroll 8
+        for (int b = rl; b < s.n; b += CO_RL) acc += (double)p[(long)b * C];
+    }
+    __syncthreads();  // the previous plane's totals have been read
+    red[rl][cl] = acc;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < CO_RL; ++k) t += red[k][cl];
+    return t;
 }
 static int cr_slices(int nblk) {
     if (nblk <= CR_DIRECT) return 0;
@@ -182,23 +222,27 @@ template <int PLANES>
 static int32_t col_prereduce(const float* partials, int nblk, int C, void* ws, int64_t ws_bytes, void* stream, ColSrc* src) {
     const int S = cr_slices(nblk);
     if (S == 0) {
-        *src = ColSrc{partials, nullptr, nblk};
+        *src = ColSrc{partials, nullptr, nblk, 0};
+        return SGX_OK;
+    }
+    if (g_fused_finalize && nblk <= CR_COOP_MAX) {
+        *src = ColSrc{partials, nullptr, nblk, 1};
         return SGX_OK;
     }
     if (!ws || ws_bytes < (int64_t)PLANES * S * C * (int64_t)sizeof(double)) SGX_FAIL(SGX_ERR_WORKSPACE, "column reduce: workspace too small (sgx_reduce_workspace)");
     const int chunk = (nblk + S - 1) / S;
     SGX_LAUNCH((colreduce_kernel<PLANES>), dim3(sgx_cdiv(C, 64), S), dim3(256), 0, stream, partials, nblk, C, S, chunk, (double*)ws);
     SGX_CHECK_LAUNCH("colreduce");
-    *src = ColSrc{nullptr, (const double*)ws, S};
+    *src = ColSrc{nullptr, (const double*)ws, S, 0};
     return SGX_OK;
 }
 
 __global__ void bn_finalize_kernel(ColSrc src, long M, int C, const float* gamma, const float* beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                                    float* scale, float* shift) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = colsrc_sum(src, 0, C, c), q = colsrc_sum(src, 1, C, c);
+    SGX_FIN_THREAD(src, C);
+    double s = col_total(src, 0, C, c, cok), q = col_total(src, 1, C, c, cok);
+    if (!writer) return;
     double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -222,7 +266,7 @@ extern "C" int32_t sgx_bn_finalize(const float* partials, int32_t nblk, int64_t 
     ColSrc src;
     int32_t rc = col_prereduce<2>(partials, nblk, C, ws, ws_bytes, stream, &src);
     if (rc) return rc;
-    SGX_LAUNCH(bn_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, src, (long)M, C, gamma, beta, eps, momentum,
+    SGX_LAUNCH(bn_finalize_kernel, fin_grid(src, C), fin_block(src), 0, stream, src, (long)M, C, gamma, beta, eps, momentum,
                running_mean, running_var, save_mean, save_invstd, scale, shift);
     SGX_CHECK_LAUNCH("bn_finalize");
     return SGX_OK;
@@ -231,16 +275,18 @@ extern "C" int32_t sgx_bn_finalize(const float* partials, int32_t nblk, int64_t 
 // ---- cross-rank (synchronised) BatchNorm: the per-channel sums leave the library as fp64 [planes][C] so that the host can
 // all-reduce them over RCCL (ONE small collective per BN layer and direction), then come back for the finalisation.
 __global__ void colsum_f64_kernel(ColSrc src, int planes, int C, double* out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    for (int p = 0; p < planes; ++p) out[(long)p * C + c] = colsrc_sum(src, p, C, c);
+    SGX_FIN_THREAD(src, C);
+    for (int p = 0; p < planes; ++p) {
+        const double t = col_total(src, p, C, c, cok);
+        if (writer) out[(long)p * C + c] = t;
+    }
 }
 extern "C" int32_t sgx_bn_reduce_sums(const float* partials, int32_t nblk, int32_t C, double* sums, void* ws, int64_t ws_bytes, void* stream) {
     SGX_CHECK_ARG(partials && sums && nblk > 0, "bn_reduce_sums: bad args");
     ColSrc src;
     int32_t rc = col_prereduce<2>(partials, nblk, C, ws, ws_bytes, stream, &src);
     if (rc) return rc;
-    SGX_LAUNCH(colsum_f64_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, src, 2, C, sums);
+    SGX_LAUNCH(colsum_f64_kernel, fin_grid(src, C), fin_block(src), 0, stream, src, 2, C, sums);
     SGX_CHECK_LAUNCH("bn_reduce_sums");
     return SGX_OK;
 }
@@ -346,9 +392,10 @@ extern "C" int32_t sgx_bn_bwd_reduce(const float* dy, int64_t dy_ld, const float
 // accumulate (the data-parallel gradient exchange adds the other ranks' later) - loc.n == 0 means "same as src"
 __global__ void bn_bwd_finalize_kernel(ColSrc src, ColSrc loc, long M, int C, const float* gamma, const float* save_mean,
                                        const float* save_invstd, float* dgamma, float* dbeta, float* coef) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double sg = colsrc_sum(src, 0, C, c), sgx = colsrc_sum(src, 1, C, c);
+    SGX_FIN_THREAD(src, C);
+    double sg = col_total(src, 0, C, c, cok), sgx = col_total(src, 1, C, c, cok);
+    // (loc: the synchronised-BatchNorm path, one fp64 row per plane, never cooperative - read by the writer lanes only)
+    if (!writer) return;
     double mean = save_mean[c], invstd = save_invstd[c], g = gamma ? (double)gamma[c] : 1.0;
     const double lsg = loc.n ? colsrc_sum(loc, 0, C, c) : sg, lsgx = loc.n ? colsrc_sum(loc, 1, C, c) : sgx;
     double sgxhat = invstd * lsgx;  // sgx is already centred: sum g*(x - mean)
@@ -368,7 +415,7 @@ extern "C" int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int6
     ColSrc src;
     int32_t rc = col_prereduce<2>(partials, nblk, C, ws, ws_bytes, stream, &src);
     if (rc) return rc;
-    SGX_LAUNCH(bn_bwd_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, src, ColSrc{nullptr, nullptr, 0}, (long)M, C, gamma, save_mean,
+    SGX_LAUNCH(bn_bwd_finalize_kernel, fin_grid(src, C), fin_block(src), 0, stream, src, ColSrc{nullptr, nullptr, 0, 0}, (long)M, C, gamma, save_mean,
                save_invstd, dgamma, dbeta, coef);
     SGX_CHECK_LAUNCH("bn_bwd_finalize");
     return SGX_OK;
@@ -376,7 +423,7 @@ extern "C" int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int6
 extern "C" int32_t sgx_bn_bwd_finalize_sums(const double* local_sums, const double* global_sums, int64_t M_total, int32_t C, const float* gamma,
                                             const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
     SGX_CHECK_ARG(local_sums && global_sums && save_mean && save_invstd && coef && M_total > 0, "bn_bwd_finalize_sums: bad args");
-    SGX_LAUNCH(bn_bwd_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, ColSrc{nullptr, global_sums, 1}, ColSrc{nullptr, local_sums, 1},
+    SGX_LAUNCH(bn_bwd_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, ColSrc{nullptr, global_sums, 1, 0}, ColSrc{nullptr, local_sums, 1, 0},
                (long)M_total, C, gamma, save_mean, save_invstd, dgamma, dbeta, coef);
     SGX_CHECK_LAUNCH("bn_bwd_finalize_sums");
     return SGX_OK;
@@ -604,9 +651,9 @@ struct ColsumF {
     }
 };
 __global__ void colsum_finalize_kernel(ColSrc src, int C, float* out, int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = colsrc_sum(src, 0, C, c);
+    SGX_FIN_THREAD(src, C);
+    double s = col_total(src, 0, C, c, cok);
+    if (!writer) return;
     out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 extern "C" int64_t sgx_colsum_workspace(int64_t M, int32_t C) {
@@ -625,7 +672,7 @@ extern "C" int32_t sgx_colsum(const float* x, int64_t ld, int64_t M, int32_t C, 
     ColSrc src;
     rc = col_prereduce<1>(ws, nblk, C, (char*)ws + part_bytes, sgx_reduce_workspace(nblk, C), stream, &src);
     if (rc) return rc;
-    SGX_LAUNCH(colsum_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, src, C, out, accumulate);
+    SGX_LAUNCH(colsum_finalize_kernel, fin_grid(src, C), fin_block(src), 0, stream, src, C, out, accumulate);
     SGX_CHECK_LAUNCH("colsum_finalize");
     return SGX_OK;
 }

@@ -785,6 +785,41 @@ def test_conv_deep_slabs(backend, case, math):
         K.set_conv_math("fp32")
 
 
+@pytest.mark.parametrize("nblk,C", [(33, 4), (512, 100), (4096, 32), (5000, 8)])
+def test_fused_finalize(backend, nblk, C):
+    """sgx_bn_set_fused_finalize (experiment switch): the BatchNorm forward / backward finalize and the column sum as ONE cooperative launch
+    must give what the pre-reduction + finalize pair gives (same fp32 partial rows, fp64 sums regrouped: equal to ~1e-7), for channel
+    counts that do not fill a workgroup, row counts around the lane count, and above the cooperative limit (5000 rows: unchanged path)."""
+    from super_gradients_amd._lib import lib
+
+    first_gpu_run_pending(backend)
+    g = torch.Generator().manual_seed(nblk + C)
+    parts = (torch.randn(2, nblk, C, generator=g) * 3 + 1).to(backend)
+    parts[1] = parts[1].abs() * 50 + 20          # sum of squares partials: keep the variance positive
+    M = nblk * 64
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(backend), torch.randn(C, generator=g).to(backend)
+    mean, invstd = torch.randn(C, generator=g).to(backend), (torch.rand(C, generator=g) + 0.5).to(backend)
+    x = torch.randn(2, 40, nblk // 8 + 3, C, generator=g).to(backend)
+    res = {}
+    try:
+        for fused in (0, 1):
+            lib().sgx_bn_set_fused_finalize(fused)
+            rm, rv = torch.zeros(C, device=backend), torch.ones(C, device=backend)
+            fwd = K.bn_finalize(parts, M, gamma, beta, 1e-3, 0.03, rm, rv)
+            coef, dg, db = torch.empty(4, C, device=backend), torch.zeros(C, device=backend), torch.zeros(C, device=backend)
+            ws = K.WORKSPACE.get(lib().sgx_reduce_workspace(nblk, C), parts.device)
+            K.check(lib().sgx_bn_bwd_finalize(K.ptr(parts), nblk, M, C, K.ptr(gamma), K.ptr(mean), K.ptr(invstd), K.ptr(dg), K.ptr(db), K.ptr(coef), K.ptr(ws),
+                                              ws.numel(), K.stream()), "sgx_bn_bwd_finalize")
+            cs = torch.zeros(C, device=backend)
+            K.colsum(x, cs, accumulate=False)
+            res[fused] = [t.cpu().clone() for t in (*fwd, rm, rv, coef, dg, db, cs)]
+        assert lib().sgx_bn_get_fused_finalize() == 1
+    finally:
+        lib().sgx_bn_set_fused_finalize(0)
+    for a, b_ in zip(res[0], res[1]):
+        assert_close(b_, a, 2e-6, f"fused finalize nblk={nblk} C={C}")
+
+
 def test_conv_tuning_table(backend):
     """sgx_conv_tuning_load: a problem listed in the table runs with the listed tile / variant (results bit-identical to the heuristic's),
     the forward statistics rows follow the table's M tile, other problems keep the heuristic, bad entries are rejected, [] clears."""

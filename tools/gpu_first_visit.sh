@@ -8,7 +8,7 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 SGX_GPU_UNVALIDATED=1 timeout 400 python -m pytest tests/test_kernels.py tests/test_blocks.py tests/test_decoding.py -m gpu -q \
-  -k "any_class_count or assignment_adversarial or distance_tie_policy or nms_degenerate_boxes or conv_every_tile_shape or conv_deep_slabs or stem_with_custom_in_channels or decod or fused_bn_backward" \
+  -k "any_class_count or assignment_adversarial or distance_tie_policy or nms_degenerate_boxes or conv_every_tile_shape or conv_deep_slabs or stem_with_custom_in_channels or decod or fused_bn_backward or fused_finalize or tuning_table or learnable_alpha" \
   > "$OUT/pytest_first_gpu_run.log" 2>&1
 echo "pytest rc=$?" >> "$OUT/pytest_first_gpu_run.log"; tail -4 "$OUT/pytest_first_gpu_run.log"
 for m in fp32 auto; do
@@ -18,6 +18,9 @@ for m in fp32 auto; do
     echo "math $m variant $v rc=$?: $(python -c "import json,sys; r=json.loads(open('$f.json').read().strip().splitlines()[-1]); print(r['value'],'img/s', r['ms_per_step'],'ms; igemm', r['roofline']['achieved'], 'TF concurrent,', r['roofline']['exclusive']['achieved'], 'TF exclusive')" 2>&1 | tail -1)"
   done
 done
+f="$OUT/bench_fused_finalize"
+SGX_FUSED_FINALIZE=1 timeout 200 python bench.py --no-nms --no-cpu-baseline ${BENCH_ARGS:-} > "$f.json" 2> "$f.err"
+echo "SGX_FUSED_FINALIZE=1 rc=$?: $(python -c "import json; r=json.loads(open('$f.json').read().strip().splitlines()[-1]); print(r['value'],'img/s', r['ms_per_step'],'ms')" 2>&1 | tail -1)"
 f="$OUT/bench_fused_bn_reduce"
 SGX_FUSE_BN_REDUCE=1 timeout 200 python bench.py --no-nms --no-cpu-baseline ${BENCH_ARGS:-} > "$f.json" 2> "$f.err"
 echo "SGX_FUSE_BN_REDUCE=1 rc=$?: $(python -c "import json; r=json.loads(open('$f.json').read().strip().splitlines()[-1]); print(r['value'],'img/s', r['ms_per_step'],'ms')" 2>&1 | tail -1)"
