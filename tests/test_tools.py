@@ -1,0 +1,62 @@
+"""Host logic of the measurement tools that can only run their measurements on the GPU box: table construction of tools/conv_tune.py and
+its round trip through the library's tuning-table loader, the timeline analysis of tools/prof_summary.py on a synthetic kernel trace."""
+import csv
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_conv_tune_table_round_trip(backend, tmp_path):
+    import conv_tune
+    from super_gradients_amd._lib import lib, load_conv_tuning
+    from util import first_gpu_run_pending
+
+    first_gpu_run_pending(backend)
+    agg = {
+        ("fwd", 32, 80, 80, 64, 64, 3, 1, 1): {(0, 0, 0): 1200.0, (64, 64, 5): 1000.0, (128, 64, 6): 1100.0},      # 17 % faster: in
+        ("dgrad", 32, 80, 80, 64, 64, 3, 1, 1): {(0, 0, 0): 900.0, (64, 64, 5): 895.0},                             # < 2 %: stays heuristic
+        ("wgrad", 32, 40, 40, 96, 96, 3, 1, 1): {(0, 0, 0): 1000.0, (96, 128, 2048): 800.0, (64, 64, 8192): float("inf")},
+        ("fwd", 32, 20, 20, 192, 192, 3, 1, 1): {(0, 0, 0): 400.0, (0, 0, 5): 300.0},                               # heuristic tile, variant 5
+    }
+    entries, meta = conv_tune.build_table(agg, 0.02)
+    assert {(e["kind"], e["bm"], e["bn"], e["variant"]) for e in entries} == {("fwd", 64, 64, 5), ("wgrad", 96, 128, 2048), ("fwd", 0, 0, 5)}
+    assert meta["ms_per_step_heuristic"] == 3.5 and meta["ms_per_step_table"] == 3.0
+    f = tmp_path / "table.json"
+    json.dump(dict(meta=meta, entries=entries), open(f, "w"))
+    try:
+        assert load_conv_tuning(str(f)) == 3 and lib().sgx_conv_tuning_size() == 3
+    finally:
+        load_conv_tuning([])
+
+
+def test_prof_timeline_on_synthetic_trace(tmp_path, capsys):
+    import prof_summary
+
+    rows, t = [], 1_000_000
+    for i in range(20):
+        rows.append(dict(Queue_Id=1, Kernel_Name=f"void igemm_kernel<{i % 2}>(IgemmParams)", Start_Timestamp=t, End_Timestamp=t + 10_000))
+        if i % 4 == 0:  # a concurrent side-stream kernel covering half of the main one
+            rows.append(dict(Queue_Id=2, Kernel_Name="void wgrad_kernel<64>(WgradParams)", Start_Timestamp=t + 5_000, End_Timestamp=t + 10_000))
+        t += 10_000 + 3_000  # 3 us idle between main-stream kernels
+    d = tmp_path / "trace"
+    d.mkdir()
+    with open(d / "x_kernel_trace.csv", "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    prof_summary.timeline(str(d))
+    out = capsys.readouterr().out
+    assert "25 dispatches" in out
+    import re
+
+    def ms(prefix):
+        line = [l for l in out.splitlines() if l.startswith(prefix)][0]
+        return float(re.search(r"([0-9.]+) ms", line).group(1))
+
+    assert abs(ms("device idle") - 19 * 3e-3) < 1e-6          # 19 gaps of 3 us
+    assert abs(ms("two or more") - 5 * 5e-3) < 1e-6           # 5 overlaps of 5 us

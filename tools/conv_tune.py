@@ -13,6 +13,24 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
+def build_table(agg, min_gain):
+    """agg: {(kind, N, H, W, C, K, R, stride, pad): {(bm, bn, variant): calls x us per step}} with (0, 0, 0) = the built-in heuristic.
+    -> (entries for _lib.load_conv_tuning, meta): the fastest configuration of every problem that beats the heuristic by min_gain."""
+    entries, t_heur, t_tab = [], 0.0, 0.0
+    for pk, cfgs in agg.items():
+        cfg, t = min(cfgs.items(), key=lambda kv: kv[1])
+        heur = cfgs[(0, 0, 0)]
+        t_heur += heur
+        if t < (1.0 - min_gain) * heur:
+            kind, n, h, w, c, k_, r, stride, pad = pk
+            entries.append(dict(kind=kind, N=n, H=h, W=w, C=c, K=k_, R=r, stride=stride, pad=pad, bm=cfg[0], bn=cfg[1], variant=cfg[2],
+                                us_heuristic=round(heur, 1), us_table=round(t, 1)))
+            t_tab += t
+        else:
+            t_tab += heur
+    return entries, dict(ms_per_step_heuristic=round(t_heur / 1e3, 3), ms_per_step_table=round(t_tab / 1e3, 3), min_gain=min_gain)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="s")
@@ -113,23 +131,10 @@ def main():
     if args.emit_table:
         import json
 
-        entries, t_heur, t_tab = [], 0.0, 0.0
-        for pk, cfgs in agg.items():
-            cfg, t = min(cfgs.items(), key=lambda kv: kv[1])
-            heur = cfgs[(0, 0, 0)]
-            t_heur += heur
-            if t < (1.0 - args.min_gain) * heur:
-                kind, n, h, w, c, k_, r, stride, pad = pk
-                entries.append(dict(kind=kind, N=n, H=h, W=w, C=c, K=k_, R=r, stride=stride, pad=pad, bm=cfg[0], bn=cfg[1], variant=cfg[2],
-                                    us_heuristic=round(heur, 1), us_table=round(t, 1)))
-                t_tab += t
-            else:
-                t_tab += heur
-        meta = dict(model=f"yolo_nas_{args.model}", batch=args.batch, size=args.size, conv_math=K.get_conv_math(),
-                    ms_per_step_heuristic=round(t_heur / 1e3, 3), ms_per_step_table=round(t_tab / 1e3, 3), min_gain=args.min_gain)
+        entries, meta = build_table(agg, args.min_gain)
+        meta.update(model=f"yolo_nas_{args.model}", batch=args.batch, size=args.size, conv_math=K.get_conv_math())
         json.dump(dict(meta=meta, entries=entries), open(args.emit_table, "w"), indent=1)
         print(f"# tuning table: {len(entries)} of {len(agg)} problems, {meta['ms_per_step_heuristic']} -> {meta['ms_per_step_table']} ms/step -> {args.emit_table}")
-
 
 if __name__ == "__main__":
     main()
