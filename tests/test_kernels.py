@@ -749,6 +749,8 @@ def test_nms_degenerate_boxes(backend):
 @pytest.mark.parametrize("case", [(1, 5, 4, 32, 40, 3, 1, 1), (1, 6, 6, 32, 32, 3, 2, 1), (1, 5, 9, 96, 40, 1, 1, 0)])
 @pytest.mark.parametrize("math", ["fp32", "bf16x3"])
 def test_conv_deep_slabs(backend, case, math):
+    if math == "bf16x3" and case[5] != 3:
+        pytest.skip("bf16x3 shares the slab addressing with fp32: one 3x3 case (stride 1 / 2) covers its plane layout")
     """32-deep slabs (igemm_kernel<..., KD = 32>, experiment switches sgx_debug_set_variant(5 | 6): one / two LDS buffers): every tile shape on problems with ragged
     edges in both tile dimensions, 3x3 / stride-2 (parity-class data gradient) / 1x1.  The reduction runs in the same order as with
     16-deep slabs, so the results must be BIT-identical to the default kernel's, not just close."""
@@ -765,7 +767,7 @@ def test_conv_deep_slabs(backend, case, math):
     K.set_conv_math(math)
     try:
         # (every instantiated tile compiles from the same template; tile plumbing itself is test_conv_every_tile_shape's job)
-        tiles = [(64, 64), (128, 32), (64, 96), (128, 128)] if r == 3 and s == 1 else [(64, 64)] if s == 2 else [(64, 32), (128, 96)]
+        tiles = [(64, 64), (128, 32), (64, 96)] if r == 3 and s == 1 else [(64, 64)] if s == 2 else [(64, 32), (128, 96)]
         for bm, bn in tiles:
             lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
             res = {}
@@ -785,11 +787,11 @@ def test_conv_deep_slabs(backend, case, math):
         K.set_conv_math("fp32")
 
 
-@pytest.mark.parametrize("nblk,C", [(33, 4), (512, 100), (4096, 32), (5000, 8)])
+@pytest.mark.parametrize("nblk,C", [(33, 4), (300, 36), (4096, 8), (4200, 4)])
 def test_fused_finalize(backend, nblk, C):
     """sgx_bn_set_fused_finalize (experiment switch): the BatchNorm forward / backward finalize and the column sum as ONE cooperative launch
     must give what the pre-reduction + finalize pair gives (same fp32 partial rows, fp64 sums regrouped: equal to ~1e-7), for channel
-    counts that do not fill a workgroup, row counts around the lane count, and above the cooperative limit (5000 rows: unchanged path)."""
+    counts that do not fill a workgroup, row counts around the lane count, at and above the cooperative limit (4096 rows; 4200: unchanged path)."""
     from super_gradients_amd._lib import lib
 
     first_gpu_run_pending(backend)
