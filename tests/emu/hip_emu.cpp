@@ -11,66 +11,6 @@ thread_local unsigned t_xgen;
 
 static std::mutex g_launch_mutex;
 
-// Persistent worker pool: creating 256-1024 OS threads per kernel launch dominated the run time of the whole-model tests (thousands of
-// launches).  Workers park on their OWN condition variable (a launch wakes exactly the threads it needs), live for the life of the
-// process and are never joined; the pool state is heap-allocated and intentionally leaked so that nothing is destroyed under a parked
-// thread at exit.  Launches are serialised by g_launch_mutex, so there is one job at a time.
-namespace {
-struct PoolWorker {
-    std::mutex m;
-    std::condition_variable cv;
-    unsigned long ticket = 0;  // incremented by launch() to hand this worker the current job
-};
-struct Pool {
-    std::vector<PoolWorker*> workers;
-    const std::function<void(int)>* job = nullptr;
-    std::mutex done_m;
-    std::condition_variable done_cv;
-    int remaining = 0;
-};
-Pool* g_pool = nullptr;
-
-void pool_thread(Pool* pool, PoolWorker* w, int tid) {
-    unsigned long seen = 0;
-    for (;;) {
-        {
-            std::unique_lock<std::mutex> lk(w->m);
-            w->cv.wait(lk, [&] { return w->ticket != seen; });
-            seen = w->ticket;
-        }
-        (*pool->job)(tid);
-        std::lock_guard<std::mutex> lk(pool->done_m);
-        if (--pool->remaining == 0) pool->done_cv.notify_one();
-    }
-}
-
-void run_on_pool(int nthreads, const std::function<void(int)>& fn) {
-    if (!g_pool) g_pool = new Pool();
-    Pool* pool = g_pool;
-    while ((int)pool->workers.size() < nthreads) {
-        PoolWorker* w = new PoolWorker();
-        const int tid = (int)pool->workers.size();
-        pool->workers.push_back(w);
-        std::thread(pool_thread, pool, w, tid).detach();
-    }
-    pool->job = &fn;
-    {
-        std::lock_guard<std::mutex> lk(pool->done_m);
-        pool->remaining = nthreads;
-    }
-    for (int t = 0; t < nthreads; ++t) {
-        PoolWorker* w = pool->workers[t];
-        {
-            std::lock_guard<std::mutex> lk(w->m);
-            ++w->ticket;
-        }
-        w->cv.notify_one();
-    }
-    std::unique_lock<std::mutex> lk(pool->done_m);
-    pool->done_cv.wait(lk, [&] { return pool->remaining == 0; });
-}
-}  // namespace
-
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
     std::lock_guard<std::mutex> lk(g_launch_mutex);
     const int nthreads = (int)(block.x * block.y * block.z);
@@ -89,7 +29,7 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
     }
     Barrier outer;
     outer.reset(nthreads);
-    const std::function<void(int)> worker = [&](int tid) {
+    auto worker = [&](int tid) {
         t_blockDim = block;
         t_gridDim = grid;
         t_threadIdx.x = tid % block.x;
@@ -116,7 +56,10 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
             outer.wait();
         }
     };
-    run_on_pool(nthreads, worker);
+    std::vector<std::thread> th;
+    th.reserve(nthreads);
+    for (int t = 0; t < nthreads; ++t) th.emplace_back(worker, t);
+    for (auto& t : th) t.join();
 }
 
 }  // namespace sgx_emu
