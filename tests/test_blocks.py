@@ -400,3 +400,51 @@ def test_stem_with_custom_in_channels(backend):
         rg = rp[name].grad   # (gradients that are analytically zero in front of a training-mode BatchNorm are judged against the largest one)
         e = float((p.grad.cpu().double() - rg.double()).abs().max()) / max(float(rg.abs().max()), 1e-2 * gmax)
         assert e <= 1e-4, f"grad {name}: {e:.3e}"
+
+
+def test_experiment_switches_compose(backend, monkeypatch):
+    """All experiment switches at once - 32-deep conv slabs (variant 5 / 6), a tuning-table entry, the fused BatchNorm-backward sweep and the
+    one-launch finalize - on a QARepVGG chain whose channel counts make every switch engage (C % 32 == 0): forward, input gradient and every
+    parameter gradient stay within rounding of the default path (the conv switches are bit-exact, the finalize regroups fp64 sums)."""
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd._lib import lib, load_conv_tuning
+    from super_gradients_amd.modules import QARepVGGBlock
+    from super_gradients_amd.modules.engine import SgxNetwork
+
+    first_gpu_run_pending(backend)
+
+    class Chain(SgxNetwork):
+        def __init__(self):
+            super().__init__()
+            self.b1 = QARepVGGBlock(32, 32, stride=1)
+            self.b2 = QARepVGGBlock(32, 64, stride=2)
+
+    n, h, w = 2, 6, 5
+    x = to_nhwc(torch.randn(n, 32, h, w, generator=torch.Generator().manual_seed(0)) + 0.5, backend)
+    dy = to_nhwc(torch.randn(n, 64, 3, 3, generator=torch.Generator().manual_seed(1)), backend)
+
+    def run():
+        torch.manual_seed(11)
+        net = Chain()
+        net.materialize(backend).train()
+        y = net.b2.fwd(net.b1.fwd(x))
+        dx = net.b1.bwd(net.b2.bwd(dy))
+        net.join_side()
+        return [y.cpu().clone(), dx.cpu().clone(), net.g_arena.buf.cpu().clone()]
+
+    base = run()
+    key = dict(N=n, H=h, W=w, C=32, K=32, R=3, stride=1, pad=1)
+    try:
+        for variant in (5, 6):
+            lib().sgx_debug_set_variant(variant)
+            lib().sgx_bn_set_fused_finalize(1)
+            monkeypatch.setattr(K, "FUSE_BN_BWD_REDUCE", True)
+            load_conv_tuning([dict(kind="fwd", bm=128, bn=32, variant=0, **key), dict(kind="dgrad", bm=64, bn=32, variant=0, **key),
+                              dict(kind="wgrad", bm=32, bn=96, variant=2048, **key)])
+            got = run()
+            for a, b, what in zip(base, got, ("forward", "input gradient", "parameter gradients")):
+                assert_close(b, a, 2e-5, f"variant {variant}: {what}")
+    finally:
+        lib().sgx_debug_set_variant(0)
+        lib().sgx_bn_set_fused_finalize(0)
+        load_conv_tuning([])

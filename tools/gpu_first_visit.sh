@@ -8,7 +8,7 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 SGX_GPU_UNVALIDATED=1 timeout 400 python -m pytest tests/test_kernels.py tests/test_blocks.py tests/test_decoding.py tests/test_tools.py -m gpu -q \
-  -k "any_class_count or assignment_adversarial or distance_tie_policy or nms_degenerate_boxes or conv_every_tile_shape or conv_deep_slabs or stem_with_custom_in_channels or decod or fused_bn_backward or fused_finalize or tuning_table or learnable_alpha or round_trip" \
+  -k "any_class_count or assignment_adversarial or distance_tie_policy or nms_degenerate_boxes or conv_every_tile_shape or conv_deep_slabs or stem_with_custom_in_channels or decod or fused_bn_backward or fused_finalize or tuning_table or learnable_alpha or round_trip or switches_compose" \
   > "$OUT/pytest_first_gpu_run.log" 2>&1
 echo "pytest rc=$?" >> "$OUT/pytest_first_gpu_run.log"; tail -4 "$OUT/pytest_first_gpu_run.log"
 for m in fp32 auto; do
