@@ -97,6 +97,7 @@ class GradientAllReducer:
             raise RuntimeError("gradient buckets must tile the arena")
         self.pending = []
         self.issued = set()
+        self.from_side = os.environ.get("SGX_ALLREDUCE_FROM_SIDE", "1") != "0"  # 0: join the side stream into the current one per bucket
         self.grad_scale = torch.full((1,), 1.0 / self.world, device=net.g_arena.buf.device)
         net._grad_ready = self.ready
         net._post_backward_hook = self.finish
@@ -107,8 +108,21 @@ class GradientAllReducer:
             return
         a, b = self.ranges[prefix]
         self.issued.add(prefix)
-        self.net.join_side()  # the bucket's weight gradients were forked onto the side stream
-        self.pending.append(dist.all_reduce(self.net.g_arena.buf[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        buf = self.net.g_arena.buf[a:b]
+        side = getattr(self.net, "side_stream", None)
+        if side is None or not self.from_side:
+            self.net.join_side()  # the bucket's weight gradients were forked onto the side stream
+            self.pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+            return
+        # The bucket's weight gradients were written on the side stream, its BatchNorm / bias gradients on the current one.  Joining the
+        # side stream into the current one here would stall the data-gradient chain (everything the rest of backward depends on) behind
+        # the weight-gradient backlog at every bucket boundary - an overlap the single-GPU step keeps until the end of backward.  Instead
+        # the SIDE stream waits for the current one and issues the collective: RCCL's stream then waits for both producers, later
+        # weight gradients (other arena ranges) keep flowing on the side stream beside the collective, and the current stream waits for
+        # nothing until finish().
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
         """End of backward: exchange whatever the network did not announce itself (a network that never calls `ready` still
