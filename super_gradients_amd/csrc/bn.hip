@@ -294,7 +294,7 @@ extern "C" int32_t sgx_bn_finalize_sums(const double* sums, int64_t M, int32_t C
                                         float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale, float* shift,
                                         void* stream) {
     SGX_CHECK_ARG(sums && scale && shift && M > 0, "bn_finalize_sums: bad args");
-    ColSrc src{nullptr, sums, 1};
+    ColSrc src{nullptr, sums, 1, 0};
     SGX_LAUNCH(bn_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, src, (long)M, C, gamma, beta, eps, momentum, running_mean, running_var,
                save_mean, save_invstd, scale, shift);
     SGX_CHECK_LAUNCH("bn_finalize_sums");
