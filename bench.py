@@ -321,9 +321,11 @@ def main():
             "config": {"workload": f"{family}-{args.model.upper()} synthetic COCO {args.size}x{args.size}, bs={args.batch}/GPU, PPYoloELoss(TAL)+AdamW"
                                    + ("" if args.no_ema else "+EMA") + ", random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
+                       # conv_math "fp32" = fp32 matrix pipe (default; SGX_CONV_MATH=auto|bf16x3 opts into the split arithmetic); conv_variant /
+                       # conv_tuning_entries: experiment switch and per-problem (tile, variant) table (tools/conv_tune.py --emit-table), 0 = heuristics
                        "conv_math": K.get_conv_math(), "conv_variant": int(os.environ.get("SGX_CONV_VARIANT") or 0),
                        "conv_tuning_entries": int(lib().sgx_conv_tuning_size()),
-                       "allreduce_from_side_stream": bool(reducer.from_side) if world > 1 else None},  # per-problem (tile, variant) table, tools/conv_tune.py --emit-table  # "fp32" = fp32 matrix pipe (default); SGX_CONV_MATH=auto|bf16x3 opts into the split arithmetic
+                       "allreduce_from_side_stream": bool(reducer.from_side) if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data gradient, "
                                                     + ("v_mfma_f32_32x32x2_f32)" if K.get_conv_math() == "fp32" else "v_mfma_f32_32x32x16_bf16 x6 / v_mfma_f32_32x32x2_f32 per problem)"),
                          "achieved": round(ig_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_tf / PEAK_FP32_MFMA_TFLOPS, 4),
