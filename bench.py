@@ -86,6 +86,34 @@ def cpu_baseline(model, size, seconds_budget=25.0, family="yolo_nas"):
                       f"{threads} threads of {cores} host cores"}
 
 
+def oracle_loss_check(net, crit, x, targets, model, family):
+    """Parity of the benchmarked workload itself (outside the timed region): the HIP forward + PPYoloELoss of THIS batch at the
+    initial weights against the CPU oracle (the reference's arithmetic) with the same weights.  Bar: 1e-4 relative on the loss items."""
+    import torch
+    from oracle.ppyolo_loss import PPYoloELossOracle
+
+    if family == "ppyoloe":
+        from oracle.pp_yolo_e import PPYoloE as Oracle
+    else:
+        from oracle.yolo_nas import YoloNAS as Oracle
+    t0 = time.time()
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    ref = Oracle(model, num_classes=80)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+    ref.train()
+    with torch.no_grad():
+        _, items_ref = PPYoloELossOracle(80, use_static_assigner=False)(ref(x.cpu()), targets.cpu())
+        _, items = crit(net(x), targets)
+    items = items.cpu()
+    err = float((items - items_ref).abs().max() / items_ref.abs().max())
+    rec = {"hip": [round(float(v), 6) for v in items], "oracle": [round(float(v), 6) for v in items_ref], "max_rel_err": float(f"{err:.3e}"),
+           "tolerance": 1e-4, "seconds": round(time.time() - t0, 1),
+           "what": "loss items [cls, iou, dfl, total] of the benchmarked batch at the initial weights: HIP path vs CPU oracle (same weights, same batch)"}
+    if not err <= 1e-4:
+        raise RuntimeError(f"bench: HIP loss differs from the CPU oracle on the benchmarked batch: {rec}")
+    return rec
+
+
 def nms_leg(device, iters=100, warmup=10):
     """BASELINE.json's second metric: NMS boxes/s.  SURVEY 8(d) config-5 style input: B=32 images, L=8400 anchors, 80 classes, scores
     ~ Beta(0.5,0.5)^4 and boxes clustered around 30 centres so that every image has >= 1000 candidates above the recipe's
@@ -243,6 +271,11 @@ def main():
     ema = None if args.no_ema else ModelEMA.from_params(net, decay=0.9997, decay_type="threshold")
     x, targets = synthetic_batch(args.batch, args.size, 42 + rank, device)
 
+    # parity of the benchmarked workload itself (rank 0 of a single-GPU run; skipped together with the CPU baseline)
+    loss_check = None
+    if world == 1 and not args.no_cpu_baseline:
+        loss_check = oracle_loss_check(net, crit, x, targets, args.model, "ppyoloe" if args.workload == "ppyoloe" else "yolo_nas")
+
     state = {"step": 0}
 
     def step():
@@ -265,7 +298,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    K.prof_enable(True)
+    K.prof_enable(os.environ.get("SGX_NO_PROF") != "1")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -348,6 +381,8 @@ def main():
                          "step_mfma_frac": round((per_gpu * TRAIN_GFLOP_PER_IMG[args.model] * (args.size / 640.0) ** 2 / 1e3 if args.workload == "yolo_nas"
                                                   else (ig_fl + wg_fl) / args.steps / (dt / args.steps) / 1e12) / PEAK_FP32_MFMA_TFLOPS, 4)},
         }
+        if loss_check is not None:
+            rec["config"]["loss_check_vs_oracle"] = loss_check
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(args.model, args.size, family="ppyoloe" if args.workload == "ppyoloe" else "yolo_nas")
         if not args.no_nms and world == 1:

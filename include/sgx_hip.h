@@ -208,11 +208,6 @@ int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int64_t M, int3
 int32_t sgx_bn_bwd_apply(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale,
                          const float* shift, const float* coef, float* dx, int64_t dx_ld, float* g_out, int64_t g_ld,
                          int64_t M, int32_t C, int32_t act, void* stream);
-/* sgx_bn_bwd_apply fused with the sgx_bn_bwd_reduce (act = none) of the BatchNorm that consumes dx as its upstream gradient:
- * next_partials [2][sgx_stats_blocks(M)][C] = what sgx_bn_bwd_reduce(dx, next_x, ..., next_mean) would write.  next_x must not alias dx. */
-int32_t sgx_bn_bwd_apply_reduce(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale, const float* shift,
-                                const float* coef, float* dx, int64_t dx_ld, int64_t M, int32_t C, int32_t act, const float* next_x,
-                                int64_t next_x_ld, const float* next_mean, float* next_partials, void* stream);
 /* Experiment switch (first GPU measurement pending): the finalize stages above (sgx_bn_finalize, sgx_bn_bwd_finalize, sgx_bn_reduce_sums,
  * sgx_colsum) as ONE cooperative launch (32 channels x 16 row lanes per workgroup fold the fp32 partial rows in fp64, fixed order) instead
  * of a pre-reduction launch + a finalize launch, for up to 4096 partial rows.  Same sums up to fp64 regrouping.  Not thread-safe.   */

@@ -101,7 +101,6 @@ PROTOTYPES = {
     "sgx_bn_bwd_reduce": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _i64, _i32, _i32, _P, _P]),
     "sgx_bn_bwd_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
     "sgx_bn_bwd_apply": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _P, _i64, _P, _i64, _i64, _i32, _i32, _P]),
-    "sgx_bn_bwd_apply_reduce": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _P, _i64, _i64, _i32, _i32, _P, _i64, _P, _P, _P]),
     "sgx_bn_set_fused_finalize": (_i32, [_i32]),
     "sgx_bn_get_fused_finalize": (_i32, []),
     "sgx_dot_partial": (_i32, [_P, _i64, _P, _i64, _i64, _i32, _P, _P]),

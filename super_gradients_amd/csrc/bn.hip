@@ -455,38 +455,6 @@ extern "C" int32_t sgx_bn_bwd_apply(const float* dy, int64_t dy_ld, const float*
     return run_sweep<BnBwdApplyF, 0>(f, M, C, nullptr, stream, "bn_bwd_apply");
 }
 
-// BN backward apply of layer A fused with the backward REDUCE of the BatchNorm B that consumes A's input gradient without an activation
-// in between (QARepVGGBlock: post_bn's dx IS branch_3x3.bn's upstream gradient): the sums B needs - sum dx and sum dx * (xB - meanB) -
-// are taken from the registers that hold dx, so B's own reduce sweep (one more read of dx and of xB) becomes one extra read of xB here.
-// Same row partition and accumulation order as sgx_bn_bwd_reduce on the written dx: the partials are the same numbers.
-struct BnBwdApplyReduceF {
-    BnBwdApplyF a;
-    const float* nx; long nx_ld; const float* nmean;
-    struct In { float4 d, v, n; };
-    __device__ In load(long r, int c) const { return In{sgx_ld4(a.dy + r * a.dy_ld + c), sgx_ld4(a.x + r * a.x_ld + c), sgx_ld4(nx + r * nx_ld + c)}; }
-    __device__ void apply(long r, int c, const In& in, float4& q0, float4& q1) const {
-        const float4 d = in.d, v = in.v, n = in.n;
-        float4 s = sgx_ld4(a.scale + c), t = sgx_ld4(a.shift + c);
-        float4 c1 = sgx_ld4(a.coef + c), mg = sgx_ld4(a.coef + a.C + c), k = sgx_ld4(a.coef + 2 * a.C + c), mu = sgx_ld4(a.coef + 3 * a.C + c);
-        float4 nmu = sgx_ld4(nmean + c);
-        float4 g = make_float4(bn_masked(d.x, v.x, s.x, t.x, a.act), bn_masked(d.y, v.y, s.y, t.y, a.act),
-                               bn_masked(d.z, v.z, s.z, t.z, a.act), bn_masked(d.w, v.w, s.w, t.w, a.act));
-        float4 o = make_float4(c1.x * ((g.x - mg.x) - (v.x - mu.x) * k.x), c1.y * ((g.y - mg.y) - (v.y - mu.y) * k.y),
-                               c1.z * ((g.z - mg.z) - (v.z - mu.z) * k.z), c1.w * ((g.w - mg.w) - (v.w - mu.w) * k.w));
-        sgx_st4(a.dx + r * a.dx_ld + c, o);
-        q0.x += o.x; q0.y += o.y; q0.z += o.z; q0.w += o.w;
-        q1.x += o.x * (n.x - nmu.x); q1.y += o.y * (n.y - nmu.y); q1.z += o.z * (n.z - nmu.z); q1.w += o.w * (n.w - nmu.w);
-    }
-};
-extern "C" int32_t sgx_bn_bwd_apply_reduce(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale, const float* shift,
-                                           const float* coef, float* dx, int64_t dx_ld, int64_t M, int32_t C, int32_t act, const float* next_x,
-                                           int64_t next_x_ld, const float* next_mean, float* next_partials, void* stream) {
-    SGX_CHECK_ARG(dy && x && scale && shift && coef && dx && next_x && next_mean && next_partials, "bn_bwd_apply_reduce: null pointer");
-    SGX_CHECK_ARG(next_x != dx, "bn_bwd_apply_reduce: the next layer's input must not alias dx");
-    BnBwdApplyReduceF f{BnBwdApplyF{dy, dy_ld, x, x_ld, scale, shift, coef, C, dx, dx_ld, nullptr, 0, act}, next_x, next_x_ld, next_mean};
-    return run_sweep<BnBwdApplyReduceF, 2>(f, M, C, next_partials, stream, "bn_bwd_apply_reduce");
-}
-
 // ---------------------------------------------------------------------------------------------
 struct DotF {
     const float* a; long a_ld; const float* b; long b_ld;

@@ -259,7 +259,7 @@ __device__ __forceinline__ sgx_f32x16 sgx_mfma_bf16(const uint4& a, const uint4&
 // cycles) ahead instead of 8.  (32, 1): ONE LDS buffer (18 KB for 64x64: occupancy stays VGPR-bound, 7 workgroups per CU) with a
 // write-after-barrier hand-over - two barriers per slab, i.e. as many per FLOP as (16, 2).  (32, 2): two buffers (37 KB for 64x64:
 // 4 workgroups per CU), one barrier per slab - half the barriers per FLOP at lower occupancy.
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2>
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && (NBUF == 1 || NBUF == 2)), "32-deep slabs: channel-chunked K axis only");
     constexpr int NTH = WM * WN * 64;   // threads per workgroup
@@ -566,7 +566,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             __syncthreads();
             continue;
         }
-        if (kt + 1 < nkt) load_tile();  // global loads in flight under the MFMA block
+        if (ABL == 4) {  // LAB: MFMA only
+            float af = ra[0].x, bf = rb[0].x;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[0][0], 0, 0, 0);
+            continue;
+        }
+        if (kt + 1 < nkt && (ABL < 1 || ABL == 3)) load_tile();  // global loads in flight under the MFMA block
 
         if (MATH == 1) {
             // (a second register stage - slabs fetched two iterations ahead, counted vmcnt - was measured: no gain, r1z/r1z2;
@@ -577,9 +583,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             continue;
         }
         compute_f32(buf, 0);
-        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        if (kt + 1 < nkt && (ABL < 2 || ABL == 3)) store_tile(buf ^ 1);
         __syncthreads();
     }
+    if (ABL == 3 && p.M > 0) return;  // LAB: no epilogue
 
     if (MATH == 1) {
 #pragma unroll
@@ -755,7 +762,7 @@ extern "C" int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n) {
                               (e[9] == 0) == (e[10] == 0),  // all 16 tiles of {32, 64, 96, 128}^2 are instantiated
                           "conv_tuning_load: entry %d: no weight-gradient kernel (tile %dx%d, split target %d)", i, e[9], e[10], e[11]);
         else
-            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && e[11] >= 0 && e[11] <= 6,
+            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && e[11] >= 0 && e[11] <= 7,
                           "conv_tuning_load: entry %d: no kernel (tile %dx%d, variant %d)", i, e[9], e[10], e[11]);
         m[std::array<int, 9>{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8]}] = TuneVal{e[9], e[10], e[11]};
     }
@@ -787,10 +794,11 @@ static TileCfg pick_tile_heuristic(long M, int N) {
     return TileCfg{M >= 16384 ? 128 : 64, 32};
 }
 
-// 32-deep slabs are an experiment switch until their first measurement on the GPU: sgx_debug_set_variant(5 | 6) / SGX_CONV_VARIANT
-// (5: one LDS buffer, 6: two), for both arithmetic modes.  Eligible: channel-chunked K axis, C a multiple of 32 (a ragged last chunk
-// would multiply zeros for up to half a slab).
-static bool igemm_deep_slabs(const IgemmParams& p) { return (conv_variant() == 5 || conv_variant() == 6) && p.C % 32 == 0; }
+// 32-deep slabs (one LDS buffer) are the default wherever they apply - channel-chunked K axis, C a multiple of 32 (a ragged last chunk
+// would multiply zeros for up to half a slab): measured on MI355X (profiles/r2d_conv_tune_variants.txt) they win on 3x3 and deep 1x1
+// layers alike (+5-10 %, whole-line loads, half the load instructions per FLOP).  Variant 6 = two LDS buffers (lower occupancy: loses
+// except on a few 128-wide tiles), variant 7 = the 16-deep loop; both reachable through the tuning table / sgx_debug_set_variant.
+static bool igemm_deep_slabs(const IgemmParams& p) { return conv_variant() != 7 && conv_variant() < 10 && p.C % 32 == 0; }
 // dispatch over the eight non-flat tile shapes for one (MATH, KD, NBUF)
 #define SGX_IGEMM_TILES(MATH_, KD_, NBUF_)                                                                  \
     do {                                                                                                    \
@@ -804,14 +812,14 @@ static bool igemm_deep_slabs(const IgemmParams& p) { return (conv_variant() == 5
         else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, MATH_, KD_, NBUF_>(p, stream);     \
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no tile %dx%d (math %d, %d-deep slabs)", bm, bn, MATH_, KD_); \
     } while (0)
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2>
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int ABL = 0>
 static void launch_igemm(IgemmParams& p, void* stream) {
     p.mt = sgx_cdiv(p.M, BM);
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
     p.chunk = sgx_cdiv(p.nblk, 8);
     int grid = p.chunk * 8;
-    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
+    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF, ABL>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
 }
 
 static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
@@ -840,7 +848,7 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         else if (flat && bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true, 1>(p, stream);
         else if (flat) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (bf16x3): no flat tile %dx%d", bm, bn);
         else if (igemm_deep_slabs(p)) {
-            if (var == 5) SGX_IGEMM_TILES(1, 32, 1);
+            if (var != 6) SGX_IGEMM_TILES(1, 32, 1);
             else SGX_IGEMM_TILES(1, 32, 2);
         } else if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, 1>(p, stream);  // 52 KB of LDS with the unpadded planes
         else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, 1>(p, stream);
@@ -858,10 +866,14 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, true>(p, stream);
         else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true>(p, stream);
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no flat tile %dx%d", bm, bn);
-    } else if (igemm_deep_slabs(p)) {  // 32-deep slabs (see igemm_kernel): whole-line loads
-        if (var == 5) SGX_IGEMM_TILES(0, 32, 1);
+    } else if (igemm_deep_slabs(p) && !(var >= 1 && var <= 4)) {  // 32-deep slabs (see igemm_kernel): whole-line loads
+        if (var != 6) SGX_IGEMM_TILES(0, 32, 1);
         else SGX_IGEMM_TILES(0, 32, 2);
-    } else if (var == 1 && bm == 64 && bn == 64) launch_igemm<64, 64, 1, 2, false>(p, stream);   // 2 waves x (64x32)
+    } else if (var == 11 && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, 16, 2, 1>(p, stream);
+    else if (var == 12 && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, 16, 2, 2>(p, stream);
+    else if (var == 13 && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, 16, 2, 3>(p, stream);
+    else if (var == 14 && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, 16, 2, 4>(p, stream);
+    else if (var == 1 && bm == 64 && bn == 64) launch_igemm<64, 64, 1, 2, false>(p, stream);   // 2 waves x (64x32)
     else if (var == 2 && bm == 128 && bn == 64) launch_igemm<128, 64, 4, 2, false>(p, stream);   // 8 waves x (32x32)
     else if (var == 3 && bm == 128 && bn == 128) launch_igemm<128, 128, 4, 2, false>(p, stream); // 8 waves x (32x64)
     else if (var == 4 && bm == 64 && bn == 128) launch_igemm<64, 128, 2, 4, false>(p, stream);   // 8 waves x (32x32)

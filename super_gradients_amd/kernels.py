@@ -346,18 +346,10 @@ def affine_act(x, scale=None, shift=None, r1=None, a1=1.0, a1_dev=None, r2=None,
     return (out, parts) if want_stats else out
 
 
-# experiment switch (first GPU measurement pending): fuse a BatchNorm's backward reduce into the apply sweep of the layer that produces
-# its upstream gradient (QARepVGGBlock: post_bn -> branch_3x3.bn), sgx_bn_bwd_apply_reduce
-FUSE_BN_BWD_REDUCE = os.environ.get("SGX_FUSE_BN_REDUCE", "0") == "1"
-
-
-def bn_bwd(dy, x, scale, shift, gamma, save_mean, save_invstd, dgamma, dbeta, act=None, dx_out=None, want_g=False, sync=False, parts=None,
-           next_reduce=None):
+def bn_bwd(dy, x, scale, shift, gamma, save_mean, save_invstd, dgamma, dbeta, act=None, dx_out=None, want_g=False, sync=False, parts=None):
     """Full BN(+activation) backward: returns dx (and the masked upstream gradient g if want_g).
     dgamma/dbeta (views into the gradient arena) are accumulated in place.
-    parts: this layer's reduce partials when an earlier sweep already produced them (skips the reduce sweep).
-    next_reduce = (next_x, next_mean): also return the reduce partials of the BatchNorm (no activation) whose upstream gradient is this dx,
-    taken inside the apply sweep -> (dx, next_parts)."""
+    parts: this layer's reduce partials when an earlier kernel already produced them (skips the reduce sweep)."""
     M, ld = rows(x)
     C = x.shape[3]
     dl = rows(dy)[1]
@@ -378,14 +370,6 @@ def bn_bwd(dy, x, scale, shift, gamma, save_mean, save_invstd, dgamma, dbeta, ac
         check(lib().sgx_bn_bwd_finalize(ptr(parts), parts.shape[1], M, C, ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(dgamma), ptr(dbeta),
                                         ptr(coef), ptr(ws), ws.numel(), stream()), "sgx_bn_bwd_finalize")
     dx = dx_out if dx_out is not None else torch.empty(x.shape, device=x.device, dtype=torch.float32)
-    if next_reduce is not None:
-        if want_g:
-            raise ValueError("bn_bwd: next_reduce and want_g are exclusive")
-        nx, nmean = next_reduce
-        nparts = torch.empty(2, stats_blocks(M), C, device=x.device, dtype=torch.float32)
-        check(lib().sgx_bn_bwd_apply_reduce(ptr(dy), dl, ptr(x), ld, ptr(scale), ptr(shift), ptr(coef), ptr(dx), rows(dx)[1], M, C, a, ptr(nx), rows(nx)[1],
-                                            ptr(nmean), ptr(nparts), stream()), "sgx_bn_bwd_apply_reduce")
-        return dx, nparts
     g = torch.empty(x.shape, device=x.device, dtype=torch.float32) if want_g else None
     check(lib().sgx_bn_bwd_apply(ptr(dy), dl, ptr(x), ld, ptr(scale), ptr(shift), ptr(coef), ptr(dx), rows(dx)[1], ptr(g), rows(g)[1] if want_g else 0,
                                  M, C, a, stream()), "sgx_bn_bwd_apply")

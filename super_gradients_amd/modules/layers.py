@@ -111,9 +111,9 @@ class BatchNorm(SgxBlock):
         sc, sh = K.bn_eval_scale_shift(self.weight, self.bias, self.running_mean, self.running_var, self.eps)
         return sc, sh, None, None
 
-    def backward(self, dy, t, scale, shift, mean, invstd, act, dx_out=None, want_g=False, parts=None, next_reduce=None):
+    def backward(self, dy, t, scale, shift, mean, invstd, act, dx_out=None, want_g=False, parts=None):
         return K.bn_bwd(dy, t, scale, shift, self.weight, mean, invstd, self.weight.grad, self.bias.grad, act=act, dx_out=dx_out, want_g=want_g,
-                        sync=self._synced(), parts=parts, next_reduce=next_reduce)
+                        sync=self._synced(), parts=parts)
 
 
 class ConvTranspose2x2(SgxBlock):

@@ -161,16 +161,13 @@ class QARepVGGBlock(SgxBlock):
     def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
         c3, bn3, c1, pbn = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1, self.post_bn
         (x, t3, s, sc3, sh3, m3, i3, scp, shp, mp, ip, t1), self._ctx = self._ctx, None
-        if K.FUSE_BN_BWD_REDUCE:  # bn3's reduce sums come out of post_bn's apply sweep (one read of ds and t3 less)
-            ds, parts3 = pbn.backward(dy, s, scp, shp, mp, ip, self.act, dx_out=s, next_reduce=(t3, m3))
-        else:
-            ds, parts3 = pbn.backward(dy, s, scp, shp, mp, ip, self.act, dx_out=s), None   # in place over s
+        ds = pbn.backward(dy, s, scp, shp, mp, ip, self.act, dx_out=s)          # in place over s
         ds1 = ds                                                                # gradient of the 1x1 branch output: alpha * ds
         if t1 is not None:                                                      # learnable alpha: d alpha = <ds, conv1x1(x) + b>
             K.dot_sum(t1, ds, self.alpha.grad, accumulate=True)
             ds1 = K.axpy(ds, a_dev=self.alpha, out=t1)                          # in place over t1
         c1.wgrad(x, ds1)
-        dt3 = bn3.backward(ds, t3, sc3, sh3, m3, i3, None, dx_out=t3, parts=parts3)   # in place over t3
+        dt3 = bn3.backward(ds, t3, sc3, sh3, m3, i3, None, dx_out=t3)   # in place over t3
         c3.wgrad(x, dt3)
         if not need_dx:
             return None

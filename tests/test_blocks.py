@@ -4,7 +4,7 @@ import pytest
 import torch
 from torch import nn
 
-from util import assert_close, first_gpu_run_pending, to_nchw_cpu, to_nhwc
+from util import assert_close, to_nchw_cpu, to_nhwc
 
 
 class _Net(nn.Module):
@@ -104,7 +104,6 @@ def test_qarepvgg_block_learnable_alpha(backend, stride):
     from oracle.yolo_nas import QARep
     from super_gradients_amd.modules import QARepVGGBlock
 
-    first_gpu_run_pending(backend)
     n, c, h, w = _shape(backend, (2, 64, 10, 10), (2, 8, 6, 5))
     co = c * stride
     x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
@@ -147,31 +146,6 @@ def test_oracle_qarepvgg_alpha_live(stride):
     yr.backward(g)
     yo.backward(g)
     assert torch.equal(xr.grad, xo.grad) and torch.equal(r.alpha.grad, o.alpha.grad)
-
-
-@pytest.mark.parametrize("stride", [1, 2])
-def test_qarepvgg_fused_bn_backward_reduce(backend, stride, monkeypatch):
-    """SGX_FUSE_BN_REDUCE (experiment switch): branch_3x3.bn's backward sums come out of post_bn's apply sweep (sgx_bn_bwd_apply_reduce)
-    instead of a sweep of their own.  Same row partition, same accumulation order: every gradient must be BIT-identical to the unfused
-    path, and the fused block still meets the parity bar against the oracle."""
-    from oracle.yolo_nas import QARep
-    from super_gradients_amd import kernels as K
-    from super_gradients_amd.modules import QARepVGGBlock
-
-    first_gpu_run_pending(backend)
-    n, c, h, w = _shape(backend, (2, 64, 10, 10), (2, 8, 7, 5))
-    co = c * stride
-    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
-    res = {}
-    for fuse in (False, True):
-        monkeypatch.setattr(K, "FUSE_BN_BWD_REDUCE", fuse)
-        torch.manual_seed(7)
-        ref, blk = QARep(c, co, stride, residual=stride == 1), QARepVGGBlock(c, co, stride=stride, use_residual_connection=stride == 1)
-        _check(ref, blk, x, backend)
-        res[fuse] = {k: v.grad.detach().cpu().clone() for k, v in blk.named_parameters() if v.grad is not None}
-    assert res[True].keys() == res[False].keys() and len(res[True]) >= 6
-    for k in res[True]:
-        assert torch.equal(res[True][k], res[False][k]), f"{k}: fused BN backward reduce changes the gradient"
 
 
 @pytest.mark.parametrize("concat", [False, True])
@@ -334,7 +308,6 @@ def test_prediction_conv_any_class_count(backend, ksize, nout):
     of 4 (the reference's own test builds 17 classes, tests/unit_tests/yolo_nas_tests.py:13-18): forward, input / weight / bias gradient."""
     from super_gradients_amd.training.models.detection_models.yolo_nas.dfl_heads import _PredConv
 
-    first_gpu_run_pending(backend)
     n, c, h, w = 2, 8, 5, 4
     g = torch.Generator().manual_seed(0)
     x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
@@ -366,7 +339,6 @@ def test_stem_with_custom_in_channels(backend):
     from super_gradients_amd.modules import QARepVGGBlock
     from super_gradients_amd.training import models
 
-    first_gpu_run_pending(backend)
     net = models.get("yolo_nas_s", arch_params=dict(in_channels=2), num_classes=17)
     sd = net.state_dict()
     assert tuple(sd["backbone.stem.conv.branch_3x3.conv.weight"].shape) == (48, 2, 3, 3) and tuple(sd["heads.head1.cls_pred.weight"].shape)[0] == 17
@@ -411,7 +383,6 @@ def test_experiment_switches_compose(backend, monkeypatch):
     from super_gradients_amd.modules import QARepVGGBlock
     from super_gradients_amd.modules.engine import SgxNetwork
 
-    first_gpu_run_pending(backend)
 
     class Chain(SgxNetwork):
         def __init__(self):
@@ -435,10 +406,9 @@ def test_experiment_switches_compose(backend, monkeypatch):
     base = run()
     key = dict(N=n, H=h, W=w, C=32, K=32, R=3, stride=1, pad=1)
     try:
-        for variant in (5, 6):
+        for variant in (7, 6):
             lib().sgx_debug_set_variant(variant)
             lib().sgx_bn_set_fused_finalize(1)
-            monkeypatch.setattr(K, "FUSE_BN_BWD_REDUCE", True)
             load_conv_tuning([dict(kind="fwd", bm=128, bn=32, variant=0, **key), dict(kind="dgrad", bm=64, bn=32, variant=0, **key),
                               dict(kind="wgrad", bm=32, bn=96, variant=2048, **key)])
             got = run()

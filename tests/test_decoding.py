@@ -5,7 +5,6 @@ import torch
 
 from oracle import decoding as odec
 from oracle import ref_shim
-from util import first_gpu_run_pending
 
 
 def _case(B, L, C, seed, ties=False):
@@ -46,7 +45,6 @@ def test_oracle_decoding_live(family):
 def test_decode_topk_vs_oracle(backend, shape):
     from super_gradients_amd import kernels as K
 
-    first_gpu_run_pending(backend)
     B, L, C, k = shape
     boxes, scores = _case(B, L, C, seed=L + C, ties=(k == 300))
     ob, os_, oi = odec.decode_topk(boxes, scores, k)
@@ -59,7 +57,6 @@ def test_decoding_modules_api(backend):
     from super_gradients_amd.training.models.detection_models.pp_yolo_e.pp_yolo_e import PPYoloEDecodingModule
     from super_gradients_amd.training.models.detection_models.yolo_nas.yolo_nas_variants import YoloNASDecodingModule
 
-    first_gpu_run_pending(backend)
     boxes, scores = _case(2, 400, 6, seed=1)
     outputs = ((boxes.to(backend), scores.to(backend)), None)
     for cls in (YoloNASDecodingModule, PPYoloEDecodingModule):

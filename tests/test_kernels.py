@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from util import assert_close, empty_nhwc, first_gpu_run_pending, rel_err, to_nchw_cpu, to_nhwc
+from util import assert_close, empty_nhwc, rel_err, to_nchw_cpu, to_nhwc
 
 from super_gradients_amd import kernels as K
 
@@ -396,7 +396,6 @@ def test_ppyoloe_loss_any_class_count(backend, C):
     """Class counts that are not a multiple of 4 (scalar classification-loss kernel): same parity bar as the vector path."""
     from oracle.ppyolo_loss import PPYoloELossOracle
 
-    first_gpu_run_pending(backend)
     B, hw = 2, [(12, 12), (6, 6), (3, 3)]
     logits, distri, anchors, pts, pts_grid, counts, strides, targets = _head_case(B, hw, C, seed=4)
     logits.requires_grad_(True)
@@ -651,7 +650,6 @@ def test_ppyoloe_assignment_adversarial(backend, kind):
     TAL and ATSS.  Zero logits make every anchor's class scores equal, so candidate ranking is decided by IoU ties and index order."""
     from oracle.ppyolo_loss import PPYoloELossOracle
 
-    first_gpu_run_pending(backend)
     B, hw, C = 2, [(12, 12), (6, 6), (3, 3)], 8
     logits, distri, anchors, pts, pts_grid, counts, strides, _ = _head_case(B, hw, C, seed=5)
     logits = torch.zeros_like(logits) if kind in ("duplicates", "many") else logits
@@ -683,7 +681,6 @@ def test_atss_distance_tie_policy(backend):
     that everything away from the tie agrees with the oracle)."""
     from oracle.ppyolo_loss import PPYoloELossOracle
 
-    first_gpu_run_pending(backend)
     B, hw, C = 1, [(12, 12), (6, 6), (3, 3)], 8
     logits, distri, anchors, pts, pts_grid, counts, strides, _ = _head_case(B, hw, C, seed=5)
     s = 96.0
@@ -722,7 +719,6 @@ def test_nms_degenerate_boxes(backend):
     (IoU exactly 1), boxes touching along an edge (IoU exactly 0), IoU exactly AT the threshold (kept: suppression is `>`), equal scores."""
     from oracle import nms as onms
 
-    first_gpu_run_pending(backend)
     bx = torch.tensor([
         [10, 10, 50, 50], [10, 10, 50, 50],        # identical pair
         [50, 10, 90, 50],                           # touches the first along x = 50
@@ -751,12 +747,11 @@ def test_nms_degenerate_boxes(backend):
 def test_conv_deep_slabs(backend, case, math):
     if math == "bf16x3" and case[5] != 3:
         pytest.skip("bf16x3 shares the slab addressing with fp32: one 3x3 case (stride 1 / 2) covers its plane layout")
-    """32-deep slabs (igemm_kernel<..., KD = 32>, experiment switches sgx_debug_set_variant(5 | 6): one / two LDS buffers): every tile shape on problems with ragged
+    """32-deep slabs (igemm_kernel<..., KD = 32>; the default where C % 32 == 0; sgx_debug_set_variant(6): two LDS buffers, (7): the 16-deep loop): every tile shape on problems with ragged
     edges in both tile dimensions, 3x3 / stride-2 (parity-class data gradient) / 1x1.  The reduction runs in the same order as with
     16-deep slabs, so the results must be BIT-identical to the default kernel's, not just close."""
     from super_gradients_amd._lib import lib
 
-    first_gpu_run_pending(backend)
     n, h, w, c, k, r, s, p = case
     x, wt, b = _conv_case(case)
     x.requires_grad_(True)
@@ -771,15 +766,15 @@ def test_conv_deep_slabs(backend, case, math):
         for bm, bn in tiles:
             lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
             res = {}
-            for var in (0, 5, 6):
+            for var in (7, 0, 6):  # 7 = the 16-deep loop, 0 = default (32-deep, one LDS buffer), 6 = 32-deep, two buffers
                 lib().sgx_debug_set_variant(var)
                 yd, parts = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s, pad=p, stat_partials=True)
                 dx = K.conv2d_bwd_data(dyd, wd, (n, h, w, c), stride=s, pad=p)
                 res[var] = (yd.cpu().clone(), parts[0].cpu().clone(), dx.cpu().clone())
-            for var in (5, 6):
+            for var in (0, 6):
                 assert_close(to_nchw_cpu(res[var][0]), y.detach(), TOL, f"variant {var} fwd tile {bm}x{bn}")
                 assert_close(to_nchw_cpu(res[var][2]), x.grad, TOL, f"variant {var} dgrad tile {bm}x{bn}")
-                for a, bb, what in zip(res[0], res[var], ("fwd", "stats", "dgrad")):
+                for a, bb, what in zip(res[7], res[var], ("fwd", "stats", "dgrad")):
                     assert torch.equal(a, bb), f"{what} tile {bm}x{bn}: 32-deep slabs (variant {var}) differ from 16-deep slabs"
     finally:
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
@@ -794,7 +789,6 @@ def test_fused_finalize(backend, nblk, C):
     counts that do not fill a workgroup, row counts around the lane count, at and above the cooperative limit (4096 rows; 4200: unchanged path)."""
     from super_gradients_amd._lib import lib
 
-    first_gpu_run_pending(backend)
     g = torch.Generator().manual_seed(nblk + C)
     parts = (torch.randn(2, nblk, C, generator=g) * 3 + 1).to(backend)
     parts[1] = parts[1].abs() * 50 + 20          # sum of squares partials: keep the variance positive
@@ -827,7 +821,6 @@ def test_conv_tuning_table(backend):
     the forward statistics rows follow the table's M tile, other problems keep the heuristic, bad entries are rejected, [] clears."""
     from super_gradients_amd._lib import lib, load_conv_tuning
 
-    first_gpu_run_pending(backend)
     case = (1, 9, 8, 32, 40, 3, 1, 1)
     n, h, w, c, k, r, s, p = case
     x, wt, b = _conv_case(case)
@@ -867,7 +860,6 @@ def test_conv_every_tile_shape(backend, math):
     one forward + data-gradient problem with ragged edges in both tile dimensions - the heuristics only ever pick a few of them."""
     from super_gradients_amd._lib import lib
 
-    first_gpu_run_pending(backend)
     n, h, w, c, k, r, s, p = (1, 9, 8, 20, 72, 3, 1, 1)   # M = 72 pixels, N = 72 filters: partial tiles everywhere
     x, wt, b = _conv_case((n, h, w, c, k, r, s, p))
     x.requires_grad_(True)

@@ -14,9 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 def test_conv_tune_table_round_trip(backend, tmp_path):
     import conv_tune
     from super_gradients_amd._lib import lib, load_conv_tuning
-    from util import first_gpu_run_pending
 
-    first_gpu_run_pending(backend)
     agg = {
         ("fwd", 32, 80, 80, 64, 64, 3, 1, 1): {(0, 0, 0): 1200.0, (64, 64, 5): 1000.0, (128, 64, 6): 1100.0},      # 17 % faster: in
         ("dgrad", 32, 80, 80, 64, 64, 3, 1, 1): {(0, 0, 0): 900.0, (64, 64, 5): 895.0},                             # < 2 %: stays heuristic

@@ -291,3 +291,69 @@ def test_trainer_yolo_nas_recipe_shape(gpu_device, tmp_path):
     got = res[0]["train"]
     for i, name in enumerate(["loss_cls", "loss_iou", "loss_dfl", "loss"]):
         assert abs(got[name] - float(tot[i])) <= 1e-3 * abs(float(tot[i])), (name, got[name], float(tot[i]))
+
+
+@pytest.mark.gpu
+def test_yolo_nas_s_headline_config_parity(gpu_device):
+    """BASELINE.json configs[2] at FULL size: YOLO-NAS-S, 32 synthetic 640x640 images (L = 8400 anchors), PPYoloELoss(TAL) + NMS,
+    HIP path vs the CPU oracle (reference tests/unit_tests/ppyoloe_unit_test.py:42-81 checks loss items to places=4).
+      forward  : raw head outputs / decoded predictions within 1e-4 (relative, max-norm) of the CPU fp32 path;
+      loss     : the four loss items within 1e-4 of the oracle's on the oracle's own forward (end to end), AND - the assigner being
+                 discontinuous - on IDENTICAL predictions (the HIP model's own raw outputs fed to both): assigned labels bit-exact,
+                 assigned boxes / scores and loss items within 1e-4;
+      NMS      : recipe settings (score 0.01, top-k 1000, IoU 0.7, max 300, multi-label) + class_agnostic_nms=True on the eval
+                 forward of the same batch: rows bit-exact against the oracle's post-processing of the same predictions."""
+    from oracle import nms as onms
+    from oracle.ppyolo_loss import PPYoloELossOracle
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd.training.losses import PPYoloELoss
+
+    tol, C, B, size = 1e-4, 80, 32, 640
+    ref, net = _build_pair("s", C, gpu_device)
+    ref.train()
+    net.train()
+    x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(42))
+    targets = synthetic_targets(B, seed=42, kmax=20, size=size, num_classes=C)
+    torch.set_num_threads(min(64, torch.get_num_threads() * 4))
+    with torch.no_grad():
+        out_ref = ref(x)
+        orc = PPYoloELossOracle(C, use_static_assigner=False)
+        loss_ref, items_ref = orc(out_ref, targets)
+    out = net(x.to(gpu_device))
+    crit = PPYoloELoss(num_classes=C, use_static_assigner=False)
+    loss, items = crit(out, targets.to(gpu_device))
+    (bx, sc), (lg, ds, an, pt, cnt, st) = out
+    (bx_r, sc_r), (lg_r, ds_r, an_r, pt_r, cnt_r, st_r) = out_ref
+    assert lg.shape[1] == 8400 and list(cnt) == list(cnt_r)
+    assert_close(lg.detach().cpu(), lg_r, tol, "cls_logits @ bs32/640")
+    assert_close(ds.detach().cpu(), ds_r, tol, "reg_distri @ bs32/640")
+    assert_close(bx.detach().cpu(), bx_r, tol, "pred_bboxes @ bs32/640")
+    assert_close(sc.detach().cpu(), sc_r, tol, "pred_scores @ bs32/640")
+    assert_close(items.cpu(), items_ref, tol, "loss items, end to end")
+    # identical predictions into both assigners + losses
+    preds_cpu = (lg.detach().cpu(), ds.detach().cpu(), an_r, pt_r, cnt_r, st_r)
+    _, a_label, a_box, a_score = orc.assign(preds_cpu, targets)
+    _, items_same = orc((None, preds_cpu), targets)
+    w = (1.0, 2.5, 0.5)
+    o = K.ppyoloe_loss_fwd(lg.detach(), ds.detach(), an, pt, st, targets.to(gpu_device), [int(c) for c in cnt], False, True, w)
+    assert torch.equal(o["label"].cpu().long(), a_label), "assigned labels differ at bs32/640"
+    pos = a_label != C
+    assert int(pos.sum()) > 32
+    assert_close(o["box"].cpu()[pos], a_box[pos], 1e-6, "assigned boxes")
+    assert_close(o["score"].cpu(), a_score, tol, "assigned scores")
+    it, _ = K.ppyoloe_loss_finalize(o["sums"], w, 1.0)
+    assert_close(it.cpu(), items_same, tol, "loss items on identical predictions")
+    # NMS at the recipe settings on the eval forward of the same batch
+    net.eval()
+    with torch.no_grad():
+        (ebx, esc), raw = net(x.to(gpu_device))
+    kw = dict(score_threshold=0.01, nms_threshold=0.7, nms_top_k=1000, max_predictions=300, multi_label_per_box=True, class_agnostic_nms=True)
+    cb = net.get_post_prediction_callback(conf=0.01, iou=0.7, nms_top_k=1000, max_predictions=300, multi_label_per_box=True, class_agnostic_nms=True)
+    res = cb(((ebx, esc), raw))
+    ref_res = onms.post_prediction(ebx.cpu(), esc.cpu(), **kw)
+    assert len(res) == B
+    nrows = 0
+    for a, b in zip(res, ref_res):
+        assert torch.equal(a.cpu(), b), "NMS rows differ at bs32/640"
+        nrows += int(b.shape[0])
+    assert nrows > 0

@@ -52,11 +52,3 @@ def synthetic_targets(batch, seed=0, kmax=20, size=640, num_classes=80):
             x1, y1, x2, y2 = max(cx - w / 2, 0), max(cy - h / 2, 0), min(cx + w / 2, size), min(cy + h / 2, size)
             rows.append([b, g.randint(0, num_classes), (x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1])
     return torch.tensor(rows, dtype=torch.float32).reshape(-1, 6)
-
-
-def first_gpu_run_pending(backend):
-    """Tests written while no GPU time was left are green on the host emulation only.  On the GPU they are skipped until their first
-    validated run: `SGX_GPU_UNVALIDATED=1 python -m pytest tests -m gpu -k ...` (tools/gpu_first_visit.sh does it, non-fatally, before
-    anything else of a GPU visit); a test that passed there gets its call to this function deleted."""
-    if backend.type == "cuda" and os.environ.get("SGX_GPU_UNVALIDATED") != "1":
-        pytest.skip("green on the host emulation; first GPU run pending (SGX_GPU_UNVALIDATED=1 runs it)")

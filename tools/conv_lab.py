@@ -1,0 +1,88 @@
+"""Kernel-design lab: time a few representative convolution problems under several kernel variants, interleaved in ONE process
+(rounds x variants, median), so that small deltas are comparable (cdna_hip_programming.md 5.4 rule 24).
+
+    python tools/conv_lab.py --variants 0,5,11,12 [--tiles 64x64,128x64] [--problems fwd:32:80:80:64:64:3:1,...] [--rounds 5] [--iters 10]
+
+variant = sgx_debug_set_variant code (0 = shipped kernel).  Measurement tool: product library only.
+"""
+import argparse
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+DEFAULT = [
+    "fwd:32:80:80:64:64:3:1", "fwd:32:160:160:32:32:3:1", "fwd:32:40:40:96:96:3:1", "fwd:32:80:80:192:384:3:2", "fwd:32:20:20:256:256:3:1",
+    "fwd:32:80:80:64:64:1:1", "fwd:32:160:160:96:32:1:1", "fwd:32:40:40:96:96:1:1", "fwd:32:20:20:1536:768:1:1", "fwd:32:320:320:48:96:3:2",
+    "dgrad:32:320:320:48:96:3:2", "dgrad:32:80:80:64:64:3:1", "wgrad:32:80:80:64:64:3:1", "wgrad:32:160:160:32:32:3:1", "wgrad:32:40:40:96:96:1:1",
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", default="0")
+    ap.add_argument("--tiles", default="0x0")
+    ap.add_argument("--problems", default=",".join(DEFAULT))
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    import torch
+
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd._lib import lib
+
+    dev = torch.device("cuda:0")
+    variants = [int(v) for v in args.variants.split(",")]
+    tiles = [tuple(int(a) for a in t.split("x")) for t in args.tiles.split(",")]
+    configs = [(v, t) for t in tiles for v in variants]
+    lines = [f"{'problem':<34}" + "".join(f"{f'v{v}/{t[0]}x{t[1]}':>14}" for v, t in configs) + "   (TFLOP/s, median of rounds; us below)"]
+    for spec in args.problems.split(","):
+        kind, n, h, w, c, k, r, s = spec.split(":")
+        n, h, w, c, k, r, s = (int(a) for a in (n, h, w, c, k, r, s))
+        pad = r // 2
+        ho, wo = (h + 2 * pad - r) // s + 1, (w + 2 * pad - r) // s + 1
+        x = torch.randn(n, h, w, c, device=dev)
+        y = torch.randn(n, ho, wo, k, device=dev)
+        wt = K.to_ohwi(torch.randn(k, c, r, r, device=dev) / (c * r * r) ** 0.5)
+        dw = torch.zeros_like(wt)
+        flops = 2.0 * n * ho * wo * k * c * r * r
+        if kind == "fwd":
+            fn = lambda: K.conv2d_fwd(x, wt, out=y, stride=s, pad=pad, stat_partials=True)
+        elif kind == "dgrad":
+            fn = lambda: K.conv2d_bwd_data(y, wt, (n, h, w, c), stride=s, pad=pad, out=x)
+        else:
+            fn = lambda: K.conv2d_bwd_weight(x, y, dw, None, stride=s, pad=pad)
+        res = {cfg: [] for cfg in configs}
+        for _ in range(args.rounds):
+            for cfg in configs:
+                v, (bm, bn) = cfg
+                lib().sgx_debug_set_variant(v)
+                lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                try:
+                    fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(args.iters):
+                        fn()
+                    e1.record()
+                    e1.synchronize()
+                    res[cfg].append(e0.elapsed_time(e1) * 1e3 / args.iters)
+                except Exception as ex:  # a variant that has no kernel for this tile
+                    res[cfg].append(float("nan"))
+        lib().sgx_debug_set_variant(0)
+        lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
+        med = {cfg: statistics.median(v) for cfg, v in res.items()}
+        lines.append(f"{spec:<34}" + "".join(f"{flops / med[cfg] / 1e6:>14.1f}" for cfg in configs))
+        lines.append(f"{'':<34}" + "".join(f"{med[cfg]:>14.1f}" for cfg in configs))
+    text = "\n".join(lines)
+    print(text)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        open(args.out, "w").write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -99,7 +99,7 @@ def main():
                 if t < best:
                     best, best_cfg = t, f"bm={bm} bn={bn} variant={var}"
             # 32-deep slabs (variant 5; eligible problems only: fp32 arithmetic, C % 32 == 0 - others run the default kernel again)
-            for var in (5, 6):  # one / two LDS buffers
+            for var in (6, 7):  # two LDS buffers / the 16-deep loop (the default is 32-deep slabs with one buffer where C % 32 == 0)
                 lib().sgx_debug_set_variant(var)
                 for bm in (0, 64, 128):
                     for bn in ((0,) if bm == 0 else (32, 64, 96, 128)):
@@ -107,7 +107,7 @@ def main():
                         t = timeit(fn)
                         note(key, calls, (bm, bn, var), t)
                         if t < best:
-                            best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + f" variant={var} (32-deep slabs)"
+                            best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + f" variant={var}"
             lib().sgx_debug_set_variant(0)
         elif args.wgrad:
             note(key, calls, (0, 0, 0), base)
