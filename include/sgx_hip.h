@@ -121,6 +121,29 @@ int32_t sgx_conv2d_transpose_jobs(const sgx_conv_desc* d, const float* w, float*
                                   int32_t max_jobs, int32_t* njobs);
 int32_t sgx_wtrans_batch(const sgx_wtrans_job* jobs_dev, int32_t njobs, void* stream);
 
+/* QARepVGG block, both convolution branches per launch (modules/qarepvgg_block.py:184-204: branch_3x3 conv and branch_1x1 read the same x).
+ * Forward: y = convRxS(x, w) (no bias; d describes it, pad = R / 2), u = conv1x1(x, w1) + bias1 with the same stride - the 1x1 filter reads the
+ * RxS filter's centre tap, so one workgroup produces both tiles; stat5 = [5][sgx_conv2d_fwd_dual_stat_blocks(d)][K] per-row-block sums of
+ * y, y^2, u0, u0^2, y*u0 with u0 = u - bias1 (every moment both BatchNorms of the block need; sgx_qarep_fwd_finalize adds the bias terms in
+ * fp64).  u has y's strides.  Needs C >= 16.
+ * Backward: dx = convT RxS(dy, wt) + convT 1x1(ds, w1t) [+ addend] [+ dx]; wt as sgx_conv2d_transpose_weights writes it, w1t = w1 transposed
+ * [C][K]; ds has its own strides.  Needs K >= 16.
+ * sgx_qarep_prep_batch: per optimizer step, for every block at once: w1p = alpha * w1 + I (identity branch and alpha folded into the 1x1
+ * filter) and its transpose w1pt.                                                                                                          */
+int32_t sgx_conv2d_fwd_dual_stat_blocks(const sgx_conv_desc* d);
+int32_t sgx_conv2d_fwd_dual(const sgx_conv_desc* d, const float* x, const float* w, const float* w1, const float* bias1, float* y, float* u,
+                            float* stat5, void* stream);
+int32_t sgx_conv2d_bwd_data_dual(const sgx_conv_desc* d, const float* dy, const float* wt, const float* ds, int64_t ds_ld_pix, int64_t ds_ld_img,
+                                 const float* w1t, const float* addend, float* dx, int32_t accumulate, void* stream);
+typedef struct sgx_qarep_prep_job {
+    const float* w1;    /* [K][C] the block's 1x1 filter (OHWI, C padded)   */
+    float* w1p;         /* [K][C] alpha * w1 + identity                      */
+    float* w1pt;        /* [C][K] its transpose                              */
+    const float* alpha; /* device scalar or NULL (= 1)                       */
+    int32_t K, C, identity, pad_;
+} sgx_qarep_prep_job;
+int32_t sgx_qarep_prep_batch(const sgx_qarep_prep_job* jobs_dev, int32_t njobs, void* stream);
+
 /* dw[k][r][s][c] += sum_pixels dy * x   (accumulates into dw: callers zero the gradient arena once per
  * optimizer step).  dbias[k] += sum dy if dbias != NULL.  ws: sgx_conv2d_bwd_weight_workspace(d).  */
 int64_t sgx_conv2d_bwd_weight_workspace(const sgx_conv_desc* d);
@@ -208,13 +231,37 @@ int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int64_t M, int3
 int32_t sgx_bn_bwd_apply(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* scale,
                          const float* shift, const float* coef, float* dx, int64_t dx_ld, float* g_out, int64_t g_ld,
                          int64_t M, int32_t C, int32_t act, void* stream);
-/* Experiment switch (first GPU measurement pending): the finalize stages above (sgx_bn_finalize, sgx_bn_bwd_finalize, sgx_bn_reduce_sums,
- * sgx_colsum) as ONE cooperative launch (32 channels x 16 row lanes per workgroup fold the fp32 partial rows in fp64, fixed order) instead
+/* QARepVGG block, training form, on sgx_conv2d_fwd_dual's outputs (y = conv3x3(x), u = conv1x1(x; alpha*W1 + I) + b1, five moment planes):
+ * replaces, per block, F.batch_norm x2 + the two branch adds + the activation (modules/qarepvgg_block.py:184-204) and their backward.
+ *   sgx_qarep_fwd_finalize  both BatchNorms' statistics from the moments (s = bn3(y) + u is affine in (y, u) per channel; fp64): running
+ *                           statistics updated like nn.BatchNorm2d; cf[4][C] = operand rows of the forward sweep
+ *                           out = act(cf0*y + cf1 + cf2*u + cf3)  (sgx_dual_affine_act_fwd(y, cf0, cf1, u, cf2, cf3));
+ *                           sv[8][C] = mean3, invstd3, scale3, shift3, mean_s, invstd_p, scale_p, shift_p for the backward.
+ *                           ws: sgx_qarep_workspace(nblk, C) bytes (also covers the backward finalize).
+ *   sgx_qarep_bwd_reduce    ONE sweep over (dout, y, u): partials4[4][sgx_stats_blocks(M)][C] = sum g, g*(s-mean_s), g*(y-mean3),
+ *                           (s-mean_s)*(y-mean3), g = dout * act'(pre-activation recomputed with the forward's roundings).
+ *   sgx_qarep_bwd_finalize  d gamma / d beta of post_bn and d gamma of bn3 accumulated in place (d beta3 is analytically zero: a BatchNorm's
+ *                           input gradient sums to zero per channel), cb[5][C] = coefficients of the apply sweep.
+ *   sgx_qarep_bwd_apply     ONE sweep over (dout, y, u) writing ds (gradient of u; may alias u) and dy (gradient of y; may alias y).     */
+int64_t sgx_qarep_workspace(int32_t nblk, int32_t C);
+int32_t sgx_qarep_fwd_finalize(const float* stat5, int32_t nblk, int64_t M, int32_t C, const float* bias1, const float* gamma3, const float* beta3,
+                               float eps3, float mom3, float* rmean3, float* rvar3, const float* gammap, const float* betap, float epsp, float momp,
+                               float* rmeanp, float* rvarp, float* cf, float* sv, void* ws, int64_t ws_bytes, void* stream);
+int32_t sgx_qarep_bwd_reduce(const float* dout, int64_t d_ld, const float* y, int64_t y_ld, const float* u, int64_t u_ld, const float* cf,
+                             const float* sv, int64_t M, int32_t C, int32_t act, float* partials4, void* stream);
+int32_t sgx_qarep_bwd_finalize(const float* partials4, int32_t nblk, int64_t M, int32_t C, const float* gamma3, const float* gammap, const float* sv,
+                               float* dgamma3, float* dgammap, float* dbetap, float* cb, void* ws, int64_t ws_bytes, void* stream);
+int32_t sgx_qarep_bwd_apply(const float* dout, int64_t d_ld, const float* y, int64_t y_ld, const float* u, int64_t u_ld, const float* cf,
+                            const float* sv, const float* cb, float* ds, int64_t ds_ld, float* dy, int64_t dy_ld, int64_t M, int32_t C, int32_t act,
+                            void* stream);
+/* Default ON (0 restores the two-launch form): the finalize stages above (sgx_bn_finalize, sgx_bn_bwd_finalize, sgx_bn_reduce_sums,
+ * sgx_colsum, sgx_qarep_*_finalize) as ONE cooperative launch (32 channels x 16 row lanes per workgroup fold the fp32 partial rows in fp64, fixed order) instead
  * of a pre-reduction launch + a finalize launch, for up to 4096 partial rows.  Same sums up to fp64 regrouping.  Not thread-safe.   */
 int32_t sgx_bn_set_fused_finalize(int32_t on);
 int32_t sgx_bn_get_fused_finalize(void);
 /* z = a*x + y with a device-resident scalar a (yolo_stages.py:61-63) and its backward pieces:
- * sgx_dot_partial gives sum(x*dz) partials [nblk] for d a; finalize with sgx_sum_partials.          */
+ * sgx_dot_partial gives sum(x*dz) partials [2][sgx_stats_blocks(M)][C] for d a (per-lane compensated sums and their compensation
+ * terms: the alpha gradients cancel ~1e3x); finalize with sgx_sum_partials over all 2*nblk*C of them.                              */
 int32_t sgx_dot_partial(const float* a, int64_t a_ld, const float* b, int64_t b_ld, int64_t M, int32_t C,
                         float* partials, void* stream);
 int32_t sgx_sum_partials(const float* partials, int32_t n, float scale, float* out, int32_t accumulate, void* stream);

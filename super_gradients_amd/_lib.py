@@ -42,6 +42,11 @@ class WtransJob(ctypes.Structure):  # == sgx_wtrans_job
     _fields_ = [("w", ctypes.c_void_p), ("wt", ctypes.c_void_p), ("K", c_int32), ("C", c_int32), ("RS", c_int32), ("T", c_int32), ("taps", ctypes.c_uint8 * 64)]
 
 
+class QarepPrepJob(ctypes.Structure):  # == sgx_qarep_prep_job
+    _fields_ = [("w1", ctypes.c_void_p), ("w1p", ctypes.c_void_p), ("w1pt", ctypes.c_void_p), ("alpha", ctypes.c_void_p), ("K", c_int32), ("C", c_int32),
+                ("identity", c_int32), ("pad_", c_int32)]
+
+
 class NmsDesc(ctypes.Structure):
     _fields_ = [
         ("B", c_int32), ("L", c_int32), ("C", c_int32), ("multi_label", c_int32), ("class_mode", c_int32),
@@ -79,6 +84,15 @@ PROTOTYPES = {
     "sgx_conv2d_bwd_data_wt": (_i32, [_CD, _P, _P, _P, _P, _i32, _P]),
     "sgx_conv2d_transpose_jobs": (_i32, [_CD, _P, _P, _i64, POINTER(WtransJob), _i32, POINTER(c_int32)]),
     "sgx_wtrans_batch": (_i32, [_P, _i32, _P]),
+    "sgx_conv2d_fwd_dual_stat_blocks": (_i32, [_CD]),
+    "sgx_conv2d_fwd_dual": (_i32, [_CD, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sgx_conv2d_bwd_data_dual": (_i32, [_CD, _P, _P, _P, _i64, _i64, _P, _P, _P, _i32, _P]),
+    "sgx_qarep_prep_batch": (_i32, [_P, _i32, _P]),
+    "sgx_qarep_workspace": (_i64, [_i32, _i32]),
+    "sgx_qarep_fwd_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _P, _f, _f, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P, _i64, _P]),
+    "sgx_qarep_bwd_reduce": (_i32, [_P, _i64, _P, _i64, _P, _i64, _P, _P, _i64, _i32, _i32, _P, _P]),
+    "sgx_qarep_bwd_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
+    "sgx_qarep_bwd_apply": (_i32, [_P, _i64, _P, _i64, _P, _i64, _P, _P, _P, _P, _i64, _P, _i64, _i64, _i32, _i32, _P]),
     "sgx_conv2d_bwd_weight_workspace": (_i64, [_CD]),
     "sgx_conv2d_bwd_weight": (_i32, [_CD, _P, _P, _P, _P, _P, _i64, _P]),
     "sgx_convT2x2_workspace": (_i64, [_i32] * 5),
@@ -173,11 +187,11 @@ def lib():
             if mode not in ("fp32", "bf16x3", "auto"):
                 raise RuntimeError(f"SGX_CONV_MATH={mode!r}: expected 'fp32', 'bf16x3' or 'auto'")
             _LIB.sgx_conv_set_math({"fp32": 0, "bf16x3": 1, "auto": 2}[mode])
-        var = os.environ.get("SGX_CONV_VARIANT")  # experiment switch of the conv kernels (sgx_debug_set_variant; 5 = 32-deep slabs)
+        var = os.environ.get("SGX_CONV_VARIANT")  # measurement switch of the conv kernels (sgx_debug_set_variant; 7 = the 16-deep loop)
         if var:
             _LIB.sgx_debug_set_variant(int(var))
-        if os.environ.get("SGX_FUSED_FINALIZE", "0") == "1":  # experiment switch: one-launch BatchNorm / column-sum finalize
-            _LIB.sgx_bn_set_fused_finalize(1)
+        if os.environ.get("SGX_FUSED_FINALIZE") == "0":  # measurement switch: two-launch BatchNorm / column-sum finalize (default: one launch)
+            _LIB.sgx_bn_set_fused_finalize(0)
         # per-problem (tile, variant) table measured by tools/conv_tune.py --emit-table: SGX_CONV_TUNING=<json> ("" / "0" = none),
         # default csrc/conv_tuning_gfx950.json when it has been committed
         tune = os.environ.get("SGX_CONV_TUNING")

@@ -133,14 +133,14 @@ struct ColSrc {  // what a finalize kernel sums over: either the fp32 partials o
     int n;     // rows per plane
     int coop;  // 1: the finalize kernel is launched with CO_CH x CO_RL threads per workgroup and folds the fp32 partial rows itself
 };
-// ---- one-launch finalize (experiment switch sgx_bn_set_fused_finalize, first GPU measurement pending): instead of a pre-reduction
+// ---- one-launch finalize (default; sgx_bn_set_fused_finalize(0) restores the two-launch form): instead of a pre-reduction
 // launch + a finalize launch, the finalize kernel runs with 32 channels x 16 row lanes per workgroup; every lane folds its rows
 // (b = lane, lane + 16, ...) in fp64, the 16 lane sums meet in LDS and are added in lane order (deterministic, no atomics).  Worth it
 // while one workgroup can stream the partial rows of its 32 channels faster than a second launch costs: nblk <= CR_COOP_MAX.
 #define CO_CH 32
 #define CO_RL 16
 #define CR_COOP_MAX 4096
-static int g_fused_finalize = 0;
+static int g_fused_finalize = 1;
 extern "C" int32_t sgx_bn_set_fused_finalize(int32_t on) {
     g_fused_finalize = on != 0;
     return SGX_OK;
@@ -456,22 +456,28 @@ extern "C" int32_t sgx_bn_bwd_apply(const float* dy, int64_t dy_ld, const float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// <a, b> with compensated (TwoSum) accumulation per lane: q0 carries the running sum, q1 the rounding errors it dropped.  The learnable
+// scalars this feeds (the bottlenecks' alpha: d alpha = <x, dz>) cancel ~1e3x, so plain fp32 accumulation left them 1e-4 off (r2h).
 struct DotF {
     const float* a; long a_ld; const float* b; long b_ld;
     struct In { float4 u, v; };
     __device__ In load(long r, int c) const { return In{sgx_ld4(a + r * a_ld + c), sgx_ld4(b + r * b_ld + c)}; }
+    static __device__ __forceinline__ void add(float& s, float& e, float p) {
+        const float t = s + p, bp = t - s;
+        e += (s - (t - bp)) + (p - bp);
+        s = t;
+    }
     __device__ void apply(long, int, const In& in, float4& q0, float4& q1) const {
-        (void)q1;
         const float4 u = in.u, v = in.v;
-        q0.x += u.x * v.x; q0.y += u.y * v.y; q0.z += u.z * v.z; q0.w += u.w * v.w;
+        add(q0.x, q1.x, u.x * v.x); add(q0.y, q1.y, u.y * v.y); add(q0.z, q1.z, u.z * v.z); add(q0.w, q1.w, u.w * v.w);
     }
 };
-// per-(block, channel) partial products: partials [nblk][C]; reduce with sgx_sum_partials(n = nblk*C)
+// per-(block, channel) partial products: partials [2][nblk][C] (sums, compensation terms); reduce with sgx_sum_partials(n = 2*nblk*C)
 extern "C" int32_t sgx_dot_partial(const float* a, int64_t a_ld, const float* b, int64_t b_ld, int64_t M, int32_t C, float* partials,
                                    void* stream) {
     SGX_CHECK_ARG(a && b && partials, "dot_partial: null pointer");
     DotF f{a, a_ld, b, b_ld};
-    return run_sweep<DotF, 1>(f, M, C, partials, stream, "dot_partial");
+    return run_sweep<DotF, 2>(f, M, C, partials, stream, "dot_partial");
 }
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partials, int n, float scale, float* out, int accumulate) {
@@ -603,6 +609,222 @@ extern "C" int32_t sgx_dual_affine_act_bwd(const float* dy, int64_t dy_ld, const
     SGX_CHECK_ARG(!x2 || (s2 && t2), "dual_affine_act_bwd: second branch needs scale and shift");
     DualAffineBwdF f{DualAffineF{x1, x1_ld, s1, t1, x2, x2_ld, s2, t2, nullptr, 0, nullptr, 0, act}, dy, dy_ld, g, g_ld};
     return run_sweep<DualAffineBwdF, 0>(f, M, C, nullptr, stream, "dual_affine_act_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// QARepVGG block, training form, on the two-output convolution (conv.hip: sgx_conv2d_fwd_dual):
+//     y = conv3x3(x)          u = conv1x1(x; alpha * W1 + I) + b1          (identity branch folded into the 1x1 filter)
+//     s = bn3(y) + u          out = act(post_bn(s))
+// Both BatchNorms are finalised from the FIVE per-channel moments the convolution epilogue leaves (sum y, y^2, u0, u0^2, y*u0, u0 = u - b1):
+// s is an affine function of (y, u) per channel, so mean / variance of s follow from the moments of (y, u) - no pass over s for its
+// statistics, and s itself is never written: the forward is ONE sweep, out = act(a*y + scp*u + c) (sgx_dual_affine_act_fwd with the
+// coefficient rows cf), instead of two sweeps and a residual read.  Backward: ONE reduce sweep (4 sums) + ONE apply sweep that writes the
+// upstream gradients of BOTH convolutions, instead of two reduce and two apply sweeps:
+//     g = dout * act'(z),  ds = cp * ((g - mean g) - shat * mean(g * shat)),  dy = c3 * (ds - mean ds - yhat * mean(ds * yhat))
+// with mean ds = 0 (a BatchNorm's input gradient sums to zero per channel) and mean(ds * yhat) = cp * (mean(g * yhat) - mean(g * shat) *
+// mean(shat * yhat)): every mean comes out of the one reduce sweep.  Reference arithmetic: modules/qarepvgg_block.py:184-204.
+// ---------------------------------------------------------------------------------------------
+template <typename F, int NQ>
+__global__ __launch_bounds__(SW_THREADS) void sweepq_kernel(F f, SweepGeom g, float* partials) {
+    __shared__ float4 red[NQ][SW_THREADS];
+    const int tid = threadIdx.x;
+    const int cg = tid % g.CG, rl = tid / g.CG;
+    const int c4 = blockIdx.y * g.CG + cg;
+    const bool live = (rl < g.RL) && (c4 < g.C4);
+    const int c = c4 * 4;
+    float4 q[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        long r0 = (long)blockIdx.x * g.rows_per_blk;
+        long r1 = r0 + g.rows_per_blk;
+        if (r1 > g.M) r1 = g.M;
+        long r = r0 + rl;
+        const long st = g.RL;
+        for (; r + st < r1; r += 2 * st) {  // three tensors per row: two rows of loads in flight per lane
+            typename F::In i0 = f.load(r, c), i1 = f.load(r + st, c);
+            f.apply(r, c, i0, q);
+            f.apply(r + st, c, i1, q);
+        }
+        for (; r < r1; r += st) {
+            typename F::In i0 = f.load(r, c);
+            f.apply(r, c, i0, q);
+        }
+    }
+    if (!partials) return;  // no reduction (apply sweeps): uniform across the workgroup
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) red[k][tid] = q[k];
+    __syncthreads();
+    if (live && rl == 0) {
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < g.RL; ++j) {
+                const float4 a = red[k][j * g.CG + cg];
+                t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+            }
+            sgx_st4(partials + ((long)k * g.nblk + blockIdx.x) * g.C + c, t);
+        }
+    }
+}
+
+extern "C" int64_t sgx_qarep_workspace(int32_t nblk, int32_t C) { return (int64_t)5 * cr_slices(nblk) * C * (int64_t)sizeof(double) + 256; }
+
+// sv rows: 0 mean3, 1 invstd3, 2 scale3, 3 shift3, 4 mean_s, 5 invstd_p, 6 scale_p, 7 shift_p;  cf rows: 0 a = scale_p * scale3, 1 c = scale_p * shift3 +
+// shift_p, 2 scale_p, 3 zeros  (out = act(cf0 * y + cf1 + cf2 * u + cf3): the operand rows of sgx_dual_affine_act_fwd)
+__global__ void qarep_fwd_finalize_kernel(ColSrc src, long M, int C, const float* bias1, const float* g3, const float* b3, float eps3, float mom3,
+                                          float* rm3, float* rv3, const float* gp, const float* bp, float epsp, float momp, float* rmp, float* rvp,
+                                          float* cf, float* sv) {
+    SGX_FIN_THREAD(src, C);
+    const double Sy = col_total(src, 0, C, c, cok), Syy = col_total(src, 1, C, c, cok), Su = col_total(src, 2, C, c, cok),
+                 Suu = col_total(src, 3, C, c, cok), Syu = col_total(src, 4, C, c, cok);
+    if (!writer) return;
+    const double m = (double)M, unb = M > 1 ? m / (m - 1.0) : 1.0;
+    const double mean3 = Sy / m;
+    double var3 = Syy / m - mean3 * mean3;
+    if (var3 < 0.0) var3 = 0.0;
+    const double invstd3 = 1.0 / sqrt(var3 + (double)eps3);
+    const float sc3 = (g3 ? g3[c] : 1.f) * (float)invstd3;  // the same fp32 roundings as bn_finalize_kernel
+    const float sh3 = (b3 ? b3[c] : 0.f) - (float)mean3 * sc3;
+    const double mu0 = Su / m, bias = bias1 ? (double)bias1[c] : 0.0;
+    double varu = Suu / m - mu0 * mu0;
+    if (varu < 0.0) varu = 0.0;
+    const double cov = Syu / m - mean3 * mu0;
+    // s = sc3 * y + sh3 + u0 + bias, per channel
+    const double mean_s = (double)sc3 * mean3 + (double)sh3 + mu0 + bias;
+    double var_s = (double)sc3 * (double)sc3 * var3 + 2.0 * (double)sc3 * cov + varu;
+    if (var_s < 0.0) var_s = 0.0;
+    const double invstdp = 1.0 / sqrt(var_s + (double)epsp);
+    const float scp = (gp ? gp[c] : 1.f) * (float)invstdp;
+    const float shp = (bp ? bp[c] : 0.f) - (float)mean_s * scp;
+    if (rm3) rm3[c] = (float)((1.0 - mom3) * (double)rm3[c] + mom3 * mean3);
+    if (rv3) rv3[c] = (float)((1.0 - mom3) * (double)rv3[c] + mom3 * var3 * unb);
+    if (rmp) rmp[c] = (float)((1.0 - momp) * (double)rmp[c] + momp * mean_s);
+    if (rvp) rvp[c] = (float)((1.0 - momp) * (double)rvp[c] + momp * var_s * unb);
+    cf[c] = scp * sc3;
+    cf[C + c] = scp * sh3 + shp;
+    cf[2 * C + c] = scp;
+    cf[3 * C + c] = 0.f;
+    sv[c] = (float)mean3; sv[C + c] = (float)invstd3; sv[2 * C + c] = sc3; sv[3 * C + c] = sh3;
+    sv[4 * C + c] = (float)mean_s; sv[5 * C + c] = (float)invstdp; sv[6 * C + c] = scp; sv[7 * C + c] = shp;
+}
+extern "C" int32_t sgx_qarep_fwd_finalize(const float* stat5, int32_t nblk, int64_t M, int32_t C, const float* bias1, const float* gamma3,
+                                          const float* beta3, float eps3, float mom3, float* rmean3, float* rvar3, const float* gammap,
+                                          const float* betap, float epsp, float momp, float* rmeanp, float* rvarp, float* cf, float* sv, void* ws,
+                                          int64_t ws_bytes, void* stream) {
+    SGX_CHECK_ARG(stat5 && cf && sv && nblk > 0 && M > 0, "qarep_fwd_finalize: bad args");
+    ColSrc src;
+    int32_t rc = col_prereduce<5>(stat5, nblk, C, ws, ws_bytes, stream, &src);
+    if (rc) return rc;
+    SGX_LAUNCH(qarep_fwd_finalize_kernel, fin_grid(src, C), fin_block(src), 0, stream, src, (long)M, C, bias1, gamma3, beta3, eps3, mom3, rmean3, rvar3,
+               gammap, betap, epsp, momp, rmeanp, rvarp, cf, sv);
+    SGX_CHECK_LAUNCH("qarep_fwd_finalize");
+    return SGX_OK;
+}
+
+struct QarepBwdIn { float4 d, y, u; };
+struct QarepBwdBase {
+    const float* dout; long d_ld; const float* y; long y_ld; const float* u; long u_ld; const float* cf; const float* sv; int C; int act;
+    __device__ QarepBwdIn load(long r, int c) const { return QarepBwdIn{sgx_ld4(dout + r * d_ld + c), sgx_ld4(y + r * y_ld + c), sgx_ld4(u + r * u_ld + c)}; }
+    // masked upstream gradient g and the centred s, y of one float4 (the pre-activation with the forward sweep's own roundings)
+    __device__ void terms(int c, const QarepBwdIn& in, float4& g, float4& sc, float4& yc) const {
+        const float4 a = sgx_ld4(cf + c), cc = sgx_ld4(cf + C + c), b = sgx_ld4(cf + 2 * C + c), t0 = sgx_ld4(cf + 3 * C + c);
+        float4 z = make_float4(a.x * in.y.x + cc.x, a.y * in.y.y + cc.y, a.z * in.y.z + cc.z, a.w * in.y.w + cc.w);
+        z.x += b.x * in.u.x + t0.x; z.y += b.y * in.u.y + t0.y; z.z += b.z * in.u.z + t0.z; z.w += b.w * in.u.w + t0.w;
+        g = make_float4(in.d.x * sgx_act_grad(z.x, act), in.d.y * sgx_act_grad(z.y, act), in.d.z * sgx_act_grad(z.z, act), in.d.w * sgx_act_grad(z.w, act));
+        const float4 m3 = sgx_ld4(sv + c), s3 = sgx_ld4(sv + 2 * C + c), h3 = sgx_ld4(sv + 3 * C + c), ms = sgx_ld4(sv + 4 * C + c);
+        // s = bn3(y) + u as the reference forms it (qarepvgg_block.py:197-202), then centred
+        sc = make_float4((s3.x * in.y.x + h3.x + in.u.x) - ms.x, (s3.y * in.y.y + h3.y + in.u.y) - ms.y, (s3.z * in.y.z + h3.z + in.u.z) - ms.z,
+                         (s3.w * in.y.w + h3.w + in.u.w) - ms.w);
+        yc = make_float4(in.y.x - m3.x, in.y.y - m3.y, in.y.z - m3.z, in.y.w - m3.w);
+    }
+};
+struct QarepBwdReduceF {
+    QarepBwdBase b;
+    typedef QarepBwdIn In;
+    __device__ In load(long r, int c) const { return b.load(r, c); }
+    __device__ void apply(long, int c, const In& in, float4 (&q)[4]) const {
+        float4 g, sc, yc;
+        b.terms(c, in, g, sc, yc);
+        q[0].x += g.x; q[0].y += g.y; q[0].z += g.z; q[0].w += g.w;
+        q[1].x += g.x * sc.x; q[1].y += g.y * sc.y; q[1].z += g.z * sc.z; q[1].w += g.w * sc.w;
+        q[2].x += g.x * yc.x; q[2].y += g.y * yc.y; q[2].z += g.z * yc.z; q[2].w += g.w * yc.w;
+        q[3].x += sc.x * yc.x; q[3].y += sc.y * yc.y; q[3].z += sc.z * yc.z; q[3].w += sc.w * yc.w;
+    }
+};
+// partials4: [4][sgx_stats_blocks(M)][C] = sum g, g*(s - mean_s), g*(y - mean3), (s - mean_s)*(y - mean3)
+extern "C" int32_t sgx_qarep_bwd_reduce(const float* dout, int64_t d_ld, const float* y, int64_t y_ld, const float* u, int64_t u_ld, const float* cf,
+                                        const float* sv, int64_t M, int32_t C, int32_t act, float* partials4, void* stream) {
+    SGX_CHECK_ARG(dout && y && u && cf && sv && partials4, "qarep_bwd_reduce: null pointer");
+    SGX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "qarep_bwd_reduce: need M>0 and C%%4==0 (C=%d)", C);
+    QarepBwdReduceF f{QarepBwdBase{dout, d_ld, y, y_ld, u, u_ld, cf, sv, C, act}};
+    SweepGeom g = sweep_geom(M, C);
+    SGX_LAUNCH((sweepq_kernel<QarepBwdReduceF, 4>), dim3(g.nblk, g.ctiles), dim3(SW_THREADS), 0, stream, f, g, partials4);
+    SGX_CHECK_LAUNCH("qarep_bwd_reduce");
+    return SGX_OK;
+}
+// cb rows: 0 cp = gamma_p * invstd_p, 1 mean g, 2 kp = invstd_p^2 * mean(g * (s - mean_s)), 3 c3 = gamma3 * invstd3, 4 k3 = invstd3^2 * mean(ds * (y - mean3))
+__global__ void qarep_bwd_finalize_kernel(ColSrc src, long M, int C, const float* gamma3, const float* gammap, const float* sv, float* dgamma3,
+                                          float* dgammap, float* dbetap, float* cb) {
+    SGX_FIN_THREAD(src, C);
+    const double Sg = col_total(src, 0, C, c, cok), Sgs = col_total(src, 1, C, c, cok), Sgy = col_total(src, 2, C, c, cok),
+                 Ssy = col_total(src, 3, C, c, cok);
+    if (!writer) return;
+    const double m = (double)M, invstd3 = sv[C + c], invstdp = sv[5 * C + c];
+    const double gp = gammap ? (double)gammap[c] : 1.0, g3 = gamma3 ? (double)gamma3[c] : 1.0;
+    if (dgammap) dgammap[c] += (float)(invstdp * Sgs);
+    if (dbetap) dbetap[c] += (float)Sg;
+    const double cp = gp * invstdp, kp = invstdp * invstdp * Sgs / m;
+    // sum ds * (y - mean3) with ds = cp * ((g - mean g) - (s - mean_s) * kp); sum (y - mean3) = 0
+    const double Sdy = cp * (Sgy - kp * Ssy);
+    if (dgamma3) dgamma3[c] += (float)(invstd3 * Sdy);
+    // (d beta3 = sum ds = 0: the input gradient of post_bn sums to zero per channel)
+    cb[c] = (float)cp;
+    cb[C + c] = (float)(Sg / m);
+    cb[2 * C + c] = (float)kp;
+    cb[3 * C + c] = (float)(g3 * invstd3);
+    cb[4 * C + c] = (float)(invstd3 * invstd3 * Sdy / m);
+}
+extern "C" int32_t sgx_qarep_bwd_finalize(const float* partials4, int32_t nblk, int64_t M, int32_t C, const float* gamma3, const float* gammap,
+                                          const float* sv, float* dgamma3, float* dgammap, float* dbetap, float* cb, void* ws, int64_t ws_bytes,
+                                          void* stream) {
+    SGX_CHECK_ARG(partials4 && sv && cb && nblk > 0 && M > 0, "qarep_bwd_finalize: bad args");
+    ColSrc src;
+    int32_t rc = col_prereduce<4>(partials4, nblk, C, ws, ws_bytes, stream, &src);
+    if (rc) return rc;
+    SGX_LAUNCH(qarep_bwd_finalize_kernel, fin_grid(src, C), fin_block(src), 0, stream, src, (long)M, C, gamma3, gammap, sv, dgamma3, dgammap, dbetap, cb);
+    SGX_CHECK_LAUNCH("qarep_bwd_finalize");
+    return SGX_OK;
+}
+struct QarepBwdApplyF {
+    QarepBwdBase b;
+    const float* cb; float* ds; long ds_ld; float* dy; long dy_ld;
+    typedef QarepBwdIn In;
+    __device__ In load(long r, int c) const { return b.load(r, c); }
+    __device__ void apply(long r, int c, const In& in, float4 (&)[1]) const {
+        float4 g, sc, yc;
+        b.terms(c, in, g, sc, yc);
+        const int C = b.C;
+        const float4 cp = sgx_ld4(cb + c), mg = sgx_ld4(cb + C + c), kp = sgx_ld4(cb + 2 * C + c), c3 = sgx_ld4(cb + 3 * C + c), k3 = sgx_ld4(cb + 4 * C + c);
+        // differences first, then the scale (the order ATen's CPU batch-norm backward uses)
+        const float4 s = make_float4(cp.x * ((g.x - mg.x) - sc.x * kp.x), cp.y * ((g.y - mg.y) - sc.y * kp.y), cp.z * ((g.z - mg.z) - sc.z * kp.z),
+                                     cp.w * ((g.w - mg.w) - sc.w * kp.w));
+        sgx_st4(ds + r * ds_ld + c, s);
+        sgx_st4(dy + r * dy_ld + c, make_float4(c3.x * (s.x - yc.x * k3.x), c3.y * (s.y - yc.y * k3.y), c3.z * (s.z - yc.z * k3.z), c3.w * (s.w - yc.w * k3.w)));
+    }
+};
+// ds (gradient of the 1x1 branch output u = upstream gradient of bn3) and dy (gradient of the 3x3 convolution output); either may alias its input
+// (ds over u, dy over y): a row is read completely before it is written
+extern "C" int32_t sgx_qarep_bwd_apply(const float* dout, int64_t d_ld, const float* y, int64_t y_ld, const float* u, int64_t u_ld, const float* cf,
+                                       const float* sv, const float* cb, float* ds, int64_t ds_ld, float* dy, int64_t dy_ld, int64_t M, int32_t C,
+                                       int32_t act, void* stream) {
+    SGX_CHECK_ARG(dout && y && u && cf && sv && cb && ds && dy, "qarep_bwd_apply: null pointer");
+    SGX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "qarep_bwd_apply: need M>0 and C%%4==0 (C=%d)", C);
+    QarepBwdApplyF f{QarepBwdBase{dout, d_ld, y, y_ld, u, u_ld, cf, sv, C, act}, cb, ds, ds_ld, dy, dy_ld};
+    SweepGeom g = sweep_geom(M, C);
+    SGX_LAUNCH((sweepq_kernel<QarepBwdApplyF, 1>), dim3(g.nblk, g.ctiles), dim3(SW_THREADS), 0, stream, f, g, (float*)nullptr);
+    SGX_CHECK_LAUNCH("qarep_bwd_apply");
+    return SGX_OK;
 }
 
 struct ColsumF {

@@ -167,6 +167,17 @@ struct IgemmParams {
     int vec;                  // 1: Nout, output strides and pointers allow 16-byte epilogue accesses
     int mt, nt, nblk, chunk;  // tile counts and XCD chunk
     int stat_nblk;
+    // Optional SECOND K-axis source (template PH2): after the taps of A / Wt the GEMM continues over another input tensor with its own
+    // taps and filter, on the same output pixel grid and with the same channel count C.
+    //   PH2 = 1: same accumulator - dx = dgrad3x3(dy3) + dgrad1x1(ds) of a QARepVGG block as ONE launch (no accumulate pass over dx);
+    //   PH2 = 2: second accumulator and second output (Y2, bias2) - conv3x3(x) and conv1x1(x) + b of a QARepVGG block as ONE launch
+    //            (x is staged once per tap by the same workgroup); stat_partials then holds FIVE planes: sum y, y^2, u0, u0^2, y*u0 (u0 = u - bias2).
+    const float* A2;
+    const float* Wt2;
+    const float* bias2;
+    float* Y2;
+    int Hin2, Win2, Th2, Tw2, dh02, dw02, dstep2;
+    long a2_ld_pix, a2_ld_img, w2_ld_n, a2_bytes, w2_bytes;
 };
 
 #define IG_BK 16
@@ -259,9 +270,10 @@ __device__ __forceinline__ sgx_f32x16 sgx_mfma_bf16(const uint4& a, const uint4&
 // cycles) ahead instead of 8.  (32, 1): ONE LDS buffer (18 KB for 64x64: occupancy stays VGPR-bound, 7 workgroups per CU) with a
 // write-after-barrier hand-over - two barriers per slab, i.e. as many per FLOP as (16, 2).  (32, 2): two buffers (37 KB for 64x64:
 // 4 workgroups per CU), one barrier per slab - half the barriers per FLOP at lower occupancy.
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int ABL = 0>
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
-    static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && (NBUF == 1 || NBUF == 2)), "32-deep slabs: channel-chunked K axis only");
+    static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && NBUF == 1), "32-deep slabs: channel-chunked K axis, one LDS buffer");
+    static_assert(PH2 == 0 || (MATH == 0 && !FLAT), "second K-axis source: fp32 arithmetic, channel-chunked K axis");
     constexpr int NTH = WM * WN * 64;   // threads per workgroup
     constexpr int CPR = KD / 4;         // threads per slab row (16 B each)
     constexpr int RPP = NTH / CPR;      // slab rows staged per pass
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     float* const As = smem;
     float* const Bs = smem + NBUF * BM * ROWW;
     __shared__ long long rowoff[BM];
-    __shared__ float red[2 * WM * BN];
+    __shared__ float red[(PH2 == 2 ? 5 : 2) * WM * BN];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -296,38 +308,61 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     const int hw = p.Ha * p.Wa;
     const int T = p.Th * p.Tw;
 
-    // buffer descriptors: A is re-based at the workgroup's first image so that lane offsets fit 31 bits
+    // ---- K-axis source state: (re)initialised by setup_src() for the primary source and, with PH2, for the second one -----------
     const int img0 = m0 / hw;
-    const sgx_buf bufA = sgx_make_buf(p.A + (long)img0 * p.a_ld_img, p.a_bytes - (long)img0 * p.a_ld_img * 4);
-    const sgx_buf bufB = sgx_make_buf(p.Wt, p.w_bytes);
-
     const int lrow = tid / CPR, chunk4 = (tid % CPR) * 4;
-    int aoff[AJ];
+    sgx_buf bufA, bufB;
+    int aoff[AJ], boff[BJ];
     unsigned long long amask[AJ];
+    bool bok[BJ];
+    int Tw_, T_, nkt, pixstep, rowstep;
+    const int cpt = (p.C + KD - 1) / KD;
+    // scalar slab state of the NEXT slab to load (non-FLAT): tap row, tap column, channel chunk
+    int s_ti = 0, s_tj = 0, s_ck = 0, s_kt = 0;
+    auto setup_src = [&](const float* A, const float* Wt, int Hin, int Win, int Th, int Tw, int dh0, int dw0, int dstep, long a_ld_pix, long a_ld_img,
+                         long w_ld_n, long a_bytes, long w_bytes) {
+        // buffer descriptors: A is re-based at the workgroup's first image so that lane offsets fit 31 bits
+        bufA = sgx_make_buf(A + (long)img0 * a_ld_img, a_bytes - (long)img0 * a_ld_img * 4);
+        bufB = sgx_make_buf(Wt, w_bytes);
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-        const int row = lrow + RPP * j;
-        const int m = m0 + row;
-        aoff[j] = 0;
-        amask[j] = 0ull;
-        if (row < BM && m < p.M) {
-            const int img = m / hw;
-            const int rem = m - img * hw;
-            const int a = rem / p.Wa;
-            const int b = rem - a * p.Wa;
-            const int hi0 = a * p.si + p.dh0, wi0 = b * p.si + p.dw0;
-            aoff[j] = (int)(((long)(img - img0) * p.a_ld_img + ((long)hi0 * p.Win + wi0) * p.a_ld_pix + (FLAT ? 0 : chunk4)) * 4);
-            unsigned long long mk = 0ull;
-            for (int i = 0; i < p.Th; ++i) {
-                const int hi = hi0 + p.dstep * i;
-                for (int jj = 0; jj < p.Tw; ++jj) {
-                    const int wi = wi0 + p.dstep * jj;
-                    if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win) mk |= 1ull << (i * p.Tw + jj);
+        for (int j = 0; j < AJ; ++j) {
+            const int row = lrow + RPP * j;
+            const int m = m0 + row;
+            aoff[j] = 0;
+            amask[j] = 0ull;
+            if (row < BM && m < p.M) {
+                const int img = m / hw;
+                const int rem = m - img * hw;
+                const int a = rem / p.Wa;
+                const int b = rem - a * p.Wa;
+                const int hi0 = a * p.si + dh0, wi0 = b * p.si + dw0;
+                aoff[j] = (int)(((long)(img - img0) * a_ld_img + ((long)hi0 * Win + wi0) * a_ld_pix + (FLAT ? 0 : chunk4)) * 4);
+                unsigned long long mk = 0ull;
+                for (int i = 0; i < Th; ++i) {
+                    const int hi = hi0 + dstep * i;
+                    for (int jj = 0; jj < Tw; ++jj) {
+                        const int wi = wi0 + dstep * jj;
+                        if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) mk |= 1ull << (i * Tw + jj);
+                    }
                 }
+                amask[j] = mk;
             }
-            amask[j] = mk;
         }
-    }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int row = lrow + RPP * j;
+            const int n = n0 + row;
+            bok[j] = (row < BN) && (n < p.Nout);
+            boff[j] = (int)(((long)n * w_ld_n + (FLAT ? 0 : chunk4)) * 4);
+        }
+        Tw_ = Tw;
+        T_ = Th * Tw;
+        nkt = FLAT ? (T_ * p.C + IG_BK - 1) / IG_BK : T_ * cpt;
+        pixstep = dstep * (int)a_ld_pix * 4;  // bytes per tap step along w
+        rowstep = pixstep * Win;               // bytes per tap step along h
+        s_ti = s_tj = s_ck = s_kt = 0;
+    };
+    setup_src(p.A, p.Wt, p.Hin, p.Win, p.Th, p.Tw, p.dh0, p.dw0, p.dstep, p.a_ld_pix, p.a_ld_img, p.w_ld_n, p.a_bytes, p.w_bytes);
     if (tid < BM) {
         const int m = m0 + tid;
         long long off = -1;
@@ -340,31 +375,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
         }
         rowoff[tid] = off;
     }
-    int boff[BJ];
-    bool bok[BJ];
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-        const int row = lrow + RPP * j;
-        const int n = n0 + row;
-        bok[j] = (row < BN) && (n < p.Nout);
-        boff[j] = (int)(((long)n * p.w_ld_n + (FLAT ? 0 : chunk4)) * 4);
-    }
 
-    const int cpt = (p.C + KD - 1) / KD;
-    const int nkt = FLAT ? (T * p.C + IG_BK - 1) / IG_BK : T * cpt;
-    const int pixstep = p.dstep * (int)p.a_ld_pix * 4;      // bytes per tap step along w
-    const int rowstep = pixstep * p.Win;                     // bytes per tap step along h
-
-    // scalar slab state of the NEXT slab to load (non-FLAT): tap row, tap column, channel chunk
-    int s_ti = 0, s_tj = 0, s_ck = 0, s_kt = 0;
     float4 ra[AJ], rb[BJ];
     auto load_tile_to = [&](float4* ra, float4* rb) {
         if (FLAT) {
             const int kk = s_kt * IG_BK + chunk4;  // flattened (tap, c) index of this lane's chunk
             const int t = kk / p.C;
             const int c = kk - t * p.C;
-            const int ti = t / p.Tw, tj = t - ti * p.Tw;
-            const bool kok = t < T;
+            const int ti = t / Tw_, tj = t - ti * Tw_;
+            const bool kok = t < T_;
             const int tapoff = ti * rowstep + tj * pixstep + c * 4;
             const int tb = kok ? t : 0;
 #pragma unroll
@@ -375,7 +394,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < BJ; ++j) rb[j] = sgx_buf_ld4(bufB, (kok && bok[j]) ? (unsigned)(boff[j] + kk * 4) : SGX_BUF_OOB);
         } else {
-            const int tbit = s_ti * p.Tw + s_tj;
+            const int tbit = s_ti * Tw_ + s_tj;
             const int tapoff = s_ti * rowstep + s_tj * pixstep + s_ck * (KD * 4);
             const int woff = (tbit * p.C + s_ck * KD) * 4;
             const bool cok = s_ck * KD + chunk4 < p.C;
@@ -388,7 +407,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             for (int j = 0; j < BJ; ++j) rb[j] = sgx_buf_ld4(bufB, (cok && bok[j]) ? (unsigned)(boff[j] + woff) : SGX_BUF_OOB);
             if (++s_ck == cpt) {
                 s_ck = 0;
-                if (++s_tj == p.Tw) {
+                if (++s_tj == Tw_) {
                     s_tj = 0;
                     ++s_ti;
                 }
@@ -449,21 +468,17 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     // bf16x3: the five correction products (<= 2^-8 of the leading one) get their own accumulator, so that their fp32 additions round
     // at 2^-8 of the result's magnitude; the leading hi*hi products are exact and add into `acc` once per 16-deep slab - fewer
     // roundings at full magnitude than the fp32 matrix pipe's eight per slab.  The two are summed once, before the epilogue.
-    sgx_f32x16 acc2[MATH == 1 ? TM : 1][MATH == 1 ? TN : 1];
-    if (MATH == 1) {
+    // PH2 = 2 (fp32 arithmetic only) reuses the name for the accumulator of the second output.
+    constexpr bool ACC2 = MATH == 1 || PH2 == 2;
+    sgx_f32x16 acc2[ACC2 ? TM : 1][ACC2 ? TN : 1];
+    if (ACC2) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[MATH == 1 ? i : 0][MATH == 1 ? j : 0][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc2[ACC2 ? i : 0][ACC2 ? j : 0][r] = 0.f;
     }
-
-    if (nkt > 0) {
-        load_tile();
-        store_tile(0);
-    }
-    __syncthreads();
 
     const int frow = lane & 31, fk = (lane >> 5) * 8;
     // bf16x3 fragment reads + the six cross-product MFMAs of one slab (smallest terms first)
@@ -534,59 +549,59 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
     };
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (KD == 32 && NBUF == 1) {
-            // one LDS buffer: the next slab travels in registers under 16 x TM x TN MFMAs and is written after every wave has read this one
-            if (kt + 1 < nkt) load_tile();
-            if (MATH == 1) {
-                compute_bf3(0, 0);
-                compute_bf3(0, 1);
-            } else {
-                compute_f32(0, 0);
-                compute_f32(0, 16);
-            }
-            __syncthreads();
-            if (kt + 1 < nkt) {
-                store_tile(0);
-                __syncthreads();
-            }
-            continue;
-        }
-        const int buf = kt & 1;
-        if (KD == 32) {
-            if (kt + 1 < nkt) load_tile();
-            if (MATH == 1) {
-                compute_bf3(buf, 0);
-                compute_bf3(buf, 1);
-            } else {
-                compute_f32(buf, 0);
-                compute_f32(buf, 16);
-            }
-            if (kt + 1 < nkt) store_tile(buf ^ 1);
-            __syncthreads();
-            continue;
-        }
-        if (ABL == 4) {  // LAB: MFMA only
-            float af = ra[0].x, bf = rb[0].x;
+    // The K loop, once per source.  (Written as an unrolled loop over sources rather than a callable taking the accumulator: hipcc spends
+    // 14 more VGPRs on the lambda form - one wave per SIMD less; left rolled, the PH2 = 2 form needs 100 VGPRs instead of 63.)  PH2 = 2: the first source's result moves to acc2 before the second source
+    // starts from zero, so after the loop acc2 = first output (y), acc = second output (u).  Every pass ends behind a barrier: the LDS
+    // slabs are free for the next source's first slab and for the epilogue's staging patches.
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[0][0], 0, 0, 0);
-            continue;
+    for (int src = 0; src < (PH2 ? 2 : 1); ++src) {
+        if (PH2 && src == 1) {
+            if (!p.A2) break;
+            setup_src(p.A2, p.Wt2, p.Hin2, p.Win2, p.Th2, p.Tw2, p.dh02, p.dw02, p.dstep2, p.a2_ld_pix, p.a2_ld_img, p.w2_ld_n, p.a2_bytes, p.w2_bytes);
+            if (PH2 == 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            acc2[ACC2 ? i : 0][ACC2 ? j : 0][r] = acc[i][j][r];
+                            acc[i][j][r] = 0.f;
+                        }
+            }
         }
-        if (kt + 1 < nkt && (ABL < 1 || ABL == 3)) load_tile();  // global loads in flight under the MFMA block
-
-        if (MATH == 1) {
-            // (a second register stage - slabs fetched two iterations ahead, counted vmcnt - was measured: no gain, r1z/r1z2;
-            // this path is bound by LDS traffic and the per-slab barrier, not by global-load latency)
-            compute_bf3(buf, 0);
+        if (nkt > 0) {
+            load_tile();
+            store_tile(0);
+        }
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (KD == 32) {
+                // one LDS buffer: the next slab travels in registers under 16 x TM x TN MFMAs and is written after every wave has read this one
+                if (kt + 1 < nkt) load_tile();
+                if (MATH == 1) {
+                    compute_bf3(0, 0);
+                    compute_bf3(0, 1);
+                } else {
+                    compute_f32(0, 0);
+                    compute_f32(0, 16);
+                }
+                __syncthreads();
+                if (kt + 1 < nkt) {
+                    store_tile(0);
+                    __syncthreads();
+                }
+                continue;
+            }
+            const int buf = kt & 1;
+            if (kt + 1 < nkt) load_tile();  // global loads in flight under the MFMA block
+            // (bf16x3: a second register stage - slabs fetched two iterations ahead, counted vmcnt - was measured: no gain, r1z/r1z2)
+            if (MATH == 1) compute_bf3(buf, 0);
+            else compute_f32(buf, 0);
             if (kt + 1 < nkt) store_tile(buf ^ 1);
             __syncthreads();
-            continue;
         }
-        compute_f32(buf, 0);
-        if (kt + 1 < nkt && (ABL < 2 || ABL == 3)) store_tile(buf ^ 1);
-        __syncthreads();
     }
-    if (ABL == 3 && p.M > 0) return;  // LAB: no epilogue
 
     if (MATH == 1) {
 #pragma unroll
@@ -594,7 +609,73 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[MATH == 1 ? i : 0][MATH == 1 ? j : 0][r];
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[ACC2 ? i : 0][ACC2 ? j : 0][r];
+    }
+    if constexpr (PH2 == 2) {
+        // ---- two-output epilogue (QARepVGG forward): y = acc2 -> Y, u = acc + bias2 -> Y2 (same strides), and the five per-channel sums both
+        // BatchNorms of the block are finalised from: sum y, y^2, u0, u0^2, y*u0 with u0 = u - bias2 (rows outside the image are exact zeros
+        // in both accumulators, so the sums need no row mask; the finalize kernel adds the bias terms in fp64).  The sums are taken in the
+        // accumulator layout (a lane owns one column and 16 rows of a 32x32 sub-tile), the stores after the usual transpose through LDS.
+        float* const stage = smem + wave * (32 * 32);
+        const int sr = lane >> 3, sc4 = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float y = acc2[ACC2 ? i : 0][ACC2 ? j : 0][r], u = acc[i][j][r];
+                    st[0] += y; st[1] += y * y; st[2] += u; st[3] += u * u; st[4] += y * u;
+                }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) st[t] += __shfl_xor(st[t], 32);
+            if (lane < 32) {
+#pragma unroll
+                for (int t = 0; t < 5; ++t) red[(t * WM + wm) * BN + wn * TN * 32 + j * 32 + lane] = st[t];
+            }
+            const int col = n0 + wn * TN * 32 + j * 32 + sc4;
+            const bool colok = col < p.Nout;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias2 && colok) bv = sgx_ld4(p.bias2 + col);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = o == 0 ? acc2[ACC2 ? i : 0][ACC2 ? j : 0][r] : acc[i][j][r];
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rowl = q * 8 + sr;
+                        const long long off = rowoff[wm * TM * 32 + i * 32 + rowl];
+                        float4 v = sgx_ld4(stage + rowl * 32 + sc4);
+                        if (off >= 0 && colok) {
+                            if (o == 1) {
+                                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                            }
+                            sgx_st4((o == 0 ? p.Y : p.Y2) + off + col, v);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int col = n0 + tid;
+            if (col < p.Nout) {
+#pragma unroll
+                for (int pl = 0; pl < 5; ++pl) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) t += red[(pl * WM + w) * BN + tid];
+                    p.stat_partials[((long)pl * p.stat_nblk + mtile) * p.Nout + col] = t;
+                }
+            }
+        }
+        return;
     }
     // ---- epilogue: bias + addend + accumulate + activation, optional BN partial statistics --------------------------
     // The MFMA accumulator layout gives a lane ONE column and 16 scattered rows (4-byte stores, 128-byte runs).  Each wave
@@ -762,7 +843,7 @@ extern "C" int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n) {
                               (e[9] == 0) == (e[10] == 0),  // all 16 tiles of {32, 64, 96, 128}^2 are instantiated
                           "conv_tuning_load: entry %d: no weight-gradient kernel (tile %dx%d, split target %d)", i, e[9], e[10], e[11]);
         else
-            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && e[11] >= 0 && e[11] <= 7,
+            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && (e[11] == 0 || e[11] == 7),
                           "conv_tuning_load: entry %d: no kernel (tile %dx%d, variant %d)", i, e[9], e[10], e[11]);
         m[std::array<int, 9>{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8]}] = TuneVal{e[9], e[10], e[11]};
     }
@@ -796,69 +877,80 @@ static TileCfg pick_tile_heuristic(long M, int N) {
 
 // 32-deep slabs (one LDS buffer) are the default wherever they apply - channel-chunked K axis, C a multiple of 32 (a ragged last chunk
 // would multiply zeros for up to half a slab): measured on MI355X (profiles/r2d_conv_tune_variants.txt) they win on 3x3 and deep 1x1
-// layers alike (+5-10 %, whole-line loads, half the load instructions per FLOP).  Variant 6 = two LDS buffers (lower occupancy: loses
-// except on a few 128-wide tiles), variant 7 = the 16-deep loop; both reachable through the tuning table / sgx_debug_set_variant.
-static bool igemm_deep_slabs(const IgemmParams& p) { return conv_variant() != 7 && conv_variant() < 10 && p.C % 32 == 0; }
-// dispatch over the eight non-flat tile shapes for one (MATH, KD, NBUF)
-#define SGX_IGEMM_TILES(MATH_, KD_, NBUF_)                                                                  \
-    do {                                                                                                    \
-        if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, MATH_, KD_, NBUF_>(p, stream);      \
-        else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, MATH_, KD_, NBUF_>(p, stream);   \
-        else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, MATH_, KD_, NBUF_>(p, stream);   \
-        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, MATH_, KD_, NBUF_>(p, stream);   \
-        else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2, false, MATH_, KD_, NBUF_>(p, stream);   \
-        else if (bm == 64 && bn == 96) launch_igemm<64, 96, 2, 1, false, MATH_, KD_, NBUF_>(p, stream);     \
-        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, MATH_, KD_, NBUF_>(p, stream);     \
-        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, MATH_, KD_, NBUF_>(p, stream);     \
-        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no tile %dx%d (math %d, %d-deep slabs)", bm, bn, MATH_, KD_); \
+// layers alike (+5-10 %, whole-line loads, half the load instructions per FLOP).  Variant 7 (tuning table / sgx_debug_set_variant) = the
+// 16-deep loop; two LDS buffers with 32-deep slabs measured slower (lower occupancy) and were removed.
+static bool igemm_deep_slabs(const IgemmParams& p) { return conv_variant() != 7 && p.C % 32 == 0; }
+// dispatch over the eight non-flat tile shapes for one (MATH, KD, NBUF, PH2)
+#define SGX_IGEMM_TILES(MATH_, KD_, NBUF_, PH2_)                                                                  \
+    do {                                                                                                          \
+        if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, MATH_, KD_, NBUF_, PH2_>(p, stream);      \
+        else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);   \
+        else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, MATH_, KD_, NBUF_, PH2_>(p, stream);   \
+        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);   \
+        else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2, false, MATH_, KD_, NBUF_, PH2_>(p, stream);   \
+        else if (bm == 64 && bn == 96) launch_igemm<64, 96, 2, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);     \
+        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, MATH_, KD_, NBUF_, PH2_>(p, stream);     \
+        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);     \
+        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no tile %dx%d (math %d, %d-deep slabs)", bm, bn, MATH_, KD_);   \
     } while (0)
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int ABL = 0>
+// the two-source kernels exist for the tiles the heuristic picks (pick_tile_heuristic): overrides / table entries do not apply to them
+#define SGX_IGEMM_TILES_PH2(KD_, NBUF_, PH2_)                                                                     \
+    do {                                                                                                          \
+        if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, 0, KD_, NBUF_, PH2_>(p, stream);            \
+        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 0, KD_, NBUF_, PH2_>(p, stream);       \
+        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, KD_, NBUF_, PH2_>(p, stream);         \
+        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, 0, KD_, NBUF_, PH2_>(p, stream);         \
+        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (two sources): no tile %dx%d", bm, bn);                          \
+    } while (0)
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0>
 static void launch_igemm(IgemmParams& p, void* stream) {
     p.mt = sgx_cdiv(p.M, BM);
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
     p.chunk = sgx_cdiv(p.nblk, 8);
     int grid = p.chunk * 8;
-    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF, ABL>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
+    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF, PH2>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
 }
 
-static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
+// ph2: 0 = one source; 1 = second source into the same accumulator; 2 = second source into a second output (see IgemmParams)
+static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 = 0) {
     const int T = p.Th * p.Tw;
-    const int var = conv_variant();
     if (T > SGX_MAX_TAPS) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: more than %d taps", SGX_MAX_TAPS);
     if (p.w_bytes > SGX_BUF_MAX) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: weight tensor larger than 2 GiB");
     {
         const long hw = (long)p.Ha * p.Wa;
         const long imgs = (bm + hw - 1) / hw + 1;  // images a pixel tile can touch
         if (imgs * p.a_ld_img * 4 > SGX_BUF_MAX) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: one pixel tile spans more than 2 GiB of input");
+        if (ph2 && p.A2 && imgs * p.a2_ld_img * 4 > SGX_BUF_MAX) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: one pixel tile spans more than 2 GiB of input");
     }
     p.vec = (p.Nout % 4 == 0 && p.y_ld_pix % 4 == 0 && p.y_ld_img % 4 == 0 && ((uintptr_t)p.Y % 16) == 0 && ((uintptr_t)p.addend % 16) == 0 &&
              ((uintptr_t)p.bias % 16) == 0)
                 ? 1
                 : 0;
-    // algorithmic bytes: every input element, weight and output element once (fp32)
-    SGX_PROF(0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * (double)T,
-             4.0 * ((double)p.M / ((double)p.Ha * p.Wa) * p.Hin * p.Win * p.C + (double)p.Nout * p.C * T + (double)p.M * p.Nout), stream);
+    // algorithmic work: every input element, weight and output element once (fp32); the second source adds its taps
+    const double T2 = (ph2 && p.A2) ? (double)p.Th2 * p.Tw2 : 0.0;
+    SGX_PROF(0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * ((double)T + T2),
+             4.0 * ((double)p.M / ((double)p.Ha * p.Wa) * p.Hin * p.Win * p.C * (ph2 == 1 && p.A2 ? 2.0 : 1.0) + (double)p.Nout * p.C * (T + T2) +
+                    (double)p.M * p.Nout * (ph2 == 2 ? 2.0 : 1.0)), stream);
     const bool flat = p.C < IG_BK && T > 1;
-    if (conv_math_for(T, p.C) == 1) {
+    if (ph2) {
+        if (flat || !p.vec) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (two sources): needs C >= 16 and 16-byte aligned outputs");
+        if (p.C % 32 == 0) {
+            if (ph2 == 1) SGX_IGEMM_TILES_PH2(32, 1, 1);
+            else SGX_IGEMM_TILES_PH2(32, 1, 2);
+        } else {
+            if (ph2 == 1) SGX_IGEMM_TILES_PH2(16, 2, 1);
+            else SGX_IGEMM_TILES_PH2(16, 2, 2);
+        }
+    } else if (conv_math_for(T, p.C) == 1) {
         if (flat && bn > 64) bn = 64;
         if (flat && bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, true, 1>(p, stream);
         else if (flat && bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, true, 1>(p, stream);
         else if (flat && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, true, 1>(p, stream);
         else if (flat && bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true, 1>(p, stream);
         else if (flat) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (bf16x3): no flat tile %dx%d", bm, bn);
-        else if (igemm_deep_slabs(p)) {
-            if (var != 6) SGX_IGEMM_TILES(1, 32, 1);
-            else SGX_IGEMM_TILES(1, 32, 2);
-        } else if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, 1>(p, stream);  // 52 KB of LDS with the unpadded planes
-        else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, 1>(p, stream);
-        else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, 1>(p, stream);
-        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 1>(p, stream);
-        else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2, false, 1>(p, stream);
-        else if (bm == 64 && bn == 96) launch_igemm<64, 96, 2, 1, false, 1>(p, stream);
-        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 1>(p, stream);
-        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, 1>(p, stream);
-        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (bf16x3): no tile %dx%d", bm, bn);
+        else if (igemm_deep_slabs(p)) SGX_IGEMM_TILES(1, 32, 1, 0);
+        else SGX_IGEMM_TILES(1, 16, 2, 0);
     } else if (flat) {
         if (bn > 64) bn = 64;  // the flat variants exist for the narrow tiles only (stem layers have few output channels)
         if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, true>(p, stream);
@@ -866,26 +958,8 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream) {
         else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, true>(p, stream);
         else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true>(p, stream);
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no flat tile %dx%d", bm, bn);
-    } else if (igemm_deep_slabs(p) && !(var >= 1 && var <= 4)) {  // 32-deep slabs (see igemm_kernel): whole-line loads
-        if (var != 6) SGX_IGEMM_TILES(0, 32, 1);
-        else SGX_IGEMM_TILES(0, 32, 2);
-    } else if (var == 11 && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, 16, 2, 1>(p, stream);
-    else if (var == 12 && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, 16, 2, 2>(p, stream);
-    else if (var == 13 && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, 16, 2, 3>(p, stream);
-    else if (var == 14 && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, 16, 2, 4>(p, stream);
-    else if (var == 1 && bm == 64 && bn == 64) launch_igemm<64, 64, 1, 2, false>(p, stream);   // 2 waves x (64x32)
-    else if (var == 2 && bm == 128 && bn == 64) launch_igemm<128, 64, 4, 2, false>(p, stream);   // 8 waves x (32x32)
-    else if (var == 3 && bm == 128 && bn == 128) launch_igemm<128, 128, 4, 2, false>(p, stream); // 8 waves x (32x64)
-    else if (var == 4 && bm == 64 && bn == 128) launch_igemm<64, 128, 2, 4, false>(p, stream);   // 8 waves x (32x32)
-    else if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false>(p, stream);
-    else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false>(p, stream);
-    else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false>(p, stream);
-    else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false>(p, stream);
-    else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2, false>(p, stream);
-    else if (bm == 64 && bn == 96) launch_igemm<64, 96, 2, 1, false>(p, stream);
-    else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false>(p, stream);
-    else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false>(p, stream);
-    else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no tile %dx%d", bm, bn);
+    } else if (igemm_deep_slabs(p)) SGX_IGEMM_TILES(0, 32, 1, 0);  // 32-deep slabs (see igemm_kernel): whole-line loads
+    else SGX_IGEMM_TILES(0, 16, 2, 0);
     SGX_CHECK_LAUNCH("igemm");
     return SGX_OK;
 }
@@ -942,6 +1016,40 @@ extern "C" int32_t sgx_conv2d_fwd(const sgx_conv_desc* d, const float* x, const 
     return run_igemm(p, t.bm, u.bn, stream);
 }
 
+// y = conv RxS(x, w) (no bias), u = conv1x1(x, w1) + bias1 with the same stride, as ONE launch: the 1x1 filter reads exactly the centre
+// tap of the RxS one (pad = R / 2), so the workgroup that owns an output tile walks the taps of w into one accumulator and then the
+// centre tap again with w1 into a second one.  stat5: [5][sgx_conv2d_fwd_dual_stat_blocks(d)][K] = sum y, y^2, u0, u0^2, y*u0 per row block (u0 = u - bias1).
+extern "C" int32_t sgx_conv2d_fwd_dual_stat_blocks(const sgx_conv_desc* d) {
+    long M = (long)d->N * d->Ho * d->Wo;
+    return sgx_cdiv(M, pick_tile_heuristic(M, d->K).bm);
+}
+extern "C" int32_t sgx_conv2d_fwd_dual(const sgx_conv_desc* d, const float* x, const float* w, const float* w1, const float* bias1, float* y,
+                                       float* u, float* stat5, void* stream) {
+    int32_t rc = check_desc(d);
+    if (rc) return rc;
+    SGX_CHECK_ARG(x && w && w1 && y && u && stat5, "conv fwd_dual: null pointer");
+    SGX_CHECK_ARG(d->R == d->S && (d->R & 1) && d->pad == d->R / 2, "conv fwd_dual: odd square filter with pad = R / 2 (the 1x1 branch reads its centre tap)");
+    SGX_CHECK_ARG(d->C >= IG_BK && ((uintptr_t)u % 16) == 0, "conv fwd_dual: needs C >= 16 and a 16-byte aligned second output");
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.Wt = w; p.Y = y; p.stat_partials = stat5;
+    p.M = d->N * d->Ho * d->Wo; p.Ha = d->Ho; p.Wa = d->Wo; p.Hin = d->H; p.Win = d->W;
+    p.C = d->C; p.Nout = d->K; p.Th = d->R; p.Tw = d->S;
+    p.dh0 = -d->pad; p.dw0 = -d->pad; p.dstep = 1;
+    p.si = d->stride; p.so = 1; p.ph = 0; p.pw = 0; p.Hout = d->Ho; p.Wout = d->Wo;
+    p.a_ld_pix = d->x_ld_pix; p.a_ld_img = d->x_ld_img; p.y_ld_pix = d->y_ld_pix; p.y_ld_img = d->y_ld_img;
+    p.w_ld_n = (long)d->R * d->S * d->C;
+    p.a_bytes = view_bytes(d->N, d->H, d->W, d->C, d->x_ld_pix, d->x_ld_img);
+    p.w_bytes = (long)d->K * p.w_ld_n * 4;
+    p.act = SGX_ACT_NONE; p.accumulate = 0;
+    p.A2 = x; p.Wt2 = w1; p.bias2 = bias1; p.Y2 = u;
+    p.Hin2 = d->H; p.Win2 = d->W; p.Th2 = 1; p.Tw2 = 1; p.dh02 = 0; p.dw02 = 0; p.dstep2 = 1;
+    p.a2_ld_pix = d->x_ld_pix; p.a2_ld_img = d->x_ld_img; p.w2_ld_n = d->C; p.a2_bytes = p.a_bytes; p.w2_bytes = (long)d->K * d->C * 4;
+    TileCfg t = pick_tile_heuristic(p.M, p.Nout);
+    p.stat_nblk = sgx_cdiv(p.M, t.bm);
+    return run_igemm(p, t.bm, t.bn, stream, 2);
+}
+
 // ------------------------------------------------------------------------------------------------
 // data gradient
 // ------------------------------------------------------------------------------------------------
@@ -988,8 +1096,13 @@ extern "C" int64_t sgx_conv2d_bwd_data_workspace(const sgx_conv_desc* d) {
 
 // mode 0: transpose the weights into ws, then run; mode 1: only transpose (dy/dx unused); mode 2: ws already holds the transposed
 // weights of sgx_conv2d_transpose_weights (the host mirror prepares them on a side stream during the forward pass)
+struct DgradSecond {  // the 1x1 branch of a QARepVGG block: dx += dgrad1x1(ds) inside the same launch
+    const float* ds;
+    long ld_pix, ld_img;
+    const float* w1t;  // [C][K]
+};
 static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const float* w, const float* bias, const float* addend,
-                                  float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream, int mode);
+                                  float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream, int mode, const DgradSecond* sec = nullptr);
 extern "C" int32_t sgx_conv2d_bwd_data(const sgx_conv_desc* d, const float* dy, const float* w, const float* addend,
                                        float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream) {
     return conv_bwd_data_impl(d, dy, w, nullptr, addend, dx, accumulate, ws, ws_bytes, stream, 0);
@@ -1021,6 +1134,28 @@ extern "C" int32_t sgx_wtrans_batch(const sgx_wtrans_job* jobs_dev, int32_t njob
     SGX_CHECK_LAUNCH("wtrans_batch");
     return SGX_OK;
 }
+// QARepVGG per-step weight preparation, all blocks in one launch: w1p[k][c] = alpha * w1[k][c] + (identity && k == c), and its transpose
+// w1pt[c][k] (the data gradient's operand).  Folding the block's identity branch (and the alpha multiplier) into the 1x1 filter removes the
+// residual read from the block's forward sweep and the `addend` read from its data gradient.
+__global__ void qarep_prep_kernel(const sgx_qarep_prep_job* jobs) {
+    __shared__ sgx_qarep_prep_job job;
+    if (threadIdx.x == 0) job = jobs[blockIdx.y];
+    __syncthreads();
+    const long n = (long)job.K * job.C;
+    const float a = job.alpha ? job.alpha[0] : 1.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % job.C), k = (int)(i / job.C);
+        const float v = a * job.w1[i] + ((job.identity && k == c) ? 1.f : 0.f);
+        job.w1p[i] = v;
+        job.w1pt[(long)c * job.K + k] = v;
+    }
+}
+extern "C" int32_t sgx_qarep_prep_batch(const sgx_qarep_prep_job* jobs_dev, int32_t njobs, void* stream) {
+    SGX_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 65535, "qarep_prep_batch: bad args (njobs=%d)", njobs);
+    SGX_LAUNCH(qarep_prep_kernel, dim3(8, (unsigned)njobs), dim3(256), 0, stream, jobs_dev);
+    SGX_CHECK_LAUNCH("qarep_prep_batch");
+    return SGX_OK;
+}
 // mode 3 of conv_bwd_data_impl records the transposes instead of launching them
 struct WtransRecorder {
     sgx_wtrans_job* jobs;
@@ -1039,8 +1174,17 @@ extern "C" int32_t sgx_conv2d_transpose_jobs(const sgx_conv_desc* d, const float
     *njobs = rec.n;
     return SGX_OK;
 }
+// dx = conv_transpose RxS(dy, w) + conv_transpose 1x1(ds, w1) [+ addend] [+ dx] as ONE launch per output-parity class: the data gradient of
+// a QARepVGG block's two convolution branches (same stride; the 1x1 branch reaches parity class (0, 0) only).  wt: the RxS weights as
+// sgx_conv2d_transpose_weights lays them out; w1t: the 1x1 weights transposed, [C][K].
+extern "C" int32_t sgx_conv2d_bwd_data_dual(const sgx_conv_desc* d, const float* dy, const float* wt, const float* ds, int64_t ds_ld_pix,
+                                            int64_t ds_ld_img, const float* w1t, const float* addend, float* dx, int32_t accumulate, void* stream) {
+    SGX_CHECK_ARG(ds && w1t && d && d->K >= IG_BK && ds_ld_pix % 4 == 0, "conv bwd_data_dual: bad args (needs K >= 16)");
+    DgradSecond sec{ds, (long)ds_ld_pix, (long)ds_ld_img, w1t};
+    return conv_bwd_data_impl(d, dy, nullptr, nullptr, addend, dx, accumulate, const_cast<float*>(wt), sgx_conv2d_bwd_data_workspace(d), stream, 2, &sec);
+}
 static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const float* w, const float* bias, const float* addend,
-                                  float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream, int mode) {
+                                  float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream, int mode, const DgradSecond* sec) {
     int32_t rc = check_desc(d);
     if (rc) return rc;
     SGX_CHECK_ARG((mode == 1 || (dy && dx)) && (mode == 2 || w), "conv bwd_data: null pointer");
@@ -1104,7 +1248,16 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
                 SGX_LAUNCH(wtrans_kernel, dim3(grid), dim3(256), 0, stream, w, wt, d->K, d->C, d->R * d->S, T, taps);
                 SGX_CHECK_LAUNCH("wtrans");
             }
-            if (mode != 1) {
+            if (mode != 1 && sec && ph == 0 && pw == 0) {
+                p.A2 = sec->ds; p.Wt2 = sec->w1t;
+                p.Hin2 = d->Ho; p.Win2 = d->Wo; p.Th2 = 1; p.Tw2 = 1; p.dh02 = 0; p.dw02 = 0; p.dstep2 = 1;
+                p.a2_ld_pix = sec->ld_pix; p.a2_ld_img = sec->ld_img; p.w2_ld_n = d->K;
+                p.a2_bytes = view_bytes(d->N, d->Ho, d->Wo, d->K, sec->ld_pix, sec->ld_img);
+                p.w2_bytes = (long)d->C * d->K * 4;
+                TileCfg t = pick_tile_heuristic(p.M, p.Nout);
+                rc = run_igemm(p, t.bm, t.bn, stream, 1);
+                if (rc) return rc;
+            } else if (mode != 1) {
                 TileCfg t = igemm_tile(p);
                 TileCfg m = pick_tile(p.M, p.Nout, conv_math_for(p.Th * p.Tw, p.C));
                 rc = run_igemm(p, m.bm, t.bn, stream);

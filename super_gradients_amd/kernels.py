@@ -179,6 +179,78 @@ def conv2d_bwd_data_wt(dy, w, wt, x_shape, stride=1, pad=0, addend=None, out=Non
     return out
 
 
+# ---- QARepVGG block: both convolution branches per launch (csrc/conv.hip, PH2 kernels) ---------------------------------------------
+def conv2d_fwd_dual(x, w, w1p, bias1, stride=1):
+    """y = conv RxS(x, w) (pad R // 2, no bias), u = conv1x1(x, w1p) + bias1 in ONE launch -> (y, u, stat5 [5, nblk, K])."""
+    K, C, R, S = w.shape
+    _chk_w(w, K, R, S, x.shape[3])
+    _chk_w(w1p, K, 1, 1, x.shape[3])
+    y = torch.empty(conv_out_shape(x, K, R, S, stride, R // 2), device=x.device, dtype=torch.float32)
+    u = torch.empty_like(y)
+    d = conv_desc(x, K, R, S, stride, R // 2, y)
+    nblk = lib().sgx_conv2d_fwd_dual_stat_blocks(ctypes.byref(d))
+    stat5 = torch.empty(5, nblk, K, device=x.device, dtype=torch.float32)
+    check(lib().sgx_conv2d_fwd_dual(ctypes.byref(d), ptr(x), ptr(w), ptr(w1p), ptr(bias1), ptr(y), ptr(u), ptr(stat5), stream()), "sgx_conv2d_fwd_dual")
+    return y, u, stat5
+
+
+def conv2d_bwd_data_dual(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, out=None, accumulate=False):
+    """dx = convT RxS(dy) + convT 1x1(ds) [+ addend] [+ dx] in one launch per parity class; wt: conv2d_transpose_weights(w), w1pt: [C, K]."""
+    K, C, R, S = w.shape
+    if out is None:
+        out = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+    d = conv_desc(out, K, R, S, stride, R // 2, dy)
+    if addend is not None and nhwc_strides(addend) != nhwc_strides(out):
+        raise _lib.SgxError("bwd_data addend must share dx's strides")
+    sl, si = nhwc_strides(ds)
+    check(lib().sgx_conv2d_bwd_data_dual(ctypes.byref(d), ptr(dy), ptr(wt), ptr(ds), sl, si, ptr(w1pt), ptr(addend), ptr(out), int(accumulate), stream()),
+          "sgx_conv2d_bwd_data_dual")
+    return out
+
+
+def qarep_prep_job(w1, w1p, w1pt, identity, alpha=None) -> bytes:
+    """One sgx_qarep_prep_job record (host bytes): w1p = alpha * w1 + I, w1pt = its transpose; operands are arena views / persistent buffers."""
+    K, C = w1.shape[0], w1.shape[1]
+    j = _lib.QarepPrepJob()
+    j.w1, j.w1p, j.w1pt, j.alpha = ptr(w1), ptr(w1p), ptr(w1pt), ptr(alpha)
+    j.K, j.C, j.identity, j.pad_ = K, C, int(bool(identity)), 0
+    return bytes(j)
+
+
+def qarep_prep_batch(jobs_dev, njobs):
+    check(lib().sgx_qarep_prep_batch(ptr(jobs_dev), int(njobs), stream()), "sgx_qarep_prep_batch")
+
+
+def qarep_fwd_finalize(stat5, M, bias1, bn3, pbn):
+    """-> (cf [4, C], sv [8, C]); bn3 / pbn: BatchNorm layers (weight, bias, eps, momentum, running stats updated in place)."""
+    nblk, C = stat5.shape[1], stat5.shape[2]
+    cf = torch.empty(4, C, device=stat5.device, dtype=torch.float32)
+    sv = torch.empty(8, C, device=stat5.device, dtype=torch.float32)
+    ws = WORKSPACE.get(lib().sgx_qarep_workspace(nblk, C), stat5.device)
+    check(lib().sgx_qarep_fwd_finalize(ptr(stat5), nblk, M, C, ptr(bias1), ptr(bn3.weight), ptr(bn3.bias), bn3.eps, bn3.momentum, ptr(bn3.running_mean),
+                                       ptr(bn3.running_var), ptr(pbn.weight), ptr(pbn.bias), pbn.eps, pbn.momentum, ptr(pbn.running_mean),
+                                       ptr(pbn.running_var), ptr(cf), ptr(sv), ptr(ws), ws.numel(), stream()), "sgx_qarep_fwd_finalize")
+    return cf, sv
+
+
+def qarep_bwd(dout, y, u, cf, sv, bn3, pbn, act):
+    """BatchNorm x2 + activation backward of the block in two sweeps: -> (ds written over u, dy written over y); d gamma / d beta accumulate."""
+    M, yl = rows(y)
+    C = y.shape[3]
+    dl, ul = rows(dout)[1], rows(u)[1]
+    a = ACT[act]
+    nblk = stats_blocks(M)
+    parts = torch.empty(4, nblk, C, device=y.device, dtype=torch.float32)
+    check(lib().sgx_qarep_bwd_reduce(ptr(dout), dl, ptr(y), yl, ptr(u), ul, ptr(cf), ptr(sv), M, C, a, ptr(parts), stream()), "sgx_qarep_bwd_reduce")
+    cb = torch.empty(5, C, device=y.device, dtype=torch.float32)
+    ws = WORKSPACE.get(lib().sgx_qarep_workspace(nblk, C), y.device)
+    check(lib().sgx_qarep_bwd_finalize(ptr(parts), nblk, M, C, ptr(bn3.weight), ptr(pbn.weight), ptr(sv), ptr(bn3.weight.grad), ptr(pbn.weight.grad),
+                                       ptr(pbn.bias.grad), ptr(cb), ptr(ws), ws.numel(), stream()), "sgx_qarep_bwd_finalize")
+    check(lib().sgx_qarep_bwd_apply(ptr(dout), dl, ptr(y), yl, ptr(u), ul, ptr(cf), ptr(sv), ptr(cb), ptr(u), ul, ptr(y), yl, M, C, a, stream()),
+          "sgx_qarep_bwd_apply")
+    return u, y
+
+
 def conv2d_bwd_weight(x, dy, dw, dbias=None, stride=1, pad=0):
     """dw (logical [K,C,R,S], OHWI memory) += grad; dbias += column sums."""
     K, C, R, S = dw.shape
@@ -381,9 +453,9 @@ def dot_sum(a, b, out, accumulate=True, scale=1.0):
     M, la = rows(a)
     C = a.shape[3]
     nblk = stats_blocks(M)
-    parts = torch.empty(nblk * C, device=a.device, dtype=torch.float32)
+    parts = torch.empty(2 * nblk * C, device=a.device, dtype=torch.float32)  # sums + their compensation terms
     check(lib().sgx_dot_partial(ptr(a), la, ptr(b), rows(b)[1], M, C, ptr(parts), stream()), "sgx_dot_partial")
-    check(lib().sgx_sum_partials(ptr(parts), nblk * C, float(scale), ptr(out), int(accumulate), stream()), "sgx_sum_partials")
+    check(lib().sgx_sum_partials(ptr(parts), 2 * nblk * C, float(scale), ptr(out), int(accumulate), stream()), "sgx_sum_partials")
 
 
 def axpy(x, a=1.0, a_dev=None, out=None, accumulate=False):

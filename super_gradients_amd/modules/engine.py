@@ -168,15 +168,16 @@ class SgxNetwork(nn.Module):
         # under the side-stream weight gradients, so it stays off by default.
         self.aux_stream = torch.cuda.Stream(device=device) if (self.side_stream is not None and os.environ.get("SGX_AUX_STREAM", "0") == "1") else None
         self._wt_valid = False
-        # SGX_WT_BATCH=1: the data-gradient weight transposes of ALL convolutions run as one launch at the start of every training forward
-        # (a job table built once - the operands are arena views, their addresses never change) instead of one launch per convolution and
-        # parity class inside backward (YOLO-NAS-S: 165 launches of ~10 us per step).
-        self.wt_batch = os.environ.get("SGX_WT_BATCH", "0") == "1" and self.aux_stream is None
+        # The data-gradient weight transposes of ALL convolutions run as one launch at the start of every training forward (a job table
+        # built once - the operands are arena views, their addresses never change) instead of one launch per convolution and parity class
+        # inside backward (YOLO-NAS-S: 165 launches of ~10 us per step; SGX_WT_BATCH=0 restores the per-call form), and so do the
+        # QARepVGG blocks' per-step filter preparations (W1 + I and its transpose, sgx_qarep_prep_batch).
+        self.wt_batch = os.environ.get("SGX_WT_BATCH", "1") == "1" and self.aux_stream is None
         for m in self.modules():
             if isinstance(m, SgxBlock):
                 object.__setattr__(m, "_net", self)  # plain attribute: must not register the network as a child module
                 m.on_materialize()
-        self._dgrad_convs = [m for m in self.modules() if hasattr(m, "transpose_weights")]
+        self._dgrad_convs = [m for m in self.modules() if hasattr(m, "transpose_weights") and getattr(m, "_wt", None) is not None]
         self._wt_jobs, self._wt_njobs = None, 0
         if self.wt_batch and self._dgrad_convs:
             from .. import _lib
@@ -185,6 +186,11 @@ class SgxNetwork(nn.Module):
             table = b"".join(K.conv2d_transpose_jobs(m._w, m._wt, stride=m.stride, pad=m.padding) for m in self._dgrad_convs)
             self._wt_njobs = len(table) // ctypes.sizeof(_lib.WtransJob)
             self._wt_jobs = torch.frombuffer(bytearray(table), dtype=torch.uint8).to(device)
+        self._qp_jobs, self._qp_njobs = None, 0
+        recs = [j for j in (m.qarep_prep_job() for m in self.modules() if hasattr(m, "qarep_prep_job")) if j is not None]
+        if recs:
+            self._qp_njobs = len(recs)
+            self._qp_jobs = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(device)
         return self
 
     def prefetch_dgrad_weights(self):
@@ -193,6 +199,8 @@ class SgxNetwork(nn.Module):
             from .. import kernels as K
 
             K.wtrans_batch(self._wt_jobs, self._wt_njobs)  # current stream: ordered after the optimizer step, before backward
+            if getattr(self, "_qp_jobs", None) is not None:
+                K.qarep_prep_batch(self._qp_jobs, self._qp_njobs)
             self._wt_valid = True
             return
         if aux is None:

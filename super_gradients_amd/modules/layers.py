@@ -62,7 +62,10 @@ class ConvLayer(SgxBlock):
         slots = {s.param: s for s in self._net.slots}
         s = slots[self.weight]
         self._w, self._gw = s.kernel_view, s.grad_kernel_view
-        self._wt = K.conv2d_wt_buffer(self._w, self._w.device) if (self._net.aux_stream is not None or self._net.wt_batch) else None
+        # persistent buffer of the data gradient's transposed weights (filled once per step by the network's batched transpose launch);
+        # filter counts that are not a multiple of 4 (class-prediction convs) run their zero-padded backward with per-call transposes
+        pre = (self._net.aux_stream is not None or self._net.wt_batch) and self._w.shape[0] % 4 == 0
+        self._wt = K.conv2d_wt_buffer(self._w, self._w.device) if pre else None
 
     def transpose_weights(self):
         K.conv2d_transpose_weights(self._w, self._wt, stride=self.stride, pad=self.padding)

@@ -6,13 +6,16 @@ with state_dict keys branch_3x3.{conv.weight,bn.*}, branch_1x1.{weight,bias}, po
 (the last one is the reference's unused deployment placeholder, qarepvgg_block.py:166-176: kept so checkpoints load,
 never touched by any kernel, excluded from optimizer / all-reduce / EMA).
 
-Kernel sequence (training), 4 launches + 2 tiny finalizes instead of the reference's 2 conv + 2 BN + 2 add + ReLU ops:
-  t3 = conv3x3(x)                      BN3 partial statistics from the conv epilogue
-  t1 = conv1x1(x) + b
-  s  = scale3*t3 + shift3 + alpha*t1 + x     one sweep, emits post_bn partial statistics
-  y  = act(scale_p*s + shift_p)              one sweep
-Backward: post_bn(+act) backward over s (in place) -> 1x1 wgrad/dbias; BN3 backward over t3 (in place) -> 3x3 wgrad;
-dx = dgrad3x3(dt3) + dgrad1x1(alpha*ds) + ds, the two extra terms folded into the data-gradient epilogues.
+Kernel sequence (training) - 3 launches forward, 7 backward, against the reference's 2 conv + 2 BN + 2 add + ReLU ops and their autograd:
+  y3, u = conv3x3(x), conv1x1(x; W1 + I) + b   ONE launch (the 1x1 filter reads the 3x3 filter's centre tap; the identity branch is folded
+                                                into the 1x1 filter once per step); its epilogue leaves the five moments of (y3, u)
+  finalize                                      BOTH BatchNorms' statistics from those moments: s = bn3(y3) + u is affine in (y3, u)
+  out = act(a*y3 + scale_p*u + c)               ONE sweep; s itself is never written
+Backward: one reduce sweep over (dout, y3, u) (four sums), finalize, one apply sweep that writes the gradients of u and y3 in place; the two
+weight gradients; dx = dgrad3x3(dy3) + dgrad1x1(ds) as ONE launch (two K-axis sources, no accumulate pass over dx).
+Blocks this form does not cover (learnable alpha, fewer than 16 channels, synchronised BatchNorm) run the general sequence:
+  t3 = conv3x3(x) (+ BN3 partial statistics), t1 = conv1x1(x) + b, s = scale3*t3 + shift3 + alpha*t1 + x (one sweep, post_bn partial
+  statistics), y = act(scale_p*s + shift_p) (one sweep); backward: post_bn and BN3 backward in place, dx = dgrad3x3 + dgrad1x1 + ds.
 """
 from torch import nn
 import torch
@@ -54,7 +57,22 @@ class QARepVGGBlock(SgxBlock):
         self._fused_w = self._fused_b = None
 
     def on_materialize(self):
-        pass
+        self._w1p = self._w1pt = None
+
+    def qarep_prep_job(self):
+        """-> the block's sgx_qarep_prep_job record (called once by SgxNetwork.materialize, after every layer owns its arena views), or None
+        when the block runs the general sequence.  Allocates the persistent buffers of the two-branch-per-launch form: W1 + I and its
+        transpose, refreshed once per step by the network's sgx_qarep_prep_batch launch (engine.prefetch_dgrad_weights)."""
+        c1 = self.branch_1x1
+        if isinstance(self.alpha, torch.Tensor) or float(self.alpha) != 1.0 or self.in_channels < 16 or self.out_channels < 16 or not self._net.wt_batch:
+            return None
+        K_, C_ = c1._w.shape[0], c1._w.shape[1]
+        self._w1p = K.ohwi_empty(K_, C_, 1, 1, c1._w.device)
+        self._w1pt = torch.empty(C_, K_, device=c1._w.device, dtype=torch.float32)
+        return K.qarep_prep_job(c1._w, self._w1p, self._w1pt, self.use_residual_connection)
+
+    def _two_branch_launch(self):
+        return (self._w1p is not None and self._net._wt_valid and not (self.branch_3x3.bn._synced() or self.post_bn._synced()))
 
     def _alpha(self):
         """-> (host float, device scalar or None) as the sweeps take it"""
@@ -68,6 +86,12 @@ class QARepVGGBlock(SgxBlock):
             if self.partially_fused or self.fully_fused:
                 raise RuntimeError("a fused QARepVGGBlock is inference-only on the HIP path (the reference's fused block trains a single conv; "
                                    "re-parameterised training is outside the hot path)")
+            if self._two_branch_launch():
+                y3, u, stat5 = K.conv2d_fwd_dual(x, c3._w, self._w1p, c1.bias, stride=self.stride)
+                cf, sv = K.qarep_fwd_finalize(stat5, y3.shape[0] * y3.shape[1] * y3.shape[2], c1.bias, bn3, pbn)
+                y = K.dual_affine_act(y3, cf[0], cf[1], u, cf[2], cf[3], act=self.act, out=out)
+                self._ctx = ("dual", x, y3, u, cf, sv)
+                return y
             # the two branches read the same x and are independent: the 1x1 branch runs on the side stream beside the 3x3 one
             t1 = torch.empty(K.conv_out_shape(x, self.out_channels, 1, 1, self.stride, 0), device=x.device, dtype=torch.float32)
             self._net.fork_side(lambda: c1.conv(x, out=t1), x, t1)
@@ -160,6 +184,15 @@ class QARepVGGBlock(SgxBlock):
 
     def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
         c3, bn3, c1, pbn = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1, self.post_bn
+        if self._ctx[0] == "dual":
+            (_, x, y3, u, cf, sv), self._ctx = self._ctx, None
+            ds, dy3 = K.qarep_bwd(dy, y3, u, cf, sv, bn3, pbn, self.act)   # in place over u / y3
+            c1.wgrad(x, ds)
+            c3.wgrad(x, dy3)
+            if not need_dx:
+                return None
+            return K.conv2d_bwd_data_dual(dy3, c3._w, c3._wt, ds, self._w1pt, tuple(x.shape), stride=self.stride, addend=addend, out=dx_out,
+                                          accumulate=accumulate)
         (x, t3, s, sc3, sh3, m3, i3, scp, shp, mp, ip, t1), self._ctx = self._ctx, None
         ds = pbn.backward(dy, s, scp, shp, mp, ip, self.act, dx_out=s)          # in place over s
         ds1 = ds                                                                # gradient of the 1x1 branch output: alpha * ds

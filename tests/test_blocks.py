@@ -36,7 +36,7 @@ def _randomize(mod, seed):
             m.eps, m.momentum = 1e-3, 0.03
 
 
-def _check(ref, blk, x, device, tol=2e-5, key_prefix="b."):
+def _check(ref, blk, x, device, tol=2e-5, key_prefix="b.", prefetch=False):
     from super_gradients_amd.modules.layers import BatchNorm
 
     _randomize(ref, 1)
@@ -53,6 +53,8 @@ def _check(ref, blk, x, device, tol=2e-5, key_prefix="b."):
     dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
     y.backward(dy)
     net.zero_grad()
+    if prefetch:  # what NetFunction.forward does at the start of every training step: per-step weight preparation of all blocks
+        net.prefetch_dgrad_weights()
     yd = blk.fwd(to_nhwc(x, device))
     assert_close(to_nchw_cpu(yd), y, tol, "forward")
     dx = blk.bwd(to_nhwc(dy, device))
@@ -95,6 +97,38 @@ def test_qarepvgg_block(backend, stride, cout):
     co = c if cout is None else c * cout
     x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
     _check(QARep(c, co, stride, residual=stride == 1), QARepVGGBlock(c, co, stride=stride, use_residual_connection=stride == 1), x, backend)
+
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("stride,cout,act", [(1, None, "relu"), (2, 2, "relu"), (1, None, "silu"), (2, 1, "relu")])
+def test_qarepvgg_block_two_branch_launch(backend, stride, cout, act, wide):
+    """The training form the network runs (after the per-step weight preparation): both convolution branches in one launch with the
+    identity folded into the 1x1 filter, both BatchNorms finalised from the five conv-epilogue moments, one forward sweep, two backward
+    sweeps, one data-gradient launch over two K-axis sources - against the oracle's QARepVGG block: forward, input gradient, every
+    parameter gradient (d beta of branch_3x3.bn is analytically zero), running statistics."""
+    from oracle.yolo_nas import QARep
+    from super_gradients_amd.modules import QARepVGGBlock
+
+    # channel counts that are / are not multiples of 32 take the 32-deep / 16-deep slab kernels; 96 output channels the 128x32 tile
+    if wide:
+        n, c, h, w = _shape(backend, (2, 96, 12, 10), (1, 32, 5, 4))
+    else:
+        n, c, h, w = _shape(backend, (2, 48, 23, 17), (2, 16, 6, 5))
+    co = c if cout is None else c * cout
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
+    kw = {} if act == "relu" else dict(activation_type=nn.SiLU)
+    ref = QARep(c, co, stride, residual=stride == 1)
+    if act == "silu":  # the oracle block hard-wires YOLO-NAS's ReLU: same arithmetic with the other activation the kernels offer
+        import types
+
+        def fwd(self, x):
+            s = self.branch_3x3(x) + self.alpha * self.branch_1x1(x)
+            return nn.functional.silu(self.post_bn(s + x if self.residual else s))
+
+        ref.forward = types.MethodType(fwd, ref)
+    blk = QARepVGGBlock(c, co, stride=stride, use_residual_connection=stride == 1, **kw)
+    _check(ref, blk, x, backend, prefetch=True)
+    assert blk._w1p is not None and blk._ctx is None
 
 
 @pytest.mark.parametrize("stride", [1, 2])

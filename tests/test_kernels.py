@@ -830,18 +830,20 @@ def test_conv_tuning_table(backend):
     dx0 = K.conv2d_bwd_data(dyd, wd, (n, h, w, c), stride=s, pad=p)
     key = dict(N=n, H=h, W=w, C=c, K=k, R=r, stride=s, pad=p)
     try:
-        assert load_conv_tuning([dict(kind="fwd", bm=128, bn=32, variant=5, **key), dict(kind="dgrad", bm=64, bn=32, variant=6, **key)]) == 2
+        assert load_conv_tuning([dict(kind="fwd", bm=128, bn=32, variant=7, **key), dict(kind="dgrad", bm=64, bn=32, variant=0, **key)]) == 2
         assert lib().sgx_conv_tuning_size() == 2
         y1, parts1 = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s, pad=p, stat_partials=True)
         dx1 = K.conv2d_bwd_data(dyd, wd, (n, h, w, c), stride=s, pad=p)
         assert torch.equal(y1.cpu(), y0.cpu()) and torch.equal(dx1.cpu(), dx0.cpu())
         assert parts1.shape[1] == 1 and parts0.shape[1] == 2, "statistics rows: one 128-row tile from the table vs two 64-row tiles (72 pixels)"
         assert_close(parts1.sum(1).cpu(), parts0.sum(1).cpu(), 1e-5, "statistics")
-        # the table is consulted per problem: an impossible wave-layout entry fails for ITS problem only
-        load_conv_tuning([dict(kind="fwd", bm=128, bn=128, variant=2, **dict(key, K=k + 4))])
+        # the table is consulted per problem: an entry for another problem changes nothing here
+        load_conv_tuning([dict(kind="fwd", bm=128, bn=128, variant=7, **dict(key, K=k + 4))])
         assert torch.equal(K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s, pad=p).cpu(), y0.cpu())
         with pytest.raises(RuntimeError, match="no kernel"):
             load_conv_tuning([dict(kind="fwd", bm=48, bn=32, variant=0, **key)])
+        with pytest.raises(RuntimeError, match="no kernel"):
+            load_conv_tuning([dict(kind="fwd", bm=64, bn=64, variant=3, **key)])
         # weight gradient: filter tile x (tap, channel) tile x split target; a different split regroups the pixel sum (rounding level)
         g0 = K.to_ohwi(torch.zeros_like(wt).to(backend))
         K.conv2d_bwd_weight(xd, dyd, g0, None, stride=s, pad=p)

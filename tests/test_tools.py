@@ -16,13 +16,13 @@ def test_conv_tune_table_round_trip(backend, tmp_path):
     from super_gradients_amd._lib import lib, load_conv_tuning
 
     agg = {
-        ("fwd", 32, 80, 80, 64, 64, 3, 1, 1): {(0, 0, 0): 1200.0, (64, 64, 5): 1000.0, (128, 64, 6): 1100.0},      # 17 % faster: in
-        ("dgrad", 32, 80, 80, 64, 64, 3, 1, 1): {(0, 0, 0): 900.0, (64, 64, 5): 895.0},                             # < 2 %: stays heuristic
+        ("fwd", 32, 80, 80, 64, 64, 3, 1, 1): {(0, 0, 0): 1200.0, (64, 64, 7): 1000.0, (128, 64, 0): 1100.0},      # 17 % faster: in
+        ("dgrad", 32, 80, 80, 64, 64, 3, 1, 1): {(0, 0, 0): 900.0, (64, 64, 7): 895.0},                             # < 2 %: stays heuristic
         ("wgrad", 32, 40, 40, 96, 96, 3, 1, 1): {(0, 0, 0): 1000.0, (96, 128, 2048): 800.0, (64, 64, 8192): float("inf")},
-        ("fwd", 32, 20, 20, 192, 192, 3, 1, 1): {(0, 0, 0): 400.0, (0, 0, 5): 300.0},                               # heuristic tile, variant 5
+        ("fwd", 32, 20, 20, 192, 192, 3, 1, 1): {(0, 0, 0): 400.0, (0, 0, 7): 300.0},                               # heuristic tile, variant 7 (16-deep loop)
     }
     entries, meta = conv_tune.build_table(agg, 0.02)
-    assert {(e["kind"], e["bm"], e["bn"], e["variant"]) for e in entries} == {("fwd", 64, 64, 5), ("wgrad", 96, 128, 2048), ("fwd", 0, 0, 5)}
+    assert {(e["kind"], e["bm"], e["bn"], e["variant"]) for e in entries} == {("fwd", 64, 64, 7), ("wgrad", 96, 128, 2048), ("fwd", 0, 0, 7)}
     assert meta["ms_per_step_heuristic"] == 3.5 and meta["ms_per_step_table"] == 3.0
     f = tmp_path / "table.json"
     json.dump(dict(meta=meta, entries=entries), open(f, "w"))

@@ -165,7 +165,10 @@ def _train_step_parity(variant, B, size, device, tol, static=False):
         acc_c += float((ref_params[n].grad.double() - t).pow(2).sum())
         acc_d += float(t.pow(2).sum())
     a_h, a_c = (acc_h / acc_d) ** 0.5, (acc_c / acc_d) ** 0.5
-    assert a_h <= max(10 * tol, 3.0 * a_c), f"random-upstream gradient L2 error vs fp64: hip {a_h:.2e}, cpu fp32 {a_c:.2e}"
+    # (2e-2: the ReLU-flip noise floor of this aggregate at these sizes - measured 1.4-1.6e-2 for the HIP path AND for the CPU fp32 path
+    # against fp64, r2g; a CPU run that happens to flip fewer elements must not fail the HIP path.  The flip-free, strict form of this
+    # check is test_yolo_nas_s_backward_exact_without_relu_flips below.)
+    assert a_h <= max(10 * tol, 3.0 * a_c, 2e-2), f"random-upstream gradient L2 error vs fp64: hip {a_h:.2e}, cpu fp32 {a_c:.2e}"
     if True:
         print(f"[{variant}] loss-gradient L2 err vs fp64: hip {l2_h:.2e} cpu32 {l2_c:.2e}; random upstream: hip {a_h:.2e} cpu32 {a_c:.2e}; "
               f"worst parameter {worst[0]:.2e} {worst[1]}")
@@ -176,6 +179,69 @@ def _train_step_parity(variant, B, size, device, tol, static=False):
 def test_yolo_nas_s_train_step_parity(gpu_device):
     l, lr = _train_step_parity("s", 2, 320, gpu_device, 1e-4)
     assert abs(l - lr) <= 2e-4 * abs(lr)
+
+
+@pytest.mark.gpu
+def test_yolo_nas_s_backward_exact_without_relu_flips(gpu_device):
+    """The strict form of the whole-model backward check.  At random init a handful of ReLU pre-activations change sign between any two
+    fp32 implementations, and every flip is an O(1) local gradient error - which is why the checks above can only bound the aggregate.
+    Here every BatchNorm that feeds an activation gets bias +4 (weights in [0.5, 1]): all pre-activations stay positive on both paths, the
+    network is smooth, and EVERY parameter gradient must agree with the CPU fp32 oracle element-wise within 1e-4 of the gradient's largest
+    element - or, where the CPU fp32 path itself is further than that from the same oracle in fp64 (the cancellation-heavy `alpha` dot
+    products, a few deep-stage weights), be no further from the fp64 truth than twice the CPU fp32 path.  A dropped or mis-scaled term
+    anywhere in the hand-written backward (>= 1e-2) fails this."""
+    import copy
+
+    C, B, size = 80, 2, 256
+    ref, net = _build_pair("s", C, gpu_device)
+    g = torch.Generator().manual_seed(5)
+    for name, p in ref.named_parameters():
+        if name.endswith("bn.weight") or name.endswith("post_bn.weight"):
+            p.data.uniform_(0.5, 1.0, generator=g)
+        elif (name.endswith("bn.bias") and "branch_3x3" not in name) or name.endswith("post_bn.bias"):
+            p.data.fill_(4.0)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    ref64 = copy.deepcopy(ref).double().train()
+    ref.train()
+    net.train()
+    x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(8))
+    out_ref = ref(x)
+    out64 = ref64(x.double())
+    out = net(x.to(gpu_device))
+    (lg, ds), (lg_r, ds_r) = out[1][:2], out_ref[1][:2]
+    assert_close(lg.detach().cpu(), lg_r.detach(), 1e-4, "cls_logits")
+    assert_close(ds.detach().cpu(), ds_r.detach(), 1e-4, "reg_distri")
+    gg = torch.Generator().manual_seed(21)
+    up_l, up_d = torch.randn(lg_r.shape, generator=gg), torch.randn(ds_r.shape, generator=gg)
+    torch.autograd.backward([lg_r, ds_r], [up_l, up_d])
+    torch.autograd.backward([out64[1][0], out64[1][1]], [up_l.double(), up_d.double()])
+    torch.autograd.backward([lg, ds], [up_l.to(gpu_device), up_d.to(gpu_device)])
+    ref_params, ref64_params = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    errs = []
+    for n, p in net.named_parameters():
+        if ".rbr_reparam." in n:
+            continue
+        rg = ref_params[n].grad
+        if n.endswith("branch_3x3.bn.bias") or n.endswith("branch_1x1.bias"):
+            # analytically zero (a per-channel constant in front of a training-mode BatchNorm): pure round-off of a sum over all pixels
+            # on either path - both must stay at that level
+            assert float(p.grad.abs().max()) <= max(10.0 * float(rg.abs().max()), 1e-3 * gmax), f"grad {n}: analytically zero, got {float(p.grad.abs().max()):.2e}"
+            continue
+        sc = max(float(rg.abs().max()), 1e-3 * gmax)
+        t = ref64_params[n].grad
+        e = float((p.grad.cpu().double() - rg.double()).abs().max()) / sc
+        e_hip, e_cpu = float((p.grad.cpu().double() - t).abs().max()) / sc, float((rg.double() - t).abs().max()) / sc
+        errs.append((e, n, e_hip, e_cpu))
+    errs.sort(reverse=True)
+    worst = errs[0]
+    # the bottlenecks' scalar `alpha`: d alpha = <x, dz> with x's per-channel mean at +4 here, so a 1e-7 per-channel offset of dz (the BN
+    # backward's mean subtraction) is amplified ~1e3x: 1e-3 for those scalars (the dot-product kernel itself is checked in test_kernels)
+    bar = lambda n: 1e-3 if ref_params[n].numel() == 1 else 1e-4
+    bad = [f"{n}: hip-cpu32 {e:.2e}, hip-fp64 {eh:.2e}, cpu32-fp64 {ec:.2e}" for e, n, eh, ec in errs if e > bar(n) and eh > max(bar(n), 2.0 * ec)]
+    assert not bad, f"{len(bad)} parameter gradients off by more than 1e-4 of their largest element (and further from fp64 than 2x the CPU fp32 path): {bad[:8]}"
+    assert sum(e > 1e-4 for e, *_ in errs) <= 8, "more than 8 parameters needed the fp64 tie-break"
+    print(f"[exact] worst parameter gradient error {worst[0]:.2e} ({worst[1]})")
 
 
 @pytest.mark.gpu
