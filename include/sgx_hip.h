@@ -260,11 +260,11 @@ int32_t sgx_qarep_bwd_apply(const float* dout, int64_t d_ld, const float* y, int
 int32_t sgx_bn_set_fused_finalize(int32_t on);
 int32_t sgx_bn_get_fused_finalize(void);
 /* z = a*x + y with a device-resident scalar a (yolo_stages.py:61-63) and its backward pieces:
- * sgx_dot_partial gives sum(x*dz) partials [2][sgx_stats_blocks(M)][C] for d a (per-lane compensated sums and their compensation
- * terms: the alpha gradients cancel ~1e3x); finalize with sgx_sum_partials over all 2*nblk*C of them.                              */
-int32_t sgx_dot_partial(const float* a, int64_t a_ld, const float* b, int64_t b_ld, int64_t M, int32_t C,
-                        float* partials, void* stream);
-int32_t sgx_sum_partials(const float* partials, int32_t n, float scale, float* out, int32_t accumulate, void* stream);
+ * sgx_dot: out[0] (+)= scale * sum(a*b) over two [M,C] views (d a = <x, dz>): per-lane error-free accumulation (those sums cancel ~1e3x),
+ * fp64 folds, two launches, deterministic.  ws: sgx_dot_workspace(M, C) bytes.                                                        */
+int64_t sgx_dot_workspace(int64_t M, int32_t C);
+int32_t sgx_dot(const float* a, int64_t a_ld, const float* b, int64_t b_ld, int64_t M, int32_t C, float scale, float* out,
+                int32_t accumulate, void* ws, int64_t ws_bytes, void* stream);
 /* y = a*x (+ y if accumulate) elementwise over [M,C] with strides; a_dev overrides a if not NULL.   */
 int32_t sgx_axpy(const float* x, int64_t x_ld, float a, const float* a_dev, float* y, int64_t y_ld, int64_t M,
                  int32_t C, int32_t accumulate, void* stream);

@@ -117,8 +117,8 @@ PROTOTYPES = {
     "sgx_bn_bwd_apply": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _P, _i64, _P, _i64, _i64, _i32, _i32, _P]),
     "sgx_bn_set_fused_finalize": (_i32, [_i32]),
     "sgx_bn_get_fused_finalize": (_i32, []),
-    "sgx_dot_partial": (_i32, [_P, _i64, _P, _i64, _i64, _i32, _P, _P]),
-    "sgx_sum_partials": (_i32, [_P, _i32, _f, _P, _i32, _P]),
+    "sgx_dot_workspace": (_i64, [_i64, _i32]),
+    "sgx_dot": (_i32, [_P, _i64, _P, _i64, _i64, _i32, _f, _P, _i32, _P, _i64, _P]),
     "sgx_axpy": (_i32, [_P, _i64, _f, _P, _P, _i64, _i64, _i32, _i32, _P]),
     "sgx_relu_bwd": (_i32, [_P, _i64, _P, _i64, _P, _i64, _i64, _i32, _P]),
     "sgx_colsum": (_i32, [_P, _i64, _i64, _i32, _i64, _i64, _P, _i32, _P, _P]),

@@ -456,34 +456,51 @@ extern "C" int32_t sgx_bn_bwd_apply(const float* dy, int64_t dy_ld, const float*
 }
 
 // ---------------------------------------------------------------------------------------------
-// <a, b> with compensated (TwoSum) accumulation per lane: q0 carries the running sum, q1 the rounding errors it dropped.  The learnable
-// scalars this feeds (the bottlenecks' alpha: d alpha = <x, dz>) cancel ~1e3x, so plain fp32 accumulation left them 1e-4 off (r2h).
-struct DotF {
-    const float* a; long a_ld; const float* b; long b_ld;
-    struct In { float4 u, v; };
-    __device__ In load(long r, int c) const { return In{sgx_ld4(a + r * a_ld + c), sgx_ld4(b + r * b_ld + c)}; }
-    static __device__ __forceinline__ void add(float& s, float& e, float p) {
+// out (+)= scale * <a, b> over NHWC views: the gradient of the learnable scalars (the bottlenecks' alpha, yolo_stages.py:61-63: d alpha =
+// <x, dz>).  Those sums cancel ~1e3x, so every lane accumulates with an error-free transformation (TwoSum: running sum + the rounding
+// errors it dropped), the workgroup folds its 256 (sum, error) pairs in fp64 into ONE value, and a single-workgroup second stage adds the
+// <= 6 144 workgroup values in fp64 in a fixed order (deterministic; the earlier form summed 2 x nblk x C fp32 partials with one workgroup:
+// 68 us per call at 160x160x96, r2k).
+template <int DUMMY>
+__global__ __launch_bounds__(SW_THREADS) void dot_kernel(const float* a, long a_ld, const float* b, long b_ld, SweepGeom g, double* out) {
+    __shared__ double red[SW_THREADS];
+    const int tid = threadIdx.x;
+    const int cg = tid % g.CG, rl = tid / g.CG;
+    const int c4 = blockIdx.y * g.CG + cg;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), e = s;
+    auto add = [](float& s, float& e, float p) {
         const float t = s + p, bp = t - s;
         e += (s - (t - bp)) + (p - bp);
         s = t;
+    };
+    if (rl < g.RL && c4 < g.C4) {
+        const int c = c4 * 4;
+        long r0 = (long)blockIdx.x * g.rows_per_blk, r1 = r0 + g.rows_per_blk;
+        if (r1 > g.M) r1 = g.M;
+        const long st = g.RL;
+        long r = r0 + rl;
+        for (; r + st < r1; r += 2 * st) {
+            const float4 u0 = sgx_ld4(a + r * a_ld + c), v0 = sgx_ld4(b + r * b_ld + c), u1 = sgx_ld4(a + (r + st) * a_ld + c), v1 = sgx_ld4(b + (r + st) * b_ld + c);
+            add(s.x, e.x, u0.x * v0.x); add(s.y, e.y, u0.y * v0.y); add(s.z, e.z, u0.z * v0.z); add(s.w, e.w, u0.w * v0.w);
+            add(s.x, e.x, u1.x * v1.x); add(s.y, e.y, u1.y * v1.y); add(s.z, e.z, u1.z * v1.z); add(s.w, e.w, u1.w * v1.w);
+        }
+        for (; r < r1; r += st) {
+            const float4 u0 = sgx_ld4(a + r * a_ld + c), v0 = sgx_ld4(b + r * b_ld + c);
+            add(s.x, e.x, u0.x * v0.x); add(s.y, e.y, u0.y * v0.y); add(s.z, e.z, u0.z * v0.z); add(s.w, e.w, u0.w * v0.w);
+        }
     }
-    __device__ void apply(long, int, const In& in, float4& q0, float4& q1) const {
-        const float4 u = in.u, v = in.v;
-        add(q0.x, q1.x, u.x * v.x); add(q0.y, q1.y, u.y * v.y); add(q0.z, q1.z, u.z * v.z); add(q0.w, q1.w, u.w * v.w);
+    red[tid] = (((double)s.x + (double)s.y) + ((double)s.z + (double)s.w)) + (((double)e.x + (double)e.y) + ((double)e.z + (double)e.w));
+    __syncthreads();
+    for (int w = SW_THREADS / 2; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
     }
-};
-// per-(block, channel) partial products: partials [2][nblk][C] (sums, compensation terms); reduce with sgx_sum_partials(n = 2*nblk*C)
-extern "C" int32_t sgx_dot_partial(const float* a, int64_t a_ld, const float* b, int64_t b_ld, int64_t M, int32_t C, float* partials,
-                                   void* stream) {
-    SGX_CHECK_ARG(a && b && partials, "dot_partial: null pointer");
-    DotF f{a, a_ld, b, b_ld};
-    return run_sweep<DotF, 2>(f, M, C, partials, stream, "dot_partial");
+    if (tid == 0) out[(long)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
 }
-
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* partials, int n, float scale, float* out, int accumulate) {
+__global__ __launch_bounds__(256) void dot_final_kernel(const double* parts, int n, float scale, float* out, int accumulate) {
     __shared__ double red[256];
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
+    for (int i = threadIdx.x; i < n; i += 256) s += parts[i];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
@@ -495,10 +512,20 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partials
         out[0] = accumulate ? out[0] + v : v;
     }
 }
-extern "C" int32_t sgx_sum_partials(const float* partials, int32_t n, float scale, float* out, int32_t accumulate, void* stream) {
-    SGX_CHECK_ARG(partials && out && n >= 0, "sum_partials: bad args");
-    SGX_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, n, scale, out, accumulate);
-    SGX_CHECK_LAUNCH("sum_partials");
+extern "C" int64_t sgx_dot_workspace(int64_t M, int32_t C) {
+    SweepGeom g = sweep_geom(M, C > 0 ? C : 4);
+    return (int64_t)g.nblk * g.ctiles * (int64_t)sizeof(double) + 256;
+}
+extern "C" int32_t sgx_dot(const float* a, int64_t a_ld, const float* b, int64_t b_ld, int64_t M, int32_t C, float scale, float* out,
+                           int32_t accumulate, void* ws, int64_t ws_bytes, void* stream) {
+    SGX_CHECK_ARG(a && b && out && ws, "dot: null pointer");
+    SGX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "dot: need M>0 and C%%4==0 (C=%d)", C);
+    if (ws_bytes < sgx_dot_workspace(M, C)) SGX_FAIL(SGX_ERR_WORKSPACE, "dot: workspace too small (sgx_dot_workspace)");
+    SweepGeom g = sweep_geom(M, C);
+    SGX_LAUNCH((dot_kernel<0>), dim3(g.nblk, g.ctiles), dim3(SW_THREADS), 0, stream, a, (long)a_ld, b, (long)b_ld, g, (double*)ws);
+    SGX_CHECK_LAUNCH("dot");
+    SGX_LAUNCH(dot_final_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, g.nblk * g.ctiles, scale, out, accumulate);
+    SGX_CHECK_LAUNCH("dot_final");
     return SGX_OK;
 }
 

@@ -741,12 +741,26 @@ __global__ __launch_bounds__(64) void softmax_ce_kernel(int B, int K, const floa
         dlogits[(long)b * K + j] = (p - t) * invB;
     }
 }
-extern "C" int32_t sgx_sum_partials(const float* partials, int32_t n, float scale, float* out, int32_t accumulate, void* stream);
+// loss[0] = mean of the B row losses (fp64 fold, fixed order)
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* rows, int n, float* out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)rows[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] / (double)n);
+}
 extern "C" int32_t sgx_softmax_ce_fwd_bwd(int32_t B, int32_t K, const float* logits, const int64_t* labels, float smoothing, float* loss,
                                           float* dlogits, void* stream) {
     SGX_CHECK_ARG(logits && labels && loss && dlogits && B > 0 && K > 0, "softmax_ce: bad args");
     // row losses go to the head of dlogits' companion scratch: we use loss[1..B] (caller allocates B+1 floats)
     SGX_LAUNCH(softmax_ce_kernel, dim3(B), dim3(64), 0, stream, B, K, logits, labels, smoothing, loss + 1, dlogits);
     SGX_CHECK_LAUNCH("softmax_ce");
-    return sgx_sum_partials(loss + 1, B, 1.f / (float)B, loss, 0, stream);
+    SGX_LAUNCH(mean_rows_kernel, dim3(1), dim3(256), 0, stream, (const float*)(loss + 1), B, loss);
+    SGX_CHECK_LAUNCH("softmax_ce mean");
+    return SGX_OK;
 }

@@ -452,10 +452,8 @@ def dot_sum(a, b, out, accumulate=True, scale=1.0):
     """out[0] (+)= scale * sum(a*b) over NHWC views a, b."""
     M, la = rows(a)
     C = a.shape[3]
-    nblk = stats_blocks(M)
-    parts = torch.empty(2 * nblk * C, device=a.device, dtype=torch.float32)  # sums + their compensation terms
-    check(lib().sgx_dot_partial(ptr(a), la, ptr(b), rows(b)[1], M, C, ptr(parts), stream()), "sgx_dot_partial")
-    check(lib().sgx_sum_partials(ptr(parts), 2 * nblk * C, float(scale), ptr(out), int(accumulate), stream()), "sgx_sum_partials")
+    ws = WORKSPACE.get(lib().sgx_dot_workspace(M, C), a.device)
+    check(lib().sgx_dot(ptr(a), la, ptr(b), rows(b)[1], M, C, float(scale), ptr(out), int(accumulate), ptr(ws), ws.numel(), stream()), "sgx_dot")
 
 
 def axpy(x, a=1.0, a_dev=None, out=None, accumulate=False):

@@ -73,9 +73,10 @@ class ConvLayer(SgxBlock):
     def conv(self, x, out=None, act=None, addend=None, stats=False):
         return K.conv2d_fwd(x, self._w, bias=self.bias, addend=addend, out=out, act=act, stride=self.stride, pad=self.padding, stat_partials=stats)
 
-    def wgrad(self, x, dy):
-        self._net.fork_side(lambda: K.conv2d_bwd_weight(x, dy, self._gw, self.bias.grad if self.bias is not None else None, stride=self.stride,
-                                                        pad=self.padding), x, dy)
+    def wgrad(self, x, dy, bias_grad=True):
+        """bias_grad=False: the caller knows sum(dy) is zero per channel (dy is a training-mode BatchNorm's input gradient)"""
+        self._net.fork_side(lambda: K.conv2d_bwd_weight(x, dy, self._gw, self.bias.grad if (self.bias is not None and bias_grad) else None,
+                                                        stride=self.stride, pad=self.padding), x, dy)
 
     def dgrad(self, dy, x_shape, out=None, accumulate=False, addend=None):
         if self._wt is not None and self._net._wt_valid:  # transposed under the forward pass (engine.prefetch_dgrad_weights)

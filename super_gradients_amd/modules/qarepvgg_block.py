@@ -187,7 +187,7 @@ class QARepVGGBlock(SgxBlock):
         if self._ctx[0] == "dual":
             (_, x, y3, u, cf, sv), self._ctx = self._ctx, None
             ds, dy3 = K.qarep_bwd(dy, y3, u, cf, sv, bn3, pbn, self.act)   # in place over u / y3
-            c1.wgrad(x, ds)
+            c1.wgrad(x, ds, bias_grad=False)  # d b1 = sum ds = 0: post_bn's input gradient sums to zero per channel
             c3.wgrad(x, dy3)
             if not need_dx:
                 return None
