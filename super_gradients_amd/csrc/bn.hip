@@ -134,11 +134,11 @@ struct ColSrc {  // what a finalize kernel sums over: either the fp32 partials o
     int coop;  // 1: the finalize kernel is launched with CO_CH x CO_RL threads per workgroup and folds the fp32 partial rows itself
 };
 // ---- one-launch finalize (default; sgx_bn_set_fused_finalize(0) restores the two-launch form): instead of a pre-reduction
-// launch + a finalize launch, the finalize kernel runs with 32 channels x 16 row lanes per workgroup; every lane folds its rows
-// (b = lane, lane + 16, ...) in fp64, the 16 lane sums meet in LDS and are added in lane order (deterministic, no atomics).  Worth it
+// launch + a finalize launch, the finalize kernel runs with 32 channels x 32 row lanes per workgroup; every lane folds its rows
+// (b = lane, lane + 32, ...) in fp64, the 32 lane sums meet in LDS and are added in lane order (deterministic, no atomics).  Worth it
 // while one workgroup can stream the partial rows of its 32 channels faster than a second launch costs: nblk <= CR_COOP_MAX.
 #define CO_CH 32
-#define CO_RL 16
+#define CO_RL 32
 #define CR_COOP_MAX 4096
 static int g_fused_finalize = 1;
 extern "C" int32_t sgx_bn_set_fused_finalize(int32_t on) {

@@ -590,7 +590,8 @@ def avgpool_fwd(x):
 def avgpool_bwd(dy, x_shape):
     n, h, w, c = x_shape
     dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
-    check(lib().sgx_avgpool_bwd(n, h * w, c, ptr(dy.contiguous()), ptr(dx), c, h * w * c, stream()), "sgx_avgpool_bwd")
+    dy = dy.contiguous()
+    check(lib().sgx_avgpool_bwd(n, h * w, c, ptr(dy), ptr(dx), c, h * w * c, stream()), "sgx_avgpool_bwd")
     return dx
 
 
@@ -640,8 +641,10 @@ def ppyoloe_loss_fwd(logits, distri, anchors, points, strides, targets, counts, 
     )
     nbytes = lib().sgx_ppyoloe_loss_workspace(ctypes.byref(d))
     ws = WORKSPACE.get(nbytes, dev)
-    check(lib().sgx_ppyoloe_loss_fwd(ctypes.byref(d), ptr(logits.contiguous()), ptr(distri.contiguous()), ptr(anchors.contiguous()), ptr(points.contiguous()),
-                                     ptr(strides.contiguous()), ptr(targets) if T else None, ptr(gt_count), ptr(gt_index) if nmax else None,
+    # converted operands stay bound until the launch is enqueued: a temporary freed earlier could be handed out again by the caching allocator
+    logits, distri, anchors, points, strides = (t.contiguous() for t in (logits, distri, anchors, points, strides))
+    check(lib().sgx_ppyoloe_loss_fwd(ctypes.byref(d), ptr(logits), ptr(distri), ptr(anchors), ptr(points),
+                                     ptr(strides), ptr(targets) if T else None, ptr(gt_count), ptr(gt_index) if nmax else None,
                                      ptr(out["sums"]), ptr(out["label"]), ptr(out["box"]), ptr(out["score"]), ptr(out["g_logits"]), ptr(out["g_distri"]),
                                      ptr(ws), ws.numel(), stream()), "sgx_ppyoloe_loss_fwd")
     return out
@@ -672,8 +675,8 @@ def nms(boxes, scores, score_threshold, iou_threshold, nms_top_k, max_prediction
     cnt = torch.empty(B, device=dev, dtype=torch.int32)
     idx = torch.empty(B, max_predictions, device=dev, dtype=torch.int32)
     ncand = torch.empty(B, device=dev, dtype=torch.int32)
-    check(lib().sgx_nms(ctypes.byref(d), ptr(boxes.contiguous().float()), ptr(scores.contiguous().float()), ptr(out), ptr(cnt), ptr(idx), ptr(ncand), None, 0,
-                        stream()), "sgx_nms")
+    boxes, scores = boxes.contiguous().float(), scores.contiguous().float()  # bound to names: alive until the launch is enqueued
+    check(lib().sgx_nms(ctypes.byref(d), ptr(boxes), ptr(scores), ptr(out), ptr(cnt), ptr(idx), ptr(ncand), None, 0, stream()), "sgx_nms")
     return out, cnt, idx, ncand
 
 
@@ -717,8 +720,9 @@ def detection_match(rows, counts, targets, crowd_targets, thresholds, height, wi
     d = MatchDesc(B, P, int(thr.numel()), int(top_k), int(height), int(width), int(bool(denormalize)), nmax, cmax)
     matched = torch.empty(B, P, thr.numel(), device=dev, dtype=torch.uint8)
     ignore = torch.empty(B, P, thr.numel(), device=dev, dtype=torch.uint8)
-    check(lib().sgx_detection_match(ctypes.byref(d), ptr(rows.contiguous().float()), ptr(counts.contiguous().int()), ptr(t), ptr(tc), ptr(ti), ptr(c), ptr(cc),
-                                    ptr(ci), ptr(thr), ptr(matched), ptr(ignore), stream()), "sgx_detection_match")
+    rows, counts = rows.contiguous().float(), counts.contiguous().int()  # bound to names: alive until the launch is enqueued
+    check(lib().sgx_detection_match(ctypes.byref(d), ptr(rows), ptr(counts), ptr(t), ptr(tc), ptr(ti), ptr(c), ptr(cc), ptr(ci), ptr(thr), ptr(matched),
+                                    ptr(ignore), stream()), "sgx_detection_match")
     return matched, ignore
 
 
@@ -726,8 +730,8 @@ def softmax_ce(logits, labels, smoothing=0.0):
     B, K = logits.shape
     loss = torch.empty(B + 1, device=logits.device, dtype=torch.float32)
     dlogits = torch.empty(B, K, device=logits.device, dtype=torch.float32)
-    check(lib().sgx_softmax_ce_fwd_bwd(B, K, ptr(logits.contiguous()), ptr(labels.contiguous().long()), float(smoothing), ptr(loss), ptr(dlogits), stream()),
-          "sgx_softmax_ce_fwd_bwd")
+    logits, labels = logits.contiguous(), labels.contiguous().long()  # bound to names: alive until the launch is enqueued
+    check(lib().sgx_softmax_ce_fwd_bwd(B, K, ptr(logits), ptr(labels), float(smoothing), ptr(loss), ptr(dlogits), stream()), "sgx_softmax_ce_fwd_bwd")
     return loss[0], dlogits
 
 

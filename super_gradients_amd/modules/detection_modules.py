@@ -74,6 +74,13 @@ class NStageBackbone(BaseDetectionModule):
     def get_input_channels(self) -> int:
         return self.stem.get_input_channels()
 
+    def replace_input_channels(self, in_channels: int, compute_new_weights_fn=None):
+        """Reference csp_darknet53.py:235-241 / detection_modules: delegate to the first block."""
+        if not hasattr(self.stem, "replace_input_channels"):
+            raise NotImplementedError(f"`{type(self.stem).__name__}` does not support `replace_input_channels`")
+        self.stem.replace_input_channels(in_channels=in_channels, compute_new_weights_fn=compute_new_weights_fn)
+        self.in_channels = in_channels
+
     def fwd(self, x, out=None):
         outs = []
         for layer in self._all_layers:

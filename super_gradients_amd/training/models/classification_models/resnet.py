@@ -217,6 +217,24 @@ class _ResNetBase(SgxNetwork):
     def get_input_channels(self) -> int:
         return self.conv1.in_channels
 
+    def replace_input_channels(self, in_channels: int, compute_new_weights_fn=None):
+        """Reference resnet.py:130-136, 249-258 with modules/weight_replacement_utils.py:24-65: conv1 keeps the weights of the channels it
+        already has; extra channels are drawn from a normal distribution with the old weights' mean / std.  Before materialisation only."""
+        if self._materialized:
+            raise RuntimeError("replace_input_channels must be called before the model is materialized in HBM (before the first forward)")
+        old = self.conv1
+        if compute_new_weights_fn is not None:
+            self.conv1 = compute_new_weights_fn(old, in_channels)
+            return
+        new = ConvLayer(in_channels, old.out_channels, old.kernel_size, old.stride, old.padding, bias=old.bias is not None)
+        w = old.weight.data
+        if in_channels <= old.in_channels:
+            new.weight.data = w[:, :in_channels].clone()
+        else:
+            new.weight.data[:, : old.in_channels] = w
+            torch.nn.init.normal_(new.weight.data[:, old.in_channels:], mean=float(w.mean()), std=float(w.std()))
+        self.conv1 = new
+
     def get_finetune_lr_dict(self, lr: float) -> Dict[str, float]:
         return {"linear": lr, "default": 0}
 

@@ -59,6 +59,21 @@ class CustomizableDetector(SgxNetwork):
             self.heads = f.get(f.insert_module_param(self.heads_params, "in_channels", self.neck.out_channels))
             self._initialize_weights(self.bn_eps, self.bn_momentum, self.inplace_act)
 
+    def get_input_channels(self) -> int:
+        if hasattr(self.backbone, "get_input_channels"):
+            return self.backbone.get_input_channels()
+        raise NotImplementedError(f"`{type(self.backbone).__name__}` does not support `replace_input_channels`")
+
+    def replace_input_channels(self, in_channels: int, compute_new_weights_fn=None):
+        """customizable_detector.py:124-129 (what models.get(num_input_channels=...) calls, model_factory.py:253-254)."""
+        if self._materialized:
+            raise RuntimeError("replace_input_channels must be called before the model is materialized in HBM (before the first forward)")
+        if not hasattr(self.backbone, "replace_input_channels"):
+            raise NotImplementedError(f"`{type(self.backbone).__name__}` does not support `replace_input_channels`")
+        self.backbone.replace_input_channels(in_channels=in_channels, compute_new_weights_fn=compute_new_weights_fn)
+        self.in_channels = self.get_input_channels()
+        self._initialize_weights(self.bn_eps, self.bn_momentum, self.inplace_act)
+
     # ---- SgxNetwork protocol -------------------------------------------------------------------------------------
     def _fwd(self, x):
         if x.dim() != 4 or x.shape[1] != self.in_channels:

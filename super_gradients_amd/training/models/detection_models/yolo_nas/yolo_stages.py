@@ -171,6 +171,13 @@ class YoloNASStem(BaseDetectionModule):
     def get_input_channels(self) -> int:
         return self.conv.in_channels
 
+    def replace_input_channels(self, in_channels: int, compute_new_weights_fn=None):
+        """Reference yolo_stages.py:176-177: the stem block is rebuilt with fresh weights for the new channel count (the optional weight
+        function is ignored there too).  Before materialisation only: the arenas own the parameters afterwards."""
+        stride = self.conv.stride
+        self.conv = QARepVGGBlock(in_channels, self._out_channels, stride=stride, use_residual_connection=False)
+        self.in_channels = in_channels
+
 
 @register_detection_module()
 class YoloNASStage(BaseDetectionModule):

@@ -35,6 +35,38 @@ def instantiate_model(model_name: str, arch_params: dict, num_classes: int, pret
     return net
 
 
+def adaptive_load_state_dict(net: torch.nn.Module, state_dict: dict, strict: Union[str, bool]):
+    """Reference training/utils/checkpoint_utils.py:79-106.  Every mode except "off" first tries a STRICT load.  When that fails:
+    "no_key_matching" pairs the checkpoint's tensors with the model's by position and shape (a checkpoint saved under other layer names) and
+    loads that strictly; "key_matching" copies exactly the tensors whose name and shape both match; anything else re-raises with the two
+    key lists.  A checkpoint that fits nothing can therefore no longer be "loaded" silently."""
+    state_dict = state_dict["net"] if "net" in state_dict else state_dict
+    if state_dict and all(k.startswith("module.") for k in state_dict):
+        state_dict = {k[len("module."):]: v for k, v in state_dict.items()}
+    mode = strict if isinstance(strict, bool) else {"on": True, "off": False}.get(str(strict), str(strict))
+    try:
+        net.load_state_dict(state_dict, strict=mode is not False)
+        return
+    except (RuntimeError, ValueError, KeyError) as ex:
+        own = net.state_dict()
+        if mode == "no_key_matching":
+            ck = [(k, v) for k, v in state_dict.items() if torch.is_tensor(v)]
+            if len(ck) != len(own) or any(tuple(v.shape) != tuple(o.shape) for (_, v), o in zip(ck, own.values())):
+                raise RuntimeError(f"no_key_matching: the checkpoint's tensors ({len(ck)}) do not pair with the model's ({len(own)}) by position and "
+                                   f"shape; first model keys {list(own)[:3]}, first checkpoint keys {[k for k, _ in ck[:3]]}") from ex
+            net.load_state_dict({name: v for name, (_, v) in zip(own.keys(), ck)}, strict=True)
+        elif mode == "key_matching":
+            hit = {k: v for k, v in state_dict.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}
+            if not hit:
+                raise RuntimeError("key_matching: no tensor of the checkpoint matches a model tensor by name and shape") from ex
+            net.load_state_dict(hit, strict=False)
+        else:
+            missing = [k for k in own if k not in state_dict]
+            unexpected = [k for k in state_dict if k not in own]
+            raise RuntimeError(f"checkpoint does not fit the model: {len(missing)} missing keys (e.g. {missing[:3]}), {len(unexpected)} unexpected "
+                               f"(e.g. {unexpected[:3]}); strict_load={strict!r}") from ex
+
+
 def get_model_name(model: torch.nn.Module) -> Optional[str]:
     return getattr(model, "_sg_model_name", None)
 
@@ -47,12 +79,11 @@ def get(model_name: str, arch_params: Optional[dict] = None, num_classes: Option
     if load_backbone and not checkpoint_path:
         raise ValueError("Please set checkpoint_path when load_backbone=True")
     if checkpoint_path:
-        ckpt = torch.load(checkpoint_path, map_location="cpu")
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)  # tensors and plain containers only: never runs pickled code
         sd = ckpt.get("ema_net", ckpt.get("net", ckpt)) if isinstance(ckpt, dict) else ckpt
-        sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
-        net.load_state_dict(sd, strict=strict_load in (True, "on"))
+        adaptive_load_state_dict(net, sd, strict_load)
     if checkpoint_num_classes != num_classes:
         net.replace_head(new_num_classes=num_classes)  # transfer learning (model_factory.py:250-251)
     if num_input_channels is not None and num_input_channels != net.get_input_channels():
-        raise NotImplementedError("pass in_channels through arch_params instead of num_input_channels")
+        net.replace_input_channels(in_channels=num_input_channels)  # model_factory.py:253-254
     return net

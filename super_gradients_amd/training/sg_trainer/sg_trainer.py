@@ -57,6 +57,13 @@ class AverageMeter:
         self.sum = v.clone() if self.sum is None else self.sum + v
         self.n += batch_size
 
+    def all_reduce(self):
+        """Sum the meter over the data-parallel ranks, so that every rank reports - and selects its best checkpoint by - the same numbers."""
+        if self.sum is not None and dtu.get_world_size() > 1:
+            t = torch.cat([self.sum.double(), torch.tensor([float(self.n)], device=self.sum.device, dtype=torch.float64)])
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+            self.sum, self.n = t[:-1].float(), int(round(float(t[-1])))
+
     @property
     def average(self):
         if self.sum is None:
@@ -289,9 +296,13 @@ class Trainer:
             meter.update(items, int(inputs.shape[0]))
             for m in train_metrics:
                 _update_metric(m, outputs, targets, inputs, extras)
+            global_step = batch_idx + 1 + len(train_loader) * context.epoch
+            if self.reducer is not None:
+                # gradient accumulation under data parallelism: the arena sums the micro-batches locally and is exchanged ONCE, by the
+                # backward that precedes the optimizer step (all-reducing an already reduced sum again would count it `world` times)
+                self.reducer.sync = global_step % tp.batch_accumulate == 0
             loss.backward()
             handler.on_train_batch_backward_end(context)
-            global_step = batch_idx + 1 + len(train_loader) * context.epoch
             if global_step % tp.batch_accumulate == 0:
                 handler.on_train_batch_gradient_step_start(context)
                 if tp.clip_grad_norm:
@@ -364,6 +375,7 @@ class Trainer:
         else:
             run(self.net)
         self.net.train()
+        meter.all_reduce()  # ranks validate different shards: _track_best must see one value everywhere
         out = dict(zip(self.loss_logging_items_names or [], meter.average))
         for m in metrics:
             out.update(_metric_results(m))
@@ -393,7 +405,8 @@ class Trainer:
         """Same dictionary layout as the reference's checkpoints (sg_trainer.py:649-720): net / ema_net / optimizer_state_dict / epoch / metrics."""
         os.makedirs(self.checkpoints_dir_path, exist_ok=True)
         state = {"net": {k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()}, "epoch": epoch, "metrics": row,
-                 "optimizer_state_dict": self._optimizer_state(), "acc": self.best_metric}
+                 "optimizer_state_dict": self._optimizer_state(), "acc": None if self.best_metric is None else float(self.best_metric)}
+        state["metrics"] = {split: {k: float(v) for k, v in vals.items()} if isinstance(vals, dict) else vals for split, vals in row.items()} if isinstance(row, dict) else row
         if self.ema_model is not None:
             state["ema_net"] = {k: v.cpu() for k, v in self.ema_model.state_dict().items()}
         torch.save(state, os.path.join(self.checkpoints_dir_path, name))
@@ -407,13 +420,18 @@ class Trainer:
         return st
 
     def _load_checkpoint(self, path, load_opt):
-        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)  # tensors, numbers, strings and plain containers only (same rule as models.get)
         self.net.load_state_dict(ckpt["net"], strict=True)
         if self.ema_model is not None and "ema_net" in ckpt:
             with self.ema_model.averaged() as net:
                 net.load_state_dict(ckpt["ema_net"], strict=True)
                 self.ema_model.p_ema.copy_(net.p_arena.buf)
                 self.ema_model.b_ema.copy_(net.b_arena.buf)
+        elif self.ema_model is not None:
+            # a checkpoint without EMA weights: the average restarts from the loaded weights (the reference builds its EMA from the
+            # already-loaded net), not from the random initialisation the EMA arenas were cloned from
+            self.ema_model.p_ema.copy_(self.net.p_arena.buf)
+            self.ema_model.b_ema.copy_(self.net.b_arena.buf)
         if load_opt and "optimizer_state_dict" in ckpt:
             st = ckpt["optimizer_state_dict"]
             for name in ("exp_avg", "exp_avg_sq", "momentum_buffer"):

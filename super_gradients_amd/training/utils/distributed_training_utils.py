@@ -99,17 +99,32 @@ class GradientAllReducer:
         self.issued = set()
         self.from_side = os.environ.get("SGX_ALLREDUCE_FROM_SIDE", "1") != "0"  # 0: join the side stream into the current one per bucket
         self.grad_scale = torch.full((1,), 1.0 / self.world, device=net.g_arena.buf.device)
+        # False on the micro-batches of a gradient accumulation that do not end in an optimizer step (DistributedDataParallel.no_sync()
+        # semantics): the arena keeps accumulating locally and is exchanged once, by the backward of the stepping micro-batch
+        self.sync = True
         net._grad_ready = self.ready
         net._post_backward_hook = self.finish
 
+    # (seams for the CPU tests, which have no HIP streams: tests/test_distributed.py substitutes recording stand-ins)
+    @staticmethod
+    def _current_stream():
+        return torch.cuda.current_stream()
+
+    @staticmethod
+    def _on_stream(stream):
+        return torch.cuda.stream(stream)
+
+    def _side_stream(self):
+        return getattr(self.net, "side_stream", None)
+
     def ready(self, prefix: str):
         """Called by the network's backward right after the kernels of sub-network `prefix` have been enqueued."""
-        if self.world == 1 or prefix not in self.ranges or prefix in self.issued:
+        if self.world == 1 or not self.sync or prefix not in self.ranges or prefix in self.issued:
             return
         a, b = self.ranges[prefix]
         self.issued.add(prefix)
         buf = self.net.g_arena.buf[a:b]
-        side = getattr(self.net, "side_stream", None)
+        side = self._side_stream()
         if side is None or not self.from_side:
             self.net.join_side()  # the bucket's weight gradients were forked onto the side stream
             self.pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
@@ -120,8 +135,8 @@ class GradientAllReducer:
         # the SIDE stream waits for the current one and issues the collective: RCCL's stream then waits for both producers, later
         # weight gradients (other arena ranges) keep flowing on the side stream beside the collective, and the current stream waits for
         # nothing until finish().
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        side.wait_stream(self._current_stream())
+        with self._on_stream(side):
             self.pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):

@@ -173,3 +173,33 @@ def test_replace_head_transfer_learning(tmp_path):
     rn = models.get("resnet18", num_classes=1000)
     rn.replace_head(new_num_classes=10)
     assert rn.linear.weight.shape[0] == 10
+
+
+def test_models_get_adaptive_load_and_input_channels(tmp_path):
+    """models.get: checkpoint loading follows the reference's adaptive_load_state_dict (checkpoint_utils.py:79-106) - every mode except
+    "off" is strict first; "no_key_matching" falls back to pairing tensors by position and shape and raises when that fails (a checkpoint
+    that fits nothing can no longer be 'loaded' silently); num_input_channels rebuilds the stem (model_factory.py:253-254)."""
+    import torch
+
+    from super_gradients_amd.training import models
+
+    net = models.get("yolo_nas_s", num_classes=80)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    torch.save({"net": sd}, tmp_path / "ok.pth")
+    a = models.get("yolo_nas_s", num_classes=80, checkpoint_path=str(tmp_path / "ok.pth"))
+    assert all(torch.equal(v, sd[k]) for k, v in a.state_dict().items())
+    renamed = {("model." + k): v for k, v in sd.items()}      # other layer names, same order and shapes
+    torch.save(renamed, tmp_path / "renamed.pth")
+    b = models.get("yolo_nas_s", num_classes=80, checkpoint_path=str(tmp_path / "renamed.pth"))
+    assert all(torch.equal(v, sd[k]) for k, v in b.state_dict().items())
+    with pytest.raises(RuntimeError):
+        models.get("yolo_nas_s", num_classes=80, checkpoint_path=str(tmp_path / "renamed.pth"), strict_load="on")
+    torch.save({"w": torch.zeros(3)}, tmp_path / "junk.pth")
+    with pytest.raises(RuntimeError):
+        models.get("yolo_nas_s", num_classes=80, checkpoint_path=str(tmp_path / "junk.pth"))
+    c = models.get("yolo_nas_s", num_classes=80, checkpoint_path=str(tmp_path / "ok.pth"), num_input_channels=5)
+    csd = c.state_dict()
+    assert c.get_input_channels() == 5 and tuple(csd["backbone.stem.conv.branch_3x3.conv.weight"].shape) == (48, 5, 3, 3)
+    assert torch.equal(csd["backbone.stage1.downsample.branch_3x3.conv.weight"], sd["backbone.stage1.downsample.branch_3x3.conv.weight"])
+    r = models.get("resnet18", num_classes=10, num_input_channels=5)
+    assert r.get_input_channels() == 5 and tuple(r.state_dict()["conv1.weight"].shape)[1] == 5

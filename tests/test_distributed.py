@@ -66,6 +66,41 @@ def _worker(rank, world, port, outdir):
     net.g_arena.buf.mul_(1.0 / world)
     opt.step()
     out["params_after_step"] = net.p_arena.buf.clone()
+    # ---- gradient accumulation under data parallelism (Trainer batch_accumulate = 2): the first micro-batch is NOT exchanged, the
+    # second one's backward exchanges the locally accumulated arena once -> sum over ranks of (g1 + g2), not world * g1 + g2
+    net._grad_ready, net._post_backward_hook = reducer.ready, reducer.finish
+    x2, y2 = torch.randn(4, 4, 8, 8, generator=g), torch.randint(0, 4, (4,), generator=g)
+    net.p_arena.buf.copy_(out["params_after_broadcast"])
+    net.zero_grad()
+    reducer.sync = False
+    crit(net(x), y).backward()
+    out["accum_after_first"] = net.g_arena.buf.clone()
+    reducer.sync = True
+    # the second micro-batch takes the collective from a (stand-in) side stream: the branch the single-GPU tests cannot reach
+    class _Stream:
+        calls = []
+
+        def wait_stream(self, other):
+            self.calls.append(("wait", other))
+
+    import contextlib
+
+    @contextlib.contextmanager
+    def on_stream(s_):
+        _Stream.calls.append(("enter", s_))
+        yield
+
+    fake = _Stream()
+    reducer.from_side = True
+    reducer._current_stream, reducer._on_stream, reducer._side_stream = (lambda: "main"), on_stream, (lambda: fake)
+    crit(net(x2), y2).backward()
+    out["accum_reduced"] = net.g_arena.buf.clone()
+    out["side_calls"] = [c[0] for c in _Stream.calls]
+    net._grad_ready, net._post_backward_hook = None, None
+    net.zero_grad()
+    crit(net(x), y).backward()
+    crit(net(x2), y2).backward()
+    out["accum_local"] = net.g_arena.buf.clone()
     # ---- loss sums exchanged as one collective -----------------------------------------------------------------------
     def anchors(hw, strides):
         a, pts, _pg, counts, strd = make_anchors(hw, strides)
@@ -127,6 +162,12 @@ def test_world_size_2_gloo(tmp_path):
     assert torch.equal(r[0]["params_after_step"], r[1]["params_after_step"])
     expect = r[0]["params_after_broadcast"] - 0.1 * total / world
     assert torch.allclose(r[0]["params_after_step"], expect, rtol=1e-6, atol=1e-7)
+    # gradient accumulation: nothing exchanged after the first micro-batch, one exchange of the accumulated arena after the second, issued
+    # through the side-stream branch of GradientAllReducer.ready (stream waits + collective under the side stream's context, per bucket)
+    for i in range(world):
+        assert not torch.allclose(r[i]["accum_after_first"], r[1 - i]["accum_after_first"]), "first micro-batch must stay local"
+        assert torch.allclose(r[i]["accum_reduced"], r[0]["accum_local"] + r[1]["accum_local"], rtol=1e-5, atol=1e-7), "accumulated arena exchanged once"
+        assert r[i]["side_calls"] and r[i]["side_calls"].count("wait") == r[i]["side_calls"].count("enter") >= 1
     # loss: items from the global sums, normaliser = clip(score_sum / world, 1); gradients = local gradient of the weighted sums / normaliser
     s = r[0]["local_sums"] + r[1]["local_sums"]
     norm = max(float(s[3]) / world, 1.0)
@@ -158,3 +199,97 @@ def test_world_size_2_gloo(tmp_path):
     assert not torch.equal(r[0]["buffers_before"][0], r[1]["buffers_before"][0])
     for i in range(world):
         assert torch.equal(r[i]["buffers_after"][0], r[0]["buffers_before"][0]) and torch.equal(r[i]["buffers_after"][1], r[0]["buffers_before"][1])
+
+
+def _worker_rccl(rank, world, port, outdir):
+    """The same exchange over RCCL on two MI355X: real HIP streams, the default side-stream issue of the bucket collectives, the fused
+    16-byte loss reduction, synchronised BatchNorm.  One process per GPU."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd.training.losses import CrossEntropyLoss, PPYoloELoss
+    from super_gradients_amd.training.utils import distributed_training_utils as DU
+    from super_gradients_amd.training.utils.distributed_training_utils import GradientAllReducer, setup_device_from_env
+    from test_trainer import _tiny_models
+    from oracle import golden_util as G
+    from oracle.yolo_nas import make_anchors
+
+    r, w, dev = setup_device_from_env()  # backend "nccl" = RCCL
+    assert (r, w) == (rank, world) and dev.type == "cuda"
+    out = {}
+    ref, net = _tiny_models(dev)
+    net.materialize(dev).train()
+    net.p_arena.buf.add_(0.01 * (rank + 1))           # ranks start apart: the broadcast must equalise them
+    reducer = GradientAllReducer(net, net.gradient_buckets())
+    assert reducer.from_side and net.side_stream is not None
+    reducer.broadcast_parameters(0)
+    out["params"] = net.p_arena.buf.cpu().clone()
+    g = torch.Generator().manual_seed(10 + rank)
+    x, y = torch.randn(4, 4, 8, 8, generator=g).to(dev), torch.randint(0, 4, (4,), generator=g).to(dev)
+    crit = CrossEntropyLoss()
+    net.zero_grad()
+    crit(net(x), y).backward()
+    torch.cuda.synchronize()
+    out["reduced"] = net.g_arena.buf.cpu().clone()
+    net._grad_ready, net._post_backward_hook = None, None
+    net.zero_grad()
+    crit(net(x), y).backward()
+    torch.cuda.synchronize()
+    out["local"] = net.g_arena.buf.cpu().clone()
+
+    def anchors(hw, strides):
+        a, pts, _pg, counts, strd = make_anchors(hw, strides)
+        return a, pts, counts, strd
+
+    preds = G.synthetic_predictions(2, [8, 4, 3], 8, 16, seed=30 + rank, make_anchors=anchors)
+    t = G.detection_targets(2, 64, seed=40 + rank, kmax=3, num_classes=8, empty_last=False)
+    dp = [p.to(dev) if torch.is_tensor(p) else p for p in preds]
+    loss, items = PPYoloELoss(8, use_static_assigner=False)((None, tuple(dp)), t.to(dev))
+    out["items"] = items.cpu().clone()
+    loc = K.ppyoloe_loss_fwd(dp[0], dp[1], dp[2], dp[3], dp[5], t.to(dev), dp[4], False, True, (1.0, 2.5, 0.5))
+    out["local_sums"] = loc["sums"].cpu().clone()
+    # synchronised BatchNorm: two ranks x half a batch == the whole batch
+    _, snet = _tiny_models(dev)
+    snet.materialize(dev).train()
+    snet.set_sync_bn(True)
+    GradientAllReducer(snet, snet.gradient_buckets())
+    gfull = torch.Generator().manual_seed(77)
+    xfull, wfull = torch.randn(8, 4, 8, 8, generator=gfull), torch.randn(8, 6, generator=gfull)
+    ys = snet(xfull[rank * 4:(rank + 1) * 4].to(dev))
+    (ys * wfull[rank * 4:(rank + 1) * 4].to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    out["sync_y"], out["sync_grad"] = ys.detach().cpu().clone(), snet.g_arena.buf.cpu().clone()
+    if rank == 0:
+        ref.train()
+        yf = ref(xfull)
+        out["full_y"] = yf.detach().clone()
+    torch.save(out, os.path.join(outdir, f"rccl{rank}.pt"))
+    DU.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_world_size_2_rccl(tmp_path):
+    """N > 1 on real hardware (reference: sg_trainer.py:452-459 DDP wrapping, ppyolo_loss.py:971-977).  Needs two GPUs: skipped on the
+    single-GPU test box, runs wherever `bench.py --gpus N` can."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 HIP GPUs")
+    world = 2
+    port = 29700 + (os.getpid() % 2000)
+    mp.spawn(_worker_rccl, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"rccl{i}.pt")) for i in range(world)]
+    assert torch.equal(r[0]["params"], r[1]["params"])
+    total = r[0]["local"] + r[1]["local"]
+    for i in range(world):
+        assert torch.allclose(r[i]["reduced"], total, rtol=1e-5, atol=1e-7)
+    s = r[0]["local_sums"] + r[1]["local_sums"]
+    norm = max(float(s[3]) / world, 1.0)
+    items = torch.tensor([1.0 * float(s[0]) / norm, 2.5 * float(s[1]) / norm, 0.5 * float(s[2]) / norm])
+    for i in range(world):
+        assert torch.allclose(r[i]["items"][:3], items, rtol=2e-5)
+        assert torch.allclose(r[i]["sync_y"], r[0]["full_y"][i * 4:(i + 1) * 4], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(r[0]["sync_grad"], r[1]["sync_grad"], rtol=1e-6, atol=1e-7)

@@ -32,7 +32,7 @@ def record_problems(model, batch, size, dev):
     t = synthetic_targets(batch, seed=0, kmax=20, size=size).to(dev)
     crit = PPYoloELoss(80, use_static_assigner=False)
     rec = collections.OrderedDict()
-    orig = (K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight)
+    orig = (K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight, K.conv2d_fwd_dual, K.conv2d_bwd_data_dual, K.conv2d_bwd_data_wt)
 
     def key_of(kind, xs, K_, R, stride, pad, xl, yl, extra):
         return (kind,) + tuple(xs) + (K_, R, stride, pad, xl, yl) + extra
@@ -55,12 +55,30 @@ def record_problems(model, batch, size, dev):
         k = key_of("wgrad", x.shape, dw.shape[0], dw.shape[2], stride, pad, x.stride(2), dy.stride(2), (dbias is not None,))
         rec[k] = rec.get(k, 0) + 1
 
-    K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight = fwd, dgrad, wgrad
+    def fwd2(x, w, w1p, bias1, stride=1):
+        r = orig[3](x, w, w1p, bias1, stride=stride)
+        k = key_of("fwd2", x.shape, w.shape[0], w.shape[2], stride, w.shape[2] // 2, x.stride(2), r[0].stride(2), ())
+        rec[k] = rec.get(k, 0) + 1
+        return r
+
+    def dgrad2(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, out=None, accumulate=False):
+        o = orig[4](dy, w, wt, ds, w1pt, x_shape, stride=stride, addend=addend, out=out, accumulate=accumulate)
+        k = key_of("dgrad2", x_shape, w.shape[0], w.shape[2], stride, w.shape[2] // 2, o.stride(2), dy.stride(2), (addend is not None, bool(accumulate)))
+        rec[k] = rec.get(k, 0) + 1
+        return o
+
+    def dgrad_wt(dy, w, wt, x_shape, stride=1, pad=0, addend=None, out=None, accumulate=False):
+        o = orig[5](dy, w, wt, x_shape, stride=stride, pad=pad, addend=addend, out=out, accumulate=accumulate)
+        k = key_of("dgrad", x_shape, w.shape[0], w.shape[2], stride, pad, o.stride(2), dy.stride(2), (addend is not None, bool(accumulate)))
+        rec[k] = rec.get(k, 0) + 1
+        return o
+
+    K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight, K.conv2d_fwd_dual, K.conv2d_bwd_data_dual, K.conv2d_bwd_data_wt = fwd, dgrad, wgrad, fwd2, dgrad2, dgrad_wt
     try:
         loss, _ = crit(net(x), t)
         loss.backward()
     finally:
-        K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight = orig
+        K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight, K.conv2d_fwd_dual, K.conv2d_bwd_data_dual, K.conv2d_bwd_data_wt = orig
     torch.cuda.synchronize()
     del net
     return rec
@@ -82,6 +100,19 @@ def make_runner(k, dev):
     yout = buf(n, ho, wo, K_, yl)
     wt = K.to_ohwi(torch.randn(K_, c, R, R, device=dev) / (c * R * R) ** 0.5)
     flops = 2.0 * n * ho * wo * K_ * c * R * R
+    if kind in ("fwd2", "dgrad2"):  # QARepVGG block: RxS conv + 1x1 conv per launch
+        flops += 2.0 * n * ho * wo * K_ * c
+        w1 = K.to_ohwi(torch.randn(K_, c, 1, 1, device=dev) / c ** 0.5)
+        if kind == "fwd2":
+            b1 = torch.randn(K_, device=dev)
+            return (lambda: K.conv2d_fwd_dual(xin, wt, w1, b1, stride=stride)), flops
+        has_add, acc = extra
+        add = buf(n, h, w, c, xl) if has_add else None
+        wtt = K.conv2d_wt_buffer(wt, dev)
+        K.conv2d_transpose_weights(wt, wtt, stride=stride, pad=pad)
+        w1t = w1.reshape(K_, c).t().contiguous()
+        ds = buf(n, ho, wo, K_, yl)
+        return (lambda: K.conv2d_bwd_data_dual(yout, wt, wtt, ds, w1t, (n, h, w, c), stride=stride, addend=add, out=xin, accumulate=acc)), flops
     if kind == "fwd":
         has_b, has_add, act, stats = extra
         b = torch.randn(K_, device=dev) if has_b else None
@@ -128,13 +159,15 @@ def main():
         rows.append((kind, n, h, w, c, K_, R, stride, xl, yl, extra, calls, us, flops / us / 1e6))
     tot = sum(r[11] * r[12] for r in rows)
     lines = [f"# YOLO-NAS-{args.model.upper()} bs={args.batch} {args.size}x{args.size}: {len(rows)} distinct conv problems, {sum(r[11] for r in rows)} conv calls/step, "
-             f"{tot / 1e3:.2f} ms/step of conv kernels when replayed back to back; total {sum(r[11] * 2.0 * r[1] * ((r[2] + 2 * (r[6] // 2) - r[6]) // r[7] + 1) * ((r[3] + 2 * (r[6] // 2) - r[6]) // r[7] + 1) * r[5] * r[4] * r[6] * r[6] for r in rows) / 1e12:.3f} TFLOP",
+             f"{tot / 1e3:.2f} ms/step of conv kernels when replayed back to back; total {sum(r[11] * r[13] * r[12] * 1e6 for r in rows) / 1e12:.3f} TFLOP",
              f"{'kind':<6}{'N':>3}{'H':>5}{'W':>5}{'C':>6}{'K':>6}{'R':>3}{'s':>3}{'x_ld':>6}{'y_ld':>6} {'calls':>5}{'us':>10}{'TFLOP/s':>9}{'step%':>7}  options"]
     for r in sorted(rows, key=lambda r: -r[11] * r[12]):
         kind, n, h, w, c, K_, R, stride, xl, yl, extra, calls, us, tf = r
         lines.append(f"{kind:<6}{n:>3}{h:>5}{w:>5}{c:>6}{K_:>6}{R:>3}{stride:>3}{xl:>6}{yl:>6} {calls:>5}{us:>10.1f}{tf:>9.1f}{100 * calls * us / tot:>7.2f}  {extra}")
-    for kind in ("fwd", "dgrad", "wgrad"):
+    for kind in ("fwd", "fwd2", "dgrad", "dgrad2", "wgrad"):
         sel = [r for r in rows if r[0] == kind]
+        if not sel:
+            continue
         t_us = sum(r[11] * r[12] for r in sel)
         fl = sum(r[11] * r[13] * r[12] * 1e6 for r in sel)
         lines.append(f"# {kind}: {t_us / 1e3:.2f} ms/step, {fl / t_us / 1e6:.1f} TFLOP/s aggregate")
