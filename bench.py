@@ -161,7 +161,14 @@ def nms_leg(device, iters=100, warmup=10):
         onms.nms(bx[i][top], conf[top], 0.7)
         n_cpu += 1000
     cpu_s = time.perf_counter() - t0
+    # HBM roofline of the call: stage 1 streams the B*L*C scores three times (two histogram passes + the gather pass); everything after
+    # that works on <= 8192 keys per image in LDS
+    stream_bytes = 3.0 * B * L * C * 4
     return {"value": round(ncand / (ms * 1e-3), 1), "unit": "boxes/s", "ms_per_batch": round(ms, 4), "candidates": ncand, "kept": kept, "batch": B,
+            "roofline": {"bound": "hbm", "achieved": round(stream_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(stream_bytes / (ms * 1e-3) / 8e12, 4), "traffic": None,
+                         "note": "algorithmic bytes = 3 passes over the fp32 scores (258 MB per batch) / time of the WHOLE post-prediction call "
+                                 "(selection + per-image sort + suppression scan, which are latency-bound and move no HBM bytes)"},
             "config": "B=32 L=8400 C=80 multi-label, score>0.01, top-k 1000, IoU 0.7, max 300, class-agnostic",
             "cpu_baseline": {"value": round(n_cpu / cpu_s, 1), "unit": "boxes/s", "cores": 1, "kind": "port",
                              "sample": "4 images x 1000 candidates: threshold + top-k (ATen) + oracle/nms.c"}}

@@ -1,13 +1,22 @@
-// Detection post-processing on gfx950: score filter -> exact top-k -> greedy NMS, one 1024-thread workgroup
-// per image, everything after the score stream stays in LDS.  No MFMA: the score stream is HBM/L2-bound
-// (B*L*C*4 bytes per pass), the suppression loop is latency-bound (one barrier per KEPT box).
+// Detection post-processing on gfx950: score filter -> exact top-k -> greedy NMS.  No MFMA: candidate selection is an HBM stream over the
+// B*L*C scores, suppression is latency-bound.
 //
 // Replaces PPYoloEPostPredictionCallback.forward (pp_yolo_e/post_prediction_callback.py:42-123) and the
 // torchvision.ops.nms / batched_nms it calls (:85,87).  Ordering rule (matches a stable descending sort):
 // candidates are ranked by (score desc, candidate index asc), candidate index = anchor*C + class
-// (the row-major order of `(scores > thr).nonzero()`), or the anchor index in single-label mode.
-// The exact k-th composite key is found by a 5-digit radix select over (score bits, ~index) - no sort of
-// the 672k scores - then <=1024 survivors are bitonic-sorted in LDS.
+// (the row-major order of `(scores > thr).nonzero()`), or the anchor index in single-label mode; the composite key
+// (score bits << 22 | ~index) is unique, so "the top k" is a set, whatever order candidates are visited in.
+//
+// Multi-label mode (the recipes' setting) runs in two stages:
+//   stage 1, the WHOLE chip (grid = score slabs x images, 16-byte loads): two histogram passes narrow the k-th largest key down to its top 22
+//            bits (11 bits per pass: LDS histogram per workgroup, merged with global atomics), a third pass appends every candidate at or
+//            above that 22-bit prefix - the top k plus the few that share the boundary bin - to a per-image list;
+//   stage 2, one workgroup per image on the list: exact radix select of the k-th key, bitonic sort in LDS, then suppression as a
+//            triangular IoU bit matrix (all pairs in parallel) scanned by ONE wave without barriers - the torchvision-CUDA formulation,
+//            kept on the device.
+// (Round 1 ran everything in one 1024-thread workgroup per image: seven passes over the image's 672k scores with 32 of 256 CUs busy and
+// two barriers per kept box - 2.17 ms per 32-image batch.)  Single-label mode and lists that overflow (more than NMS_LIST_CAP candidates
+// sharing the boundary prefix: pathological ties) take stage 2's streaming path over the raw scores, which needs no list.
 // Compile with -ffp-contract=off: the IoU test must round exactly like the CPU restatement.
 #include "sgx_common.h"
 
@@ -15,12 +24,15 @@
 #define NMS_MAXK_LIMIT 4096  // largest instantiated top-k capacity (LDS: 37 B per candidate + 8 KB histogram <= 160 KB)
 #define NMS_IDXBITS 22
 #define NMS_HBINS 2048
+#define NMS_LIST_CAP 8192    // per-image candidate list of stage 1 (top k <= 4096 + boundary-bin slack)
+#define NMS_S1_THREADS 256
 
 typedef unsigned long long u64;
 
+// workspace layout (ints unless noted): hist1 [B][2048] | hist2 [B][2048] | list_count [B] | total [B] | list (u64) [B][NMS_LIST_CAP]
 extern "C" int64_t sgx_nms_workspace(const sgx_nms_desc* d) {
-    (void)d;
-    return 256;  // everything lives in LDS; kept for ABI stability
+    if (!d || !d->multi_label) return 256;
+    return (int64_t)d->B * (2 * NMS_HBINS + 2) * 4 + 256 + (int64_t)d->B * NMS_LIST_CAP * 8;
 }
 
 __device__ __forceinline__ bool nms_candidate(const sgx_nms_desc& d, const float* sc, long e, float& score, int& cls) {
@@ -45,9 +57,135 @@ __device__ __forceinline__ u64 nms_key(float score, long e) {
     return ((u64)__float_as_uint(score) << NMS_IDXBITS) | (u64)(((1u << NMS_IDXBITS) - 1u) - (unsigned)e);
 }
 
+// ---- stage 1 (multi-label): candidate selection over the whole chip ---------------------------------------------------------------
+// Bin of the k-th largest entry of a histogram counted from the top bin, how many entries lie strictly above that bin, and the total.
+// Every thread of the NT-thread workgroup calls it (three barriers); thread t owns nbins / NT consecutive bins, a suffix sum over the threads
+// (wave shuffles + one LDS hop across waves) finds the thread whose bins contain the k-th entry - no serial walk over the bins (round 1's
+// thread-0 loop over 2048 bins per radix digit was most of the per-image time).  Fewer than k entries in total: bin = 0, above = 0
+// ("everything at or above bin 0").  hist may be global memory written by an earlier kernel.  sh: NT / 64 + 3 ints of LDS.
+template <int NT>
+__device__ __forceinline__ void nms_kth_from_top(const int* hist, int nbins, int k, int* sh, int& bin, int& above, int& total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = NT / 64;
+    const int per = nbins / NT;
+    int local = 0;
+    for (int q = 0; q < per; ++q) local += hist[tid * per + q];
+    int v = local;  // -> sum over the lanes >= lane of this wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_down(v, off);
+        if (lane + off < 64) v += t;
+    }
+    if (tid == 0) {
+        sh[NW] = 0;
+        sh[NW + 1] = 0;
+    }
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    int higher = 0, all = 0;
+    for (int w = 0; w < NW; ++w) {
+        const int t = sh[w];
+        all += t;
+        if (w > wave) higher += t;
+    }
+    const int incl = v + higher, excl = incl - local;
+    if (excl < k && incl >= k) {
+        int cum = excl, b = (tid + 1) * per - 1;
+        for (; b > tid * per; --b) {
+            if (cum + hist[b] >= k) break;
+            cum += hist[b];
+        }
+        sh[NW] = b;
+        sh[NW + 1] = cum;
+    }
+    __syncthreads();
+    bin = sh[NW];
+    above = sh[NW + 1];
+    total = all;
+    __syncthreads();  // sh may be reused by the next call
+}
+// PASS 0: hist1 over key bits 52..42 (score bits 30..20).  PASS 1: hist2 over key bits 41..31 among keys in hist1's boundary bin.
+// PASS 2: append the keys at or above the 22-bit boundary prefix to the image's list; total[b] = number of candidates.
+template <int PASS>
+__global__ __launch_bounds__(NMS_S1_THREADS) void nms_select_kernel(sgx_nms_desc d, const float* scores, int* ws, int slab) {
+    __shared__ int lh[NMS_HBINS];
+    __shared__ int part[NMS_S1_THREADS / 64 + 3];
+    __shared__ int lcount, lbase;
+    u64* const lbuf = reinterpret_cast<u64*>(lh);  // PASS 2 reuses the histogram's LDS: up to NMS_HBINS / 2 selected keys per workgroup
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const long E = (long)d.L * d.C;
+    const float* sc = scores + (long)b * E;
+    int* hist1 = ws + (long)b * NMS_HBINS;
+    int* hist2 = ws + ((long)d.B + b) * NMS_HBINS;
+    int* list_count = ws + 2L * d.B * NMS_HBINS + b;
+    int* total = ws + 2L * d.B * NMS_HBINS + d.B + b;
+    u64* list = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + (((long)d.B * (2 * NMS_HBINS + 2) * 4 + 255) & ~255L)) + (long)b * NMS_LIST_CAP;
+    const int K = d.nms_top_k;
+    int b1 = 0, above1 = 0, b2 = 0, above2 = 0, tot1 = 0, tot2 = 0;
+    if (PASS >= 1) nms_kth_from_top<NMS_S1_THREADS>(hist1, NMS_HBINS, K, part, b1, above1, tot1);
+    if (PASS >= 2) {
+        nms_kth_from_top<NMS_S1_THREADS>(hist2, NMS_HBINS, K - above1, part, b2, above2, tot2);
+        if (blockIdx.x == 0 && tid == 0) total[0] = tot1;
+    }
+    if (PASS < 2) {
+        for (int q = tid; q < NMS_HBINS; q += NMS_S1_THREADS) lh[q] = 0;
+    } else if (tid == 0) lcount = 0;
+    __syncthreads();
+    const long e0 = (long)blockIdx.x * slab, e1 = e0 + slab < E ? e0 + slab : E;
+    const bool vec = ((((uintptr_t)sc) & 15) == 0) && (e0 % 4 == 0);
+    auto visit = [&](float s, long e) {
+        if (!(s > d.score_threshold)) return;
+        const u64 k = nms_key(s, e);
+        const int h1 = (int)(k >> 42), h2 = (int)((k >> 31) & (NMS_HBINS - 1));
+        if (PASS == 0) atomicAdd(&lh[h1], 1);
+        else if (PASS == 1) {
+            if (h1 == b1) atomicAdd(&lh[h2], 1);
+        } else if (h1 > b1 || (h1 == b1 && h2 >= b2)) {
+            // collected in LDS first: ONE global atomic per workgroup reserves its range of the image's list (one atomic per key, on 32
+            // counters that share a cache line, cost 220 us per batch - r2n); a workgroup with more than NMS_HBINS / 2 selected keys
+            // (pathological ties) appends the excess directly
+            const int slot = atomicAdd(&lcount, 1);
+            if (slot < NMS_HBINS / 2) lbuf[slot] = k;
+            else {
+                const int g = atomicAdd(list_count, 1);
+                if (g < NMS_LIST_CAP) list[g] = k;
+            }
+        }
+    };
+    long e = e0 + (vec ? 4L * tid : tid);
+    if (vec) {
+        for (; e + 3 < e1; e += 4L * NMS_S1_THREADS) {
+            const float4 v = sgx_ld4(sc + e);
+            visit(v.x, e); visit(v.y, e + 1); visit(v.z, e + 2); visit(v.w, e + 3);
+        }
+        for (long r = e; r < e1 && r < e + 4; ++r) visit(sc[r], r);  // ragged tail of the slab (at most one lane has one)
+    } else {
+        for (; e < e1; e += NMS_S1_THREADS) visit(sc[e], e);
+    }
+    __syncthreads();
+    if (PASS < 2) {
+        int* gh = PASS == 0 ? hist1 : hist2;
+        for (int q = tid; q < NMS_HBINS; q += NMS_S1_THREADS)
+            if (lh[q]) atomicAdd(&gh[q], lh[q]);
+    } else {
+        const int cnt = lcount < NMS_HBINS / 2 ? lcount : NMS_HBINS / 2;
+        if (tid == 0 && cnt) lbase = atomicAdd(list_count, cnt);
+        __syncthreads();
+        for (int q = tid; q < cnt; q += NMS_S1_THREADS)
+            if (lbase + q < NMS_LIST_CAP) list[lbase + q] = lbuf[q];
+    }
+}
+
+// ---- stage 2: one workgroup per image --------------------------------------------------------------------------------------------
+// Triangular suppression bit matrix for NMS_MAXK = 1024: row i keeps the 64-bit words w >= i / 64 (bit j of word w: "i suppresses 64*w + j").
+// Rows are grouped in blocks of 64 (g = i / 64, 16 - g words per row): 8 704 words = 68 KB of LDS.
+#define NMS_MW 16
+__device__ __forceinline__ int nms_mask_row(int i) {
+    const int g = i >> 6;
+    return 64 * (NMS_MW * g - g * (g - 1) / 2) + (i & 63) * (NMS_MW - g);
+}
 template <int NMS_MAXK>
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const float* boxes, const float* scores, float* out, int* out_count,
-                                                          int* out_index, int* num_candidates) {
+                                                          int* out_index, int* num_candidates, const int* ws) {
+    constexpr bool MASK = NMS_MAXK == 1024;
     __shared__ int hist[NMS_HBINS];
     __shared__ u64 keys[NMS_MAXK];
     __shared__ float bx[NMS_MAXK][4];
@@ -60,23 +198,41 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
     __shared__ int keep_list[NMS_MAXK];
     __shared__ float wmax[NMS_THREADS / 64];
     __shared__ float cur[5];
+    __shared__ int kth_sh[NMS_THREADS / 64 + 3];
+    __shared__ u64 rem[NMS_MW];
+    __shared__ u64 mask[MASK ? 64 * (NMS_MW * (NMS_MW + 1) / 2) : 1];
 
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* sc = scores + (long)b * d.L * d.C;
     const float* bxs = boxes + (long)b * d.L * 4;
     const long E = d.multi_label ? (long)d.L * d.C : (long)d.L;
     const int K = d.nms_top_k < NMS_MAXK ? d.nms_top_k : NMS_MAXK;
+    // stage 1's list (multi-label with a workspace): every candidate at or above the 22-bit boundary prefix - a superset of the top K
+    const int m_list = ws ? ws[2L * d.B * NMS_HBINS + b] : 0;
+    const bool use_list = ws != nullptr && m_list <= NMS_LIST_CAP;
+    const u64* list = ws ? reinterpret_cast<const u64*>(reinterpret_cast<const char*>(ws) + (((long)d.B * (2 * NMS_HBINS + 2) * 4 + 255) & ~255L)) + (long)b * NMS_LIST_CAP
+                         : nullptr;
+    // visits every candidate's composite key: the list, or (single-label / overflowing list) the raw scores of the image
+    auto for_each_key = [&](auto fn) {
+        if (use_list) {
+            for (int i = tid; i < m_list; i += NMS_THREADS) fn(list[i]);
+        } else {
+            for (long e = tid; e < E; e += NMS_THREADS) {
+                float s;
+                int c;
+                if (nms_candidate(d, sc, e, s, c)) fn(nms_key(s, e));
+            }
+        }
+    };
 
     // ---- pass 0: count candidates ----
     if (tid == 0) s_count = 0;
     __syncthreads();
-    {
+    if (use_list) {
+        if (tid == 0) s_count = ws[2L * d.B * NMS_HBINS + d.B + b];
+    } else {
         int local = 0;
-        for (long e = tid; e < E; e += NMS_THREADS) {
-            float s;
-            int c;
-            if (nms_candidate(d, sc, e, s, c)) ++local;
-        }
+        for_each_key([&](u64) { ++local; });
         if (local) atomicAdd(&s_count, local);
     }
     __syncthreads();
@@ -98,25 +254,14 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
             for (int i = tid; i < NMS_HBINS; i += NMS_THREADS) hist[i] = 0;
             __syncthreads();
             const u64 prefix = s_prefix;
-            for (long e = tid; e < E; e += NMS_THREADS) {
-                float s;
-                int c;
-                if (nms_candidate(d, sc, e, s, c)) {
-                    u64 k = nms_key(s, e);
-                    if ((k >> (shift + wbits)) == prefix) atomicAdd(&hist[(int)((k >> shift) & ((1u << wbits) - 1u))], 1);
-                }
-            }
+            for_each_key([&](u64 k) {
+                if ((k >> (shift + wbits)) == prefix) atomicAdd(&hist[(int)((k >> shift) & ((1u << wbits) - 1u))], 1);
+            });
             __syncthreads();
+            int dsel, cum, tot;
+            nms_kth_from_top<NMS_THREADS>(hist, NMS_HBINS, s_remaining, kth_sh, dsel, cum, tot);  // (a 9-bit last digit leaves the upper bins at zero)
             if (tid == 0) {
-                int rem = s_remaining, cum = 0, dsel = 0;
-                for (int bin = (1 << wbits) - 1; bin >= 0; --bin) {
-                    if (cum + hist[bin] >= rem) {
-                        dsel = bin;
-                        break;
-                    }
-                    cum += hist[bin];
-                }
-                s_remaining = rem - cum;
+                s_remaining = s_remaining - cum;
                 s_prefix = (prefix << wbits) | (u64)dsel;
             }
             __syncthreads();
@@ -127,17 +272,12 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
     if (tid == 0) s_n = 0;
     for (int i = tid; i < NMS_MAXK; i += NMS_THREADS) keys[i] = 0;  // 0 sorts last (real keys have score bits > 0)
     __syncthreads();
-    for (long e = tid; e < E; e += NMS_THREADS) {
-        float s;
-        int c;
-        if (nms_candidate(d, sc, e, s, c)) {
-            u64 k = nms_key(s, e);
-            if (k >= thr_key) {
-                int slot = atomicAdd(&s_n, 1);
-                if (slot < NMS_MAXK) keys[slot] = k;
-            }
+    for_each_key([&](u64 k) {
+        if (k >= thr_key) {
+            int slot = atomicAdd(&s_n, 1);
+            if (slot < NMS_MAXK) keys[slot] = k;
         }
-    }
+    });
     __syncthreads();
     for (int size = 2; size <= NMS_MAXK; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -207,17 +347,79 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
     }
     if (tid == 0) s_kept = 0;
     __syncthreads();
+    // does box i (kept) suppress box t?  (the arithmetic order of torchvision's nms kernel)
+    auto suppresses = [&](const float* ci, float ai, int t) {
+        float nb[4];
+        nbox(t, nb);
+        float xx1 = fmaxf(ci[0], nb[0]), yy1 = fmaxf(ci[1], nb[1]);
+        float xx2 = fminf(ci[2], nb[2]), yy2 = fminf(ci[3], nb[3]);
+        float w = xx2 - xx1; w = w < 0.f ? 0.f : w;
+        float h = yy2 - yy1; h = h < 0.f ? 0.f : h;
+        float inter = w * h;
+        float ovr = inter / (ai + area[t] - inter);
+        return ovr > d.iou_threshold;
+    };
     // An IoU never exceeds 1, so with a threshold >= 2 nothing can be suppressed and the scan degenerates to "the first max_predictions
-    // of the sorted candidates": the pre-NMS top-k of the decoding modules (kernels.decode_topk) takes this exit instead of n barrier pairs.
+    // of the sorted candidates": the pre-NMS top-k of the decoding modules (kernels.decode_topk) takes this exit instead of a scan.
     const bool no_suppression = d.iou_threshold >= 2.0f;
     if (no_suppression) {
         const int kn = n < d.max_predictions ? n : d.max_predictions;
         for (int t = tid; t < kn; t += NMS_THREADS) keep_list[t] = t;
         if (tid == 0) s_kept = kn;
         __syncthreads();
+    } else if (MASK) {
+        // ---- suppression as a triangular bit matrix, 64 candidates (one flag word) at a time: the 16 waves build the matrix rows of the
+        // chunk's candidates that are still alive (a wave owns a row, a lane one column: 64 IoU tests per step, the word is their ballot),
+        // then wave 0 walks the chunk without barriers.  Rows of candidates suppressed by earlier chunks are never built (about two thirds
+        // of them at the recipe thresholds), and nothing past the max_predictions-th kept box is.
+        const int nw = (n + 63) >> 6;  // flag words in use
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int w = tid; w < NMS_MW; w += NMS_THREADS) rem[w] = 0;
+        __syncthreads();
+        u64 later = 0;  // wave 0, lane w: flags this chunk's kept boxes set in word w > chunk
+        for (int c = 0; c < nw; ++c) {
+            const u64 remc = rem[c];
+            for (int r = wave; r < 64; r += NMS_THREADS / 64) {
+                const int i = 64 * c + r;
+                if (i >= n || ((remc >> r) & 1ull)) continue;  // wave-uniform
+                float ci[4];
+                nbox(i, ci);
+                const float ai = area[i];
+                const int ic = cls_s[i], base = nms_mask_row(i);
+                for (int w = c; w < nw; ++w) {
+                    const int t = 64 * w + lane;
+                    const bool hit = t > i && t < n && (class_mode != 2 || cls_s[t] == ic) && suppresses(ci, ai, t);
+                    const u64 bits = __ballot(hit);
+                    if (lane == 0) mask[base + (w - c)] = bits;
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                // the kept candidates of this word are the flags that are still clear - found with ffs, so suppressed ones cost nothing; every
+                // kept candidate ORs its row into the flags (its own word through a same-address LDS read, the later words lane by lane)
+                int kept = s_kept;
+                u64 cur = remc;
+                if (c == nw - 1 && (n & 63)) cur |= ~0ull << (n & 63);  // slots past the last candidate
+                u64 avail = ~cur;
+                while (avail && kept < d.max_predictions) {  // wave-uniform
+                    const int bit = __ffsll(avail) - 1;
+                    const int i = 64 * c + bit;
+                    if (lane == 0) keep_list[kept] = i;
+                    ++kept;
+                    const int base = nms_mask_row(i);
+                    cur |= mask[base];
+                    if (lane > c && lane < nw) later |= mask[base + (lane - c)];
+                    avail = ~cur & ~((2ull << bit) - 1ull);
+                }
+                if (lane > c && lane < nw) rem[lane] |= later;
+                if (lane == 0) s_kept = kept;
+            }
+            __syncthreads();
+            if (s_kept >= d.max_predictions) break;  // uniform
+        }
     }
-    // ---- greedy scan: one barrier pair per kept box; box i is broadcast through LDS (offset form) ----
-    for (int i = 0; i < (no_suppression ? 0 : n); ++i) {
+    // ---- greedy scan (top-k capacities above 1024: the bit matrix would not fit in LDS): one barrier pair per kept box ----
+    for (int i = 0; i < ((no_suppression || MASK) ? 0 : n); ++i) {
         if (sup[i]) continue;  // uniform: flags only change before a barrier
         if (tid == 0) {
             float nb[4];
@@ -228,17 +430,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
         }
         __syncthreads();
         for (int t = tid; t < n; t += NMS_THREADS) {
-            if (t > i && !sup[t] && (class_mode != 2 || cls_s[t] == cls_s[i])) {
-                float nb[4];
-                nbox(t, nb);
-                float xx1 = fmaxf(cur[0], nb[0]), yy1 = fmaxf(cur[1], nb[1]);
-                float xx2 = fminf(cur[2], nb[2]), yy2 = fminf(cur[3], nb[3]);
-                float w = xx2 - xx1; w = w < 0.f ? 0.f : w;
-                float h = yy2 - yy1; h = h < 0.f ? 0.f : h;
-                float inter = w * h;
-                float ovr = inter / (cur[4] + area[t] - inter);
-                if (ovr > d.iou_threshold) sup[t] = 1;
-            }
+            if (t > i && !sup[t] && (class_mode != 2 || cls_s[t] == cls_s[i]) && suppresses(cur, cur[4], t)) sup[t] = 1;
         }
         __syncthreads();
         if (s_kept >= d.max_predictions) break;  // uniform
@@ -268,8 +460,6 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
 
 extern "C" int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const float* scores, float* out, int32_t* out_count, int32_t* out_index,
                            int32_t* num_candidates, void* ws, int64_t ws_bytes, void* stream) {
-    (void)ws;
-    (void)ws_bytes;
     SGX_CHECK_ARG(d && boxes && scores && out && out_count, "nms: null pointer");
     SGX_CHECK_ARG(d->B > 0 && d->L > 0 && d->C > 0, "nms: bad dims");
     SGX_CHECK_ARG(d->nms_top_k > 0 && d->nms_top_k <= NMS_MAXK_LIMIT, "nms: nms_top_k=%d unsupported (max %d)", d->nms_top_k, NMS_MAXK_LIMIT);
@@ -277,10 +467,28 @@ extern "C" int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const floa
     SGX_CHECK_ARG((long)d->L * (d->multi_label ? d->C : 1) <= (1L << NMS_IDXBITS), "nms: too many candidates for the %d-bit index field", NMS_IDXBITS);
     SGX_CHECK_ARG(d->class_mode >= 0 && d->class_mode <= 3, "nms: bad class_mode");
     SGX_CHECK_ARG(d->score_threshold >= 0.f, "nms: negative score threshold unsupported (keys assume non-negative scores)");
+    const int* wsi = nullptr;
+    if (d->multi_label) {
+        // stage 1 on the whole chip (a caller without a workspace gets the streaming stage 2: same rows, one workgroup per image)
+        if (ws && ws_bytes >= sgx_nms_workspace(d)) {
+            wsi = (const int*)ws;
+            SGX_MEMSET_ASYNC(ws, 0, (size_t)d->B * (2 * NMS_HBINS + 2) * 4, stream);
+            const long E = (long)d->L * d->C;
+            int S = (int)((E + 16383) / 16384);  // >= 16 k scores per workgroup, at most ~2048 workgroups in flight
+            if (S * d->B > 2048) S = (2048 + d->B - 1) / d->B;
+            if (S < 1) S = 1;
+            const int slab = (int)((((E + S - 1) / S) + 3) / 4 * 4);
+            const dim3 grid((unsigned)((E + slab - 1) / slab), (unsigned)d->B);
+            SGX_LAUNCH(nms_select_kernel<0>, grid, dim3(NMS_S1_THREADS), 0, stream, *d, scores, (int*)ws, slab);
+            SGX_LAUNCH(nms_select_kernel<1>, grid, dim3(NMS_S1_THREADS), 0, stream, *d, scores, (int*)ws, slab);
+            SGX_LAUNCH(nms_select_kernel<2>, grid, dim3(NMS_S1_THREADS), 0, stream, *d, scores, (int*)ws, slab);
+            SGX_CHECK_LAUNCH("nms_select");
+        }
+    }
     const int need = d->nms_top_k > d->max_predictions ? d->nms_top_k : d->max_predictions;
-    if (need <= 1024) SGX_LAUNCH(nms_kernel<1024>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates);
-    else if (need <= 2048) SGX_LAUNCH(nms_kernel<2048>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates);
-    else SGX_LAUNCH(nms_kernel<4096>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates);
+    if (need <= 1024) SGX_LAUNCH(nms_kernel<1024>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates, wsi);
+    else if (need <= 2048) SGX_LAUNCH(nms_kernel<2048>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates, wsi);
+    else SGX_LAUNCH(nms_kernel<4096>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates, wsi);
     SGX_CHECK_LAUNCH("nms");
     return SGX_OK;
 }

@@ -676,7 +676,8 @@ def nms(boxes, scores, score_threshold, iou_threshold, nms_top_k, max_prediction
     idx = torch.empty(B, max_predictions, device=dev, dtype=torch.int32)
     ncand = torch.empty(B, device=dev, dtype=torch.int32)
     boxes, scores = boxes.contiguous().float(), scores.contiguous().float()  # bound to names: alive until the launch is enqueued
-    check(lib().sgx_nms(ctypes.byref(d), ptr(boxes), ptr(scores), ptr(out), ptr(cnt), ptr(idx), ptr(ncand), None, 0, stream()), "sgx_nms")
+    ws = WORKSPACE.get(lib().sgx_nms_workspace(ctypes.byref(d)), dev)
+    check(lib().sgx_nms(ctypes.byref(d), ptr(boxes), ptr(scores), ptr(out), ptr(cnt), ptr(idx), ptr(ncand), ptr(ws), ws.numel(), stream()), "sgx_nms")
     return out, cnt, idx, ncand
 
 

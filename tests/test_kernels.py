@@ -460,6 +460,26 @@ def _nms_case(B, L, C, seed, clusters=12, size=640.0):
     return torch.from_numpy(boxes), torch.from_numpy(scores)
 
 
+def test_nms_boundary_ties_overflow_the_candidate_list(backend):
+    """More candidates share the k-th key's 22-bit prefix than stage 1's per-image list holds (all scores equal: the whole image sits in the
+    boundary bin): stage 2 must fall back to streaming the raw scores and still return the stable-sort answer (lowest candidate index first)."""
+    from oracle import nms as onms
+
+    B, L, C = 2, 130, 80  # 10 400 equal-score candidates per image > NMS_LIST_CAP = 8192
+    g = np.random.RandomState(3)
+    c = g.uniform(50, 590, (B, L, 2))
+    wh = g.uniform(10, 60, (B, L, 2))
+    boxes = torch.from_numpy(np.concatenate([c - wh / 2, c + wh / 2], -1).astype(np.float32))
+    scores = torch.full((B, L, C), 0.5)
+    scores[1, :, 1::2] = 0.25  # image 1: 5 200 candidates at 0.5 (fits the list), the rest below them
+    kw = dict(score_threshold=0.1, nms_threshold=0.6, nms_top_k=64, max_predictions=20, multi_label_per_box=True)
+    ref = onms.post_prediction(boxes, scores, class_agnostic_nms=True, **kw)
+    out, cnt, idx, ncand = K.nms(boxes.to(backend), scores.to(backend), 0.1, 0.6, 64, 20, multi_label=True, class_mode=0)
+    for b in range(B):
+        assert torch.equal(out[b, : int(cnt[b])].cpu(), ref[b]), f"image {b}"
+    assert int(ncand[0]) == 64 and int(idx[0, 0]) == 0
+
+
 @pytest.mark.parametrize("multi_label,class_mode", [(True, 0), (False, 0), (True, 1), (False, 2), (True, 2)])
 def test_nms(backend, multi_label, class_mode):
     from oracle import nms as onms
