@@ -45,16 +45,18 @@ def synthetic_batch(batch, size, seed, device):
     return x.to(device), t.to(device)
 
 
-def cpu_baseline(model, size, seconds_budget=25.0, family="yolo_nas"):
-    """Oracle train step on the host cores: bounded sample (batch 8, 1 warm-up + up to 3 timed steps)."""
+def cpu_baseline(model, size, batch=32, seconds_budget=45.0, family="yolo_nas"):
+    """the reference's arithmetic (CPU oracle: oracle/yolo_nas.py + oracle/ppyolo_loss.py on ATen / oneDNN kernels) on
+    THIS box's host cores - the config batch size, every core (torch.set_num_threads(os.cpu_count())), AdamW lr 2e-4 wd 1e-5, fp32,
+    forward / loss / backward / optimizer timed separately.  Bounded: 1 warm-up step, then timed steps until `seconds_budget` is spent
+    (at most 5, at least 1) so that the default bench run stays within minutes."""
     import torch
     from oracle.ppyolo_loss import PPYoloELossOracle
     from oracle.yolo_nas import YoloNAS as OracleYoloNAS
     from util import synthetic_targets
 
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
+    torch.set_num_threads(cores)
     torch.manual_seed(0)
     if family == "ppyoloe":
         from oracle.pp_yolo_e import PPYoloE as OraclePPYoloE
@@ -64,26 +66,36 @@ def cpu_baseline(model, size, seconds_budget=25.0, family="yolo_nas"):
         net = OracleYoloNAS(model, num_classes=80).train()
     opt = torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-5)
     crit = PPYoloELossOracle(80, use_static_assigner=False)
-    bs = 8
-    x = torch.rand(bs, 3, size, size)
-    t = synthetic_targets(bs, seed=0, kmax=20, size=size)
+    x = torch.rand(batch, 3, size, size)
+    t = synthetic_targets(batch, seed=42, kmax=20, size=size)
+    split = {"fwd": 0.0, "loss": 0.0, "bwd": 0.0, "opt": 0.0}
 
-    def step():
-        loss, _ = crit(net(x), t)
+    def step(record):
+        t0 = time.perf_counter()
+        out = net(x)
+        t1 = time.perf_counter()
+        loss, _ = crit(out, t)
+        t2 = time.perf_counter()
         loss.backward()
+        t3 = time.perf_counter()
         opt.step()
         opt.zero_grad()
+        t4 = time.perf_counter()
+        if record:
+            for k, v in zip(split, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                split[k] += v
 
-    step()
-    t0 = time.time()
+    step(False)
+    t0 = time.perf_counter()
     n = 0
-    while n < 3 and time.time() - t0 < seconds_budget:
-        step()
+    while n < 5 and (n == 0 or time.perf_counter() - t0 < seconds_budget):
+        step(True)
         n += 1
-    dt = time.time() - t0
-    return {"value": round(bs * n / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"oracle {'PP-YOLOE' if family == 'ppyoloe' else 'YOLO-NAS'}-{model.upper()} {size}x{size} fp32 train step (fwd+PPYoloELoss+bwd+AdamW), batch {bs}, {n} timed steps after 1 warm-up, "
-                      f"{threads} threads of {cores} host cores"}
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * n / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "seconds_per_step": {k: round(v / n, 3) for k, v in split.items()},
+            "sample": f"oracle {'PP-YOLOE' if family == 'ppyoloe' else 'YOLO-NAS'}-{model.upper()} {size}x{size} fp32 train step (fwd + PPYoloELoss + bwd + AdamW), batch {batch}, "
+                      f"{n} timed step(s) after 1 warm-up, torch.set_num_threads({cores})"}
 
 
 def oracle_loss_check(net, crit, x, targets, model, family):
@@ -317,7 +329,7 @@ def main():
     for _ in range(args.steps):
         step()
     fence()
-    ig_bytes = K.prof_bytes(0)
+    ig_bytes, wg_bytes = K.prof_bytes(0), K.prof_bytes(1)
     ig_ms, ig_fl, ig_n = K.prof_summary(0)
     wg_ms, wg_fl, wg_n = K.prof_summary(1)
     # per-launch roofline time: max(FLOPs / MFMA peak, algorithmic bytes / achievable HBM rate) summed over the same launches
@@ -390,7 +402,8 @@ def main():
                                        "note": "same kernels and launches with the side HIP stream disabled (no concurrent weight-gradient kernels): "
                                                "3 extra untimed steps after the timed region"},
                          "wgrad": {"achieved": round(wg_tf, 2), "frac": round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4), "launches_per_step": wg_n // max(args.steps, 1),
-                                   "kernel_ms_per_step": round(wg_ms / args.steps, 3)},
+                                   "kernel_ms_per_step": round(wg_ms / args.steps, 3),
+                                   "algorithmic_bytes_per_launch": round(wg_bytes / max(wg_n, 1)), "gflop_per_launch": round(wg_fl / max(wg_n, 1) / 1e9, 3)},
                          # whole-step MFMA utilisation: algorithmic conv FLOPs of one step (model table; measured launches for PP-YOLOE) / step time
                          "step_mfma_frac": round((per_gpu * TRAIN_GFLOP_PER_IMG[args.model] * (args.size / 640.0) ** 2 / 1e3 if args.workload == "yolo_nas"
                                                   else (ig_fl + wg_fl) / args.steps / (dt / args.steps) / 1e12) / PEAK_FP32_MFMA_TFLOPS, 4)},
@@ -398,7 +411,7 @@ def main():
         if loss_check is not None:
             rec["config"]["loss_check_vs_oracle"] = loss_check
         if not args.no_cpu_baseline and world == 1:
-            rec["cpu_baseline"] = cpu_baseline(args.model, args.size, family="ppyoloe" if args.workload == "ppyoloe" else "yolo_nas")
+            rec["cpu_baseline"] = cpu_baseline(args.model, args.size, batch=args.batch, family="ppyoloe" if args.workload == "ppyoloe" else "yolo_nas")
         if not args.no_nms and world == 1:
             rec["nms"] = nms_leg(device)
         print(json.dumps(rec), flush=True)

@@ -16,7 +16,9 @@
  *   - Every call is asynchronous on the given hipStream_t (passed as void*), never allocates, never
  *     synchronises, keeps no pointer after return.  Scratch comes from the caller (workspace queries).
  *   - Return value: 0 = OK, negative = error (see codes); sgx_last_error() gives a thread-local message.
- *   - Re-entrant: safe from the Python main thread and the autograd engine thread concurrently.
+ *   - Re-entrant: safe from the Python main thread and the autograd engine thread concurrently.  The few process-wide settings
+ *     (sgx_conv_set_math, sgx_conv_tuning_load, sgx_bn_set_fused_finalize, the sgx_debug_* measurement aids) are atomics / lock-protected:
+ *     changing one while another thread is inside a call affects the calls that follow.
  */
 #ifndef SGX_HIP_H
 #define SGX_HIP_H

@@ -80,6 +80,11 @@ def make_model_fixture(variant):
         torch.set_default_dtype(torch.float32)
     loss64.backward()
     fx["grad_norms_f64"] = torch.tensor([float(p.grad.norm()) for n, p in net64.named_parameters() if p.grad is not None], dtype=torch.float64)
+    # 64 seeded elements of every parameter gradient (fp64 truth here, the reference's fp32 values below): an element-wise check of the
+    # product's gradients against the reference that a norm comparison cannot give (a permuted or sign-flipped gradient has the right norm)
+    gs = torch.Generator().manual_seed(7)
+    fx["grad_sample_index"] = {n: torch.randperm(p.numel(), generator=gs)[:64].clone() for n, p in net64.named_parameters() if p.grad is not None}
+    fx["grad_samples_f64"] = {n: p.grad.reshape(-1)[fx["grad_sample_index"][n]].clone() for n, p in net64.named_parameters() if p.grad is not None}
     del net64
     net64_eval.eval()
     with torch.no_grad():
@@ -101,6 +106,7 @@ def make_model_fixture(variant):
                 norms.append(float(p.grad.double().norm()))
                 sums.append(float(p.grad.double().sum()))
             fx["grad_names"], fx["grad_norms"], fx["grad_sums"] = names, torch.tensor(norms, dtype=torch.float64), torch.tensor(sums, dtype=torch.float64)
+            fx["grad_samples"] = {n: p.grad.reshape(-1)[fx["grad_sample_index"][n]].clone() for n, p in net.named_parameters() if p.grad is not None}
     bn = {k: float(v.double().sum()) for k, v in net.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
     fx["bn_running_checksum"] = bn
     # eval-mode forward returns the same 2-tuple (SURVEY 8c edge case)
@@ -248,7 +254,9 @@ def main():
     os.makedirs(G.GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(8)
     only = set(sys.argv[1:])   # e.g. `python oracle/make_golden.py ppyoloe_s` regenerates just that fixture
-    for v in ([] if only else MODEL_CASES):
+    for v in MODEL_CASES:
+        if only and f"yolo_nas_{v}" not in only:
+            continue
         fx = make_model_fixture(v)
         torch.save(fx, os.path.join(G.GOLDEN_DIR, f"yolo_nas_{v}.pt"))
         print(v, "loss items TAL", fx["loss_items_tal"].tolist(), "ATSS", fx["loss_items_atss"].tolist())

@@ -8,6 +8,7 @@
 // fp32, a tiny finalize kernel accumulating them in fp64 in a fixed order (no float atomics).
 // Reference call sites: include/sgx_hip.h (BatchNorm section).
 #include "sgx_common.h"
+#include <atomic>
 
 #define SW_THREADS 256
 #define SW_MAXCG 64  // float4 channel groups per workgroup strip (256 channels)
@@ -140,7 +141,7 @@ struct ColSrc {  // what a finalize kernel sums over: either the fp32 partials o
 #define CO_CH 32
 #define CO_RL 32
 #define CR_COOP_MAX 4096
-static int g_fused_finalize = 1;
+static std::atomic<int> g_fused_finalize{1};
 extern "C" int32_t sgx_bn_set_fused_finalize(int32_t on) {
     g_fused_finalize = on != 0;
     return SGX_OK;

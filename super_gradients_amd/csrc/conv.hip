@@ -20,7 +20,9 @@
 
 #define SGX_MAX_TAPS 64
 #include <array>
+#include <atomic>
 #include <map>
+#include <mutex>
 
 // ------------------------------------------------------------------------------------------------
 // Optional per-launch timing of the two MFMA kernel classes (bench.py's roofline leg): HIP events recorded on the
@@ -789,9 +791,11 @@ struct TileCfg {
     int bm, bn;
 };
 // measurement aid (tools/conv_tune.py): force tile shapes / split target; 0 = heuristic
-static int g_ovr_bm = 0, g_ovr_bn = 0, g_ovr_wk = 0, g_ovr_wj = 0, g_ovr_split = 0, g_ovr_var = 0;
+// (process-wide settings are atomics: a change made while another thread is inside a convolution call applies to the calls that follow -
+// the library stays re-entrant, as include/sgx_hip.h promises)
+static std::atomic<int> g_ovr_bm{0}, g_ovr_bn{0}, g_ovr_wk{0}, g_ovr_wj{0}, g_ovr_split{0}, g_ovr_var{0};
 // arithmetic of the forward / data-gradient GEMMs: 0 = fp32 MFMA (exact fp32 FMA chains), 1 = bf16x3 split (see IG_LDP above)
-static int g_conv_math = 0;
+static std::atomic<int> g_conv_math{0};
 extern "C" int32_t sgx_conv_set_math(int32_t mode) {
     SGX_CHECK_ARG(mode >= 0 && mode <= 2, "conv math mode %d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = per problem)", mode);
     g_conv_math = mode;
@@ -802,7 +806,10 @@ extern "C" int32_t sgx_conv_get_math(void) { return g_conv_math; }
 // is deep enough to be matrix-pipe bound.  Measured on all YOLO-NAS-S problems (profiles/r1y_conv_bench_bf16x3.txt vs r1n): bf16x3
 // wins from a depth (taps x channels) of ~192 (1.2-1.3x on the 3x3 layers), loses 5-30 % on shallow 1x1 layers.
 #define SGX_BF3_MIN_DEPTH 192
-static int conv_math_for(int taps, int C) { return g_conv_math == 2 ? ((long)taps * C >= SGX_BF3_MIN_DEPTH ? 1 : 0) : g_conv_math; }
+static int conv_math_for(int taps, int C) {
+    const int m = g_conv_math.load(std::memory_order_relaxed);
+    return m == 2 ? ((long)taps * C >= SGX_BF3_MIN_DEPTH ? 1 : 0) : m;
+}
 extern "C" int32_t sgx_debug_set_variant(int32_t v) {
     g_ovr_var = v;
     return SGX_OK;
@@ -819,17 +826,34 @@ struct TuneVal {
     int bm, bn, var;
 };
 static std::map<std::array<int, 9>, TuneVal> g_tune;
+static std::mutex g_tune_mu;  // lookups copy the entry out under the lock: a concurrent sgx_conv_tuning_load cannot invalidate it
+static std::atomic<int> g_tune_size{0};
+struct TuneSlot {
+    TuneVal v;
+    bool set;
+};
+static thread_local TuneSlot t_slot = {{0, 0, 0}, false};
 static thread_local const TuneVal* t_tune = nullptr;  // entry of the API call running on this thread
 struct TuneScope {
+    TuneSlot prev_slot;
     const TuneVal* prev;
-    TuneScope(int kind, const sgx_conv_desc* d) : prev(t_tune) {
+    TuneScope(int kind, const sgx_conv_desc* d) : prev_slot(t_slot), prev(t_tune) {
         t_tune = nullptr;
-        if (!g_tune.empty() && d) {
+        t_slot.set = false;
+        if (g_tune_size.load(std::memory_order_acquire) && d) {
+            std::lock_guard<std::mutex> g(g_tune_mu);
             auto it = g_tune.find(std::array<int, 9>{kind, d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->pad});
-            if (it != g_tune.end()) t_tune = &it->second;
+            if (it != g_tune.end()) {
+                t_slot.v = it->second;
+                t_slot.set = true;
+            }
         }
+        if (t_slot.set) t_tune = &t_slot.v;
     }
-    ~TuneScope() { t_tune = prev; }
+    ~TuneScope() {
+        t_slot = prev_slot;
+        t_tune = prev ? &t_slot.v : nullptr;
+    }
 };
 extern "C" int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n) {
     SGX_CHECK_ARG(n >= 0 && (n == 0 || entries), "conv_tuning_load: bad args");
@@ -847,20 +871,27 @@ extern "C" int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n) {
                           "conv_tuning_load: entry %d: no kernel (tile %dx%d, variant %d)", i, e[9], e[10], e[11]);
         m[std::array<int, 9>{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8]}] = TuneVal{e[9], e[10], e[11]};
     }
-    g_tune.swap(m);
+    {
+        std::lock_guard<std::mutex> g(g_tune_mu);
+        g_tune.swap(m);
+        g_tune_size.store((int)g_tune.size(), std::memory_order_release);
+    }
     return SGX_OK;
 }
-extern "C" int32_t sgx_conv_tuning_size(void) { return (int32_t)g_tune.size(); }
+extern "C" int32_t sgx_conv_tuning_size(void) { return g_tune_size.load(std::memory_order_acquire); }
 // the experiment switch wins over the table (measurements must see what they ask for)
-static int conv_variant() { return g_ovr_var ? g_ovr_var : (t_tune ? t_tune->var : 0); }
+static int conv_variant() {
+    const int v = g_ovr_var.load(std::memory_order_relaxed);
+    return v ? v : (t_tune ? t_tune->var : 0);
+}
 
 static TileCfg pick_tile_heuristic(long M, int N);
 static TileCfg pick_tile(long M, int N, int math) {
     TileCfg t = pick_tile_heuristic(M, N);
     if (t_tune && t_tune->bm) t.bm = t_tune->bm;
     if (t_tune && t_tune->bn) t.bn = t_tune->bn;
-    if (g_ovr_bm) t.bm = g_ovr_bm;
-    if (g_ovr_bn) t.bn = g_ovr_bn;
+    if (const int o = g_ovr_bm.load(std::memory_order_relaxed)) t.bm = o;
+    if (const int o = g_ovr_bn.load(std::memory_order_relaxed)) t.bn = o;
     return t;
 }
 static TileCfg pick_tile_heuristic(long M, int N) {
@@ -1500,15 +1531,16 @@ static WgradPlan wgrad_plan(const sgx_conv_desc* d) {
     else if (bnk == 32) bj = J >= 128 ? 128 : wg_tile(J);
     else bj = J >= 64 ? 64 : wg_tile(J);
     if (t_tune && t_tune->bm) bnk = t_tune->bm, bj = t_tune->bn;  // tuning table entry of this problem (kind 2)
-    pl.bnk = g_ovr_wk ? g_ovr_wk : bnk;
-    pl.bj = g_ovr_wj ? g_ovr_wj : bj;
+    const int owk = g_ovr_wk.load(std::memory_order_relaxed), owj = g_ovr_wj.load(std::memory_order_relaxed), osp = g_ovr_split.load(std::memory_order_relaxed);
+    pl.bnk = owk ? owk : bnk;
+    pl.bj = owj ? owj : bj;
     pl.waves = wg_waves(pl.bnk, pl.bj);
     pl.kt_tiles = sgx_cdiv(d->K, pl.bnk);
     pl.jt_tiles = sgx_cdiv(J, pl.bj);
     long M = (long)d->N * d->Ho * d->Wo;
     long tiles = (long)pl.kt_tiles * pl.jt_tiles;
     const int tuned_split = t_tune ? t_tune->var : 0;
-    long target = (g_ovr_split ? g_ovr_split : tuned_split ? tuned_split : (pl.bnk == 64 && pl.bj == 64 ? 8192 : 4096)) / pl.waves;  // 4-8 waves per SIMD over the chip
+    long target = (osp ? osp : tuned_split ? tuned_split : (pl.bnk == 64 && pl.bj == 64 ? 8192 : 4096)) / pl.waves;  // 4-8 waves per SIMD over the chip
     long ks = (target + tiles - 1) / tiles;
     long maxsplit = (M + 255) / 256;         // at least 256 pixels (16 slabs) per split
     if (ks > maxsplit) ks = maxsplit;

@@ -97,7 +97,7 @@ def _train_step_parity(variant, B, size, device, tol, static=False):
     bar("reg_distri", ds, ds_r, ds_t)
     bar("pred_bboxes", bx, bx_r, bx_t)
     bar("pred_scores", sc, sc_r, sc_t)
-    assert_close(items.cpu(), items_ref, 2 * tol, "loss items")
+    assert_close(items.cpu(), items_ref, tol, "loss items")
     ref_bufs = dict(ref.named_buffers())
     for name, b in net.named_buffers():
         if name.endswith("num_batches_tracked"):
