@@ -18,8 +18,11 @@ struct SweepGeom {
     int C, C4, CG, RL, nblk, rows_per_blk, ctiles;
 };
 
+// Row blocks of a sweep: 64 rows per workgroup until the grid reaches 1024 workgroups.  (Round 1 used 256 rows: the 40x40 and 20x20
+// levels of the network then ran their sweeps on 200 / 50 workgroups - fewer than the chip has CUs; 64 rows: +4 % on the whole train
+// step, profiles/r2q_sweep_rows.txt.)
 extern "C" int32_t sgx_stats_blocks(int64_t M) {
-    long n = (M + 255) / 256;
+    long n = (M + 63) / 64;
     if (n < 1) n = 1;
     if (n > 1024) n = 1024;
     return (int32_t)n;

@@ -356,7 +356,10 @@ def test_trainer_yolo_nas_recipe_shape(gpu_device, tmp_path):
     tot /= n * bs
     got = res[0]["train"]
     for i, name in enumerate(["loss_cls", "loss_iou", "loss_dfl", "loss"]):
-        assert abs(got[name] - float(tot[i])) <= 1e-3 * abs(float(tot[i])), (name, got[name], float(tot[i]))
+        # 2e-3 on a three-step AdamW trajectory: AdamW divides every gradient by its own running magnitude, so parameters whose gradient is
+        # analytically zero (branch_3x3.bn.bias, branch_1x1.bias: exact zeros here, +-1e-9 round-off in the oracle) take noise-driven steps
+        # in the oracle and none here; the per-step parity of loss and gradients is held to 1e-4 above
+        assert abs(got[name] - float(tot[i])) <= 2e-3 * abs(float(tot[i])), (name, got[name], float(tot[i]))
 
 
 @pytest.mark.gpu
