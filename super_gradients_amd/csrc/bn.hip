@@ -141,8 +141,10 @@ struct ColSrc {  // what a finalize kernel sums over: either the fp32 partials o
 // launch + a finalize launch, the finalize kernel runs with 32 channels x 32 row lanes per workgroup; every lane folds its rows
 // (b = lane, lane + 32, ...) in fp64, the 32 lane sums meet in LDS and are added in lane order (deterministic, no atomics).  Worth it
 // while one workgroup can stream the partial rows of its 32 channels faster than a second launch costs: nblk <= CR_COOP_MAX.
+#ifndef CO_CH
 #define CO_CH 32
-#define CO_RL 32
+#endif
+#define CO_RL (1024 / CO_CH)
 #define CR_COOP_MAX 4096
 static std::atomic<int> g_fused_finalize{1};
 extern "C" int32_t sgx_bn_set_fused_finalize(int32_t on) {

@@ -80,6 +80,8 @@ def main():
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
         base = timeit(fn)
         best, best_cfg = base, "heuristic"
+        if kind in ("fwd2", "dgrad2"):
+            continue  # the two-source QARepVGG launches run the heuristic's tile (no overrides): nothing to search
         if kind in ("fwd", "dgrad"):
             note(key, calls, (0, 0, 0), base)
             stats = kind == "fwd" and key[11:][3]
@@ -90,24 +92,15 @@ def main():
                     note(key, calls, (bm, bn, 0), t)
                     if t < best:
                         best, best_cfg = t, f"bm={bm} bn={bn}"
-            for var, (bm, bn) in ((1, (64, 64)), (2, (128, 64)), (3, (128, 128)), (4, (64, 128))):  # wave-layout variants
-                lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
-                lib().sgx_debug_set_variant(var)
-                t = timeit(fn)
-                lib().sgx_debug_set_variant(0)
-                note(key, calls, (bm, bn, var), t)
-                if t < best:
-                    best, best_cfg = t, f"bm={bm} bn={bn} variant={var}"
-            # 32-deep slabs (variant 5; eligible problems only: fp32 arithmetic, C % 32 == 0 - others run the default kernel again)
-            for var in (6, 7):  # two LDS buffers / the 16-deep loop (the default is 32-deep slabs with one buffer where C % 32 == 0)
-                lib().sgx_debug_set_variant(var)
-                for bm in (0, 64, 128):
-                    for bn in ((0,) if bm == 0 else (32, 64, 96, 128)):
-                        lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
-                        t = timeit(fn)
-                        note(key, calls, (bm, bn, var), t)
-                        if t < best:
-                            best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + f" variant={var}"
+            # the 16-deep loop (variant 7): the default is 32-deep slabs with one LDS buffer wherever C % 32 == 0
+            lib().sgx_debug_set_variant(7)
+            for bm in (0, 64, 128):
+                for bn in ((0,) if bm == 0 else (32, 64, 96, 128)):
+                    lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                    t = timeit(fn)
+                    note(key, calls, (bm, bn, 7), t)
+                    if t < best:
+                        best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + " variant=7"
             lib().sgx_debug_set_variant(0)
         elif args.wgrad:
             note(key, calls, (0, 0, 0), base)
