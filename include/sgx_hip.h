@@ -414,11 +414,15 @@ int32_t sgx_detection_match(const sgx_match_desc* d, const float* preds, const i
                             const int32_t* crowd_index, const float* thresholds, uint8_t* matched, uint8_t* ignore, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Classification loss (training/losses/label_smoothing_cross_entropy_loss.py:86-111, mean reduction).
+ * Classification loss (training/losses/label_smoothing_cross_entropy_loss.py:32-111).
  * ------------------------------------------------------------------------------------------- */
-/* loss: B+1 floats (loss[0] = mean loss, loss[1..B] = per-row losses); dlogits = d loss[0] / d logits.   */
-int32_t sgx_softmax_ce_fwd_bwd(int32_t B, int32_t K, const float* logits, const int64_t* labels, float smoothing,
-                               float* loss, float* dlogits, void* stream);
+/* F.cross_entropy semantics (per-class weight, ignore_index, "mean" = sum w[y] * nll / sum w[y] over the rows that are not ignored) and,
+ * with smoothing > 0, the reference's smoothed form (cross_entropy :32-83: weight multiplies the log-softmax, ignored rows - ignore_index
+ * >= 0 - contribute 0, "mean" divides by the number of rows that are not ignored).  weight may be NULL; reduction_sum = 1 skips the division.
+ * loss: 2*B + 2 floats; loss[0] = the loss, loss[1] = 1 / denominator.  dlogits = d(numerator) / d logits: multiply by loss[1] and the
+ * upstream gradient (sgx_scale_by_device_scalar).                                                                                   */
+int32_t sgx_softmax_ce_fwd_bwd(int32_t B, int32_t K, const float* logits, const int64_t* labels, float smoothing, const float* weight,
+                               int32_t ignore_index, int32_t reduction_sum, float* loss, float* dlogits, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer / EMA over flat fp32 arenas (one launch per arena instead of ~500 tiny ATen kernels):

@@ -711,56 +711,88 @@ extern "C" int32_t sgx_ppyoloe_loss_finalize(const float* sums, float w_cls, flo
 }
 
 // ---------------------------------------------------------------------------------------------
-// softmax cross-entropy (mean) with optional label smoothing: fwd + bwd in one pass; one wave per row.
-// training/losses/label_smoothing_cross_entropy_loss.py:86-111 (nn.CrossEntropyLoss semantics)
+// softmax cross-entropy: fwd + bwd in one pass, one wave per row.  training/losses/label_smoothing_cross_entropy_loss.py:32-83:
+//   smoothing == 0 : F.cross_entropy(logits, labels, weight, ignore_index, reduction)
+//                    loss = sum_i w[y_i] * (lse_i - x_i[y_i]) / sum_i w[y_i]   over the rows whose label is not ignore_index ("mean")
+//   smoothing  > 0 : lw = weight * log_softmax;  loss_i = -((1 - eps) * lw_i[y_i] + eps * mean_j lw_i[j]);  rows with label == ignore_index
+//                    (>= 0) contribute 0;  loss = sum_i loss_i / (B - masked rows)   ("mean": NOT weight-normalised, as in the reference)
+//   reduction "sum": the same sums without the division.
+// dlogits is written WITHOUT the 1 / denominator factor; it comes out as loss[1] (the backward multiplies it in with the upstream gradient).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void softmax_ce_kernel(int B, int K, const float* logits, const int64_t* labels, float smoothing, float* row_loss,
-                                                        float* dlogits) {
+__global__ __launch_bounds__(64) void softmax_ce_kernel(int B, int K, const float* logits, const int64_t* labels, float smoothing, const float* weight,
+                                                        int ignore_index, float* row_loss, float* row_den, float* dlogits) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const float* x = logits + (long)b * K;
+    const int y = (int)labels[b];
+    const bool ignored = y == ignore_index && (smoothing == 0.f || ignore_index >= 0);
+    if (ignored || y < 0 || y >= K) {  // (an out-of-range label that is not the ignore index is a caller error: treated as ignored)
+        if (lane == 0) {
+            row_loss[b] = 0.f;
+            row_den[b] = 0.f;
+        }
+        for (int j = lane; j < K; j += 64) dlogits[(long)b * K + j] = 0.f;
+        return;
+    }
     float m = -INFINITY;
     for (int j = lane; j < K; j += 64) m = fmaxf(m, x[j]);
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    float s = 0.f, sx = 0.f;
+    float s = 0.f, swx = 0.f, sw = 0.f;  // sum exp, sum_j w_j * x_j, sum_j w_j
     for (int j = lane; j < K; j += 64) {
+        const float wj = weight ? weight[j] : 1.f;
         s += expf(x[j] - m);
-        sx += x[j];
+        swx += wj * x[j];
+        sw += wj;
     }
     for (int off = 32; off > 0; off >>= 1) {
         s += __shfl_xor(s, off);
-        sx += __shfl_xor(sx, off);
+        swx += __shfl_xor(swx, off);
+        sw += __shfl_xor(sw, off);
     }
     const float lse = logf(s) + m;
-    const int y = (int)labels[b];
-    // loss = (1-eps) * (lse - x_y) + eps/K * sum_j (lse - x_j)
-    if (lane == 0) row_loss[b] = (1.f - smoothing) * (lse - x[y]) + smoothing / (float)K * ((float)K * lse - sx);
-    const float invB = 1.f / (float)B;
+    const float wy = weight ? weight[y] : 1.f;
+    // -lw[y] = wy * (lse - x_y);   -mean_j lw[j] = (sw * lse - swx) / K
+    if (lane == 0) {
+        row_loss[b] = (1.f - smoothing) * wy * (lse - x[y]) + smoothing / (float)K * (sw * lse - swx);
+        row_den[b] = smoothing == 0.f ? wy : 1.f;
+    }
+    const float pk = (1.f - smoothing) * wy + smoothing / (float)K * sw;  // coefficient of the softmax probability
     for (int j = lane; j < K; j += 64) {
-        float p = expf(x[j] - m) / s;
-        float t = (j == y ? 1.f - smoothing : 0.f) + smoothing / (float)K;
-        dlogits[(long)b * K + j] = (p - t) * invB;
+        const float p = expf(x[j] - m) / s, wj = weight ? weight[j] : 1.f;
+        dlogits[(long)b * K + j] = p * pk - ((j == y ? (1.f - smoothing) * wy : 0.f) + smoothing / (float)K * wj);
     }
 }
-// loss[0] = mean of the B row losses (fp64 fold, fixed order)
-__global__ __launch_bounds__(256) void mean_rows_kernel(const float* rows, int n, float* out) {
-    __shared__ double red[256];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += (double)rows[i];
-    red[threadIdx.x] = s;
+// loss[0] = sum of the row losses / denominator, loss[1] = 1 / denominator (fp64 folds, fixed order); denominator = sum of row_den, or 1 for "sum"
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* row_loss, const float* row_den, int n, int reduction_sum, float* out) {
+    __shared__ double red[2][256];
+    double s = 0.0, d = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        s += (double)row_loss[i];
+        d += (double)row_den[i];
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = d;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = (float)(red[0] / (double)n);
+    if (threadIdx.x == 0) {
+        const double den = reduction_sum ? 1.0 : red[1][0];
+        out[0] = (float)(red[0][0] / den);  // every row ignored: 0 / 0 = nan, like torch
+        out[1] = (float)(1.0 / den);
+    }
 }
-extern "C" int32_t sgx_softmax_ce_fwd_bwd(int32_t B, int32_t K, const float* logits, const int64_t* labels, float smoothing, float* loss,
-                                          float* dlogits, void* stream) {
+// loss: 2 * B + 2 floats of scratch; loss[0] = the loss, loss[1] = 1 / denominator (multiply dlogits by it and by the upstream gradient)
+extern "C" int32_t sgx_softmax_ce_fwd_bwd(int32_t B, int32_t K, const float* logits, const int64_t* labels, float smoothing, const float* weight,
+                                          int32_t ignore_index, int32_t reduction_sum, float* loss, float* dlogits, void* stream) {
     SGX_CHECK_ARG(logits && labels && loss && dlogits && B > 0 && K > 0, "softmax_ce: bad args");
-    // row losses go to the head of dlogits' companion scratch: we use loss[1..B] (caller allocates B+1 floats)
-    SGX_LAUNCH(softmax_ce_kernel, dim3(B), dim3(64), 0, stream, B, K, logits, labels, smoothing, loss + 1, dlogits);
+    SGX_CHECK_ARG(smoothing >= 0.f && smoothing <= 1.f, "softmax_ce: smoothing must be in [0, 1]");
+    SGX_LAUNCH(softmax_ce_kernel, dim3(B), dim3(64), 0, stream, B, K, logits, labels, smoothing, weight, ignore_index, loss + 2, loss + 2 + B, dlogits);
     SGX_CHECK_LAUNCH("softmax_ce");
-    SGX_LAUNCH(mean_rows_kernel, dim3(1), dim3(256), 0, stream, (const float*)(loss + 1), B, loss);
-    SGX_CHECK_LAUNCH("softmax_ce mean");
+    SGX_LAUNCH(ce_reduce_kernel, dim3(1), dim3(256), 0, stream, (const float*)(loss + 2), (const float*)(loss + 2 + B), B, reduction_sum, loss);
+    SGX_CHECK_LAUNCH("softmax_ce reduce");
     return SGX_OK;
 }

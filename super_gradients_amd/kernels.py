@@ -727,13 +727,16 @@ def detection_match(rows, counts, targets, crowd_targets, thresholds, height, wi
     return matched, ignore
 
 
-def softmax_ce(logits, labels, smoothing=0.0):
+def softmax_ce(logits, labels, smoothing=0.0, weight=None, ignore_index=-100, reduction="mean"):
+    """-> (loss scalar, dlogits without the 1 / denominator factor, the device scalar 1 / denominator)."""
     B, K = logits.shape
-    loss = torch.empty(B + 1, device=logits.device, dtype=torch.float32)
+    loss = torch.empty(2 * B + 2, device=logits.device, dtype=torch.float32)
     dlogits = torch.empty(B, K, device=logits.device, dtype=torch.float32)
     logits, labels = logits.contiguous(), labels.contiguous().long()  # bound to names: alive until the launch is enqueued
-    check(lib().sgx_softmax_ce_fwd_bwd(B, K, ptr(logits), ptr(labels), float(smoothing), ptr(loss), ptr(dlogits), stream()), "sgx_softmax_ce_fwd_bwd")
-    return loss[0], dlogits
+    weight = weight.contiguous().float() if weight is not None else None
+    check(lib().sgx_softmax_ce_fwd_bwd(B, K, ptr(logits), ptr(labels), float(smoothing), ptr(weight), int(ignore_index), int(reduction == "sum"), ptr(loss),
+                                       ptr(dlogits), stream()), "sgx_softmax_ce_fwd_bwd")
+    return loss[0], dlogits, loss[1:2]
 
 
 # --------------------------------------------------------------------------------------------- optimizer

@@ -295,16 +295,60 @@ def test_avgpool(backend):
     assert_close(to_nchw_cpu(K.avgpool_bwd(dy.to(backend), tuple(xd.shape))), x.grad, TOL, "avgpool bwd")
 
 
+def _reference_cross_entropy(inputs, target, weight, ignore_index, reduction, smooth_eps):
+    """training/losses/label_smoothing_cross_entropy_loss.py:32-83, integer targets on logits (restated; checked live against the reference's
+    own function by test_cross_entropy_restatement_live where /root/reference exists)."""
+    if not smooth_eps:
+        return F.cross_entropy(inputs, target, weight, ignore_index=ignore_index, reduction=reduction)
+    lsm = F.log_softmax(inputs, dim=-1)
+    masked = target.eq(ignore_index) if ignore_index >= 0 else None
+    if weight is not None:
+        lsm = lsm * weight.unsqueeze(0)
+    likelihood = lsm.gather(dim=-1, index=target.unsqueeze(-1)).squeeze(-1)
+    loss = -((1.0 - smooth_eps) * likelihood + smooth_eps * lsm.mean(-1))
+    if masked is not None:
+        loss = loss.masked_fill(masked, 0)
+    if reduction == "sum":
+        return loss.sum()
+    return loss.mean() if masked is None else loss.sum() / float(loss.size(0) - masked.sum())
+
+
+@pytest.mark.skipif(not __import__("oracle.ref_shim", fromlist=["x"]).available(), reason="/root/reference not present (GPU box)")
+def test_cross_entropy_restatement_live():
+    from oracle import ref_shim
+
+    ref_shim.install()
+    from super_gradients.training.losses.label_smoothing_cross_entropy_loss import cross_entropy
+
+    g = torch.Generator().manual_seed(0)
+    x, y, w = torch.randn(12, 7, generator=g) * 2, torch.randint(0, 7, (12,), generator=g), torch.rand(7, generator=g) + 0.5
+    for eps in (0.0, 0.1):
+        for weight in (None, w):
+            for ig in (-100, 3):
+                for red in ("mean", "sum"):
+                    assert torch.equal(cross_entropy(x, y, weight=weight, ignore_index=ig, reduction=red, smooth_eps=eps),
+                                       _reference_cross_entropy(x, y, weight, ig, red, eps))
+
+
 def test_softmax_ce(backend):
-    B, Kc = _sizes(backend, (64, 1000), (5, 10))
+    B, Kc = _sizes(backend, (64, 1000), (6, 10))
+    g = torch.Generator().manual_seed(1)
+    w = torch.rand(Kc, generator=g) + 0.5
     for smoothing in (0.0, 0.1):
-        logits = (torch.randn(B, Kc) * 3).requires_grad_(True)
-        labels = torch.randint(0, Kc, (B,))
-        loss = F.cross_entropy(logits, labels, label_smoothing=smoothing)
-        loss.backward()
-        l, dl = K.softmax_ce(logits.detach().to(backend), labels.to(backend), smoothing)
-        assert_close(l.cpu().view(1), loss.detach().view(1), TOL, "ce")
-        assert_close(dl.cpu(), logits.grad, TOL, "ce grad")
+        for weight in (None, w):
+            for ig in (-100, 2):
+                for red in ("mean", "sum"):
+                    logits = (torch.randn(B, Kc, generator=g) * 3).requires_grad_(True)
+                    labels = torch.randint(0, Kc, (B,), generator=g)
+                    labels[1] = 2  # one row that ignore_index = 2 masks
+                    if smoothing == 0.0 and ig == -100:
+                        labels[3] = -100  # F.cross_entropy's default ignore index
+                    loss = _reference_cross_entropy(logits, labels, weight, ig, red, smoothing)
+                    loss.backward()
+                    l, dl, inv = K.softmax_ce(logits.detach().to(backend), labels.to(backend), smoothing, weight.to(backend) if weight is not None else None, ig, red)
+                    what = f"eps {smoothing} weight {weight is not None} ignore {ig} {red}"
+                    assert_close(l.cpu().view(1), loss.detach().view(1), TOL, "ce " + what)
+                    assert_close((dl * inv).cpu(), logits.grad, TOL, "ce grad " + what)
 
 
 def test_optimizers(backend):
