@@ -181,6 +181,13 @@ int32_t sgx_nhwc_to_nchw(int32_t N, int32_t C, int32_t H, int32_t W, const float
 int32_t sgx_standardize_u8_hwc(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cpad, const uint8_t* x, float max_value,
                                const float* mean, const float* std, float* y, void* stream);
 
+/* The same for ragged batches: ONE image [h,w,C] uint8 into its slot y [H,W,Cpad] of the padded batch at offset (top, left), the standardized
+ * pad_value[C] (uint8 scale, e.g. 114) everywhere else - DetectionPadIfNeeded / DetectionPadToSize (transforms.py:846-941; "center" or
+ * "bottom_right" offsets, transforms/utils.py:79-106) + DetectionStandardize + the collate on the device, one launch per image.            */
+int32_t sgx_pad_standardize_u8_hwc(int32_t h, int32_t w, int32_t C, const uint8_t* x, int32_t H, int32_t W, int32_t Cpad, int32_t top,
+                                   int32_t left, float max_value, const float* mean, const float* std, const float* pad_value, float* y,
+                                   void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm (training mode) and the fused elementwise stages around it.
  * Replaces F.batch_norm + ReLU/SiLU + the branch adds at

@@ -102,6 +102,7 @@ PROTOTYPES = {
     "sgx_nchw_to_nhwc": (_i32, [_i32] * 5 + [_P, _P, _P]),
     "sgx_nhwc_to_nchw": (_i32, [_i32] * 4 + [_P, _i64, _i64, _P, _P]),
     "sgx_standardize_u8_hwc": (_i32, [_i32] * 5 + [_P, _f, _P, _P, _P, _P]),
+    "sgx_pad_standardize_u8_hwc": (_i32, [_i32, _i32, _i32, _P, _i32, _i32, _i32, _i32, _i32, _f, _P, _P, _P, _P, _P]),
     "sgx_stats_blocks": (_i32, [_i64]),
     "sgx_channel_stats_partial": (_i32, [_P, _i64, _i32, _i64, _P, _P]),
     "sgx_reduce_workspace": (_i64, [_i32, _i32]),

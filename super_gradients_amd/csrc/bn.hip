@@ -998,3 +998,44 @@ extern "C" int32_t sgx_standardize_u8_hwc(int32_t N, int32_t H, int32_t W, int32
     SGX_CHECK_LAUNCH("standardize_u8");
     return SGX_OK;
 }
+
+// One ragged image into its slot of the padded batch: dst pixel (yy, xx) = standardized src pixel (yy - top, xx - left) inside the image,
+// the standardized pad value outside (DetectionPadIfNeeded / DetectionPadToSize on the device: transforms.py:846-941 with the padding
+// coordinates of transforms/utils.py:79-106, followed by DetectionStandardize :490-510).  Same arithmetic as standardize_u8_kernel.
+__global__ void pad_standardize_u8_kernel(int h, int w, int C, const uint8_t* x, int H, int W, int Cpad, int top, int left, float max_value,
+                                          const float* mean, const float* stdv, const float* pad_value, float* y) {
+    const long npix = (long)H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        const int yy = (int)(i / W), xx = (int)(i - (long)yy * W);
+        const int sy = yy - top, sx = xx - left;
+        const bool inside = sy >= 0 && sy < h && sx >= 0 && sx < w;
+        const uint8_t* px = x + ((long)(inside ? sy : 0) * w + (inside ? sx : 0)) * C;
+        float* py = y + i * Cpad;
+        for (int c0 = 0; c0 < Cpad; c0 += 4) {
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = c0 + t;
+                float f = 0.f;
+                if (c < C) {
+                    f = (inside ? (float)px[c] : pad_value[c]) / max_value;
+                    if (mean) f = (f - mean[c]) / stdv[c];
+                }
+                v[t] = f;
+            }
+            sgx_st4(py + c0, make_float4(v[0], v[1], v[2], v[3]));
+        }
+    }
+}
+extern "C" int32_t sgx_pad_standardize_u8_hwc(int32_t h, int32_t w, int32_t C, const uint8_t* x, int32_t H, int32_t W, int32_t Cpad, int32_t top,
+                                              int32_t left, float max_value, const float* mean, const float* stdv, const float* pad_value, float* y,
+                                              void* stream) {
+    SGX_CHECK_ARG(x && y && pad_value && h > 0 && w > 0 && C > 0 && Cpad >= C && Cpad % 4 == 0, "pad_standardize_u8: bad args (C=%d Cpad=%d)", C, Cpad);
+    SGX_CHECK_ARG(top >= 0 && left >= 0 && top + h <= H && left + w <= W, "pad_standardize_u8: the %dx%d image at (%d, %d) does not fit %dx%d", h, w, top, left, H, W);
+    SGX_CHECK_ARG(max_value > 0.f && ((mean == nullptr) == (stdv == nullptr)), "pad_standardize_u8: max_value > 0, mean and std go together");
+    const long npix = (long)H * W, blocks = (npix + 255) / 256;
+    SGX_LAUNCH(pad_standardize_u8_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, stream, h, w, C, x, H, W, Cpad, top, left,
+               max_value, mean, stdv, pad_value, y);
+    SGX_CHECK_LAUNCH("pad_standardize_u8");
+    return SGX_OK;
+}

@@ -329,6 +329,17 @@ def standardize_u8(x_u8, max_value=255.0, mean=None, std=None, cpad=None):
     return y
 
 
+def pad_standardize_u8(img_u8, out_slot, top, left, pad_value, max_value=255.0, mean=None, std=None):
+    """One uint8 [h,w,C] image into `out_slot` (a [H,W,Cpad] fp32 view of the padded batch) at (top, left); pad_value: fp32 [C] on the uint8 scale."""
+    h, w, c = img_u8.shape
+    H, W, cpad = out_slot.shape
+    if img_u8.dtype != torch.uint8 or not out_slot.is_contiguous():
+        raise _lib.SgxError("pad_standardize_u8 needs a uint8 HWC image and a contiguous [H,W,Cpad] slot")
+    img_u8 = img_u8.contiguous()
+    check(lib().sgx_pad_standardize_u8_hwc(h, w, c, ptr(img_u8), H, W, cpad, int(top), int(left), float(max_value), ptr(mean), ptr(std), ptr(pad_value),
+                                           ptr(out_slot), stream()), "sgx_pad_standardize_u8_hwc")
+
+
 def nhwc_as_nchw_view(y, channels):
     """Logical NCHW [N,C,H,W] view of an NHWC buffer (what model(x) receives from DeviceDetectionCollateFN): no copy."""
     return y.permute(0, 3, 1, 2)[:, :channels]

@@ -47,7 +47,12 @@ class DeviceDetectionCollateFN(DetectionCollateFN):
     """Items: (uint8 HWC image, targets [Ni,5]).  max_value / mean / std: the standardisation the reference recipe applies on the host
     (YOLO-NAS: DetectionStandardize(max_value=255); ImageNet-style models: / 255 then (x - mean) / std)."""
 
-    def __init__(self, device="cuda", max_value: float = 255.0, mean=None, std=None):
+    def __init__(self, device="cuda", max_value: float = 255.0, mean=None, std=None, pad_to=None, pad_value=114, padding_mode: str = "bottom_right",
+                 targets_format: str = "LABEL_CXCYWH"):
+        """pad_to=(H, W): images of DIFFERENT sizes (each <= H x W) are padded on the device into one [N, C, H, W] batch - the reference's
+        DetectionPadIfNeeded / DetectionPadToSize (transforms.py:846-941; padding_mode "center" or "bottom_right", pad_value as there) moved
+        behind the PCIe transfer, one launch per image; boxes are shifted by the padding offsets like the transform does
+        (transforms/utils.py:155-166).  targets_format: "LABEL_CXCYWH" (class, cx, cy, w, h - what the loss consumes) or "XYXY_LABEL"."""
         super().__init__()
         self.device = torch.device(device)
         self.max_value = float(max_value)
@@ -55,12 +60,53 @@ class DeviceDetectionCollateFN(DetectionCollateFN):
             raise ValueError("mean and std go together")
         self._mean = None if mean is None else torch.as_tensor(mean, dtype=torch.float32)
         self._std = None if std is None else torch.as_tensor(std, dtype=torch.float32)
+        if padding_mode not in ("center", "bottom_right"):
+            raise ValueError(f"padding_mode {padding_mode!r}: 'center' or 'bottom_right'")
+        if targets_format not in ("LABEL_CXCYWH", "XYXY_LABEL"):
+            raise ValueError(f"targets_format {targets_format!r}: 'LABEL_CXCYWH' or 'XYXY_LABEL'")
+        self.pad_to = None if pad_to is None else (int(pad_to[0]), int(pad_to[1])) if not isinstance(pad_to, int) else (pad_to, pad_to)
+        self.pad_value, self.padding_mode, self.targets_format = pad_value, padding_mode, targets_format
+
+    def _padded(self, images_batch, labels_batch):
+        H, W = self.pad_to
+        c = int(images_batch[0].shape[2])
+        cp = (c + 3) // 4 * 4
+        pv = torch.as_tensor([float(self.pad_value)] * c if not hasattr(self.pad_value, "__len__") else [float(v) for v in self.pad_value],
+                             dtype=torch.float32)
+        if pv.numel() != c:
+            raise ValueError(f"A pad_value tuple ({self.pad_value} length should be {c} for an image with {c} channels")
+        pv = pv.to(self.device)
+        mean = None if self._mean is None else self._mean.to(self.device)
+        std = None if self._std is None else self._std.to(self.device)
+        batch = torch.empty(len(images_batch), H, W, cp, device=self.device, dtype=torch.float32)
+        shifted = []
+        for i, (img, labels) in enumerate(zip(images_batch, labels_batch)):
+            img = torch.as_tensor(img)
+            if img.dtype != torch.uint8 or img.dim() != 3:
+                raise ValueError(f"DeviceDetectionCollateFN expects uint8 HWC images, got {img.dtype} {tuple(img.shape)}")
+            h, w = int(img.shape[0]), int(img.shape[1])
+            if h > H or w > W:
+                raise ValueError(f"image {i} is {h}x{w}: larger than pad_to={self.pad_to} (rescale before padding, as the reference's transform chain does)")
+            top, left = ((H - h) // 2, (W - w) // 2) if self.padding_mode == "center" else (0, 0)
+            K.pad_standardize_u8(img.to(self.device, non_blocking=True), batch[i], top, left, pv, self.max_value, mean, std)
+            t = torch.as_tensor(labels).clone().float()
+            if t.numel():
+                if self.targets_format == "LABEL_CXCYWH":
+                    t[:, 1] += left
+                    t[:, 2] += top
+                else:
+                    t[:, [0, 2]] += left
+                    t[:, [1, 3]] += top
+            shifted.append(t)
+        return K.nhwc_as_nchw_view(batch, c), self._format_targets(shifted).float().to(self.device, non_blocking=True)
 
     def __call__(self, data) -> Tuple[torch.Tensor, torch.Tensor]:
         try:
             images_batch, labels_batch = list(zip(*data))
         except (ValueError, TypeError):
             raise ValueError(f"DeviceDetectionCollateFN expects items {self.expected_item_names}, got {type(data[0])}")
+        if self.pad_to is not None:
+            return self._padded(images_batch, labels_batch)
         stack = torch.stack([torch.as_tensor(img) for img in images_batch], 0)
         if stack.dtype != torch.uint8 or stack.dim() != 4:
             raise ValueError(f"DeviceDetectionCollateFN expects uint8 HWC images (the dataset's native form), got {stack.dtype} {tuple(stack.shape)}")

@@ -694,6 +694,36 @@ def test_standardize_u8_and_device_collate(backend):
     assert torch.equal(plain.cpu(), nhwc.cpu()) or rel_err(plain.cpu(), nhwc.cpu()) < 1e-6
 
 
+def test_device_collate_pads_ragged_images(backend):
+    """SURVEY 8f-4, device-side pad + collate: images of different sizes -> one padded, standardized batch; against the reference's host chain
+    (DetectionPadIfNeeded with center / bottom-right padding coordinates, transforms/utils.py:79-133,155-166, then DetectionStandardize and
+    the collate) restated with numpy - bit-identical pixels, shifted boxes."""
+    from super_gradients_amd.training.utils.collate_fn import DetectionCollateFN, DeviceDetectionCollateFN
+
+    H, W = _sizes(backend, (96, 128), (9, 12))
+    rs = np.random.RandomState(3)
+    sizes = [(H, W), (H - 3, W - 5), (H // 2, W // 3), (1, 1)]
+    items = [(rs.randint(0, 256, (h, w, 3)).astype(np.uint8), np.concatenate([rs.randint(0, 5, (i + 1, 1)), rs.rand(i + 1, 4) * min(h, w)], 1).astype(np.float32))
+             for i, (h, w) in enumerate(sizes)]
+    for mode in ("center", "bottom_right"):
+        x_dev, t_dev = DeviceDetectionCollateFN(device=backend, pad_to=(H, W), pad_value=114, padding_mode=mode)(items)
+        host = []
+        for img, t in items:
+            h, w = img.shape[:2]
+            ph, pw = H - h, W - w
+            top, left = (ph // 2, pw // 2) if mode == "center" else (0, 0)
+            padded = np.pad(img, ((top, ph - top), (left, pw - left), (0, 0)), mode="constant", constant_values=114)
+            t = t.copy()
+            t[:, 1] += left
+            t[:, 2] += top
+            host.append(((padded / 255.0).astype(np.float32), t))
+        x_ref, t_ref = DetectionCollateFN()(host)
+        assert torch.equal(x_dev.cpu(), x_ref), f"{mode}: padded pixels"
+        assert torch.equal(t_dev.cpu(), t_ref.float()), f"{mode}: shifted targets"
+    with pytest.raises(ValueError, match="larger than pad_to"):
+        DeviceDetectionCollateFN(device=backend, pad_to=(H - 1, W))(items)
+
+
 def test_wtrans_batch_equals_per_conv_transposes(backend):
     """sgx_conv2d_transpose_jobs + ONE sgx_wtrans_batch launch == the per-convolution sgx_conv2d_transpose_weights launches (bit-exact),
     over 1x1 / 3x3 / stride-2 / 7x7-stride-2 filters (1, 1, 4 and 4 output-parity classes)."""
