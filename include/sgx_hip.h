@@ -129,14 +129,16 @@ int32_t sgx_wtrans_batch(const sgx_wtrans_job* jobs_dev, int32_t njobs, void* st
  * y, y^2, u0, u0^2, y*u0 with u0 = u - bias1 (every moment both BatchNorms of the block need; sgx_qarep_fwd_finalize adds the bias terms in
  * fp64).  u has y's strides.  Needs C >= 16.
  * Backward: dx = convT RxS(dy, wt) + convT 1x1(ds, w1t) [+ addend] [+ dx]; wt as sgx_conv2d_transpose_weights writes it, w1t = w1 transposed
- * [C][K]; ds has its own strides.  Needs K >= 16.
+ * [C][K]; ds has its own strides.  Needs K >= 16.  addend2 (optional, stride-1 blocks): dx += a2_scale * a2_scale_dev[0] * addend2 with its own
+ * strides - the residual branch of a YOLO-NAS bottleneck (yolo_stages.py:61-63: d(alpha * x) = alpha * dz) folded into the launch.
  * sgx_qarep_prep_batch: per optimizer step, for every block at once: w1p = alpha * w1 + I (identity branch and alpha folded into the 1x1
  * filter) and its transpose w1pt.                                                                                                          */
 int32_t sgx_conv2d_fwd_dual_stat_blocks(const sgx_conv_desc* d);
 int32_t sgx_conv2d_fwd_dual(const sgx_conv_desc* d, const float* x, const float* w, const float* w1, const float* bias1, float* y, float* u,
                             float* stat5, void* stream);
 int32_t sgx_conv2d_bwd_data_dual(const sgx_conv_desc* d, const float* dy, const float* wt, const float* ds, int64_t ds_ld_pix, int64_t ds_ld_img,
-                                 const float* w1t, const float* addend, float* dx, int32_t accumulate, void* stream);
+                                 const float* w1t, const float* addend, const float* addend2, int64_t a2_ld_pix, int64_t a2_ld_img, float a2_scale,
+                                 const float* a2_scale_dev, float* dx, int32_t accumulate, void* stream);
 typedef struct sgx_qarep_prep_job {
     const float* w1;    /* [K][C] the block's 1x1 filter (OHWI, C padded)   */
     float* w1p;         /* [K][C] alpha * w1 + identity                      */
@@ -282,10 +284,11 @@ int32_t sgx_relu_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_l
                      void* stream);
 /* RepVGGBlock training forward (modules/repvgg_block.py:98-107: act(bn3(conv3x3 x) + bn1(conv1x1 x))) and the post-activation
  * residuals around it (csp_resnet.py:43-49 `x + y`, pp_yolo_head.py:205 `stem_cls(feat) + feat`) as ONE sweep:
- *   y = act(s1[c]*x1 + t1[c] [+ s2[c]*x2 + t2[c]]) [+ r]        x2 / r may be NULL.                                          */
+ *   y = act(s1[c]*x1 + t1[c] [+ s2[c]*x2 + t2[c]]) [+ r_scale * r_scale_dev[0] * r]        x2 / r / r_scale_dev may be NULL.
+ * The scaled form is the YOLO-NAS bottleneck's `alpha * x + cv2(cv1(x))` (yolo_stages.py:61-63) written by cv2's own sweep.            */
 int32_t sgx_dual_affine_act_fwd(const float* x1, int64_t x1_ld, const float* s1, const float* t1, const float* x2, int64_t x2_ld,
-                                const float* s2, const float* t2, const float* r, int64_t r_ld, float* y, int64_t y_ld, int64_t M,
-                                int32_t C, int32_t act, void* stream);
+                                const float* s2, const float* t2, const float* r, int64_t r_ld, float r_scale, const float* r_scale_dev,
+                                float* y, int64_t y_ld, int64_t M, int32_t C, int32_t act, void* stream);
 /* its backward through the activation: g = dy * act'(s1*x1 + t1 [+ s2*x2 + t2]) - the upstream gradient both BatchNorm backward
  * passes (sgx_bn_bwd_*, act = none) then consume.                                                                            */
 int32_t sgx_dual_affine_act_bwd(const float* dy, int64_t dy_ld, const float* x1, int64_t x1_ld, const float* s1, const float* t1,

@@ -86,7 +86,7 @@ PROTOTYPES = {
     "sgx_wtrans_batch": (_i32, [_P, _i32, _P]),
     "sgx_conv2d_fwd_dual_stat_blocks": (_i32, [_CD]),
     "sgx_conv2d_fwd_dual": (_i32, [_CD, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "sgx_conv2d_bwd_data_dual": (_i32, [_CD, _P, _P, _P, _i64, _i64, _P, _P, _P, _i32, _P]),
+    "sgx_conv2d_bwd_data_dual": (_i32, [_CD, _P, _P, _P, _i64, _i64, _P, _P, _P, _i64, _i64, _f, _P, _P, _i32, _P]),
     "sgx_qarep_prep_batch": (_i32, [_P, _i32, _P]),
     "sgx_qarep_workspace": (_i64, [_i32, _i32]),
     "sgx_qarep_fwd_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _P, _f, _f, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P, _i64, _P]),
@@ -127,7 +127,7 @@ PROTOTYPES = {
     "sgx_maxpool_bwd": (_i32, [_i32] * 7 + [_P, _P, _i64, _i64, _P, _i64, _i64, _i32, _P]),
     "sgx_avgpool_fwd": (_i32, [_i32] * 3 + [_P, _i64, _i64, _P, _P]),
     "sgx_avgpool_bwd": (_i32, [_i32] * 3 + [_P, _P, _i64, _i64, _P]),
-    "sgx_dual_affine_act_fwd": (_i32, [_P, _i64, _P, _P, _P, _i64, _P, _P, _P, _i64, _P, _i64, _i64, _i32, _i32, _P]),
+    "sgx_dual_affine_act_fwd": (_i32, [_P, _i64, _P, _P, _P, _i64, _P, _P, _P, _i64, _f, _P, _P, _i64, _i64, _i32, _i32, _P]),
     "sgx_dual_affine_act_bwd": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _i64, _P, _P, _P, _i64, _i64, _i32, _i32, _P]),
     "sgx_image_colsum_workspace": (_i64, [_i32] * 3),
     "sgx_image_colsum": (_i32, [_i32] * 3 + [_P, _i64, _i64, _P, _i64, _i64, _f, _P, _i32, _P, _P, _i64, _P]),

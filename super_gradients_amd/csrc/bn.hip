@@ -585,6 +585,7 @@ struct DualAffineF {
     const float* x1; long x1_ld; const float* s1; const float* t1;
     const float* x2; long x2_ld; const float* s2; const float* t2;
     const float* r; long r_ld; float* y; long y_ld; int act;
+    float r_scale; const float* r_scale_dev;  // post-activation residual: y = act(..) + r_scale * r_scale_dev[0] * r
     struct In { float4 a, b, u; };
     __device__ In load(long row, int c) const {
         In in;
@@ -606,16 +607,19 @@ struct DualAffineF {
         (void)q0; (void)q1;
         float4 v = pre(c, in.a, in.b);
         float4 o = make_float4(sgx_act(v.x, act), sgx_act(v.y, act), sgx_act(v.z, act), sgx_act(v.w, act));
-        if (r) { o.x += in.u.x; o.y += in.u.y; o.z += in.u.z; o.w += in.u.w; }
+        if (r) {
+            const float sc = r_scale * (r_scale_dev ? r_scale_dev[0] : 1.f);
+            o.x += sc * in.u.x; o.y += sc * in.u.y; o.z += sc * in.u.z; o.w += sc * in.u.w;
+        }
         sgx_st4(y + row * y_ld + c, o);
     }
 };
 extern "C" int32_t sgx_dual_affine_act_fwd(const float* x1, int64_t x1_ld, const float* s1, const float* t1, const float* x2, int64_t x2_ld,
-                                           const float* s2, const float* t2, const float* r, int64_t r_ld, float* y, int64_t y_ld, int64_t M,
-                                           int32_t C, int32_t act, void* stream) {
+                                           const float* s2, const float* t2, const float* r, int64_t r_ld, float r_scale, const float* r_scale_dev,
+                                           float* y, int64_t y_ld, int64_t M, int32_t C, int32_t act, void* stream) {
     SGX_CHECK_ARG(x1 && s1 && t1 && y, "dual_affine_act_fwd: null pointer");
     SGX_CHECK_ARG(!x2 || (s2 && t2), "dual_affine_act_fwd: second branch needs scale and shift");
-    DualAffineF f{x1, x1_ld, s1, t1, x2, x2_ld, s2, t2, r, r_ld, y, y_ld, act};
+    DualAffineF f{x1, x1_ld, s1, t1, x2, x2_ld, s2, t2, r, r_ld, y, y_ld, act, r_scale, r_scale_dev};
     return run_sweep<DualAffineF, 0>(f, M, C, nullptr, stream, "dual_affine_act_fwd");
 }
 struct DualAffineBwdF {
@@ -640,7 +644,7 @@ extern "C" int32_t sgx_dual_affine_act_bwd(const float* dy, int64_t dy_ld, const
                                            int32_t C, int32_t act, void* stream) {
     SGX_CHECK_ARG(dy && x1 && s1 && t1 && g, "dual_affine_act_bwd: null pointer");
     SGX_CHECK_ARG(!x2 || (s2 && t2), "dual_affine_act_bwd: second branch needs scale and shift");
-    DualAffineBwdF f{DualAffineF{x1, x1_ld, s1, t1, x2, x2_ld, s2, t2, nullptr, 0, nullptr, 0, act}, dy, dy_ld, g, g_ld};
+    DualAffineBwdF f{DualAffineF{x1, x1_ld, s1, t1, x2, x2_ld, s2, t2, nullptr, 0, nullptr, 0, act, 1.f, nullptr}, dy, dy_ld, g, g_ld};
     return run_sweep<DualAffineBwdF, 0>(f, M, C, nullptr, stream, "dual_affine_act_bwd");
 }
 

@@ -169,6 +169,12 @@ struct IgemmParams {
     int vec;                  // 1: Nout, output strides and pointers allow 16-byte epilogue accesses
     int mt, nt, nblk, chunk;  // tile counts and XCD chunk
     int stat_nblk;
+    // second addend with its own strides and a scale (host value x optional device scalar): the residual branch of a YOLO-NAS bottleneck,
+    // dx += alpha * dz, folded into the data gradient of its first block instead of an axpy pass + an accumulate pass over dx
+    const float* addend2;
+    const float* addend2_scale_dev;
+    float addend2_scale;
+    long a2d_ld_pix, a2d_ld_img;
     // Optional SECOND K-axis source (template PH2): after the taps of A / Wt the GEMM continues over another input tensor with its own
     // taps and filter, on the same output pixel grid and with the same channel count C.
     //   PH2 = 1: same accumulator - dx = dgrad3x3(dy3) + dgrad1x1(ds) of a QARepVGG block as ONE launch (no accumulate pass over dx);
@@ -294,6 +300,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     float* const As = smem;
     float* const Bs = smem + NBUF * BM * ROWW;
     __shared__ long long rowoff[BM];
+    __shared__ long long rowoff2[PH2 == 1 ? BM : 1];  // offsets into addend2 (two-source data gradient only)
     __shared__ float red[(PH2 == 2 ? 5 : 2) * WM * BN];
 
     const int tid = threadIdx.x;
@@ -374,6 +381,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             const int a = rem / p.Wa;
             const int b = rem - a * p.Wa;
             off = (long long)img * p.y_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.y_ld_pix;
+            if (PH2 == 1 && p.addend2) rowoff2[tid] = (long long)img * p.a2d_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.a2d_ld_pix;
         }
         rowoff[tid] = off;
     }
@@ -720,6 +728,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                         if (p.addend) {
                             float4 u = sgx_ld4(p.addend + off + col);
                             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                        }
+                        if (PH2 == 1 && p.addend2) {
+                            const float4 u = sgx_ld4(p.addend2 + rowoff2[wm * TM * 32 + i * 32 + rowl] + col);
+                            const float sc = p.addend2_scale * (p.addend2_scale_dev ? p.addend2_scale_dev[0] : 1.f);
+                            v.x += sc * u.x; v.y += sc * u.y; v.z += sc * u.z; v.w += sc * u.w;
                         }
                         if (p.accumulate) {
                             float4 u = sgx_ld4(yp);
@@ -1131,6 +1144,10 @@ struct DgradSecond {  // the 1x1 branch of a QARepVGG block: dx += dgrad1x1(ds) 
     const float* ds;
     long ld_pix, ld_img;
     const float* w1t;  // [C][K]
+    const float* addend2;  // optional: dx += scale * addend2 (its own strides)
+    long a2_ld_pix, a2_ld_img;
+    float a2_scale;
+    const float* a2_scale_dev;
 };
 static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const float* w, const float* bias, const float* addend,
                                   float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream, int mode, const DgradSecond* sec = nullptr);
@@ -1209,9 +1226,13 @@ extern "C" int32_t sgx_conv2d_transpose_jobs(const sgx_conv_desc* d, const float
 // a QARepVGG block's two convolution branches (same stride; the 1x1 branch reaches parity class (0, 0) only).  wt: the RxS weights as
 // sgx_conv2d_transpose_weights lays them out; w1t: the 1x1 weights transposed, [C][K].
 extern "C" int32_t sgx_conv2d_bwd_data_dual(const sgx_conv_desc* d, const float* dy, const float* wt, const float* ds, int64_t ds_ld_pix,
-                                            int64_t ds_ld_img, const float* w1t, const float* addend, float* dx, int32_t accumulate, void* stream) {
+                                            int64_t ds_ld_img, const float* w1t, const float* addend, const float* addend2, int64_t a2_ld_pix,
+                                            int64_t a2_ld_img, float a2_scale, const float* a2_scale_dev, float* dx, int32_t accumulate,
+                                            void* stream) {
     SGX_CHECK_ARG(ds && w1t && d && d->K >= IG_BK && ds_ld_pix % 4 == 0, "conv bwd_data_dual: bad args (needs K >= 16)");
-    DgradSecond sec{ds, (long)ds_ld_pix, (long)ds_ld_img, w1t};
+    SGX_CHECK_ARG(!addend2 || (d->stride == 1 && a2_ld_pix % 4 == 0 && a2_ld_img % 4 == 0 && ((uintptr_t)addend2 % 16) == 0),
+                  "conv bwd_data_dual: the scaled second addend needs stride 1 and 16-byte aligned rows");
+    DgradSecond sec{ds, (long)ds_ld_pix, (long)ds_ld_img, w1t, addend2, (long)a2_ld_pix, (long)a2_ld_img, a2_scale, a2_scale_dev};
     return conv_bwd_data_impl(d, dy, nullptr, nullptr, addend, dx, accumulate, const_cast<float*>(wt), sgx_conv2d_bwd_data_workspace(d), stream, 2, &sec);
 }
 static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const float* w, const float* bias, const float* addend,
@@ -1285,6 +1306,8 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
                 p.a2_ld_pix = sec->ld_pix; p.a2_ld_img = sec->ld_img; p.w2_ld_n = d->K;
                 p.a2_bytes = view_bytes(d->N, d->Ho, d->Wo, d->K, sec->ld_pix, sec->ld_img);
                 p.w2_bytes = (long)d->C * d->K * 4;
+                p.addend2 = sec->addend2; p.a2d_ld_pix = sec->a2_ld_pix; p.a2d_ld_img = sec->a2_ld_img;
+                p.addend2_scale = sec->a2_scale; p.addend2_scale_dev = sec->a2_scale_dev;
                 TileCfg t = pick_tile_heuristic(p.M, p.Nout);
                 rc = run_igemm(p, t.bm, t.bn, stream, 1);
                 if (rc) return rc;

@@ -194,8 +194,9 @@ def conv2d_fwd_dual(x, w, w1p, bias1, stride=1):
     return y, u, stat5
 
 
-def conv2d_bwd_data_dual(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, out=None, accumulate=False):
-    """dx = convT RxS(dy) + convT 1x1(ds) [+ addend] [+ dx] in one launch per parity class; wt: conv2d_transpose_weights(w), w1pt: [C, K]."""
+def conv2d_bwd_data_dual(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, out=None, accumulate=False, addend2=None, addend2_scale=None):
+    """dx = convT RxS(dy) + convT 1x1(ds) [+ addend] [+ addend2_scale * addend2] [+ dx] in one launch per parity class; wt:
+    conv2d_transpose_weights(w), w1pt: [C, K]; addend2 has its own strides, its scale is a float or a one-element device tensor."""
     K, C, R, S = w.shape
     if out is None:
         out = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
@@ -203,8 +204,11 @@ def conv2d_bwd_data_dual(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, ou
     if addend is not None and nhwc_strides(addend) != nhwc_strides(out):
         raise _lib.SgxError("bwd_data addend must share dx's strides")
     sl, si = nhwc_strides(ds)
-    check(lib().sgx_conv2d_bwd_data_dual(ctypes.byref(d), ptr(dy), ptr(wt), ptr(ds), sl, si, ptr(w1pt), ptr(addend), ptr(out), int(accumulate), stream()),
-          "sgx_conv2d_bwd_data_dual")
+    a2l, a2i = nhwc_strides(addend2) if addend2 is not None else (0, 0)
+    a2_dev = addend2_scale if torch.is_tensor(addend2_scale) else None
+    a2s = 1.0 if addend2_scale is None or a2_dev is not None else float(addend2_scale)
+    check(lib().sgx_conv2d_bwd_data_dual(ctypes.byref(d), ptr(dy), ptr(wt), ptr(ds), sl, si, ptr(w1pt), ptr(addend), ptr(addend2), a2l, a2i, a2s,
+                                         ptr(a2_dev), ptr(out), int(accumulate), stream()), "sgx_conv2d_bwd_data_dual")
     return out
 
 
@@ -484,15 +488,18 @@ def relu_bwd(dy, y, out=None):
     return out
 
 
-def dual_affine_act(x1, s1, t1, x2=None, s2=None, t2=None, post_add=None, act=None, out=None):
-    """y = act(s1*x1 + t1 [+ s2*x2 + t2]) [+ post_add]   (RepVGG two-branch BatchNorm sum; post-activation residual)."""
+def dual_affine_act(x1, s1, t1, x2=None, s2=None, t2=None, post_add=None, act=None, out=None, post_scale=None):
+    """y = act(s1*x1 + t1 [+ s2*x2 + t2]) [+ post_scale * post_add]   (RepVGG two-branch BatchNorm sum; post-activation residual;
+    post_scale: a float or a one-element device tensor, default 1)."""
+    ps_dev = post_scale if torch.is_tensor(post_scale) else None
+    ps = 1.0 if post_scale is None or ps_dev is not None else float(post_scale)
     M, ld1 = rows(x1)
     C = x1.shape[3]
     if out is None:
         out = torch.empty(x1.shape, device=x1.device, dtype=torch.float32)
     check(lib().sgx_dual_affine_act_fwd(ptr(x1), ld1, ptr(s1), ptr(t1), ptr(x2), rows(x2)[1] if x2 is not None else 0, ptr(s2), ptr(t2), ptr(post_add),
-                                        rows(post_add)[1] if post_add is not None else 0, ptr(out), rows(out)[1], M, C, ACT[act], stream()),
-          "sgx_dual_affine_act_fwd")
+                                        rows(post_add)[1] if post_add is not None else 0, ps, ptr(ps_dev), ptr(out), rows(out)[1], M, C, ACT[act],
+                                        stream()), "sgx_dual_affine_act_fwd")
     return out
 
 

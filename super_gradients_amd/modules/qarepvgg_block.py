@@ -78,7 +78,13 @@ class QARepVGGBlock(SgxBlock):
         """-> (host float, device scalar or None) as the sweeps take it"""
         return (1.0, self.alpha) if isinstance(self.alpha, torch.Tensor) else (float(self.alpha), None)
 
-    def fwd(self, x, out=None):
+    def fwd(self, x, out=None, post_add=None, post_scale=None):
+        """post_add / post_scale: out = block(x) + post_scale * post_add (the YOLO-NAS bottleneck's shortcut, yolo_stages.py:61-63),
+        written by the block's last sweep on the two-branch path."""
+        if post_add is not None and not (self.training and self._two_branch_launch()):
+            y = self.fwd(x)
+            a, a_dev = (1.0, post_scale) if torch.is_tensor(post_scale) else (1.0 if post_scale is None else float(post_scale), None)
+            return K.affine_act(y, r1=post_add, a1=a, a1_dev=a_dev, out=out if out is not None else y)
         c3, bn3, c1, pbn = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1, self.post_bn
         res = x if self.use_residual_connection else None
         a, a_dev = self._alpha()
@@ -89,7 +95,7 @@ class QARepVGGBlock(SgxBlock):
             if self._two_branch_launch():
                 y3, u, stat5 = K.conv2d_fwd_dual(x, c3._w, self._w1p, c1.bias, stride=self.stride)
                 cf, sv = K.qarep_fwd_finalize(stat5, y3.shape[0] * y3.shape[1] * y3.shape[2], c1.bias, bn3, pbn)
-                y = K.dual_affine_act(y3, cf[0], cf[1], u, cf[2], cf[3], act=self.act, out=out)
+                y = K.dual_affine_act(y3, cf[0], cf[1], u, cf[2], cf[3], act=self.act, out=out, post_add=post_add, post_scale=post_scale)
                 self._ctx = ("dual", x, y3, u, cf, sv)
                 return y
             # the two branches read the same x and are independent: the 1x1 branch runs on the side stream beside the 3x3 one
@@ -182,8 +188,14 @@ class QARepVGGBlock(SgxBlock):
         else:
             self.partial_fusion()
 
-    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
+    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True, addend2=None, addend2_scale=None):
+        """addend (dx's strides) and addend2_scale * addend2 (its own strides) are added to dx; on the two-branch path both ride in
+        the data-gradient launch's epilogue."""
         c3, bn3, c1, pbn = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1, self.post_bn
+        if addend2 is not None and need_dx and not (self._ctx[0] == "dual" and self.stride == 1 and K.nhwc_strides(addend2)[0] % 4 == 0):
+            a, a_dev = (1.0, addend2_scale) if torch.is_tensor(addend2_scale) else (1.0 if addend2_scale is None else float(addend2_scale), None)
+            dx_out = K.axpy(addend2, a=a, a_dev=a_dev, out=dx_out, accumulate=accumulate and dx_out is not None)
+            accumulate, addend2 = True, None
         if self._ctx[0] == "dual":
             (_, x, y3, u, cf, sv), self._ctx = self._ctx, None
             ds, dy3 = K.qarep_bwd(dy, y3, u, cf, sv, bn3, pbn, self.act)   # in place over u / y3
@@ -192,7 +204,7 @@ class QARepVGGBlock(SgxBlock):
             if not need_dx:
                 return None
             return K.conv2d_bwd_data_dual(dy3, c3._w, c3._wt, ds, self._w1pt, tuple(x.shape), stride=self.stride, addend=addend, out=dx_out,
-                                          accumulate=accumulate)
+                                          accumulate=accumulate, addend2=addend2, addend2_scale=addend2_scale)
         (x, t3, s, sc3, sh3, m3, i3, scp, shp, mp, ip, t1), self._ctx = self._ctx, None
         ds = pbn.backward(dy, s, scp, shp, mp, ip, self.act, dx_out=s)          # in place over s
         ds1 = ds                                                                # gradient of the 1x1 branch output: alpha * ds
@@ -206,7 +218,11 @@ class QARepVGGBlock(SgxBlock):
             return None
         shape = tuple(x.shape)
         if self.use_residual_connection:
-            dx = c3.dgrad(dt3, shape, out=dx_out, accumulate=accumulate, addend=ds)
+            if dx_out is not None and K.nhwc_strides(dx_out) != K.nhwc_strides(ds):  # a strided destination: the epilogue addend can't be ds
+                K.axpy(ds, out=dx_out, accumulate=accumulate)
+                dx = c3.dgrad(dt3, shape, out=dx_out, accumulate=True)
+            else:
+                dx = c3.dgrad(dt3, shape, out=dx_out, accumulate=accumulate, addend=ds)
             return c1.dgrad(ds1, shape, out=dx, accumulate=True, addend=addend)
         dx = c3.dgrad(dt3, shape, out=dx_out, accumulate=accumulate, addend=addend)
         return c1.dgrad(ds1, shape, out=dx, accumulate=True)

@@ -51,11 +51,12 @@ class YoloNASBottleneck(SgxBlock):
     def fwd(self, x, out=None):
         if not self.add:
             return self.cv2.fwd(self.cv1.fwd(x), out=out)
-        y = self.cv2.fwd(self.cv1.fwd(x))
         a, a_dev = self._alpha()
-        z = K.affine_act(y, r1=x, a1=a, a1_dev=a_dev, out=out if out is not None else y)
         self._x = x if self.training else None
-        return z
+        if isinstance(self.cv2, QARepVGGBlock):  # the shortcut rides in cv2's last sweep
+            return self.cv2.fwd(self.cv1.fwd(x), out=out, post_add=x, post_scale=a_dev if a_dev is not None else a)
+        y = self.cv2.fwd(self.cv1.fwd(x))
+        return K.affine_act(y, r1=x, a1=a, a1_dev=a_dev, out=out if out is not None else y)
 
     def bwd(self, dz, dx_out=None, accumulate=False, addend=None, need_dx=True):
         if not self.add:
@@ -65,6 +66,8 @@ class YoloNASBottleneck(SgxBlock):
         if a_dev is not None:
             K.dot_sum(x, dz, self.alpha.grad, accumulate=True)
         dmid = self.cv2.bwd(dz)
+        if isinstance(self.cv1, QARepVGGBlock):  # d(alpha * x) = alpha * dz rides in cv1's data-gradient launch
+            return self.cv1.bwd(dmid, dx_out=dx_out, accumulate=accumulate, addend=addend, addend2=dz, addend2_scale=a_dev if a_dev is not None else a)
         if dx_out is not None:
             K.axpy(dz, a=a, a_dev=a_dev, out=dx_out, accumulate=accumulate)
             pre = dx_out
@@ -141,9 +144,8 @@ class YoloNASCSPLayer(SgxBlock):
         blocks = list(self.bottlenecks)
         if self.concat_intermediates:
             g = sl(len(blocks))
-            for i in range(len(blocks) - 1, -1, -1):
-                g = blocks[i].bwd(g)
-                K.axpy(sl(i), out=g, accumulate=True)
+            for i in range(len(blocks) - 1, -1, -1):  # the block's input gradient accumulates onto the concat slice of the same tensor
+                g = blocks[i].bwd(g, dx_out=sl(i), accumulate=True)
         else:
             g = sl(0)
             for i in range(len(blocks) - 1, -1, -1):

@@ -182,16 +182,20 @@ def test_oracle_qarepvgg_alpha_live(stride):
     assert torch.equal(xr.grad, xo.grad) and torch.equal(r.alpha.grad, o.alpha.grad)
 
 
+@pytest.mark.parametrize("two_branch", [False, True])
 @pytest.mark.parametrize("concat", [False, True])
-def test_csp_layer(backend, concat):
+def test_csp_layer(backend, concat, two_branch):
+    """two_branch: the blocks run their one-launch-per-pair form, the bottleneck shortcut `alpha * x + cv2(cv1(x))` (yolo_stages.py:61-63)
+    rides in cv2's last sweep and its gradient in cv1's data-gradient launch; concat: that launch accumulates onto the concat slice."""
     from oracle.yolo_nas import CSP, _qa
     from super_gradients_amd.modules import QARepVGGBlock
     from super_gradients_amd.training.models.detection_models.yolo_nas.yolo_stages import YoloNASCSPLayer
 
-    n, c, h, w, hid, nb = _shape(backend, (2, 96, 10, 10, 32, 2), (1, 8, 4, 4, 4, 2))
+    n, c, h, w, hid, nb = _shape(backend, (2, 96, 10, 10, 32, 2), (1, 32, 5, 4, 16, 2) if two_branch else (1, 8, 4, 4, 4, 2))
     x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
-    _check(CSP(c, c, nb, hid, concat, _qa), YoloNASCSPLayer(c, c, nb, QARepVGGBlock, "relu", True, hidden_channels=hid, concat_intermediates=concat), x,
-           backend)
+    blk = YoloNASCSPLayer(c, c, nb, QARepVGGBlock, "relu", True, hidden_channels=hid, concat_intermediates=concat)
+    _check(CSP(c, c, nb, hid, concat, _qa), blk, x, backend, prefetch=two_branch)
+    assert not two_branch or all(b.cv1._w1p is not None for b in blk.bottlenecks)
 
 
 def test_spp(backend):
