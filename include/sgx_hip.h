@@ -190,6 +190,25 @@ int32_t sgx_pad_standardize_u8_hwc(int32_t h, int32_t w, int32_t C, const uint8_
                                    int32_t left, float max_value, const float* mean, const float* std, const float* pad_value, float* y,
                                    void* stream);
 
+/* predict(): a whole batch of ragged uint8 HWC images -> the standardized fp32 NHWC batch y [N][H][W][Cpad], ONE launch.  Replaces the
+ * reference's per-image host passes (training/processing/processing.py): ReverseImageChannels :230-257, Detection[LongestMaxSize]Rescale
+ * :510-589 (cv2.resize INTER_LINEAR, transforms/utils.py:17-25), Detection{Center,BottomRight,Auto}Padding :326-471 (np.pad of the uint8
+ * image), StandardizeImage :260-295 (float64 division, cast to float32), NormalizeImage :298-323 ((x - mean) / std in float32) and the
+ * batching of pipelines.py:241-247.  Image n: source [h0][w0][C] is rescaled to [h][w] (h == h0 and w == w0: copied), placed at (top, left)
+ * of its H x W slot, pad_value[C] (uint8, in output channel order) elsewhere; caller guarantees top + h <= H, left + w <= W.  Rescale =
+ * OpenCV's 8-bit INTER_LINEAR fixed-point arithmetic restated (exact 2x reductions: its INTER_AREA shortcut) - cv2 is absent from the
+ * reference tree and from this image, so that one stage is not pinned against cv2 output (csrc/image.hip header).  standardize == 0:
+ * y = (float)pixel; mean/std NULL: no normalisation.                                                                                      */
+typedef struct sgx_image_job {
+    const uint8_t* src; /* [h0][w0][C] uint8, device memory */
+    int32_t h0, w0;     /* source size                      */
+    int32_t h, w;       /* size after the rescale           */
+    int32_t top, left;  /* position inside the H x W slot   */
+} sgx_image_job;
+int32_t sgx_preprocess_u8_hwc(const sgx_image_job* jobs_dev, int32_t N, int32_t C, int32_t Cpad, int32_t H, int32_t W, int32_t reverse_channels,
+                              int32_t standardize, double max_value, const float* mean, const float* std, const uint8_t* pad_value, float* y,
+                              void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm (training mode) and the fused elementwise stages around it.
  * Replaces F.batch_norm + ReLU/SiLU + the branch adds at

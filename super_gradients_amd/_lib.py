@@ -47,6 +47,10 @@ class QarepPrepJob(ctypes.Structure):  # == sgx_qarep_prep_job
                 ("identity", c_int32), ("pad_", c_int32)]
 
 
+class ImageJob(ctypes.Structure):  # == sgx_image_job
+    _fields_ = [("src", ctypes.c_void_p), ("h0", c_int32), ("w0", c_int32), ("h", c_int32), ("w", c_int32), ("top", c_int32), ("left", c_int32)]
+
+
 class NmsDesc(ctypes.Structure):
     _fields_ = [
         ("B", c_int32), ("L", c_int32), ("C", c_int32), ("multi_label", c_int32), ("class_mode", c_int32),
@@ -103,6 +107,7 @@ PROTOTYPES = {
     "sgx_nhwc_to_nchw": (_i32, [_i32] * 4 + [_P, _i64, _i64, _P, _P]),
     "sgx_standardize_u8_hwc": (_i32, [_i32] * 5 + [_P, _f, _P, _P, _P, _P]),
     "sgx_pad_standardize_u8_hwc": (_i32, [_i32, _i32, _i32, _P, _i32, _i32, _i32, _i32, _i32, _f, _P, _P, _P, _P, _P]),
+    "sgx_preprocess_u8_hwc": (_i32, [_P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, ctypes.c_double, _P, _P, _P, _P, _P]),
     "sgx_stats_blocks": (_i32, [_i64]),
     "sgx_channel_stats_partial": (_i32, [_P, _i64, _i32, _i64, _P, _P]),
     "sgx_reduce_workspace": (_i64, [_i32, _i32]),

@@ -61,6 +61,26 @@ class DetectionModulesFactory(BaseFactory):
         return conf
 
 
+class ProcessingFactory(BaseFactory):
+    """`{TypeName: {kwargs}}` (or a list of them, composed) -> Processing (common/factories/processing_factory.py:8-19)."""
+
+    def __init__(self):
+        from .registry import PROCESSINGS
+
+        super().__init__(PROCESSINGS)
+
+    def get(self, conf):
+        from ..training.processing import processing as _p  # noqa: F401  (fills the registry)
+
+        if isinstance(conf, (list, tuple)):
+            return _p.ComposeProcessing([self.get(c) for c in conf])
+        if isinstance(conf, Mapping) and len(conf) == 1 and "ComposeProcessing" in conf:
+            kw = dict(conf["ComposeProcessing"])
+            kw["processings"] = [self.get(c) for c in kw["processings"]]
+            return _p.ComposeProcessing(**kw)
+        return super().get(conf)
+
+
 class LossesFactory(BaseFactory):
     def __init__(self):
         super().__init__(LOSSES)

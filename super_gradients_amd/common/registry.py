@@ -2,7 +2,7 @@
 
 Mirrors the public surface of common/registry/registry.py:14-196 for the hot path: decorator factories
 `register_model / register_detection_module / register_loss / register_callback / register_optimizer /
-register_lr_scheduler / register_metric / register_dataloader(name=None, deprecated_name=None)` and the dictionaries they fill.
+register_lr_scheduler / register_metric / register_dataloader / register_processing(name=None, deprecated_name=None)` and the dictionaries they fill.
 These registries are owned by this package (the reference raises when a different class is re-registered under an
 existing name, registry.py:36-41, so sharing its dictionaries is not an option).
 """
@@ -42,6 +42,7 @@ LR_SCHEDULERS_CLS_DICT = Registry()
 LR_WARMUP_CLS_DICT = Registry()
 METRICS = Registry()
 ALL_DATALOADERS = Registry()
+PROCESSINGS = Registry()
 
 register_model = ARCHITECTURES.register
 register_detection_module = ALL_DETECTION_MODULES.register
@@ -52,3 +53,4 @@ register_lr_scheduler = LR_SCHEDULERS_CLS_DICT.register
 register_lr_warmup = LR_WARMUP_CLS_DICT.register
 register_metric = METRICS.register
 register_dataloader = ALL_DATALOADERS.register
+register_processing = PROCESSINGS.register

@@ -14,7 +14,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "libsgx_hip.so")
-SOURCES = ["conv.hip", "bn.hip", "pool.hip", "se.hip", "loss.hip", "nms.hip", "optim.hip", "api.cpp"]
+SOURCES = ["conv.hip", "bn.hip", "pool.hip", "se.hip", "loss.hip", "nms.hip", "optim.hip", "image.hip", "api.cpp"]
 # decisions in loss/nms must round like the CPU op-by-op arithmetic: no fma contraction there
 NO_CONTRACT = {"loss.hip", "nms.hip"}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
         u64 later = 0;  // wave 0, lane w: flags this chunk's kept boxes set in word w > chunk
         for (int c = 0; c < nw; ++c) {
             const u64 remc = rem[c];
+            const int kept_in = s_kept;  // read on this side of the barriers: wave 0's lane 0 rewrites it at the end of its walk
             for (int r = wave; r < 64; r += NMS_THREADS / 64) {
                 const int i = 64 * c + r;
                 if (i >= n || ((remc >> r) & 1ull)) continue;  // wave-uniform
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
             if (wave == 0) {
                 // the kept candidates of this word are the flags that are still clear - found with ffs, so suppressed ones cost nothing; every
                 // kept candidate ORs its row into the flags (its own word through a same-address LDS read, the later words lane by lane)
-                int kept = s_kept;
+                int kept = kept_in;
                 u64 cur = remc;
                 if (c == nw - 1 && (n & 63)) cur |= ~0ull << (n & 63);  // slots past the last candidate
                 u64 avail = ~cur;

@@ -344,6 +344,31 @@ def pad_standardize_u8(img_u8, out_slot, top, left, pad_value, max_value=255.0, 
                                            ptr(out_slot), stream()), "sgx_pad_standardize_u8_hwc")
 
 
+def preprocess_u8(images, geometry, H, W, pad_value, reverse_channels=False, max_value=None, mean=None, std=None):
+    """A batch of ragged uint8 HWC device images -> the fp32 NHWC batch [N, H, W, Cpad] in one launch (sgx_preprocess_u8_hwc).
+    geometry[n] = (h, w, top, left): the size image n is rescaled to and where it sits in its H x W slot; pad_value: uint8 [C] device
+    tensor; max_value None: no standardisation; mean / std: fp32 [C] device tensors or None."""
+    n, c = len(images), images[0].shape[2]
+    cpad = ((c + 3) // 4) * 4
+    jobs = (_lib.ImageJob * n)()
+    keep = []
+    for i, (img, (h, w, top, left)) in enumerate(zip(images, geometry)):
+        if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != c:
+            raise _lib.SgxError("preprocess_u8 needs uint8 [h, w, C] images with one channel count")
+        if min(h, w) <= 0 or top < 0 or left < 0 or top + h > H or left + w > W:
+            raise _lib.SgxError(f"preprocess_u8: a {h}x{w} image at ({top}, {left}) does not fit the {H}x{W} batch")
+        img = img.contiguous()
+        keep.append(img)
+        jobs[i].src, jobs[i].h0, jobs[i].w0, jobs[i].h, jobs[i].w, jobs[i].top, jobs[i].left = ptr(img), img.shape[0], img.shape[1], h, w, top, left
+    dev = images[0].device
+    jobs_dev = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+    y = torch.empty(n, H, W, cpad, device=dev, dtype=torch.float32)
+    check(lib().sgx_preprocess_u8_hwc(ptr(jobs_dev), n, c, cpad, H, W, int(bool(reverse_channels)), int(max_value is not None),
+                                      float(max_value if max_value is not None else 1.0), ptr(mean), ptr(std), ptr(pad_value), ptr(y), stream()),
+          "sgx_preprocess_u8_hwc")
+    return y
+
+
 def nhwc_as_nchw_view(y, channels):
     """Logical NCHW [N,C,H,W] view of an NHWC buffer (what model(x) receives from DeviceDetectionCollateFN): no copy."""
     return y.permute(0, 3, 1, 2)[:, :channels]

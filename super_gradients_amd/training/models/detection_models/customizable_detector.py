@@ -13,9 +13,10 @@ from .... import kernels as K
 from ....common.factories import DetectionModulesFactory
 from ....modules.engine import SgxNetwork
 from ....modules.layers import BatchNorm
+from .predict_mixin import DetectionPredictMixin
 
 
-class CustomizableDetector(SgxNetwork):
+class CustomizableDetector(DetectionPredictMixin, SgxNetwork):
     def __init__(self, backbone, heads, neck=None, num_classes: int = None, bn_eps: Optional[float] = None, bn_momentum: Optional[float] = None,
                  inplace_act: Optional[bool] = True, in_channels: int = 3):
         super().__init__()
@@ -30,8 +31,7 @@ class CustomizableDetector(SgxNetwork):
         self.neck = f.get(f.insert_module_param(neck, "in_channels", self.backbone.out_channels))
         self.heads = f.get(f.insert_module_param(self.heads_params, "in_channels", self.neck.out_channels))
         self._initialize_weights(bn_eps, bn_momentum, inplace_act)
-        self._default_nms_iou, self._default_nms_conf, self._default_nms_top_k = 0.7, 0.5, 1024
-        self._default_max_predictions, self._default_multi_label_per_box, self._default_class_agnostic_nms = 300, True, False
+        self._init_processing_params()
 
     def _initialize_weights(self, bn_eps=None, bn_momentum=None, inplace_act=True):
         for m in self.modules():

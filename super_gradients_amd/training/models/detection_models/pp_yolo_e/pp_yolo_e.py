@@ -15,6 +15,7 @@ from .....modules.engine import SgxNetwork
 from ....utils.utils import HpmStruct
 from ...arch_params_factory import get_arch_params
 from ..csp_resnet import CSPResNetBackbone
+from ..predict_mixin import DetectionPredictMixin
 from .pan import PPYoloECSPPAN
 from .post_prediction_callback import PPYoloEPostPredictionCallback
 from .pp_yolo_head import PPYOLOEHead
@@ -41,7 +42,7 @@ class PPYoloEDecodingModule(torch.nn.Module):
         return boxes, scores
 
 
-class PPYoloE(SgxNetwork):
+class PPYoloE(DetectionPredictMixin, SgxNetwork):
     def __init__(self, arch_params):
         super().__init__()
         if isinstance(arch_params, HpmStruct):
@@ -51,8 +52,7 @@ class PPYoloE(SgxNetwork):
         self.neck = PPYoloECSPPAN(**arch_params["neck"], depth_mult=arch_params["depth_mult"], width_mult=arch_params["width_mult"])
         self.head = PPYOLOEHead(**arch_params["head"], width_mult=arch_params["width_mult"], num_classes=arch_params["num_classes"])
         self.in_channels = 3
-        self._default_nms_iou, self._default_nms_conf, self._default_nms_top_k = 0.7, 0.5, 1024
-        self._default_max_predictions, self._default_multi_label_per_box, self._default_class_agnostic_nms = 300, True, False
+        self._init_processing_params()
 
     def get_post_prediction_callback(self, *, conf: float, iou: float, nms_top_k: int, max_predictions: int, multi_label_per_box: bool,
                                      class_agnostic_nms: bool) -> PPYoloEPostPredictionCallback:

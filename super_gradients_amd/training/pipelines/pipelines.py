@@ -1,0 +1,170 @@
+"""predict(): images -> device pre-processing -> fused eval forward -> NMS -> boxes in the original image frames.
+
+Reference: training/pipelines/pipelines.py:47-283 (Pipeline) and :285-370 (DetectionPipeline).  Same constructor arguments, call
+protocol (`pipeline(images, batch_size)`) and result containers; what differs is where the work runs:
+
+  reference (per batch)                                    here
+  image_processor.preprocess_image per image, numpy/cv2    ONE launch for the batch (ComposeProcessing.preprocess_batch, csrc/image.hip)
+  np.array(list) -> torch.from_numpy -> .to(device)        raw uint8 images are uploaded, the fp32 batch is born in HBM
+  deepcopy + prep_model_for_conversion on first batch      same (QARepVGG / RepVGG blocks collapse to their fused convolution)
+  autocast(fp16) forward                                   fp32 forward on the MFMA fp32 path (fp16 is accepted and ignored: the build has no
+                                                           reduced-precision convolution; results are at least as precise as the reference's)
+  post_prediction_callback (python loop + torchvision)     the batched NMS kernels (csrc/nms.hip)
+  postprocess_predictions per image (numpy)                same arithmetic, on the <= max_predictions boxes of each image
+Video / webcam sources are cv2 I/O and outside the path.
+"""
+import copy
+import os
+from abc import ABC, abstractmethod
+from typing import Iterable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from ..processing.processing import ComposeProcessing, ImagePermute, Processing
+from ..utils.predict import DetectionPrediction, ImageDetectionPrediction, ImagesDetectionPrediction
+
+IMG_EXTENSIONS = ("bmp", "dng", "jpeg", "jpg", "mpo", "pfm", "pgm", "png", "ppm", "tif", "tiff", "webp")
+VIDEO_EXTENSIONS = (".mp4", ".avi", ".mov", ".wmv", ".flv", ".gif")
+
+
+def _load_image(image) -> Union[np.ndarray, torch.Tensor]:
+    """utils/media/image.py:107-141: arrays / tensors as they are, PIL images and image files as RGB uint8 arrays."""
+    if isinstance(image, (np.ndarray, torch.Tensor)):
+        return image
+    try:
+        from PIL import Image
+    except ImportError:  # pragma: no cover
+        Image = None
+    if Image is not None and isinstance(image, Image.Image):
+        return np.asarray(image.convert("RGB"))
+    if isinstance(image, str):
+        if image.startswith(("http://", "https://")):
+            raise ValueError("predict(): URL sources need network access; pass a local file, an array or a tensor")
+        if Image is None:  # pragma: no cover
+            raise ValueError("predict(): reading image files needs PIL")
+        return np.asarray(Image.open(image).convert("RGB"))
+    raise ValueError(f"Input {type(image)} not supported for prediction.")
+
+
+def load_images(images) -> List[Union[np.ndarray, torch.Tensor]]:
+    """utils/media/image.py:19-68: one image, a list / iterator of images, a 4-D stack, or a folder of image files."""
+    if isinstance(images, str) and os.path.isdir(images):
+        names = sorted(n for n in os.listdir(images) if n.lower().rsplit(".", 1)[-1] in IMG_EXTENSIONS)
+        return [_load_image(os.path.join(images, n)) for n in names]
+    if isinstance(images, (np.ndarray, torch.Tensor)) and images.ndim == 4:
+        return [images[i] for i in range(images.shape[0])]
+    if isinstance(images, (list, tuple)) or hasattr(images, "__next__"):
+        return [_load_image(i) for i in images]
+    return [_load_image(images)]
+
+
+class Pipeline(ABC):
+    def __init__(self, model, image_processor: Union[Processing, List[Processing]], class_names: List[str], device: Optional[str] = None,
+                 fuse_model: bool = True, dtype: Optional[torch.dtype] = None, fp16: bool = True):
+        self.model = model
+        if device is not None:
+            self.device = torch.device(device)
+        else:
+            p = next(iter(model.parameters()), None)
+            self.device = p.device if p is not None and getattr(model, "_materialized", True) else torch.device("cuda")
+        self.dtype = dtype or torch.float32
+        self.class_names = class_names
+        if isinstance(image_processor, list):
+            image_processor = ComposeProcessing(image_processor)
+        self.image_processor = image_processor
+        self.fuse_model = fuse_model  # fused on the first batch, like the reference (pipelines.py:91,95-100)
+        self.fp16 = fp16
+
+    def _fuse_model(self, input_size):
+        cache, self.model._pipeline_cache = getattr(self.model, "_pipeline_cache", None), None  # (it holds this pipeline: not part of the copy)
+        try:
+            fused = copy.deepcopy(self.model)
+        finally:
+            self.model._pipeline_cache = cache
+        self.model = fused
+        self.model.eval()
+        self.model.prep_model_for_conversion(input_size=input_size)
+        self.fuse_model = False
+
+    def __call__(self, inputs, batch_size: Optional[int] = 32):
+        if isinstance(inputs, str) and inputs.lower().endswith(VIDEO_EXTENSIONS):
+            raise NotImplementedError("predict() on video files is cv2 I/O, outside the MI355X hot path; pass frames as images")
+        return self.predict_images(inputs, batch_size)
+
+    def predict_images(self, images, batch_size: Optional[int] = 32):
+        images = load_images(images)
+        return self._combine_image_prediction_to_images(self._generate_prediction_result(images, batch_size), n_images=len(images))
+
+    def _generate_prediction_result(self, images, batch_size: Optional[int] = None):
+        batch_size = batch_size or len(images)
+        for start in range(0, len(images), batch_size):
+            yield from self._generate_prediction_result_single_batch(images[start:start + batch_size])
+
+    def _generate_prediction_result_single_batch(self, images):
+        batch, metadatas = self.image_processor.preprocess_batch(images, device=self.device)
+        predictions = self.pass_images_through_model(batch)
+        for image, prediction, metadata in zip(images, predictions, metadatas):
+            prediction = self.image_processor.postprocess_predictions(predictions=prediction, metadata=metadata)
+            host_image = image.cpu().numpy() if isinstance(image, torch.Tensor) else image
+            yield self._instantiate_image_prediction(image=host_image, prediction=prediction)
+
+    def pass_images_through_model(self, batch: torch.Tensor):
+        if hasattr(self.model, "get_input_shape_steps"):  # SupportsInputShapeCheck.validate_input_shape
+            sh, sw = self.model.get_input_shape_steps()
+            mh, mw = self.model.get_minimum_input_shape_size()
+            h, w = batch.shape[-2:]
+            if h % sh or w % sw or h < mh or w < mw:
+                raise ValueError(f"Invalid input size ({h}, {w}): the model takes sizes that are multiples of ({sh}, {sw}) and at least ({mh}, {mw})")
+        if self.fuse_model:
+            self._fuse_model(tuple(batch.shape[-2:]))
+        was_training = self.model.training
+        self.model.eval()
+        try:
+            with torch.no_grad():
+                out = self.model(batch)
+                return self._decode_model_output(out, model_input=batch)
+        finally:
+            self.model.train(was_training)
+
+    @abstractmethod
+    def _decode_model_output(self, model_output, model_input):
+        pass
+
+    @abstractmethod
+    def _instantiate_image_prediction(self, image, prediction):
+        pass
+
+    @abstractmethod
+    def _combine_image_prediction_to_images(self, images_prediction_lst: Iterable, n_images: Optional[int] = None):
+        pass
+
+
+class DetectionPipeline(Pipeline):
+    def __init__(self, model, class_names: List[str], post_prediction_callback, device: Optional[str] = None,
+                 image_processor: Union[Processing, List[Processing]] = None, fuse_model: bool = True, fp16: bool = True):
+        if isinstance(image_processor, list):
+            image_processor = ComposeProcessing(image_processor)
+        if not isinstance(image_processor, ComposeProcessing):
+            image_processor = ComposeProcessing([image_processor])
+        if not any(isinstance(p, ImagePermute) for p in image_processor._flat()):  # pipelines.py:311-313
+            image_processor = ComposeProcessing(list(image_processor.processings) + [ImagePermute()])
+        super().__init__(model=model, device=device, image_processor=image_processor, class_names=class_names, fuse_model=fuse_model, fp16=fp16)
+        self.post_prediction_callback = post_prediction_callback
+
+    def _decode_model_output(self, model_output, model_input):
+        post_nms = self.post_prediction_callback(model_output, device=self.device)
+        preds = []
+        for rows, image in zip(post_nms, model_input):
+            rows = rows.detach().cpu().numpy() if rows is not None else np.zeros((0, 6), dtype=np.float32)
+            preds.append(DetectionPrediction(bboxes=rows[:, :4], confidence=rows[:, 4], labels=rows[:, 5].astype(int), bbox_format="xyxy",
+                                             image_shape=tuple(image.shape)))
+        return preds
+
+    def _instantiate_image_prediction(self, image, prediction):
+        return ImageDetectionPrediction(image=image, prediction=prediction, class_names=self.class_names)
+
+    def _combine_image_prediction_to_images(self, images_predictions, n_images: Optional[int] = None):
+        if n_images == 1:
+            return next(iter(images_predictions))
+        return ImagesDetectionPrediction(_images_prediction_lst=list(images_predictions))

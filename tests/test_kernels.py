@@ -7,6 +7,8 @@ Each test runs twice through the `backend` fixture:
 Tolerances: fp32 with a different summation order -> 2e-5 of the tensor's max-abs (north star: 1e-4 rel);
 integer/index outputs bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -576,6 +578,25 @@ def test_nms(backend, multi_label, class_mode):
         n = int(cnt[b])
         assert n == ref[b].shape[0], f"image {b}: kept {n} vs oracle {ref[b].shape[0]}"
         assert torch.equal(out[b, :n], ref[b]), f"image {b}: rows differ"  # bit-exact boxes/scores/classes
+
+
+def test_nms_per_class_case_is_reproducible(backend):
+    """A per-class case (detections of a random-init YOLO-NAS on two 64x64 images: 252 candidates, scores within 0.0093..0.0106, boxes far
+    larger than the image) on which the chunked suppression walk keeps candidates in all four flag words.  Under the host emulation - one OS
+    thread per lane, no wave lock-step - the walk once read the kept-count after lane 0 of the same wave had advanced it; the rows must equal
+    the oracle's on every repetition."""
+    from oracle import nms as onms
+
+    case = torch.load(os.path.join(os.path.dirname(__file__), "golden", "nms_perclass_case.pt"))
+    boxes, scores = case["boxes"], case["scores"]
+    for class_mode, agnostic in ((1, False), (2, False), (0, True)):
+        ref = onms.post_prediction(boxes, scores, score_threshold=0.0, nms_threshold=0.6, nms_top_k=200, max_predictions=20, multi_label_per_box=True,
+                                   class_agnostic_nms=agnostic)
+        for rep in range(4):
+            out, cnt, idx, _ = K.nms(boxes.to(backend), scores.to(backend), 0.0, 0.6, 200, 20, multi_label=True, class_mode=class_mode)
+            for b in range(2):
+                n = int(cnt[b])
+                assert n == ref[b].shape[0] and torch.equal(out[b, :n].cpu(), ref[b]), f"mode {class_mode} repetition {rep} image {b}"
 
 
 def test_nms_large_topk(backend):
