@@ -2,6 +2,8 @@
 Same signature; the architectures come from this package's registry and run on libsgx_hip."""
 from typing import Optional, Union
 
+import warnings
+
 import torch
 
 from ...common.factories import UnknownTypeException
@@ -71,6 +73,21 @@ def get_model_name(model: torch.nn.Module) -> Optional[str]:
     return getattr(model, "_sg_model_name", None)
 
 
+def _maybe_load_preprocessing_params(net, ckpt) -> bool:
+    """checkpoint_utils.py:1625-1651: a checkpoint's "processing_params" (class names, image processor, NMS defaults) go to
+    model.set_dataset_processing_params; a failure only warns.  The image processor is stored as a `{TypeName: kwargs}` config
+    (Processing.to_config) so the file stays loadable with weights_only=True."""
+    if not (isinstance(ckpt, dict) and "processing_params" in ckpt and hasattr(net, "set_dataset_processing_params")):
+        return False
+    try:
+        net.set_dataset_processing_params(**ckpt["processing_params"])
+        return True
+    except Exception as e:  # noqa: BLE001  (the reference swallows everything here too)
+        warnings.warn(f"Could not set preprocessing pipeline from the checkpoint dataset: {e}. Before calling predict make sure to call "
+                      "set_dataset_processing_params.")
+        return False
+
+
 def get(model_name: str, arch_params: Optional[dict] = None, num_classes: Optional[int] = None, strict_load: Union[str, bool] = "no_key_matching",
         checkpoint_path: Optional[str] = None, pretrained_weights: Optional[str] = None, load_backbone: bool = False,
         download_required_code: bool = True, checkpoint_num_classes: Optional[int] = None, num_input_channels: Optional[int] = None):
@@ -82,6 +99,7 @@ def get(model_name: str, arch_params: Optional[dict] = None, num_classes: Option
         ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)  # tensors and plain containers only: never runs pickled code
         sd = ckpt.get("ema_net", ckpt.get("net", ckpt)) if isinstance(ckpt, dict) else ckpt
         adaptive_load_state_dict(net, sd, strict_load)
+        _maybe_load_preprocessing_params(net, ckpt)
     if checkpoint_num_classes != num_classes:
         net.replace_head(new_num_classes=num_classes)  # transfer learning (model_factory.py:250-251)
     if num_input_channels is not None and num_input_channels != net.get_input_channels():

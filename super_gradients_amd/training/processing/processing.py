@@ -113,6 +113,14 @@ class Processing(ABC):
     def resizes_image(self) -> bool:
         return False
 
+    def to_config(self):
+        """`{TypeName: {constructor kwargs}}` of plain values: what ProcessingFactory.get() rebuilds this stage from, and the form the Trainer
+        stores in checkpoints (loadable with torch.load(weights_only=True); the reference pickles the objects, sg_trainer.py:710-712)."""
+        return {type(self).__name__: {k: (list(v) if isinstance(v, tuple) else v) for k, v in self._config_kwargs().items()}}
+
+    def _config_kwargs(self) -> dict:
+        return {}
+
 
 class AutoPadding(Processing, ABC):
     def __init__(self, shape_multiple: Tuple[int, int], pad_value: int):
@@ -120,6 +128,9 @@ class AutoPadding(Processing, ABC):
             shape_multiple = (shape_multiple, shape_multiple)
         self.shape_multiple = tuple(shape_multiple)
         self.pad_value = pad_value
+
+    def _config_kwargs(self):
+        return dict(shape_multiple=self.shape_multiple, pad_value=self.pad_value)
 
     def _get_padding_params(self, input_shape: Tuple[int, int]) -> PaddingCoordinates:
         h, w = input_shape
@@ -141,6 +152,9 @@ def _to_device_u8(image, device):
 class ComposeProcessing(Processing):
     def __init__(self, processings: List[Processing]):
         self.processings = list(processings)
+
+    def to_config(self):
+        return {"ComposeProcessing": {"processings": [p.to_config() for p in self.processings]}}
 
     def _flat(self):
         for p in self.processings:
@@ -226,6 +240,9 @@ class ImagePermute(Processing):
     def __init__(self, permutation: Tuple[int, int, int] = (2, 0, 1)):
         self.permutation = tuple(permutation)
 
+    def _config_kwargs(self):
+        return dict(permutation=self.permutation)
+
     def _describe(self, plan):
         plan.enter("permute", self)
         plan.permutation = self.permutation
@@ -251,6 +268,9 @@ class StandardizeImage(Processing):
     def __init__(self, max_value: float = 255.0):
         self.max_value = float(max_value)
 
+    def _config_kwargs(self):
+        return dict(max_value=self.max_value)
+
     def _describe(self, plan):
         plan.enter("standardize", self)
         plan.max_value = self.max_value
@@ -265,6 +285,10 @@ class NormalizeImage(Processing):
     def __init__(self, mean: List[float], std: List[float]):
         self.mean = np.array(mean).reshape((1, 1, -1)).astype(np.float32)
         self.std = np.array(std).reshape((1, 1, -1)).astype(np.float32)
+        self._mean_arg, self._std_arg = [float(v) for v in np.ravel(mean)], [float(v) for v in np.ravel(std)]
+
+    def _config_kwargs(self):
+        return dict(mean=self._mean_arg, std=self._std_arg)
 
     def _describe(self, plan):
         plan.enter("normalize", self)
@@ -297,6 +321,9 @@ class _DetectionPadding(Processing, ABC):
     def __init__(self, output_shape: Tuple[int, int], pad_value: int):
         self.output_shape = tuple(output_shape)
         self.pad_value = pad_value
+
+    def _config_kwargs(self):
+        return dict(output_shape=self.output_shape, pad_value=self.pad_value)
 
     @abstractmethod
     def _get_padding_params(self, input_shape) -> PaddingCoordinates:
@@ -353,6 +380,9 @@ class DetectionAutoPadding(AutoPadding):
 class _DetectionRescaleBase(Processing, ABC):
     def __init__(self, output_shape: Tuple[int, int]):
         self.output_shape = tuple(output_shape)
+
+    def _config_kwargs(self):
+        return dict(output_shape=self.output_shape)
 
     def postprocess_predictions(self, predictions: DetectionPrediction, metadata: RescaleMetadata):
         predictions.bboxes_xyxy = _rescale_bboxes(predictions.bboxes_xyxy, (1 / metadata.scale_factor_h, 1 / metadata.scale_factor_w))

@@ -240,6 +240,9 @@ class Trainer:
                                ckpt_dir=self.checkpoints_dir_path, train_loader=train_loader, valid_loader=valid_loader, training_params=tp,
                                ema_model=self.ema_model, metric_to_watch=tp.metric_to_watch, valid_metrics=valid_metrics, lr_warmup_epochs=tp.lr_warmup_epochs,
                                stop_training=False)
+        self._processing_params = self._get_preprocessing_from_valid_loader(valid_loader)
+        if self._processing_params is not None:  # sg_trainer.py:1704-1707: the trained model can predict() without further set-up
+            self.net.set_dataset_processing_params(**self._processing_params)
         start_epoch = 0
         if tp.resume or tp.resume_path:
             start_epoch = self._load_checkpoint(tp.resume_path or os.path.join(self.checkpoints_dir_path, tp.ckpt_name), tp.load_opt_params)
@@ -400,6 +403,19 @@ class Trainer:
                 self._save_checkpoint(epoch, tp.ckpt_best_name, row)
             handler.on_validation_end_best_epoch(context)
 
+    def _get_preprocessing_from_valid_loader(self, valid_loader) -> Optional[dict]:
+        """sg_trainer.py:1709-1720: a validation dataset that knows its pre-processing (`get_dataset_preprocessing_params()` -> class_names,
+        image_processor, iou, conf) hands it to a model that can predict(); failures only warn."""
+        ds = getattr(valid_loader, "dataset", None)
+        if not (hasattr(self.net, "set_dataset_processing_params") and hasattr(ds, "get_dataset_preprocessing_params")):
+            return None
+        try:
+            return dict(ds.get_dataset_preprocessing_params())
+        except Exception as e:  # noqa: BLE001
+            warnings.warn(f"Could not set preprocessing pipeline from the validation dataset:\n {e}.\n Before calling predict make sure to call "
+                          "set_dataset_processing_params.")
+            return None
+
     # ------------------------------------------------------------------------------------------------ checkpoints
     def _save_checkpoint(self, epoch, name, row):
         """Same dictionary layout as the reference's checkpoints (sg_trainer.py:649-720): net / ema_net / optimizer_state_dict / epoch / metrics."""
@@ -409,6 +425,13 @@ class Trainer:
         state["metrics"] = {split: {k: float(v) for k, v in vals.items()} if isinstance(vals, dict) else vals for split, vals in row.items()} if isinstance(row, dict) else row
         if self.ema_model is not None:
             state["ema_net"] = {k: v.cpu() for k, v in self.ema_model.state_dict().items()}
+        if getattr(self, "_processing_params", None) is not None:  # sg_trainer.py:710-712, with the image processor as a plain config
+            pp = dict(self._processing_params)
+            if hasattr(pp.get("image_processor"), "to_config"):
+                pp["image_processor"] = pp["image_processor"].to_config()
+            if pp.get("class_names") is not None:
+                pp["class_names"] = list(pp["class_names"])
+            state["processing_params"] = pp
         torch.save(state, os.path.join(self.checkpoints_dir_path, name))
 
     def _optimizer_state(self):

@@ -305,3 +305,42 @@ def test_predict_eval_forward_matches_oracle(gpu_device):
 
     assert_close(sc.cpu(), sc_r, 1e-4, "scores")
     assert float((bx.cpu() - bx_r).abs().max()) < 1e-3
+
+
+def test_processing_params_round_trip_through_checkpoint(tmp_path):
+    """Processing.to_config() -> checkpoint["processing_params"] (plain containers: loads with weights_only=True) -> models.get(checkpoint_path)
+    -> set_dataset_processing_params (checkpoint_utils.py:1625-1651); the Trainer's hand-over from a validation dataset that knows its
+    pre-processing (sg_trainer.py:1704-1720)."""
+    from super_gradients_amd.common.factories import ProcessingFactory
+    from super_gradients_amd.training import Trainer, models
+    from super_gradients_amd.training.processing import ComposeProcessing, default_ppyoloe_coco_processing_params, default_yolo_nas_coco_processing_params
+
+    for params in (default_yolo_nas_coco_processing_params(), default_ppyoloe_coco_processing_params()):
+        cfg = params["image_processor"].to_config()
+        again = ProcessingFactory().get(cfg)
+        assert isinstance(again, ComposeProcessing) and again.to_config() == cfg
+        p0, m0 = params["image_processor"].plan_image((480, 640, 3))
+        p1, m1 = again.plan_image((480, 640, 3))
+        assert p0.photometric_key() == p1.photometric_key() and (p0.h, p0.w, p0.top, p0.left) == (p1.h, p1.w, p1.top, p1.left) and m0 == m1
+
+    net = models.get("yolo_nas_s", num_classes=80)
+    params = default_yolo_nas_coco_processing_params()
+    path = str(tmp_path / "ckpt.pth")
+    torch.save({"net": net.state_dict(), "processing_params": dict(class_names=list(params["class_names"]), iou=0.65, conf=0.3,
+                                                                  image_processor=params["image_processor"].to_config())}, path)
+    loaded = models.get("yolo_nas_s", num_classes=80, checkpoint_path=path)
+    assert loaded.get_class_names() == tuple(params["class_names"]) and loaded._default_nms_iou == 0.65 and loaded._default_nms_conf == 0.3
+    assert loaded.get_processing_params().to_config() == params["image_processor"].to_config()
+
+    class _DS:
+        def get_dataset_preprocessing_params(self):
+            return default_yolo_nas_coco_processing_params()
+
+    class _Loader:
+        dataset = _DS()
+
+    tr = Trainer("pp", ckpt_root_dir=str(tmp_path))
+    tr.net = net
+    got = tr._get_preprocessing_from_valid_loader(_Loader())
+    assert got["conf"] == 0.25 and isinstance(got["image_processor"], ComposeProcessing)
+    assert tr._get_preprocessing_from_valid_loader(object()) is None
