@@ -157,11 +157,23 @@ class SgxNetwork(nn.Module):
             m._buffers[bname] = self.i_arena[i]
         self._device = device
         self._materialized = True
+        for m in self.modules():
+            if isinstance(m, SgxBlock):
+                object.__setattr__(m, "_net", self)  # plain attribute: must not register the network as a child module
+        self._build_runtime()
+        return self
+
+    def _build_runtime(self):
+        """Everything that refers to this instance's device memory by address or lives outside tensors: the HIP streams, and the per-step
+        job tables (arena views never move, so they are built once).  Called by materialize() and, for a copy, by __deepcopy__."""
+        import os
+
+        from .. import kernels as K
+
+        device = self._device
         # Weight gradients are independent of the data-gradient chain: they are forked onto a side HIP stream so that they fill
         # the CUs the (dependent) main-stream kernels leave idle in their tails (most YOLO-NAS layers are 1-2 waves of
         # workgroups).  SGX_SIDE_STREAM=0 disables the fork.
-        import os
-
         self.side_stream = torch.cuda.Stream(device=device) if (device.type == "cuda" and os.environ.get("SGX_SIDE_STREAM", "1") != "0") else None
         # Optional (SGX_AUX_STREAM=1): transpose all data-gradient weights on a third stream underneath the forward pass instead of
         # per call.  Measured neutral-to-negative on YOLO-NAS-S (r1p: 528.7 vs 533.3 images/s): the per-call transposes already hide
@@ -175,7 +187,6 @@ class SgxNetwork(nn.Module):
         self.wt_batch = os.environ.get("SGX_WT_BATCH", "1") == "1" and self.aux_stream is None
         for m in self.modules():
             if isinstance(m, SgxBlock):
-                object.__setattr__(m, "_net", self)  # plain attribute: must not register the network as a child module
                 m.on_materialize()
         self._dgrad_convs = [m for m in self.modules() if hasattr(m, "transpose_weights") and getattr(m, "_wt", None) is not None]
         self._wt_jobs, self._wt_njobs = None, 0
@@ -191,7 +202,22 @@ class SgxNetwork(nn.Module):
         if recs:
             self._qp_njobs = len(recs)
             self._qp_jobs = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(device)
-        return self
+
+    _RUNTIME_ATTRS = ("side_stream", "aux_stream", "_wt_jobs", "_qp_jobs", "_dgrad_convs")
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model) - what the reference's predict() pipeline does before fusing (pipelines.py:95-100): parameters, buffers and
+        arenas are copied (views stay views of the copied arenas); streams and the address-bearing job tables are rebuilt for the copy."""
+        import copy
+
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._RUNTIME_ATTRS:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        if self._materialized:
+            new._build_runtime()
+        return new
 
     def prefetch_dgrad_weights(self):
         aux = getattr(self, "aux_stream", None)
