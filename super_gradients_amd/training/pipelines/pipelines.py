@@ -106,8 +106,7 @@ class Pipeline(ABC):
         predictions = self.pass_images_through_model(batch)
         for image, prediction, metadata in zip(images, predictions, metadatas):
             prediction = self.image_processor.postprocess_predictions(predictions=prediction, metadata=metadata)
-            host_image = image.cpu().numpy() if isinstance(image, torch.Tensor) else image
-            yield self._instantiate_image_prediction(image=host_image, prediction=prediction)
+            yield self._instantiate_image_prediction(image=image, prediction=prediction)  # the caller's own object (a device tensor stays one)
 
     def pass_images_through_model(self, batch: torch.Tensor):
         if hasattr(self.model, "get_input_shape_steps"):  # SupportsInputShapeCheck.validate_input_shape
@@ -154,9 +153,12 @@ class DetectionPipeline(Pipeline):
 
     def _decode_model_output(self, model_output, model_input):
         post_nms = self.post_prediction_callback(model_output, device=self.device)
-        preds = []
-        for rows, image in zip(post_nms, model_input):
-            rows = rows.detach().cpu().numpy() if rows is not None else np.zeros((0, 6), dtype=np.float32)
+        counts = [0 if r is None else int(r.shape[0]) for r in post_nms]
+        kept = [r.detach().reshape(-1, 6) for r in post_nms if r is not None and r.shape[0]]
+        flat = torch.cat(kept).cpu().numpy() if kept else np.zeros((0, 6), dtype=np.float32)  # ONE device-to-host copy for the batch
+        preds, start = [], 0
+        for n, image in zip(counts, model_input):
+            rows, start = flat[start:start + n], start + n
             preds.append(DetectionPrediction(bboxes=rows[:, :4], confidence=rows[:, 4], labels=rows[:, 5].astype(int), bbox_format="xyxy",
                                              image_shape=tuple(image.shape)))
         return preds
