@@ -243,18 +243,46 @@ def check(rc, what=""):
         raise SgxError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
 
 
+_PTR_DTYPES = frozenset((torch.float32, torch.float64, torch.int32, torch.int64, torch.uint8))
+
+
 def ptr(t):
     """Device pointer of a tensor (None -> NULL).  Tensors must live on the HIP device."""
     if t is None:
         return None
-    if not t.is_cuda and not _TEST_HOST_MODE:
+    if not (t.is_cuda or _TEST_HOST_MODE):
         raise SgxError("libsgx_hip kernels need tensors on the HIP device (got a CPU tensor); there is no CPU fallback")
-    if t.dtype not in (torch.float32, torch.float64, torch.int32, torch.int64, torch.uint8):
+    if t.dtype not in _PTR_DTYPES:
         raise SgxError(f"unsupported dtype {t.dtype}")
     return t.data_ptr()
 
 
+def _stream_slow():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _stream_fast():
+    return torch._C._cuda_getCurrentRawStream(-1)  # -1: the current device
+
+
+def _stream_probe():
+    """First launch: adopt the raw-handle call only if this torch build has it and it agrees with the public API."""
+    global _stream_impl
+    slow = _stream_slow()
+    try:
+        ok = _stream_fast() == slow
+    except Exception:  # noqa: BLE001
+        ok = False
+    _stream_impl = _stream_fast if ok else _stream_slow
+    return slow
+
+
+_stream_impl = _stream_probe
+
+
 def stream():
+    """The current HIP stream of the current device as a raw handle (what torch.cuda.current_stream().cuda_stream returns, without
+    building the Python Stream object: this runs once per kernel launch, ~1100 times per train step)."""
     if _TEST_HOST_MODE:
         return None
-    return torch.cuda.current_stream().cuda_stream
+    return _stream_impl()

@@ -5,6 +5,7 @@ Tensor convention on the hot path: activations are torch tensors of logical shap
 Everything here enqueues on the current torch stream and returns immediately.
 """
 import ctypes
+import functools
 import os
 from typing import Optional, Tuple
 
@@ -25,7 +26,7 @@ class _Workspace:
         self.buf = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        key = (str(device), torch.cuda.current_stream().cuda_stream if (torch.cuda.is_available() and not _lib._TEST_HOST_MODE) else 0)
+        key = (device, stream() or 0)  # (host emulation: stream() is None)
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
@@ -38,20 +39,21 @@ WORKSPACE = _Workspace()
 
 # --------------------------------------------------------------------------------------------- layout helpers
 def nhwc_strides(t: torch.Tensor) -> Tuple[int, int]:
-    if t.dim() != 4 or (t.shape[3] > 1 and t.stride(3) != 1):
-        raise _lib.SgxError(f"tensor is not an NHWC view with contiguous channels: shape {tuple(t.shape)} strides {t.stride()}")
-    n, h, w, c = t.shape
+    shp, st = t.shape, t.stride()  # one call each: this runs ~1300 times per train step
+    if len(shp) != 4 or (shp[3] > 1 and st[3] != 1):
+        raise _lib.SgxError(f"tensor is not an NHWC view with contiguous channels: shape {tuple(shp)} strides {st}")
+    n, h, w, c = shp
     # strides of size-1 dims carry no information (torch leaves arbitrary values there, e.g. after permute on a 1x1 map): derive the
     # pixel stride from the first dimension that has one
     if w > 1:
-        ld_pix = t.stride(2)
+        ld_pix = st[2]
+        if h > 1 and st[1] != w * ld_pix:
+            raise _lib.SgxError(f"tensor is not an NHWC view with contiguous channels: shape {tuple(shp)} strides {st}")
     elif h > 1:
-        ld_pix = t.stride(1)
+        ld_pix = st[1]
     else:  # a single pixel per image: keep a plausible recorded stride (a channel slice of a wider one-pixel buffer), else fall back to C
-        ld_pix = t.stride(2) if t.stride(2) >= c else (t.stride(1) if t.stride(1) >= c else c)
-    if w > 1 and h > 1 and t.stride(1) != w * ld_pix:
-        raise _lib.SgxError(f"tensor is not an NHWC view with contiguous channels: shape {tuple(t.shape)} strides {t.stride()}")
-    return ld_pix, (t.stride(0) if n > 1 else h * w * ld_pix)
+        ld_pix = st[2] if st[2] >= c else (st[1] if st[1] >= c else c)
+    return ld_pix, (st[0] if n > 1 else h * w * ld_pix)
 
 
 def rows(t: torch.Tensor) -> Tuple[int, int]:
@@ -63,7 +65,29 @@ def rows(t: torch.Tensor) -> Tuple[int, int]:
     return n * h * w, ld_pix
 
 
+_DESC_CACHE = {}
+
+
+def clear_desc_cache():
+    """Forget cached descriptors and their size queries: call after changing anything those queries depend on (sgx_debug_set_tiles /
+    sgx_debug_set_variant / sgx_conv_tuning_load - the measurement tools do).  A stale size can only fail loudly: the C side checks every
+    workspace against its own requirement."""
+    _DESC_CACHE.clear()
+
+
 def conv_desc(x: torch.Tensor, K: int, R: int, S: int, stride: int, pad: int, y: Optional[torch.Tensor] = None) -> ConvDesc:
+    """The sgx_conv_desc of (x [, y]) - built and validated once per distinct (shapes, strides, filter) and shared afterwards (a training
+    loop presents the same few hundred problems every step; the C side only reads the descriptor during the call)."""
+    key = (x.shape, x.stride(), K, R, S, stride, pad, None if y is None else (y.shape, y.stride()))
+    d = _DESC_CACHE.get(key)
+    if d is None:
+        if len(_DESC_CACHE) > 65536:
+            _DESC_CACHE.clear()
+        d = _DESC_CACHE[key] = _conv_desc_build(x, K, R, S, stride, pad, y)
+    return d
+
+
+def _conv_desc_build(x, K, R, S, stride, pad, y):
     n, h, w, c = x.shape
     ho = (h + 2 * pad - R) // stride + 1
     wo = (w + 2 * pad - S) // stride + 1
@@ -76,6 +100,8 @@ def conv_desc(x: torch.Tensor, K: int, R: int, S: int, stride: int, pad: int, y:
         d.y_ld_pix, d.y_ld_img = nhwc_strides(y)
     else:
         d.y_ld_pix, d.y_ld_img = K, ho * wo * K
+    d.ref = ctypes.byref(d)  # (plain Python attributes of the ctypes object: the by-reference handle and lazily cached size queries)
+    d.wgrad_ws = d.dgrad_ws = None
     return d
 
 
@@ -111,11 +137,11 @@ def conv2d_fwd(x, w, bias=None, addend=None, out=None, act=None, stride=1, pad=0
     d = conv_desc(x, K, R, S, stride, pad, out)
     parts = None
     if stat_partials:
-        nblk = lib().sgx_conv2d_fwd_stat_blocks(ctypes.byref(d))
+        nblk = lib().sgx_conv2d_fwd_stat_blocks(d.ref)  # (not cached: it follows the tile choice, and the kernel trusts the buffer's size)
         parts = torch.empty(2, nblk, K, device=x.device, dtype=torch.float32)
     if addend is not None and nhwc_strides(addend) != nhwc_strides(out):
         raise _lib.SgxError("conv addend must share the output's strides")
-    check(lib().sgx_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(addend), ptr(out), ACT[act], ptr(parts), stream()), "sgx_conv2d_fwd")
+    check(lib().sgx_conv2d_fwd(d.ref, ptr(x), ptr(w), ptr(bias), ptr(addend), ptr(out), ACT[act], ptr(parts), stream()), "sgx_conv2d_fwd")
     return (out, parts) if stat_partials else out
 
 
@@ -127,9 +153,10 @@ def conv2d_bwd_data(dy, w, x_shape, stride=1, pad=0, addend=None, out=None, accu
     d = conv_desc(out, K, R, S, stride, pad, dy)
     if addend is not None and nhwc_strides(addend) != nhwc_strides(out):
         raise _lib.SgxError("bwd_data addend must share dx's strides")
-    nbytes = lib().sgx_conv2d_bwd_data_workspace(ctypes.byref(d))
-    ws = WORKSPACE.get(nbytes, dy.device)
-    check(lib().sgx_conv2d_bwd_data(ctypes.byref(d), ptr(dy), ptr(w), ptr(addend), ptr(out), int(accumulate), ptr(ws), ws.numel(), stream()),
+    if d.dgrad_ws is None:
+        d.dgrad_ws = lib().sgx_conv2d_bwd_data_workspace(d.ref)
+    ws = WORKSPACE.get(d.dgrad_ws, dy.device)
+    check(lib().sgx_conv2d_bwd_data(d.ref, ptr(dy), ptr(w), ptr(addend), ptr(out), int(accumulate), ptr(ws), ws.numel(), stream()),
           "sgx_conv2d_bwd_data")
     return out
 
@@ -150,7 +177,7 @@ def _wt_desc(w, stride, pad):
 
 def conv2d_transpose_weights(w, wt, stride=1, pad=0):
     d = _wt_desc(w, stride, pad)
-    check(lib().sgx_conv2d_transpose_weights(ctypes.byref(d), ptr(w), ptr(wt), wt.numel() * 4, stream()), "sgx_conv2d_transpose_weights")
+    check(lib().sgx_conv2d_transpose_weights(d.ref, ptr(w), ptr(wt), wt.numel() * 4, stream()), "sgx_conv2d_transpose_weights")
 
 
 def conv2d_transpose_jobs(w, wt, stride=1, pad=0) -> bytes:
@@ -158,7 +185,7 @@ def conv2d_transpose_jobs(w, wt, stride=1, pad=0) -> bytes:
     d = _wt_desc(w, stride, pad)
     jobs = (_lib.WtransJob * 16)()
     n = ctypes.c_int32()
-    check(lib().sgx_conv2d_transpose_jobs(ctypes.byref(d), ptr(w), ptr(wt), wt.numel() * 4, jobs, 16, ctypes.byref(n)), "sgx_conv2d_transpose_jobs")
+    check(lib().sgx_conv2d_transpose_jobs(d.ref, ptr(w), ptr(wt), wt.numel() * 4, jobs, 16, ctypes.byref(n)), "sgx_conv2d_transpose_jobs")
     return bytes(jobs)[: n.value * ctypes.sizeof(_lib.WtransJob)]
 
 
@@ -175,7 +202,7 @@ def conv2d_bwd_data_wt(dy, w, wt, x_shape, stride=1, pad=0, addend=None, out=Non
     d = conv_desc(out, K, R, S, stride, pad, dy)
     if addend is not None and nhwc_strides(addend) != nhwc_strides(out):
         raise _lib.SgxError("bwd_data addend must share dx's strides")
-    check(lib().sgx_conv2d_bwd_data_wt(ctypes.byref(d), ptr(dy), ptr(wt), ptr(addend), ptr(out), int(accumulate), stream()), "sgx_conv2d_bwd_data_wt")
+    check(lib().sgx_conv2d_bwd_data_wt(d.ref, ptr(dy), ptr(wt), ptr(addend), ptr(out), int(accumulate), stream()), "sgx_conv2d_bwd_data_wt")
     return out
 
 
@@ -188,9 +215,9 @@ def conv2d_fwd_dual(x, w, w1p, bias1, stride=1):
     y = torch.empty(conv_out_shape(x, K, R, S, stride, R // 2), device=x.device, dtype=torch.float32)
     u = torch.empty_like(y)
     d = conv_desc(x, K, R, S, stride, R // 2, y)
-    nblk = lib().sgx_conv2d_fwd_dual_stat_blocks(ctypes.byref(d))
+    nblk = lib().sgx_conv2d_fwd_dual_stat_blocks(d.ref)
     stat5 = torch.empty(5, nblk, K, device=x.device, dtype=torch.float32)
-    check(lib().sgx_conv2d_fwd_dual(ctypes.byref(d), ptr(x), ptr(w), ptr(w1p), ptr(bias1), ptr(y), ptr(u), ptr(stat5), stream()), "sgx_conv2d_fwd_dual")
+    check(lib().sgx_conv2d_fwd_dual(d.ref, ptr(x), ptr(w), ptr(w1p), ptr(bias1), ptr(y), ptr(u), ptr(stat5), stream()), "sgx_conv2d_fwd_dual")
     return y, u, stat5
 
 
@@ -207,7 +234,7 @@ def conv2d_bwd_data_dual(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, ou
     a2l, a2i = nhwc_strides(addend2) if addend2 is not None else (0, 0)
     a2_dev = addend2_scale if torch.is_tensor(addend2_scale) else None
     a2s = 1.0 if addend2_scale is None or a2_dev is not None else float(addend2_scale)
-    check(lib().sgx_conv2d_bwd_data_dual(ctypes.byref(d), ptr(dy), ptr(wt), ptr(ds), sl, si, ptr(w1pt), ptr(addend), ptr(addend2), a2l, a2i, a2s,
+    check(lib().sgx_conv2d_bwd_data_dual(d.ref, ptr(dy), ptr(wt), ptr(ds), sl, si, ptr(w1pt), ptr(addend), ptr(addend2), a2l, a2i, a2s,
                                          ptr(a2_dev), ptr(out), int(accumulate), stream()), "sgx_conv2d_bwd_data_dual")
     return out
 
@@ -230,7 +257,7 @@ def qarep_fwd_finalize(stat5, M, bias1, bn3, pbn):
     nblk, C = stat5.shape[1], stat5.shape[2]
     cf = torch.empty(4, C, device=stat5.device, dtype=torch.float32)
     sv = torch.empty(8, C, device=stat5.device, dtype=torch.float32)
-    ws = WORKSPACE.get(lib().sgx_qarep_workspace(nblk, C), stat5.device)
+    ws = WORKSPACE.get(_qarep_workspace(nblk, C), stat5.device)
     check(lib().sgx_qarep_fwd_finalize(ptr(stat5), nblk, M, C, ptr(bias1), ptr(bn3.weight), ptr(bn3.bias), bn3.eps, bn3.momentum, ptr(bn3.running_mean),
                                        ptr(bn3.running_var), ptr(pbn.weight), ptr(pbn.bias), pbn.eps, pbn.momentum, ptr(pbn.running_mean),
                                        ptr(pbn.running_var), ptr(cf), ptr(sv), ptr(ws), ws.numel(), stream()), "sgx_qarep_fwd_finalize")
@@ -247,7 +274,7 @@ def qarep_bwd(dout, y, u, cf, sv, bn3, pbn, act):
     parts = torch.empty(4, nblk, C, device=y.device, dtype=torch.float32)
     check(lib().sgx_qarep_bwd_reduce(ptr(dout), dl, ptr(y), yl, ptr(u), ul, ptr(cf), ptr(sv), M, C, a, ptr(parts), stream()), "sgx_qarep_bwd_reduce")
     cb = torch.empty(5, C, device=y.device, dtype=torch.float32)
-    ws = WORKSPACE.get(lib().sgx_qarep_workspace(nblk, C), y.device)
+    ws = WORKSPACE.get(_qarep_workspace(nblk, C), y.device)
     check(lib().sgx_qarep_bwd_finalize(ptr(parts), nblk, M, C, ptr(bn3.weight), ptr(pbn.weight), ptr(sv), ptr(bn3.weight.grad), ptr(pbn.weight.grad),
                                        ptr(pbn.bias.grad), ptr(cb), ptr(ws), ws.numel(), stream()), "sgx_qarep_bwd_finalize")
     check(lib().sgx_qarep_bwd_apply(ptr(dout), dl, ptr(y), yl, ptr(u), ul, ptr(cf), ptr(sv), ptr(cb), ptr(u), ul, ptr(y), yl, M, C, a, stream()),
@@ -260,9 +287,10 @@ def conv2d_bwd_weight(x, dy, dw, dbias=None, stride=1, pad=0):
     K, C, R, S = dw.shape
     _chk_w(dw, K, R, S, x.shape[3])
     d = conv_desc(x, K, R, S, stride, pad, dy)
-    nbytes = lib().sgx_conv2d_bwd_weight_workspace(ctypes.byref(d))
-    ws = WORKSPACE.get(nbytes, x.device)
-    check(lib().sgx_conv2d_bwd_weight(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), stream()), "sgx_conv2d_bwd_weight")
+    if d.wgrad_ws is None:
+        d.wgrad_ws = lib().sgx_conv2d_bwd_weight_workspace(d.ref)
+    ws = WORKSPACE.get(d.wgrad_ws, x.device)
+    check(lib().sgx_conv2d_bwd_weight(d.ref, ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), stream()), "sgx_conv2d_bwd_weight")
 
 
 def _chk_wt(wt, C, K):
@@ -393,8 +421,24 @@ def nhwc_to_nchw(x):
 
 
 # --------------------------------------------------------------------------------------------- batch norm & sweeps
+@functools.lru_cache(maxsize=None)
 def stats_blocks(M: int) -> int:
     return lib().sgx_stats_blocks(M)
+
+
+@functools.lru_cache(maxsize=None)
+def _reduce_workspace(nblk: int, C: int) -> int:
+    return lib().sgx_reduce_workspace(nblk, C)
+
+
+@functools.lru_cache(maxsize=None)
+def _qarep_workspace(nblk: int, C: int) -> int:
+    return lib().sgx_qarep_workspace(nblk, C)
+
+
+@functools.lru_cache(maxsize=None)
+def _dot_workspace(M: int, C: int) -> int:
+    return lib().sgx_dot_workspace(M, C)
 
 
 def channel_stats_partial(x):
@@ -409,10 +453,11 @@ def bn_finalize(parts, M, gamma, beta, eps, momentum, running_mean, running_var)
     """-> scale, shift, save_mean, save_invstd (each [C]); running stats updated in place."""
     C = parts.shape[2]
     st = torch.empty(4, C, device=parts.device, dtype=torch.float32)
-    ws = WORKSPACE.get(lib().sgx_reduce_workspace(parts.shape[1], C), parts.device)
+    ws = WORKSPACE.get(_reduce_workspace(parts.shape[1], C), parts.device)
+    p0, row = ptr(st), 4 * C  # rows of st: scale, shift, save_mean, save_invstd
     check(lib().sgx_bn_finalize(ptr(parts), parts.shape[1], M, C, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean), ptr(running_var),
-                                ptr(st[2]), ptr(st[3]), ptr(st[0]), ptr(st[1]), ptr(ws), ws.numel(), stream()), "sgx_bn_finalize")
-    return st[0], st[1], st[2], st[3]
+                                p0 + 2 * row, p0 + 3 * row, p0, p0 + row, ptr(ws), ws.numel(), stream()), "sgx_bn_finalize")
+    return st.unbind(0)
 
 
 def _allreduce_sums(sums):
@@ -426,7 +471,7 @@ def bn_finalize_sync(parts, M, gamma, beta, eps, momentum, running_mean, running
     """bn_finalize with the statistics summed over all data-parallel ranks (equal per-rank element counts, as DistributedSampler
     guarantees): one 2*C fp64 all-reduce."""
     C = parts.shape[2]
-    ws = WORKSPACE.get(lib().sgx_reduce_workspace(parts.shape[1], C), parts.device)
+    ws = WORKSPACE.get(_reduce_workspace(parts.shape[1], C), parts.device)
     sums = torch.empty(2, C, device=parts.device, dtype=torch.float64)
     check(lib().sgx_bn_reduce_sums(ptr(parts), parts.shape[1], C, ptr(sums), ptr(ws), ws.numel(), stream()), "sgx_bn_reduce_sums")
     world = _allreduce_sums(sums)
@@ -470,7 +515,7 @@ def bn_bwd(dy, x, scale, shift, gamma, save_mean, save_invstd, dgamma, dbeta, ac
         parts = torch.empty(2, stats_blocks(M), C, device=x.device, dtype=torch.float32)
         check(lib().sgx_bn_bwd_reduce(ptr(dy), dl, ptr(x), ld, ptr(scale), ptr(shift), ptr(save_mean), M, C, a, ptr(parts), stream()), "sgx_bn_bwd_reduce")
     coef = torch.empty(4, C, device=x.device, dtype=torch.float32)
-    ws = WORKSPACE.get(lib().sgx_reduce_workspace(parts.shape[1], C), x.device)
+    ws = WORKSPACE.get(_reduce_workspace(parts.shape[1], C), x.device)
     if sync:
         local = torch.empty(2, C, device=x.device, dtype=torch.float64)
         check(lib().sgx_bn_reduce_sums(ptr(parts), parts.shape[1], C, ptr(local), ptr(ws), ws.numel(), stream()), "sgx_bn_reduce_sums")
@@ -492,7 +537,7 @@ def dot_sum(a, b, out, accumulate=True, scale=1.0):
     """out[0] (+)= scale * sum(a*b) over NHWC views a, b."""
     M, la = rows(a)
     C = a.shape[3]
-    ws = WORKSPACE.get(lib().sgx_dot_workspace(M, C), a.device)
+    ws = WORKSPACE.get(_dot_workspace(M, C), a.device)
     check(lib().sgx_dot(ptr(a), la, ptr(b), rows(b)[1], M, C, float(scale), ptr(out), int(accumulate), ptr(ws), ws.numel(), stream()), "sgx_dot")
 
 
@@ -806,6 +851,7 @@ def set_conv_math(mode: str):
     bf16 matrix pipe with fp32 accumulation - fp32-accurate, 2.7x fewer matrix-pipe cycles.  "auto": bf16x3 for reductions of depth
     (taps x channels) >= 192, fp32 MFMA for shallow ones (include/sgx_hip.h: sgx_conv_set_math)."""
     check(lib().sgx_conv_set_math(CONV_MATH[mode]), "sgx_conv_set_math")
+    clear_desc_cache()
 
 
 def get_conv_math() -> str:

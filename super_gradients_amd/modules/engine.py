@@ -29,6 +29,14 @@ def _round_up(v, m):
 class SgxBlock(nn.Module):
     """Base of every block that runs on libsgx_hip kernels."""
 
+    def __setattr__(self, name, value):
+        # per-call state (`self._ctx = ...`, `self._x = x`: ~250 assignments per train step) bypasses nn.Module's parameter / buffer /
+        # sub-module bookkeeping, which only matters for public names and for Parameter / Module values
+        if name[0] == "_" and not isinstance(value, nn.Module) and not getattr(value, "_is_param", False):
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
     def fwd(self, x, out=None):
         raise NotImplementedError
 
@@ -202,6 +210,16 @@ class SgxNetwork(nn.Module):
         if recs:
             self._qp_njobs = len(recs)
             self._qp_jobs = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(device)
+        # Sub-modules, parameters and buffers are fixed objects from here on (arena views never move, load_state_dict copies in place, the
+        # network refuses to be moved): mirror them into the instance dictionaries so that `self.bn.weight` is a plain attribute read
+        # instead of nn.Module.__getattr__'s three dictionary probes (~2400 of those per YOLO-NAS-S train step).  nn.Module.__setattr__
+        # drops the mirror entry if a name is ever re-assigned, so the registries stay authoritative.
+        for m in self.modules():
+            if isinstance(m, (SgxBlock, SgxNetwork)):
+                for table in (m._modules, m._parameters, m._buffers):
+                    for name, v in table.items():
+                        if v is not None:
+                            m.__dict__[name] = v
 
     _RUNTIME_ATTRS = ("side_stream", "aux_stream", "_wt_jobs", "_qp_jobs", "_dgrad_convs")
 

@@ -61,6 +61,7 @@ def main():
                 v, (bm, bn) = cfg
                 lib().sgx_debug_set_variant(v)
                 lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                K.clear_desc_cache()
                 try:
                     fn()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -74,6 +75,7 @@ def main():
                     res[cfg].append(float("nan"))
         lib().sgx_debug_set_variant(0)
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
+        K.clear_desc_cache()
         med = {cfg: statistics.median(v) for cfg, v in res.items()}
         lines.append(f"{spec:<34}" + "".join(f"{flops / med[cfg] / 1e6:>14.1f}" for cfg in configs))
         lines.append(f"{'':<34}" + "".join(f"{med[cfg]:>14.1f}" for cfg in configs))

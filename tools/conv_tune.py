@@ -78,6 +78,7 @@ def main():
         kind = key[0]
         fn, flops = CB.make_runner(key, dev)
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
+        K.clear_desc_cache()
         base = timeit(fn)
         best, best_cfg = base, "heuristic"
         if kind in ("fwd2", "dgrad2"):
@@ -88,6 +89,7 @@ def main():
             for bm in (64, 128):
                 for bn in (32, 64, 96, 128):
                     lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                    K.clear_desc_cache()
                     t = timeit(fn)
                     note(key, calls, (bm, bn, 0), t)
                     if t < best:
@@ -97,6 +99,7 @@ def main():
             for bm in (0, 64, 128):
                 for bn in ((0,) if bm == 0 else (32, 64, 96, 128)):
                     lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                    K.clear_desc_cache()
                     t = timeit(fn)
                     note(key, calls, (bm, bn, 7), t)
                     if t < best:
@@ -108,11 +111,13 @@ def main():
                 for bj in (32, 64, 96, 128):
                     for split in (2048, 4096, 8192):
                         lib().sgx_debug_set_tiles(0, 0, bnk, bj, split)
+                        K.clear_desc_cache()
                         t = timeit(fn)
                         note(key, calls, (bnk, bj, split), t)
                         if t < best:
                             best, best_cfg = t, f"bnk={bnk} bj={bj} split={split}"
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
+        K.clear_desc_cache()
         tot_base += calls * base
         tot_best += calls * best
         lines.append((calls * (base - best), f"{kind:<6}{key[1:11]} x{calls:<3} heuristic {base:8.1f} us  best {best:8.1f} us ({flops / best / 1e6:6.1f} TF)  {best_cfg}"))
