@@ -89,3 +89,48 @@ class LossesFactory(BaseFactory):
 class CallbacksFactory(BaseFactory):
     def __init__(self):
         super().__init__(CALLBACKS)
+
+
+class MetricsFactory(BaseFactory):
+    def __init__(self):
+        from .registry import METRICS
+
+        super().__init__(METRICS)
+
+
+def _target_table():
+    """Short class name -> class for hydra-style `_target_: dotted.path.ClassName` entries of the reference's recipes: the recipe names the
+    reference's module path, the class of the same name registered here is what gets built."""
+    from . import registry as R
+    from ..training.models.detection_models.pp_yolo_e.post_prediction_callback import PPYoloEPostPredictionCallback
+
+    table = {"PPYoloEPostPredictionCallback": PPYoloEPostPredictionCallback, "empty_list": list}
+    for reg in (R.METRICS, R.LOSSES, R.CALLBACKS, R.ALL_DETECTION_MODULES, R.PROCESSINGS, R.LR_SCHEDULERS_CLS_DICT, R.LR_WARMUP_CLS_DICT):
+        for k, v in reg.items():
+            if isinstance(k, str) and not k.startswith("_") and isinstance(v, type):
+                table.setdefault(v.__name__, v)
+    return table
+
+
+_EXP_FLOAT = re.compile(r"^[+-]?\d+(\.\d*)?[eE][+-]?\d+$")
+
+
+def resolve_recipe_values(conf):
+    """Recursively turn the plain containers of a recipe (yaml.safe_load of the reference's training_hyperparams files, or an
+    already-resolved hydra config) into objects: `{_target_: a.b.Class, **kwargs}` -> Class(**kwargs) by short class name, and exponent-form
+    numbers that YAML 1.1 loaders leave as strings (`2e-4`, `1e-6` - hydra/omegaconf parse them as floats) -> float.  Anything else is
+    returned unchanged."""
+    if isinstance(conf, Mapping):
+        if "_target_" in conf:
+            name = str(conf["_target_"]).rsplit(".", 1)[-1]
+            table = _target_table()
+            if name not in table:
+                raise UnknownTypeException(name, sorted(table))
+            kwargs = {k: resolve_recipe_values(v) for k, v in conf.items() if k not in ("_target_", "_convert_", "_recursive_", "_partial_")}
+            return table[name](**kwargs)
+        return {k: resolve_recipe_values(v) for k, v in conf.items()}
+    if isinstance(conf, (list, tuple)):
+        return type(conf)(resolve_recipe_values(v) for v in conf)
+    if isinstance(conf, str) and _EXP_FLOAT.match(conf):
+        return float(conf)
+    return conf

@@ -162,12 +162,22 @@ class Trainer:
             raise ValueError(f"training_params is missing required entries {missing} (required: {list(REQUIRED)})")
         merged = dict(DEFAULT_TRAINING_PARAMS)
         merged.update(given)
+        # a recipe file's own containers (yaml.safe_load of training_hyperparams/*.yaml): `_target_` entries and exponent-form numbers
+        from ...common.factories import resolve_recipe_values
+
+        keep = {k: merged.pop(k) for k in ("loss", "optimizer", "phase_callbacks", "warmup_mode", "lr_mode") if k in merged and not isinstance(merged[k], (str, dict, list))}
+        merged = resolve_recipe_values(merged)
+        merged.update(keep)
         if merged["mixed_precision"]:
             warnings.warn("mixed_precision=True is accepted for recipe compatibility; the MI355X path computes in fp32 (parity mode)")
         return HpmStruct(**merged)
 
     def _build_loss(self, tp):
         loss = tp.loss
+        if isinstance(loss, Mapping):  # {LossName: {kwargs}} (LossesFactory)
+            from ...common.factories import LossesFactory
+
+            loss = LossesFactory().get(loss)
         if isinstance(loss, str):
             warn_if_deprecated(loss, LOSSES)
             if loss not in LOSSES:
@@ -234,8 +244,10 @@ class Trainer:
         lr_callbacks = self._build_lr_callbacks(tp, len(train_loader))
         self.ema_model = ModelEMA.from_params(self.net, **dict(tp.ema_params or {})) if tp.ema else None
         handler = CallbackHandler(lr_callbacks + list(tp.phase_callbacks or []))
-        valid_metrics = [METRICS[m]() if isinstance(m, str) else m for m in (tp.valid_metrics_list or [])]
-        train_metrics = [METRICS[m]() if isinstance(m, str) else m for m in (tp.train_metrics_list or [])]
+        from ...common.factories import MetricsFactory
+
+        valid_metrics = [MetricsFactory().get(m) for m in (tp.valid_metrics_list or [])]  # name / {Name: kwargs} / instance
+        train_metrics = [MetricsFactory().get(m) for m in (tp.train_metrics_list or [])]
         context = PhaseContext(optimizer=self.optimizer, net=self.net, criterion=self.criterion, experiment_name=self.experiment_name,
                                ckpt_dir=self.checkpoints_dir_path, train_loader=train_loader, valid_loader=valid_loader, training_params=tp,
                                ema_model=self.ema_model, metric_to_watch=tp.metric_to_watch, valid_metrics=valid_metrics, lr_warmup_epochs=tp.lr_warmup_epochs,

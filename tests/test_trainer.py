@@ -256,3 +256,71 @@ def test_batched_weight_transposes_do_not_change_the_step(backend, monkeypatch):
         results.append(outs)
     for (y0, g0), (y1, g1) in zip(*results):
         assert torch.equal(y0, y1) and torch.equal(g0, g1)
+
+
+def _yolo_nas_recipe_containers(num_classes=3):
+    """training_hyperparams/coco2017_yolo_nas_train_params.yaml over default_train_params.yaml as yaml.safe_load leaves them (the reference's
+    files when /root/reference is present; otherwise the same entries written out), `${arch_params.num_classes}` - a hydra interpolation -
+    substituted.  Exponent-form numbers arrive as strings from a YAML 1.1 loader, `_target_` entries as plain mappings."""
+    ref = "/root/reference/src/super_gradients/recipes/training_hyperparams/"
+    if os.path.isdir(ref):
+        import yaml
+
+        tp = yaml.safe_load(open(ref + "default_train_params.yaml"))
+        tp.update(yaml.safe_load(open(ref + "coco2017_yolo_nas_train_params.yaml")))
+        tp.pop("defaults", None)
+    else:
+        tp = dict(max_epochs=300, warmup_mode="LinearBatchLRWarmup", warmup_initial_lr="1e-6", lr_warmup_steps=1000, lr_warmup_epochs=0, initial_lr="2e-4",
+                  lr_mode="CosineLRScheduler", cosine_final_lr_ratio=0.1, zero_weight_decay_on_bias_and_bn=True, batch_accumulate=1,
+                  save_ckpt_epoch_list=[100, 200, 250], loss="PPYoloELoss", criterion_params=dict(use_static_assigner=False, num_classes="${arch_params.num_classes}"),
+                  optimizer="AdamW", optimizer_params=dict(weight_decay=0.00001), ema=True, ema_params=dict(decay=0.9997, decay_type="threshold"),
+                  mixed_precision=False, sync_bn=True, lr_updates={"_target_": "super_gradients.training.utils.utils.empty_list"},
+                  valid_metrics_list=[{"DetectionMetrics": dict(
+                      score_thres=0.1, top_k_predictions=300, num_cls="${arch_params.num_classes}", normalize_targets=True,
+                      post_prediction_callback={"_target_": "super_gradients.training.models.detection_models.pp_yolo_e.PPYoloEPostPredictionCallback",
+                                                "score_threshold": 0.01, "nms_top_k": 1000, "max_predictions": 300, "nms_threshold": 0.7})}],
+                  pre_prediction_callback=None, metric_to_watch="mAP@0.50:0.95", greater_metric_to_watch_is_better=True, _convert_="all")
+
+    def sub(o):
+        if isinstance(o, dict):
+            return {k: sub(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [sub(v) for v in o]
+        return num_classes if o == "${arch_params.num_classes}" else o
+
+    return sub(tp)
+
+
+def test_reference_recipe_containers_resolve(tmp_path):
+    """The reference's YOLO-NAS recipe as a YAML loader hands it over is accepted as it is: exponent-form strings become numbers, the
+    `_target_` entries (post-prediction callback of the metric, the empty lr_updates list) become objects of the classes registered here, the
+    metric list goes through the factory."""
+    from super_gradients_amd.common.factories import MetricsFactory
+    from super_gradients_amd.training import Trainer
+    from super_gradients_amd.training.metrics import DetectionMetrics
+    from super_gradients_amd.training.models.detection_models.pp_yolo_e.post_prediction_callback import PPYoloEPostPredictionCallback
+
+    tp = Trainer("recipe", ckpt_root_dir=str(tmp_path))._params(_yolo_nas_recipe_containers())
+    assert tp.initial_lr == 2e-4 and tp.warmup_initial_lr == 1e-6 and tp.optimizer_params["weight_decay"] == 1e-5
+    assert tp.lr_updates == [] and tp.sync_bn is True and tp.ema_params["decay_type"] == "threshold"
+    (m,) = [MetricsFactory().get(c) for c in tp.valid_metrics_list]
+    assert isinstance(m, DetectionMetrics) and isinstance(m.post_prediction_callback, PPYoloEPostPredictionCallback)
+    assert m.post_prediction_callback.nms_top_k == 1000 and m.score_threshold == 0.1 and m.top_k_predictions == 300
+    assert tp.metric_to_watch in m.component_names
+
+
+@pytest.mark.gpu
+def test_reference_recipe_dict_trains(gpu_device, tmp_path):
+    """... and one epoch of it runs: YOLO-NAS-S, the recipe's own loss / optimizer / EMA / warm-up + cosine / DetectionMetrics entries."""
+    from super_gradients_amd.training import Trainer, models
+    from util import synthetic_targets
+
+    tp = _yolo_nas_recipe_containers(num_classes=3)
+    tp.update(max_epochs=1, lr_warmup_steps=2, sync_bn=False)
+    net = models.get("yolo_nas_s", num_classes=3)
+    g = torch.Generator().manual_seed(0)
+    loader = [(torch.rand(2, 3, 128, 128, generator=g), synthetic_targets(2, seed=i, size=128, num_classes=3)) for i in range(3)]
+    res = Trainer("recipe_run", ckpt_root_dir=str(tmp_path)).train(net, training_params=tp, train_loader=loader, valid_loader=loader[:1])
+    row = res[-1] if isinstance(res, list) else res
+    assert np.isfinite(row["train"]["loss"]) and "mAP@0.50:0.95" in row["valid"]
+    assert os.path.exists(os.path.join(str(tmp_path), "recipe_run", "ckpt_latest.pth"))
