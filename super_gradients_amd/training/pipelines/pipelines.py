@@ -63,11 +63,16 @@ class Pipeline(ABC):
     def __init__(self, model, image_processor: Union[Processing, List[Processing]], class_names: List[str], device: Optional[str] = None,
                  fuse_model: bool = True, dtype: Optional[torch.dtype] = None, fp16: bool = True):
         self.model = model
-        if device is not None:
-            self.device = torch.device(device)
+        if getattr(model, "_materialized", False):
+            self.device = model._device  # a materialised model lives in its HBM arenas and cannot move (the reference moves the model here)
+            if device is not None and torch.device(device).type != self.device.type:
+                raise RuntimeError(f"the model is materialised on {self.device}; predict(device={device!r}) cannot move it")
         else:
-            p = next(iter(model.parameters()), None)
-            self.device = p.device if p is not None and getattr(model, "_materialized", True) else torch.device("cuda")
+            from ... import _lib
+
+            self.device = torch.device(device) if device is not None else torch.device("cpu" if _lib._TEST_HOST_MODE else "cuda")
+            if hasattr(model, "materialize"):
+                model.materialize(self.device)  # before the fused copy is taken: fusion reads the arena views
         self.dtype = dtype or torch.float32
         self.class_names = class_names
         if isinstance(image_processor, list):

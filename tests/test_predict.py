@@ -344,3 +344,18 @@ def test_processing_params_round_trip_through_checkpoint(tmp_path):
     got = tr._get_preprocessing_from_valid_loader(_Loader())
     assert got["conf"] == 0.25 and isinstance(got["image_processor"], ComposeProcessing)
     assert tr._get_preprocessing_from_valid_loader(object()) is None
+
+
+def test_predict_on_a_fresh_model(backend):
+    """models.get(...) -> set_dataset_processing_params -> predict() with nothing in between (the reference's usual call sequence): the
+    pipeline materialises the model in HBM before it takes the fused copy."""
+    from super_gradients_amd.training import models
+    from super_gradients_amd.training.utils.predict import ImageDetectionPrediction
+
+    net = models.get("yolo_nas_s", num_classes=3, arch_params=None if backend.type == "cuda" else _shrunk_arch())
+    net.set_dataset_processing_params(class_names=["a", "b", "c"], conf=0.0, image_processor=[
+        {"DetectionCenterPadding": {"output_shape": (32, 32), "pad_value": 114}}, {"StandardizeImage": {"max_value": 255.0}}])
+    img = np.random.default_rng(0).integers(0, 256, (30, 28, 3), dtype=np.uint8)
+    res = net.predict(img, max_predictions=3)
+    assert isinstance(res, ImageDetectionPrediction) and len(res.prediction) == 3 and net._materialized
+    assert res.prediction.bboxes_xyxy.dtype == np.float32 and res.prediction.labels.dtype.kind == "i"
