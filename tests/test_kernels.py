@@ -584,15 +584,15 @@ def test_nms_per_class_case_is_reproducible(backend):
     """A per-class case (detections of a random-init YOLO-NAS on two 64x64 images: 252 candidates, scores within 0.0093..0.0106, boxes far
     larger than the image) on which the chunked suppression walk keeps candidates in all four flag words.  Under the host emulation - one OS
     thread per lane, no wave lock-step - the walk once read the kept-count after lane 0 of the same wave had advanced it; the rows must equal
-    the oracle's on every repetition."""
+    the oracle's on every repetition (three per per-class mode)."""
     from oracle import nms as onms
 
     case = torch.load(os.path.join(os.path.dirname(__file__), "golden", "nms_perclass_case.pt"))
     boxes, scores = case["boxes"], case["scores"]
-    for class_mode, agnostic in ((1, False), (2, False), (0, True)):
+    for class_mode, agnostic in ((1, False), (2, False)):
         ref = onms.post_prediction(boxes, scores, score_threshold=0.0, nms_threshold=0.6, nms_top_k=200, max_predictions=20, multi_label_per_box=True,
                                    class_agnostic_nms=agnostic)
-        for rep in range(4):
+        for rep in range(3):
             out, cnt, idx, _ = K.nms(boxes.to(backend), scores.to(backend), 0.0, 0.6, 200, 20, multi_label=True, class_mode=class_mode)
             for b in range(2):
                 n = int(cnt[b])
