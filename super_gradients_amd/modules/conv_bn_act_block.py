@@ -19,17 +19,43 @@ from .layers import BatchNorm, ConvLayer, act_name
 class _ConvBN(SgxBlock):
     """Shared implementation; subclasses only choose where `conv`/`bn` are registered (key names)."""
 
+    _folded = None  # (filter with the BatchNorm scale folded in, shift as bias): eval form set by prep_model_for_conversion
+
     def _parts(self):
         raise NotImplementedError
 
     def on_materialize(self):
         pass
 
+    def prep_model_for_conversion(self, input_size=None, **kwargs):
+        """Eval form as ONE launch: act(conv(x, w * s[k]) + t[k]) with s = gamma / sqrt(running_var + eps), t = beta - running_mean * s -
+        bias and activation live in the conv epilogue, the BatchNorm apply sweep and the scale/shift kernel of the eval path disappear.
+        What torch.nn.utils.fusion.fuse_conv_bn_eval does for the reference's export paths; here the parameters stay as they are (the block
+        still trains: train() drops the folded copy), only eval-mode forward reads the folded filter.  One-off preparation in torch ops."""
+        conv, bn = self._parts()
+        w = conv._w
+        if w is None:
+            raise RuntimeError("prep_model_for_conversion needs a materialised model (the fold reads the arena views)")
+        K_, C_, R_, S_ = w.shape
+        if w.stride() != (R_ * S_ * C_, 1, S_ * C_, C_):  # channel-padded filters (C % 4 != 0): keep the general eval sequence
+            return
+        with torch.no_grad():
+            s = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+            wf = K.ohwi_empty(K_, C_, R_, S_, w.device)
+            wf.copy_(w.detach() * s.view(-1, 1, 1, 1))
+            self._folded = (wf, (bn.bias.detach() - bn.running_mean * s).contiguous())
+
+    def train(self, mode: bool = True):
+        if mode:
+            self._folded = None  # the weights are about to change
+        return super().train(mode)
+
     def fwd(self, x, out=None, post_add=None):
         """post_add: tensor added AFTER the activation (pp_yolo_head.py:205 `stem_cls(feat, avg_feat) + feat`); its gradient is the
         caller's (dy reaches it unchanged)."""
         conv, bn = self._parts()
         if self.training:
+            self._folded = None  # a training step follows: a folded eval filter would be stale afterwards
             t, parts = conv.conv(x, stats=True)
             M = t.shape[0] * t.shape[1] * t.shape[2]
             scale, shift, mean, invstd = bn.scale_shift(parts, M, True)
@@ -39,6 +65,8 @@ class _ConvBN(SgxBlock):
                 y = K.dual_affine_act(t, scale, shift, post_add=post_add, act=self.act, out=out)
             self._ctx = (x, t, scale, shift, mean, invstd)
             return y
+        if self._folded is not None and post_add is None:
+            return K.conv2d_fwd(x, self._folded[0], bias=self._folded[1], out=out, act=self.act, stride=conv.stride, pad=conv.padding)
         t = conv.conv(x)
         scale, shift, _, _ = bn.scale_shift(None, 0, False)
         if post_add is not None:

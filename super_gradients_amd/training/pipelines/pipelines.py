@@ -6,7 +6,8 @@ protocol (`pipeline(images, batch_size)`) and result containers; what differs is
   reference (per batch)                                    here
   image_processor.preprocess_image per image, numpy/cv2    ONE launch for the batch (ComposeProcessing.preprocess_batch, csrc/image.hip)
   np.array(list) -> torch.from_numpy -> .to(device)        raw uint8 images are uploaded, the fp32 batch is born in HBM
-  deepcopy + prep_model_for_conversion on first batch      same (QARepVGG / RepVGG blocks collapse to their fused convolution)
+  deepcopy + prep_model_for_conversion on first batch      same, full fusion (QARepVGG / RepVGG blocks and every conv+BN pair become ONE conv launch
+                                                           with bias + activation in its epilogue)
   autocast(fp16) forward                                   fp32 forward on the MFMA fp32 path (fp16 is accepted and ignored: the build has no
                                                            reduced-precision convolution; results are at least as precise as the reference's)
   post_prediction_callback (python loop + torchvision)     the batched NMS kernels (csrc/nms.hip)
@@ -89,7 +90,9 @@ class Pipeline(ABC):
             self.model._pipeline_cache = cache
         self.model = fused
         self.model.eval()
-        self.model.prep_model_for_conversion(input_size=input_size)
+        # the copy is private to this pipeline and inference-only, so it takes the deepest form every block offers (the reference's call
+        # leaves QARepVGG blocks partially fused - post-BN as a separate op - because its copy stays trainable): same function, fewer passes
+        self.model.prep_model_for_conversion(input_size=input_size, full_fusion=True)
         self.fuse_model = False
 
     def __call__(self, inputs, batch_size: Optional[int] = 32):

@@ -182,6 +182,44 @@ def test_oracle_qarepvgg_alpha_live(stride):
     assert torch.equal(xr.grad, xo.grad) and torch.equal(r.alpha.grad, o.alpha.grad)
 
 
+@pytest.mark.parametrize("k,s", [(1, 1), (3, 2)])
+def test_conv_block_folded_eval_form(backend, k, s):
+    """prep_model_for_conversion on a Conv block: eval forward = ONE conv launch with the BatchNorm folded into filter and bias and the
+    activation in the epilogue; equal to the unfolded eval sequence and to the oracle within fp32 round-off; the parameters are untouched
+    and a training forward drops the folded copy (it would be stale after the step)."""
+    from oracle.yolo_nas import ConvBnAct
+    from super_gradients_amd.modules import Conv
+
+    n, cin, cout, h, w = _shape(backend, (2, 32, 64, 20, 20), (1, 8, 8, 6, 6))
+    ref = ConvBnAct(cin, cout, k, s)
+    _randomize(ref, 3)
+    blk = Conv(cin, cout, k, s, "relu")
+    blk.bn.eps, blk.bn.momentum = 1e-3, 0.03  # the YOLO-NAS arch values the oracle blocks are built with
+    net = _wrap(blk, backend)
+    blk.load_state_dict(ref.state_dict(), strict=True)
+    x = torch.randn(n, cin, h, w, generator=torch.Generator().manual_seed(1))
+    ref.eval()
+    net.eval()
+    with torch.no_grad():
+        y_ref = ref(x)
+        y0 = to_nchw_cpu(blk.fwd(to_nhwc(x, backend)))
+        before = {kk: v.clone() for kk, v in blk.state_dict().items()}
+        net.prep_model_for_conversion(input_size=(h, w))
+        assert blk._folded is not None
+        y1 = to_nchw_cpu(blk.fwd(to_nhwc(x, backend)))
+    assert_close(y1, y0, 1e-5, "folded vs unfolded eval form")
+    assert_close(y1, y_ref, 2e-5, "folded eval form vs oracle")
+    assert all(torch.equal(v, blk.state_dict()[kk]) for kk, v in before.items())
+    net.train()
+    assert blk._folded is None
+    net.eval()
+    net.prep_model_for_conversion(input_size=(h, w))
+    net.train()
+    blk._folded = ("stale",)  # e.g. prepared while in training mode
+    blk.fwd(to_nhwc(x, backend))
+    assert blk._folded is None
+
+
 @pytest.mark.parametrize("two_branch", [False, True])
 @pytest.mark.parametrize("concat", [False, True])
 def test_csp_layer(backend, concat, two_branch):

@@ -240,7 +240,7 @@ def test_predict_pipeline(backend):
     images = [rng.integers(0, 256, s, dtype=np.uint8) for s in [(25, 35, 3), (45, 20, 3)]]
     net.train()
     res = net.predict(images, batch_size=2, max_predictions=10, nms_top_k=40)
-    assert net.training and not any(m.partially_fused for m in net.modules() if isinstance(m, QARepVGGBlock))  # the caller's model is untouched
+    assert net.training and not any(m.partially_fused or m.fully_fused for m in net.modules() if isinstance(m, QARepVGGBlock))  # the caller's model is untouched
     assert isinstance(res, ImagesDetectionPrediction) and len(res) == 2
 
     # the same stages by hand
@@ -248,7 +248,7 @@ def test_predict_pipeline(backend):
     pipe = net._get_pipeline(max_predictions=10, nms_top_k=40)
     assert pipe is net._get_pipeline(max_predictions=10, nms_top_k=40)  # cached per argument set
     fused = pipe.model
-    assert fused is not net and all(m.partially_fused for m in fused.modules() if isinstance(m, QARepVGGBlock))
+    assert fused is not net and all(m.fully_fused for m in fused.modules() if isinstance(m, QARepVGGBlock))
     cb = net.get_post_prediction_callback(conf=0.0, iou=0.6, nms_top_k=40, max_predictions=10, multi_label_per_box=True, class_agnostic_nms=False)
     for start in (0,):
         chunk = images[start:start + 2]
