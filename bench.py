@@ -189,6 +189,36 @@ def nms_leg(device, iters=100, warmup=10):
                              "sample": "4 images x 1000 candidates: threshold + top-k (ATen) + oracle/nms.c"}}
 
 
+def predict_leg(device, model="s", batch=32, batches=10):
+    """Inference side of the same model, reported next to the headline number: `model.predict()` end to end on `batch`
+    synthetic 480x640 uint8 images resident in HBM with the reference's default YOLO-NAS COCO processing (longest side -> 636, centre pad to
+    640x640, /255): one device pre-processing launch, the fused eval forward (fp32), the NMS kernels, one device-to-host copy of the kept
+    rows, the reference's box maps and result objects.  A failure is reported in the object, it does not take the bench line down."""
+    import torch
+
+    try:
+        from super_gradients_amd.training import models
+        from super_gradients_amd.training.processing import default_yolo_nas_coco_processing_params
+
+        net = models.get(f"yolo_nas_{model}", num_classes=80).materialize(device)
+        net.set_dataset_processing_params(**default_yolo_nas_coco_processing_params())
+        g = torch.Generator().manual_seed(0)
+        images = [torch.randint(0, 256, (480, 640, 3), generator=g, dtype=torch.uint8).to(device) for _ in range(batch)]
+        pipe = net._get_pipeline(conf=0.01)
+        pipe(images, batch_size=batch)  # warm-up; takes the fused copy
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(batches):
+            res = pipe(images, batch_size=batch)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / batches
+        return {"value": round(batch / dt, 1), "unit": "images/s", "ms_per_batch": round(1e3 * dt, 3), "batch": batch, "dtype": "fp32",
+                "detections_first_image": len(res[0].prediction),
+                "config": f"YOLO-NAS-{model.upper()} predict(): 480x640 uint8 -> 640x640, conf 0.01, iou 0.7, fused copy, random-init weights"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
 def measured_traffic():
     """HBM bytes per igemm launch from the committed rocprofv3 PMC passes of this same command (profiles/igemm_traffic.json,
     written by tools/pmc_traffic.py from the FETCH_SIZE / WRITE_SIZE passes, with MI355X_MICROARCH.md's gfx950 correction)."""
@@ -249,6 +279,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ema", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
+    ap.add_argument("--no-predict", action="store_true", help="skip the predict() leg (YOLO-NAS only)")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the 3 extra untimed steps that time the conv kernels without the side stream")
     ap.add_argument("--sync-bn", action="store_true", help="synchronised BatchNorm across ranks (recipe setting; off in the reference's own benchmark)")
     ap.add_argument("--workload", default="yolo_nas", choices=["yolo_nas", "resnet50", "ppyoloe"],
@@ -417,6 +448,8 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(args.model, args.size, batch=args.batch, family="ppyoloe" if args.workload == "ppyoloe" else "yolo_nas")
         if not args.no_nms and world == 1:
             rec["nms"] = nms_leg(device)
+        if not args.no_predict and world == 1 and args.workload == "yolo_nas":
+            rec["predict"] = predict_leg(device, args.model, min(args.batch, 32))
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist_barrier()

@@ -24,7 +24,7 @@ if has convbench; then
   echo "convbench rc=$?" >> "$OUT/conv_bench.log"
   tail -4 "$OUT/conv_bench.log"
 fi
-PROF_CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-nms --no-exclusive"
+PROF_CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-nms --no-predict --no-exclusive"
 if has stats; then
   cd /tmp
   timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o bench -- bash -c "cd $REPO && $PROF_CMD" > "$OUT/stats.log" 2>&1
@@ -38,7 +38,7 @@ if has stats; then
   find "$OUT/stats" -name "*kernel_trace.csv" -size +8M -delete
 fi
 if has pmc; then
-  PMC_CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-nms --no-exclusive"
+  PMC_CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-nms --no-predict --no-exclusive"
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
     i=$((i+1))
