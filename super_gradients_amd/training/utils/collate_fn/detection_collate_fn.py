@@ -48,8 +48,12 @@ class DeviceDetectionCollateFN(DetectionCollateFN):
     (YOLO-NAS: DetectionStandardize(max_value=255); ImageNet-style models: / 255 then (x - mean) / std)."""
 
     def __init__(self, device="cuda", max_value: float = 255.0, mean=None, std=None, pad_to=None, pad_value=114, padding_mode: str = "bottom_right",
-                 targets_format: str = "LABEL_CXCYWH"):
-        """pad_to=(H, W): images of DIFFERENT sizes (each <= H x W) are padded on the device into one [N, C, H, W] batch - the reference's
+                 targets_format: str = "LABEL_CXCYWH", rescale_to=None):
+        """rescale_to=(H, W): the reference's last image transform of the YOLO-NAS / YOLOX dataset recipes, DetectionPaddedRescale
+        (transforms.py:945-975 -> transforms/utils.py:202-227: r = min(H / h, W / w), cv2.resize to (int(h * r), int(w * r)), bottom-right
+        pad with pad_value, boxes * r), followed by DetectionStandardize, for the WHOLE ragged batch in ONE launch from the raw uint8 images
+        (sgx_preprocess_u8_hwc; rescale arithmetic: the restated 8-bit INTER_LINEAR of csrc/image.hip).  Excludes pad_to.
+        pad_to=(H, W): images of DIFFERENT sizes (each <= H x W) are padded on the device into one [N, C, H, W] batch - the reference's
         DetectionPadIfNeeded / DetectionPadToSize (transforms.py:846-941; padding_mode "center" or "bottom_right", pad_value as there) moved
         behind the PCIe transfer, one launch per image; boxes are shifted by the padding offsets like the transform does
         (transforms/utils.py:155-166).  targets_format: "LABEL_CXCYWH" (class, cx, cy, w, h - what the loss consumes) or "XYXY_LABEL"."""
@@ -64,8 +68,45 @@ class DeviceDetectionCollateFN(DetectionCollateFN):
             raise ValueError(f"padding_mode {padding_mode!r}: 'center' or 'bottom_right'")
         if targets_format not in ("LABEL_CXCYWH", "XYXY_LABEL"):
             raise ValueError(f"targets_format {targets_format!r}: 'LABEL_CXCYWH' or 'XYXY_LABEL'")
-        self.pad_to = None if pad_to is None else (int(pad_to[0]), int(pad_to[1])) if not isinstance(pad_to, int) else (pad_to, pad_to)
+        two = lambda v: None if v is None else ((int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1])))  # noqa: E731
+        self.pad_to, self.rescale_to = two(pad_to), two(rescale_to)
+        if self.pad_to is not None and self.rescale_to is not None:
+            raise ValueError("rescale_to already pads to its size: give pad_to or rescale_to, not both")
         self.pad_value, self.padding_mode, self.targets_format = pad_value, padding_mode, targets_format
+
+    def _padded_rescale(self, images_batch, labels_batch):
+        H, W = self.rescale_to
+        c = int(images_batch[0].shape[2])
+        pv = [self.pad_value] * c if not hasattr(self.pad_value, "__len__") else list(self.pad_value)
+        if len(pv) != c or any(int(v) != v or not 0 <= v <= 255 for v in pv):
+            raise ValueError(f"pad_value {self.pad_value!r}: one uint8 value, or one per channel ({c})")
+        pad = torch.tensor([int(v) for v in pv], dtype=torch.uint8).to(self.device)
+        mean = None if self._mean is None else self._mean.to(self.device)
+        std = None if self._std is None else self._std.to(self.device)
+        dev_imgs, geometry, scaled = [], [], []
+        for i, (img, labels) in enumerate(zip(images_batch, labels_batch)):
+            img = torch.as_tensor(img)
+            if img.dtype != torch.uint8 or img.dim() != 3:
+                raise ValueError(f"DeviceDetectionCollateFN expects uint8 HWC images, got {img.dtype} {tuple(img.shape)}")
+            h, w = int(img.shape[0]), int(img.shape[1])
+            r = min(H / h, W / w)
+            nh, nw = int(h * r), int(w * r)
+            top, left = ((H - nh) // 2, (W - nw) // 2) if self.padding_mode == "center" else (0, 0)
+            dev_imgs.append(img.to(self.device, non_blocking=True))
+            geometry.append((nh, nw, top, left))
+            t = torch.as_tensor(labels).clone().float()
+            if t.numel():
+                box = slice(1, 5) if self.targets_format == "LABEL_CXCYWH" else slice(0, 4)
+                t[:, box] *= torch.tensor(r, dtype=torch.float32)  # _rescale_bboxes: float32 boxes times the float32 factor
+                if self.targets_format == "LABEL_CXCYWH":
+                    t[:, 1] += left
+                    t[:, 2] += top
+                else:
+                    t[:, [0, 2]] += left
+                    t[:, [1, 3]] += top
+            scaled.append(t)
+        batch = K.preprocess_u8(dev_imgs, geometry, H, W, pad, max_value=self.max_value, mean=mean, std=std)
+        return K.nhwc_as_nchw_view(batch, c), self._format_targets(scaled).float().to(self.device, non_blocking=True)
 
     def _padded(self, images_batch, labels_batch):
         H, W = self.pad_to
@@ -105,6 +146,8 @@ class DeviceDetectionCollateFN(DetectionCollateFN):
             images_batch, labels_batch = list(zip(*data))
         except (ValueError, TypeError):
             raise ValueError(f"DeviceDetectionCollateFN expects items {self.expected_item_names}, got {type(data[0])}")
+        if self.rescale_to is not None:
+            return self._padded_rescale(images_batch, labels_batch)
         if self.pad_to is not None:
             return self._padded(images_batch, labels_batch)
         stack = torch.stack([torch.as_tensor(img) for img in images_batch], 0)

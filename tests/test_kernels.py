@@ -745,6 +745,34 @@ def test_device_collate_pads_ragged_images(backend):
         DeviceDetectionCollateFN(device=backend, pad_to=(H - 1, W))(items)
 
 
+def test_device_collate_padded_rescale(backend):
+    """the reference's last image transforms of the YOLO-NAS dataset recipe - DetectionPaddedRescale (r = min(H/h, W/w), resize to
+    (int(h r), int(w r)), bottom-right pad 114, boxes * r; transforms.py:945-975, transforms/utils.py:202-227), DetectionStandardize and the
+    collate - as ONE launch over the ragged uint8 batch, against oracle/image.py (whose resize restates cv2's arithmetic: unpinned)."""
+    from oracle import image as O
+    from super_gradients_amd.training.utils.collate_fn import DeviceDetectionCollateFN
+
+    H, W = _sizes(backend, (96, 128), (24, 32))
+    rs = np.random.RandomState(5)
+    sizes = [(H, W), (2 * H, 2 * W), (H + 7, W // 2), (H // 3, W - 3), (3 * H, W)]
+    items = [(rs.randint(0, 256, (h, w, 3)).astype(np.uint8), np.concatenate([rs.randint(0, 5, (i + 1, 1)), rs.rand(i + 1, 4) * min(h, w)], 1).astype(np.float32))
+             for i, (h, w) in enumerate(sizes)]
+    x_dev, t_dev = DeviceDetectionCollateFN(device=backend, rescale_to=(H, W), pad_value=114)(items)
+    assert tuple(x_dev.shape) == (len(items), 3, H, W)
+    rows = []
+    for i, (img, t) in enumerate(items):
+        h, w = img.shape[:2]
+        r = min(H / h, W / w)
+        small = O.resize_linear_u8(img, (int(h * r), int(w * r)))
+        ref = O.standardize(O.pad(small, O.bottom_right_padding(small.shape[:2], (H, W)), 114)).transpose(2, 0, 1)
+        assert np.array_equal(x_dev[i].cpu().numpy(), ref), f"image {i} ({h}x{w} -> {small.shape[:2]})"
+        boxes = O.rescale_boxes(t[:, 1:], (r, r))
+        rows.append(np.concatenate([np.full((len(t), 1), i, np.float32), t[:, :1], boxes], 1))
+    assert np.array_equal(t_dev.cpu().numpy(), np.concatenate(rows, 0))
+    with pytest.raises(ValueError, match="not both"):
+        DeviceDetectionCollateFN(device=backend, rescale_to=(H, W), pad_to=(H, W))
+
+
 def test_wtrans_batch_equals_per_conv_transposes(backend):
     """sgx_conv2d_transpose_jobs + ONE sgx_wtrans_batch launch == the per-convolution sgx_conv2d_transpose_weights launches (bit-exact),
     over 1x1 / 3x3 / stride-2 / 7x7-stride-2 filters (1, 1, 4 and 4 output-parity classes)."""
