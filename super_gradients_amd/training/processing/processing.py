@@ -190,7 +190,10 @@ class ComposeProcessing(Processing):
         H, W = p0.out_hw
         dev_imgs = [_to_device_u8(i, device) for i in images]
         c = p0.channels
-        pad = torch.tensor(np.broadcast_to(np.asarray(p0.pad_value), (c,)).astype(np.uint8), dtype=torch.uint8).to(device)
+        pv = np.broadcast_to(np.asarray(p0.pad_value), (c,))
+        if np.any(pv != np.round(pv)) or pv.min() < 0 or pv.max() > 255:
+            raise ValueError(f"pad_value {p0.pad_value!r}: the padding is applied to the uint8 image (integers 0..255)")
+        pad = torch.tensor(pv.astype(np.uint8), dtype=torch.uint8).to(device)
         mean = None if p0.mean is None else torch.tensor(p0.mean, dtype=torch.float32).to(device)
         std = None if p0.std is None else torch.tensor(p0.std, dtype=torch.float32).to(device)
         y = K.preprocess_u8(dev_imgs, [(p.h, p.w, p.top, p.left) for p in plans], H, W, pad, reverse_channels=p0.reverse, max_value=p0.max_value,

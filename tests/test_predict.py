@@ -188,6 +188,8 @@ def test_processing_errors():
         ComposeProcessing([DetectionCenterPadding((16, 16), 0)]).plan_image((32, 32, 3))
     with pytest.raises(ValueError):
         ComposeProcessing([ImagePermute()]).plan_image((32, 32))
+    with pytest.raises(ValueError, match="0..255"):  # checked before anything is uploaded
+        ComposeProcessing([DetectionCenterPadding((64, 64), 300)]).preprocess_batch([np.zeros((32, 32, 3), np.uint8)], device="cpu")
 
 
 def _shrunk_arch():
