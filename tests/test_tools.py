@@ -58,3 +58,19 @@ def test_prof_timeline_on_synthetic_trace(tmp_path, capsys):
 
     assert abs(ms("device idle") - 19 * 3e-3) < 1e-6          # 19 gaps of 3 us
     assert abs(ms("two or more") - 5 * 5e-3) < 1e-6           # 5 overlaps of 5 us
+
+
+def test_host_overhead_null_library_covers_the_abi(tmp_path):
+    """tools/host_overhead.py: the generated no-op library must export every entry point of include/sgx_hip.h (else binding it fails), and a
+    train step of a small detector must run against it - i.e. nothing on the step's host path reads a kernel result back."""
+    import ctypes
+    import subprocess
+
+    import host_overhead
+    from super_gradients_amd import _lib
+
+    so = host_overhead.build_null_library()
+    lib = ctypes.CDLL(so)
+    assert all(hasattr(lib, name) for name in _lib.PROTOTYPES)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_overhead.py"), "--steps", "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "host time per step without kernels" in out.stdout, out.stderr[-2000:]
