@@ -105,6 +105,9 @@ def test_oracle_resize_is_bilinear_within_one_level():
         f = img.astype(np.float64)
         ideal = (f[yc][:, xc] * (1 - fx) + f[yc][:, x1] * fx) * (1 - fy) + (f[y1][:, xc] * (1 - fx) + f[y1][:, x1] * fx) * fy
         assert np.abs(O.resize_linear_u8(img, (h, w)) - ideal).max() <= 1.0
+    # the textbook two-pixel case: cv2.resize(np.array([[0, 255]], np.uint8), (4, 1)) is [[0, 64, 191, 255]] (quarter / three-quarter weights
+    # 512 and 1536 of 2048, rounded by the fixed-point cast) - a known answer, hand-checked through the arithmetic, not a cv2 run
+    assert O.resize_linear_u8(np.array([[[0], [255]]], np.uint8), (1, 4))[0, :, 0].tolist() == [0, 64, 191, 255]
     even = rng.integers(0, 256, (40, 64, 3), dtype=np.uint8)  # exact 2x: the 2x2 mean shortcut
     area = O.resize_linear_u8(even, (20, 32)).astype(int)
     mean = even.reshape(20, 2, 32, 2, 3).astype(int).sum((1, 3))
