@@ -95,7 +95,8 @@ class QARepVGGBlock(SgxBlock):
             if self._two_branch_launch():
                 y3, u, stat5 = K.conv2d_fwd_dual(x, c3._w, self._w1p, c1.bias, stride=self.stride)
                 cf, sv = K.qarep_fwd_finalize(stat5, y3.shape[0] * y3.shape[1] * y3.shape[2], c1.bias, bn3, pbn)
-                y = K.dual_affine_act(y3, cf[0], cf[1], u, cf[2], cf[3], act=self.act, out=out, post_add=post_add, post_scale=post_scale)
+                a3, c3_, ap, cp = cf.unbind(0)  # the four operand rows of the forward sweep
+                y = K.dual_affine_act(y3, a3, c3_, u, ap, cp, act=self.act, out=out, post_add=post_add, post_scale=post_scale)
                 self._ctx = ("dual", x, y3, u, cf, sv)
                 return y
             # the two branches read the same x and are independent: the 1x1 branch runs on the side stream beside the 3x3 one
