@@ -35,6 +35,7 @@ class SgxBlock(nn.Module):
         if name[0] == "_" and not isinstance(value, nn.Module) and not getattr(value, "_is_param", False):
             object.__setattr__(self, name, value)
         else:
+            self.__dict__.pop(name, None)  # a registry mirror (SgxNetwork._build_runtime) must not outlive a re-assignment of the name
             super().__setattr__(name, value)
 
     def fwd(self, x, out=None):
@@ -92,6 +93,12 @@ class SgxNetwork(nn.Module):
     the first forward; `.to()/.cuda()` before that are fine, after that they are rejected (the arenas are the model)."""
 
     _materialized = False
+
+    def __setattr__(self, name, value):
+        d = self.__dict__
+        if name in d and (name in d.get("_modules", ()) or name in d.get("_parameters", ()) or name in d.get("_buffers", ())):
+            del d[name]  # a registry mirror (_build_runtime) must not outlive a re-assignment of the name
+        super().__setattr__(name, value)
 
     # ----------------------------------------------------------------------------------------- arenas
     def dead_parameter(self, name: str) -> bool:

@@ -203,3 +203,18 @@ def test_models_get_adaptive_load_and_input_channels(tmp_path):
     assert torch.equal(csd["backbone.stage1.downsample.branch_3x3.conv.weight"], sd["backbone.stage1.downsample.branch_3x3.conv.weight"])
     r = models.get("resnet18", num_classes=10, num_input_channels=5)
     assert r.get_input_channels() == 5 and tuple(r.state_dict()["conv1.weight"].shape)[1] == 5
+
+
+def test_registry_mirrors_follow_reassignment(backend):
+    """After materialisation sub-modules / parameters / buffers are mirrored into the instance dictionaries (plain attribute reads on the
+    hot path); re-assigning a name must drop its mirror so that nn.Module's registries stay the single source of truth."""
+    from test_trainer import _tiny_models
+
+    _, net = _tiny_models(backend)
+    net.materialize(backend)
+    bn = net.c1.bn
+    assert bn.__dict__["running_mean"] is bn._buffers["running_mean"] and net.__dict__["c1"] is net._modules["c1"]
+    new = torch.ones(8, device=backend)
+    bn.running_mean = new
+    assert bn.running_mean is new and bn._buffers["running_mean"] is new and "running_mean" not in bn.__dict__
+    assert dict(bn.named_buffers())["running_mean"] is new
