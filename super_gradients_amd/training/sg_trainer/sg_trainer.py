@@ -170,6 +170,10 @@ class Trainer:
         merged.update(keep)
         if merged["mixed_precision"]:
             warnings.warn("mixed_precision=True is accepted for recipe compatibility; the MI355X path computes in fp32 (parity mode)")
+        # recipe switches that change what is trained must not be ignored silently (logging / tensorboard / torch.compile entries may be)
+        for key, what in (("finetune", "freezing all but the fine-tune layers (get_finetune_lr_dict)"), ("precise_bn", "the precise-BN pass after each epoch")):
+            if merged.get(key):
+                raise NotImplementedError(f"training_params.{key}=True ({what}) is outside the MI355X train-step path")
         return HpmStruct(**merged)
 
     def _build_loss(self, tp):
@@ -220,6 +224,9 @@ class Trainer:
     def train(self, model: nn.Module, training_params=None, train_loader=None, valid_loader=None, test_loaders=None, additional_configs_to_log: Dict = None):
         if train_loader is None:
             raise ValueError("No `train_loader` found. Please provide a value for `train_loader`")
+        if test_loaders:
+            raise NotImplementedError("test_loaders (extra evaluation sets per epoch) are outside the MI355X train-step path; validate them with "
+                                      "separate calls")
         if not isinstance(model, SgxNetwork):
             raise TypeError("Trainer on the MI355X path trains models obtained from super_gradients_amd.training.models.get() (SgxNetwork)")
         tp = self.training_params = self._params(training_params)
