@@ -369,3 +369,37 @@ def test_predict_on_a_fresh_model(backend):
     res = net.predict(img, max_predictions=3)
     assert isinstance(res, ImageDetectionPrediction) and len(res.prediction) == 3 and net._materialized
     assert res.prediction.bboxes_xyxy.dtype == np.float32 and res.prediction.labels.dtype.kind == "i"
+
+
+def test_reference_unit_test_vectors_for_processing_helpers():
+    """The reference's own known answers for this path (tests/unit_tests/transforms_test.py: test_rescale_bboxes :231-244, test_shift_bboxes
+    :301-308, test_rescale_xyxy_bboxes :310-317, test_padding :319-349, test_get_padding_coordinates :351-405), transplanted: the numbers are
+    the reference's, the functions under test are oracle/image.py and the product's processing helpers."""
+    from super_gradients_amd.training.processing import DetectionBottomRightPadding, DetectionCenterPadding, PaddingCoordinates
+    from super_gradients_amd.training.processing.processing import _rescale_bboxes, _shift_bboxes_xyxy
+
+    # box rescale by (sy, sx) = (2.0, 0.5): empty and non-empty (extra columns travel unchanged)
+    boxes = np.array([[10, 20, 50, 60, 1], [30, 40, 80, 90, 2]], dtype=np.float32)
+    want = np.array([[5.0, 40.0, 25.0, 120.0, 1.0], [15.0, 80.0, 40.0, 180.0, 2.0]], dtype=np.float32)
+    for fn in (_rescale_bboxes, O.rescale_boxes):
+        assert np.array_equal(fn(np.zeros((0, 4)), (2.0, 0.5)), np.zeros((0, 4)))
+        assert np.array_equal(fn(boxes, (2.0, 0.5)), want)
+        assert np.array_equal(fn(boxes, (0.5, 0.5)), np.array([[5.0, 10.0, 25.0, 30.0, 1.0], [15.0, 20.0, 40.0, 45.0, 2.0]], dtype=np.float32))
+    # box shift by (w, h) = (60, 80)
+    shifted = np.array([[70, 100, 110, 140, 1], [90, 120, 140, 170, 2]], dtype=np.float32)
+    assert np.array_equal(_shift_bboxes_xyxy(boxes, 60, 80), shifted) and np.array_equal(O.shift_boxes(boxes, 60, 80), shifted)
+    # padding coordinates: width only, height only, both, image larger than the output (negative coordinates), 3-channel shape
+    cases = [((640, 480), (640, 640), (0, 0, 80, 80), (0, 0, 0, 160)), ((480, 640), (640, 640), (80, 80, 0, 0), (0, 160, 0, 0)),
+             ((480, 640), (800, 800), (160, 160, 80, 80), (0, 320, 0, 160)), ((800, 800), (640, 640), (-80, -80, -80, -80), (0, -160, 0, -160)),
+             ((480, 640, 3), (800, 800), (160, 160, 80, 80), (0, 320, 0, 160))]
+    for shape, out, center, br in cases:
+        assert O.center_padding(shape, out) == center and O.bottom_right_padding(shape, out) == br
+        c = DetectionCenterPadding(out, 114)._get_padding_params(shape)
+        b = DetectionBottomRightPadding(out, 114)._get_padding_params(shape)
+        assert c == PaddingCoordinates(top=center[0], bottom=center[1], left=center[2], right=center[3])
+        assert b == PaddingCoordinates(top=br[0], bottom=br[1], left=br[2], right=br[3])
+    # padding itself: bottom 1 / right 2 with 0 on a 2x2x3 image
+    img = np.array([[[1, 2, 3], [4, 5, 6]], [[7, 8, 9], [10, 11, 12]]], dtype=np.uint8)
+    want = np.array([[[1, 2, 3], [4, 5, 6], [0, 0, 0], [0, 0, 0]], [[7, 8, 9], [10, 11, 12], [0, 0, 0], [0, 0, 0]], [[0, 0, 0]] * 4], dtype=np.uint8)
+    assert np.array_equal(O.pad(img, (0, 1, 0, 2), 0), want)
+    assert np.array_equal(O.pad(img, (0, 0, 0, 0), 114), img)
