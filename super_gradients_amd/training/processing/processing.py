@@ -75,12 +75,22 @@ class _ImagePlan:
         self.permutation = None
         self._stage = -1
 
-    def enter(self, stage: str, who):
+    def enter(self, stage: str, who) -> bool:
+        """-> True when the stage repeats the previous one (only a rescale may: dataset-derived lists hold e.g. DetectionLongestMaxSize
+        followed by DetectionPaddedRescale's own rescale, preprocessing_unit_test.py:119-123 - the second one is then a no-op)."""
         i = _STAGES.index(stage)
-        if i <= self._stage:
+        if i < self._stage or (i == self._stage and stage != "rescale"):
             raise NotImplementedError(f"{type(who).__name__} after '{_STAGES[self._stage]}': the fused device pre-processing covers the stage order "
-                                      f"{' -> '.join(_STAGES)} (each at most once)")
+                                      f"{' -> '.join(_STAGES)} (each at most once; a repeated rescale only when it leaves the size unchanged)")
+        repeat = i == self._stage
         self._stage = i
+        return repeat
+
+    def resize_to(self, h: int, w: int, repeat: bool, who):
+        if repeat and (h, w) != (self.h, self.w):
+            raise NotImplementedError(f"{type(who).__name__}: a second rescale that changes the size again ({self.h}x{self.w} -> {h}x{w}) would be "
+                                      "two successive resamplings; the fused device pre-processing resamples once")
+        self.h, self.w = int(h), int(w)
 
     @property
     def out_hw(self):
@@ -401,9 +411,9 @@ class DetectionRescale(_DetectionRescaleBase):
     """To output_shape without keeping the aspect ratio (processing.py:510-538)."""
 
     def _describe(self, plan):
-        plan.enter("rescale", self)
+        repeat = plan.enter("rescale", self)
         h0, w0 = plan.h, plan.w
-        plan.h, plan.w = int(self.output_shape[0]), int(self.output_shape[1])
+        plan.resize_to(self.output_shape[0], self.output_shape[1], repeat, self)
         return RescaleMetadata(original_shape=(h0, w0), scale_factor_h=self.output_shape[0] / h0, scale_factor_w=self.output_shape[1] / w0)
 
     def infer_image_input_shape(self):
@@ -415,11 +425,11 @@ class DetectionLongestMaxSizeRescale(_DetectionRescaleBase):
     """Longest side to output_shape, aspect ratio kept (processing.py:541-575): scale = min(H / h, W / w), new size = round(h * scale), ..."""
 
     def _describe(self, plan):
-        plan.enter("rescale", self)
+        repeat = plan.enter("rescale", self)
         h0, w0 = plan.h, plan.w
         s = min(self.output_shape[0] / h0, self.output_shape[1] / w0)
         if s != 1.0:
-            plan.h, plan.w = round(h0 * s), round(w0 * s)
+            plan.resize_to(round(h0 * s), round(w0 * s), repeat, self)
         return RescaleMetadata(original_shape=(h0, w0), scale_factor_h=s, scale_factor_w=s)
 
 

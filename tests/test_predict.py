@@ -191,6 +191,15 @@ def test_processing_errors():
         ComposeProcessing([DetectionCenterPadding((16, 16), 0)]).plan_image((32, 32, 3))
     with pytest.raises(ValueError):
         ComposeProcessing([ImagePermute()]).plan_image((32, 32))
+    # dataset-derived lists repeat the rescale (preprocessing_unit_test.py:119-123): fine while the second one changes nothing
+    from super_gradients_amd.training.processing import DetectionBottomRightPadding, DetectionLongestMaxSizeRescale, DetectionRescale, ReverseImageChannels
+
+    twice = ComposeProcessing([ReverseImageChannels(), DetectionLongestMaxSizeRescale((64, 64)), DetectionLongestMaxSizeRescale((64, 64)),
+                               DetectionBottomRightPadding((64, 64), 114), ImagePermute()])
+    plan, md = twice.plan_image((100, 50, 3))
+    assert (plan.h, plan.w, plan.out_hw) == (64, 32, (64, 64)) and md.metadata_lst[1].scale_factor_h == 0.64 and md.metadata_lst[2].scale_factor_h == 1.0
+    with pytest.raises(NotImplementedError, match="successive resamplings"):
+        ComposeProcessing([DetectionLongestMaxSizeRescale((64, 64)), DetectionRescale((32, 32))]).plan_image((100, 50, 3))
     with pytest.raises(ValueError, match="0..255"):  # checked before anything is uploaded
         ComposeProcessing([DetectionCenterPadding((64, 64), 300)]).preprocess_batch([np.zeros((32, 32, 3), np.uint8)], device="cpu")
 
