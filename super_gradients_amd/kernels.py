@@ -75,6 +75,14 @@ def clear_desc_cache():
     _DESC_CACHE.clear()
 
 
+def clear_caches():
+    """Everything this module remembers about the bound library (descriptors, size queries): for code that re-binds the library (the tests'
+    host emulation / no-op builds)."""
+    clear_desc_cache()
+    for f in (stats_blocks, _reduce_workspace, _qarep_workspace, _dot_workspace):
+        f.cache_clear()
+
+
 def conv_desc(x: torch.Tensor, K: int, R: int, S: int, stride: int, pad: int, y: Optional[torch.Tensor] = None) -> ConvDesc:
     """The sgx_conv_desc of (x [, y]) - built and validated once per distinct (shapes, strides, filter) and shared afterwards (a training
     loop presents the same few hundred problems every step; the C side only reads the descriptor during the call)."""

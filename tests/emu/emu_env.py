@@ -15,7 +15,16 @@ def activate():
     so = build_emu.build()
     _lib._LIB = _lib.bind(ctypes.CDLL(so))
     _lib._TEST_HOST_MODE = True
+    _clear_caches()
     return _lib
+
+
+def _clear_caches():
+    import sys as _sys
+
+    k = _sys.modules.get("super_gradients_amd.kernels")
+    if k is not None:
+        k.clear_caches()
 
 
 def deactivate():
@@ -23,3 +32,4 @@ def deactivate():
 
     _lib._LIB = None
     _lib._TEST_HOST_MODE = False
+    _clear_caches()

@@ -324,3 +324,87 @@ def test_reference_recipe_dict_trains(gpu_device, tmp_path):
     row = res[-1] if isinstance(res, list) else res
     assert np.isfinite(row["train"]["loss"]) and "mAP@0.50:0.95" in row["valid"]
     assert os.path.exists(os.path.join(str(tmp_path), "recipe_run", "ckpt_latest.pth"))
+
+
+class _CollectLR:
+    """The reference tests' CollectLRCallback / TestLRCallback (tests/unit_tests/lr_warmup_test.py:12-21, callbacks.py:768-780) in one."""
+
+    def __new__(cls):
+        from super_gradients_amd.training.utils.callbacks import Callback
+
+        class Collect(Callback):
+            def __init__(self):
+                self.per_step, self.per_epoch, self.after_validation = [], [], []
+
+            def on_train_batch_end(self, context):
+                self.per_step.append(context.optimizer.param_groups[0]["lr"])
+
+            def on_train_loader_end(self, context):
+                self.per_epoch.append(context.optimizer.param_groups[0]["lr"])
+
+            def on_validation_loader_end(self, context):
+                self.after_validation.append(context.optimizer.param_groups[0]["lr"])
+
+        return Collect()
+
+
+@pytest.fixture
+def no_op_kernels():
+    """Host logic only: every entry point bound to a function that returns at once (tools/host_overhead.py's generated library), tensors on the
+    CPU.  Results of 'kernels' are garbage; the tests that use this read none."""
+    import ctypes
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import host_overhead
+    from super_gradients_amd import _lib
+    from super_gradients_amd import kernels as K
+
+    _lib._LIB = _lib.bind(ctypes.CDLL(host_overhead.build_null_library()))
+    _lib._TEST_HOST_MODE = True
+    K.clear_caches()
+    try:
+        yield torch.device("cpu")
+    finally:
+        _lib._LIB = None
+        _lib._TEST_HOST_MODE = False
+        K.clear_caches()
+
+
+@pytest.mark.parametrize("case", ["warmup_step", "warmup_cosine", "warmup_cosine_cooldown", "warmup_from_above", "batch_warmup_cosine"])
+def test_reference_lr_unit_test_vectors(no_op_kernels, tmp_path, case):
+    """The reference's own expected learning-rate sequences (tests/unit_tests/lr_warmup_test.py:54-218, lr_cooldown_test.py:11-52), produced here
+    by Trainer.train() on a small network: LinearEpochLRWarmup into StepLR / cosine (with and without cool-down epochs), a warm-up that starts
+    above the initial rate, and LinearBatchLRWarmup into a per-step cosine.  The numbers are the reference's."""
+    from super_gradients_amd.training import Trainer
+    from super_gradients_amd.training.utils.callbacks import CosineLRScheduler
+
+    _, net = _tiny_models(no_op_kernels)
+    n_train = 2 if case != "batch_warmup_cosine" else 6  # the reference's loaders have two batches per epoch (5 samples, batch 4): the cosine is per step
+    loader = _loader(n_train, 4, 7)
+    cb = _CollectLR()
+    common = dict(initial_lr=1, loss="CrossEntropyLoss", optimizer="SGD", optimizer_params={"weight_decay": 1e-4, "momentum": 0.9}, ema=False,
+                  phase_callbacks=[cb], silent_mode=True, save_model=False)
+    if case == "warmup_step":
+        tp = dict(common, max_epochs=5, lr_updates=[10], lr_decay_factor=0.1, lr_mode="StepLRScheduler", lr_warmup_epochs=3, warmup_mode="LinearEpochLRWarmup")
+        expected, got = [0.25, 0.5, 0.75, 1.0, 1.0], "after_validation"
+    elif case == "warmup_cosine":
+        tp = dict(common, max_epochs=5, cosine_final_lr_ratio=0.2, lr_mode="CosineLRScheduler", lr_warmup_epochs=3, warmup_mode="LinearEpochLRWarmup")
+        expected, got = [0.25, 0.5, 0.75, 0.9236067977499791, 0.4763932022500211], "after_validation"
+    elif case == "warmup_cosine_cooldown":
+        tp = dict(common, max_epochs=7, cosine_final_lr_ratio=0.2, lr_mode="CosineLRScheduler", lr_cooldown_epochs=2, lr_warmup_epochs=3)
+        expected, got = [0.25, 0.5, 0.75, 0.9236067977499791, 0.4763932022500211, 0.4763932022500211, 0.4763932022500211], "after_validation"
+    elif case == "warmup_from_above":
+        tp = dict(common, max_epochs=5, lr_updates=[10], lr_decay_factor=0.1, lr_mode="StepLRScheduler", lr_warmup_epochs=3, warmup_initial_lr=4.0,
+                  warmup_mode="LinearEpochLRWarmup")
+        expected, got = [4.0, 3.0, 2.0, 1.0, 1.0], "per_epoch"
+    else:
+        steps, epochs = 4, 3
+        tp = dict(common, max_epochs=epochs, lr_mode="CosineLRScheduler", cosine_final_lr_ratio=0.2, warmup_initial_lr=0.05, warmup_mode="LinearBatchLRWarmup",
+                  lr_warmup_steps=steps)
+        total = epochs * n_train - steps
+        expected = np.linspace(0.05, 1, steps).tolist() + list(CosineLRScheduler.compute_learning_rate(step=np.arange(0, total), total_steps=total,
+                                                                                                       initial_lr=1, final_lr_ratio=0.2))
+        got = "per_step"
+    Trainer("lr_vectors", ckpt_root_dir=str(tmp_path)).train(net, tp, loader, valid_loader=loader[:1])
+    np.testing.assert_allclose(np.array(getattr(cb, got)), np.array(expected), rtol=1e-6 if got != "per_step" else 1e-4)
