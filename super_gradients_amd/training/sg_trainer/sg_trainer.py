@@ -350,10 +350,14 @@ class Trainer:
             loss, items = loss
         else:
             items = loss.unsqueeze(0).detach()
-        if self.loss_logging_items_names is None:
+        if self.loss_logging_items_names is None:  # sg_trainer.py:2407-2420: "<Criterion>/<component>" titles, or the bare class name
+            crit = type(self.criterion).__name__
             names = getattr(self.criterion, "component_names", None)
-            self.loss_logging_items_names = list(names) if names is not None else ([type(self.criterion).__name__] if len(items) == 1 else
-                                                                                  [f"{type(self.criterion).__name__}/loss_{i}" for i in range(len(items))])
+            if names is None and len(items) > 1:
+                names = [f"loss_{i}" for i in range(len(items))]
+            self.loss_logging_items_names = [f"{crit}/{n}" for n in names] if names is not None else [crit]
+            if names is not None and self.training_params.metric_to_watch in names:  # a bare component name is what recipes write
+                self.training_params.metric_to_watch = f"{crit}/{self.training_params.metric_to_watch}"
         if len(items) != len(self.loss_logging_items_names):
             raise ValueError(f"Loss output length must match loss_logging_items_names. Got {len(items)}, and {len(self.loss_logging_items_names)}")
         return loss, items

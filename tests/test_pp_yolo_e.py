@@ -222,7 +222,7 @@ def test_trainer_ppyoloe_recipe_shape(gpu_device, tmp_path):
               ema_params=dict(decay=0.9997, decay_type="threshold"), silent_mode=True, save_model=False,
               valid_metrics_list=[DetectionMetrics_050(num_cls=80, post_prediction_callback=cb, normalize_targets=True)], metric_to_watch="mAP@0.50")
     res = Trainer("ppyoloe_mini", ckpt_root_dir=str(tmp_path)).train(net, tp, dev_loader, valid_loader=dev_loader[:2])
-    assert 0.0 <= res[0]["valid"]["mAP@0.50"] <= 1.0 and "loss" in res[0]["valid"]
+    assert 0.0 <= res[0]["valid"]["mAP@0.50"] <= 1.0 and "PPYoloELoss/loss" in res[0]["valid"]
     decay = [p for k, p in ref.named_parameters() if p.dim() > 1]
     no_decay = [p for k, p in ref.named_parameters() if p.dim() <= 1]
     o = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay}], lr=2e-4, weight_decay=1e-5)
@@ -238,7 +238,7 @@ def test_trainer_ppyoloe_recipe_shape(gpu_device, tmp_path):
     tot /= n * bs
     got = res[0]["train"]
     for i, name in enumerate(["loss_cls", "loss_iou", "loss_dfl", "loss"]):
-        assert abs(got[name] - float(tot[i])) <= 1e-3 * abs(float(tot[i])), (name, got[name], float(tot[i]))
+        assert abs(got["PPYoloELoss/" + name] - float(tot[i])) <= 1e-3 * abs(float(tot[i])), (name, got, float(tot[i]))
 
 
 def test_ppyoloe_gradient_buckets_tile_the_arena(backend):

@@ -322,7 +322,7 @@ def test_reference_recipe_dict_trains(gpu_device, tmp_path):
     loader = [(torch.rand(2, 3, 128, 128, generator=g), synthetic_targets(2, seed=i, size=128, num_classes=3)) for i in range(3)]
     res = Trainer("recipe_run", ckpt_root_dir=str(tmp_path)).train(net, training_params=tp, train_loader=loader, valid_loader=loader[:1])
     row = res[-1] if isinstance(res, list) else res
-    assert np.isfinite(row["train"]["loss"]) and "mAP@0.50:0.95" in row["valid"]
+    assert np.isfinite(row["train"]["PPYoloELoss/loss"]) and "mAP@0.50:0.95" in row["valid"]
     assert os.path.exists(os.path.join(str(tmp_path), "recipe_run", "ckpt_latest.pth"))
 
 
@@ -408,3 +408,34 @@ def test_reference_lr_unit_test_vectors(no_op_kernels, tmp_path, case):
         got = "per_step"
     Trainer("lr_vectors", ckpt_root_dir=str(tmp_path)).train(net, tp, loader, valid_loader=loader[:1])
     np.testing.assert_allclose(np.array(getattr(cb, got)), np.array(expected), rtol=1e-6 if got != "per_step" else 1e-4)
+
+
+def test_reference_loss_logging_names(no_op_kernels, tmp_path):
+    """tests/unit_tests/loss_loggings_test.py:23-105 transplanted: a scalar loss logs under the criterion's class name, a tuple loss without
+    names under "<Class>/loss_i", with `component_names` under "<Class>/<name>" (sg_trainer.py:2407-2420); a bare component name given as
+    metric_to_watch is prefixed the same way."""
+    from super_gradients_amd.training import Trainer
+
+    class Unnamed(torch.nn.CrossEntropyLoss):
+        def forward(self, input, target):
+            loss = super().forward(input, target)
+            return loss, torch.cat((loss.unsqueeze(0), loss.unsqueeze(0))).detach()
+
+    class Named(Unnamed):
+        component_names = ["loss_A", "loss_B"]
+
+    def run(loss, **kw):
+        _, net = _tiny_models(no_op_kernels)
+        tr = Trainer("loss_names", ckpt_root_dir=str(tmp_path))
+        tp = dict(max_epochs=1, lr_updates=[1], lr_decay_factor=0.1, lr_mode="StepLRScheduler", initial_lr=0.1, loss=loss, optimizer="SGD",
+                  optimizer_params={"weight_decay": 1e-4, "momentum": 0.9}, silent_mode=True, save_model=False, **kw)
+        res = tr.train(net, tp, _loader(1, 4, 3), valid_loader=_loader(1, 4, 4))
+        return tr, res
+
+    tr, _ = run(torch.nn.CrossEntropyLoss())
+    assert tr.loss_logging_items_names == ["CrossEntropyLoss"]
+    tr, _ = run(Unnamed())
+    assert tr.loss_logging_items_names == ["Unnamed/loss_0", "Unnamed/loss_1"]
+    tr, res = run(Named(), metric_to_watch="loss_B", greater_metric_to_watch_is_better=False)
+    assert tr.loss_logging_items_names == ["Named/loss_A", "Named/loss_B"] and tr.training_params.metric_to_watch == "Named/loss_B"
+    assert set(res[0]["train"]) == {"Named/loss_A", "Named/loss_B"} and "Named/loss_B" in res[0]["valid"]
