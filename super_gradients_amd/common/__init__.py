@@ -1,0 +1,2 @@
+
+from .data_types import StrictLoad  # noqa: F401,E402

@@ -45,6 +45,7 @@ def adaptive_load_state_dict(net: torch.nn.Module, state_dict: dict, strict: Uni
     state_dict = state_dict["net"] if "net" in state_dict else state_dict
     if state_dict and all(k.startswith("module.") for k in state_dict):
         state_dict = {k[len("module."):]: v for k, v in state_dict.items()}
+    strict = getattr(strict, "value", strict)  # a StrictLoad member
     mode = strict if isinstance(strict, bool) else {"on": True, "off": False}.get(str(strict), str(strict))
     try:
         net.load_state_dict(state_dict, strict=mode is not False)

@@ -218,3 +218,31 @@ def test_registry_mirrors_follow_reassignment(backend):
     bn.running_mean = new
     assert bn.running_mean is new and bn._buffers["running_mean"] is new and "running_mean" not in bn.__dict__
     assert dict(bn.named_buffers())["running_mean"] is new
+
+
+def test_reference_strict_load_unit_test_scenarios(tmp_path):
+    """tests/unit_tests/strictload_enum_test.py:104-158 transplanted (a second random-init model stands in for the downloaded ImageNet weights):
+    StrictLoad.ON loads an exact checkpoint and raises RuntimeError on missing or renamed keys; OFF tolerates the missing classifier;
+    NO_KEY_MATCHING loads a checkpoint whose keys were renamed to their positions."""
+    from super_gradients_amd.training import StrictLoad, models
+
+    def same(a, b, skip=()):
+        return all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items() if not k.startswith(skip))
+
+    torch.manual_seed(0)
+    pre = models.get("resnet18", num_classes=1000)
+    torch.manual_seed(1)
+    assert not same(models.get("resnet18", num_classes=1000), pre)
+    p = str(tmp_path / "on.pth")
+    torch.save(pre.state_dict(), p)
+    assert same(models.get("resnet18", num_classes=1000, checkpoint_path=p, strict_load=StrictLoad.ON), pre)
+    p = str(tmp_path / "off.pth")
+    torch.save({k: v for k, v in pre.state_dict().items() if not k.startswith("linear.")}, p)
+    with pytest.raises(RuntimeError):
+        models.get("resnet18", num_classes=1000, checkpoint_path=p, strict_load=StrictLoad.ON)
+    assert same(models.get("resnet18", num_classes=1000, checkpoint_path=p, strict_load=StrictLoad.OFF), pre, skip=("linear.",))
+    p = str(tmp_path / "renamed.pth")
+    torch.save({str(i): v for i, (k, v) in enumerate(pre.state_dict().items())}, p)
+    with pytest.raises(RuntimeError):
+        models.get("resnet18", num_classes=1000, checkpoint_path=p, strict_load=StrictLoad.ON)
+    assert same(models.get("resnet18", num_classes=1000, checkpoint_path=p, strict_load=StrictLoad.NO_KEY_MATCHING), pre)
