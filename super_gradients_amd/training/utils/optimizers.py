@@ -101,9 +101,19 @@ def build_optimizer(net, lr: float, training_params) -> torch.optim.Optimizer:
     name = get_param(training_params, "optimizer", "SGD")
     if not isinstance(name, str):
         return name  # an already-built optimizer
-    params = dict(get_param(training_params, "optimizer_params", {}) or {})
     zero = bool(get_param(training_params, "zero_weight_decay_on_bias_and_bn", False))
     cls = {"adamw": ArenaAdamW, "sgd": ArenaSGD}.get(name.lower())
     if cls is None:
         raise NotImplementedError(f"optimizer '{name}' is not available on the HIP path (AdamW, SGD)")
+    # optimizer_utils.py:23-28,104-106: the recipe's optimizer_params are laid over per-optimizer defaults (SGD: weight decay 1e-4 and momentum
+    # 0.9 - not torch's zeros; AdamW has no entry there and keeps torch's own defaults), and the merged dictionary is written back
+    params = dict(OPTIMIZERS_DEFAULT_PARAMS.get(cls, {}))
+    params.update(get_param(training_params, "optimizer_params", {}) or {})
+    if hasattr(training_params, "override"):
+        training_params.override(optimizer_params=dict(params))
+    elif isinstance(training_params, dict):
+        training_params["optimizer_params"] = dict(params)
     return cls(net, lr=lr, zero_weight_decay_on_bias_and_bn=zero, **params)
+
+
+OPTIMIZERS_DEFAULT_PARAMS = {ArenaSGD: {"weight_decay": 1e-4, "momentum": 0.9}}  # training/params.py:88

@@ -439,3 +439,23 @@ def test_reference_loss_logging_names(no_op_kernels, tmp_path):
     tr, res = run(Named(), metric_to_watch="loss_B", greater_metric_to_watch_is_better=False)
     assert tr.loss_logging_items_names == ["Named/loss_A", "Named/loss_B"] and tr.training_params.metric_to_watch == "Named/loss_B"
     assert set(res[0]["train"]) == {"Named/loss_A", "Named/loss_B"} and "Named/loss_B" in res[0]["valid"]
+
+
+def test_reference_optimizer_params_defaults(no_op_kernels):
+    """tests/unit_tests/optimizer_params_override_test.py:9-70 transplanted: SGD's recipe defaults (weight decay 1e-4, momentum 0.9:
+    training/params.py:88) sit under whatever `optimizer_params` the recipe gives, and the merged dictionary is written back to the training
+    params; AdamW has no recipe defaults (torch's own apply)."""
+    from super_gradients_amd.training.utils.optimizers import build_optimizer
+    from super_gradients_amd.training.utils.utils import HpmStruct
+
+    _, net = _tiny_models(no_op_kernels)
+    net.materialize(no_op_kernels)
+    tp = HpmStruct(optimizer="SGD", optimizer_params={"momentum": 0.8}, zero_weight_decay_on_bias_and_bn=True)
+    opt = build_optimizer(net, 0.1, tp)
+    assert tp.optimizer_params == {"weight_decay": 1e-4, "momentum": 0.8}
+    assert opt.defaults["momentum"] == 0.8 and opt.defaults["weight_decay"] == 1e-4
+    tp = HpmStruct(optimizer="SGD", optimizer_params={}, zero_weight_decay_on_bias_and_bn=False)
+    opt = build_optimizer(net, 0.1, tp)
+    assert opt.defaults["momentum"] == 0.9 and opt.defaults["weight_decay"] == 1e-4 and tp.optimizer_params == {"weight_decay": 1e-4, "momentum": 0.9}
+    tp = HpmStruct(optimizer="AdamW", optimizer_params={}, zero_weight_decay_on_bias_and_bn=False)
+    assert build_optimizer(net, 0.1, tp).defaults["weight_decay"] == 1e-2
