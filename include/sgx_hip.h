@@ -153,6 +153,24 @@ int32_t sgx_qarep_prep_batch(const sgx_qarep_prep_job* jobs_dev, int32_t njobs, 
 int64_t sgx_conv2d_bwd_weight_workspace(const sgx_conv_desc* d);
 int32_t sgx_conv2d_bwd_weight(const sgx_conv_desc* d, const float* x, const float* dy, float* dw,
                               float* dbias, void* ws, int64_t ws_bytes, void* stream);
+/* The weight gradients of a training step are mutually independent (the reference's autograd issues one aten::convolution_backward per
+ * nn.Conv2d, sg_trainer.py:611-647 -> qarepvgg_block.py:105-128): a GROUP of them runs as one launch per tile shape, the pixel split of
+ * every job sized so that the group - not each layer alone - fills the chip, and the split partials are folded inside the launch by
+ * arrival tickets in a fixed order (deterministic; no separate reduce launch).  jobs: HOST array (read during the call only); ws:
+ * sgx_conv2d_bwd_weight_group_sizes bytes of scratch; tickets: that many int32, ZERO on entry, owned by this stream between calls (the
+ * kernels leave them zero, so a caller clears the buffer once).  dw += gradient, as above.                                            */
+typedef struct sgx_wgrad_job {
+    sgx_conv_desc d;
+    const float* x;
+    const float* dy;
+    float* dw;
+} sgx_wgrad_job;
+int32_t sgx_conv2d_bwd_weight_group_sizes(const sgx_wgrad_job* jobs, int32_t njobs, int64_t* ws_bytes, int64_t* ticket_ints);
+int32_t sgx_conv2d_bwd_weight_group(const sgx_wgrad_job* jobs, int32_t njobs, void* ws, int64_t ws_bytes, int32_t* tickets,
+                                    int64_t ticket_ints, void* stream);
+/* Measurement aid for the grouped weight gradient: rounds of work items a large group is cut into (0 = default 6), work of an item below
+ * which a small group is not cut further (MFLOP, 0 = default 8), XCD-aware workgroup order (default 1).  Never set by the product.     */
+int32_t sgx_debug_set_wgrad_group(int32_t rounds, int32_t item_mflop, int32_t xcd_order);
 
 /* ConvTranspose2d kernel 2, stride 2 (+bias): modules/sampling.py:72-73 via yolo_stages.py:292-294.
  * x [N,H,W,C] -> y [N,2H,2W,K].  It is the adjoint of a 2x2 stride-2 convolution, so it runs on the same

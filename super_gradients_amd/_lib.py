@@ -42,6 +42,10 @@ class WtransJob(ctypes.Structure):  # == sgx_wtrans_job
     _fields_ = [("w", ctypes.c_void_p), ("wt", ctypes.c_void_p), ("K", c_int32), ("C", c_int32), ("RS", c_int32), ("T", c_int32), ("taps", ctypes.c_uint8 * 64)]
 
 
+class WgradJob(ctypes.Structure):  # == sgx_wgrad_job
+    _fields_ = [("d", ConvDesc), ("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p)]
+
+
 class QarepPrepJob(ctypes.Structure):  # == sgx_qarep_prep_job
     _fields_ = [("w1", ctypes.c_void_p), ("w1p", ctypes.c_void_p), ("w1pt", ctypes.c_void_p), ("alpha", ctypes.c_void_p), ("K", c_int32), ("C", c_int32),
                 ("identity", c_int32), ("pad_", c_int32)]
@@ -99,6 +103,9 @@ PROTOTYPES = {
     "sgx_qarep_bwd_apply": (_i32, [_P, _i64, _P, _i64, _P, _i64, _P, _P, _P, _P, _i64, _P, _i64, _i64, _i32, _i32, _P]),
     "sgx_conv2d_bwd_weight_workspace": (_i64, [_CD]),
     "sgx_conv2d_bwd_weight": (_i32, [_CD, _P, _P, _P, _P, _P, _i64, _P]),
+    "sgx_conv2d_bwd_weight_group_sizes": (_i32, [POINTER(WgradJob), _i32, POINTER(c_int64), POINTER(c_int64)]),
+    "sgx_conv2d_bwd_weight_group": (_i32, [POINTER(WgradJob), _i32, _P, _i64, _P, _i64, _P]),
+    "sgx_debug_set_wgrad_group": (_i32, [_i32] * 3),
     "sgx_convT2x2_workspace": (_i64, [_i32] * 5),
     "sgx_convT2x2_fwd": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _P, _i64, _i64, _P, _i64, _P]),
     "sgx_convT2x2_bwd_data": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _i64, _i64, _P]),
@@ -196,6 +203,9 @@ def lib():
         var = os.environ.get("SGX_CONV_VARIANT")  # measurement switch of the conv kernels (sgx_debug_set_variant; 7 = the 16-deep loop)
         if var:
             _LIB.sgx_debug_set_variant(int(var))
+        wgg = os.environ.get("SGX_WGRAD_GROUP")  # measurement switch of the grouped weight gradient: "rounds,item_mflop,xcd_order" (0 = default)
+        if wgg:
+            _LIB.sgx_debug_set_wgrad_group(*[int(v) for v in wgg.split(",")])
         if os.environ.get("SGX_FUSED_FINALIZE") == "0":  # measurement switch: two-launch BatchNorm / column-sum finalize (default: one launch)
             _LIB.sgx_bn_set_fused_finalize(0)
         # per-problem (tile, variant) table measured by tools/conv_tune.py --emit-table: SGX_CONV_TUNING=<json> ("" / "0" = none),

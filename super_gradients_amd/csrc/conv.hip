@@ -23,6 +23,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <vector>
 
 // ------------------------------------------------------------------------------------------------
 // Optional per-launch timing of the two MFMA kernel classes (bench.py's roofline leg): HIP events recorded on the
@@ -1326,27 +1327,78 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
 // Weight gradient as ONE GEMM over the flattened filter axis:  dW[k][j] = sum_m dY[m][k] * Xcol[m][j],  j = tap*C + c
 // (exactly the OHWI memory order of the weights, so a tile of j may span several taps: narrow-channel layers - the
 // 3->48 stem, the 32/48/64-channel CSP blocks - still fill a 96- or 128-wide MFMA tile).  Pixels are the GEMM-K axis:
-// a workgroup owns a (k tile, j tile) and a contiguous pixel range [split], stages 16-pixel slabs of dY and of the
-// shifted X in LDS (pixel-major, so MFMA fragments are conflict-free ds_read_b32), and writes its partial tile;
-// a second kernel folds the splits in a fixed order (deterministic, no float atomics).
+// a workgroup owns a (k tile, j tile) and a contiguous pixel range [split] and stages 16-pixel slabs of dY and of the
+// shifted X in LDS (pixel-major, so MFMA fragments are conflict-free ds_read_b32).
 // A lane owns ONE pixel row of the slab and walks it forward 16 pixels per step (no divisions in the loop); its column
 // groups have fixed (tap, channel) -> fixed byte deltas, so each load is base + delta with a 4-compare bounds mask.
+//
+// GROUPED launches (round 3).  The weight gradients of a step are mutually independent, so one launch carries a TABLE of
+// them (kernel arguments: up to WG_MAX_JOBS jobs of one tile shape) and the pixel split of every job is sized so that the
+// GROUP fills the chip, not each layer on its own: fewer, longer work items -> fewer partial tiles in HBM, ~8x fewer
+// launches, no per-layer tail.  Workgroup -> (job, split, tile) is XCD-aware: the (k, j) tiles of one pixel range run
+// back to back on ONE XCD, so the range is fetched from HBM once and re-read from that XCD's L2 by the other tiles.
+// The split partials are folded INSIDE the launch, deterministically: a workgroup publishes its partial tile, bumps an
+// arrival ticket, and the LAST arriver of a group of <= WG_GROUP splits adds the group's partials in split order (a
+// second ticket level folds the group sums the same way when a job has more than WG_GROUP splits) and accumulates the
+// result into dW - fixed summation order whatever the arrival order, no float atomics, no separate reduce launch.
+// Tickets are zero on entry and are left zero (the last arriver resets its counter).
 // ------------------------------------------------------------------------------------------------
-struct WgradParams {
+#define WG_BKP 16
+#define WG_GROUP 16
+#define WG_MAX_JOBS 20  // the job table travels as kernel arguments: 20 x 176 B + 8 B < 4 KB
+
+struct WgJob {
     const float* X;
     const float* DY;
-    float* part;  // [ksplit][K][J]
-    int N, H, W, C, K, R, S, stride, pad, Ho, Wo;
+    float* dw;
+    float* part;    // [tile][ksplit][BNK * BJ]
+    float* gpart;   // [tile][ngroups][BNK * BJ]   (ksplit > WG_GROUP)
+    int* tickets;   // [tile][ngroups + 1]
     long x_ld_pix, x_ld_img, y_ld_pix, y_ld_img;
     long x_bytes, dy_bytes;
-    int M, J, ksplit, mchunk;  // pixels per split (multiple of 16)
-    int kt_tiles, jt_tiles;
+    int H, W, C, K, S, stride, pad, Ho, Wo;
+    int M, J, ksplit, mchunk, kt_tiles, jt_tiles, ngroups;
+    int blk0;  // first workgroup of the job in its launch (a multiple of 8: XCD phase 0)
+    int vec;   // dW rows are 16-byte aligned
+};
+struct WgGroupParams {
+    int njobs, xcd_order;
+    WgJob jobs[WG_MAX_JOBS];
 };
 
-#define WG_BKP 16
+// dst (+)= src[0] + src[1] + ... + src[count - 1] (tiles `stride` floats apart), added in index order
+template <int NTH, int BNK, int BJ>
+__device__ __forceinline__ void wg_fold(const float* src, long stride, int count, float* tile_dst, float* dw, int K, int J, int k0, int j0, int vec) {
+    constexpr int E4 = BNK * BJ / 4;
+    for (int e4 = threadIdx.x; e4 < E4; e4 += NTH) {
+        const float* s = src + (long)e4 * 4;
+        float4 v = sgx_ld4(s);
+        for (int q = 1; q < count; ++q) {
+            const float4 u = sgx_ld4(s + q * stride);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        if (tile_dst) {
+            sgx_st4(tile_dst + (long)e4 * 4, v);
+            continue;
+        }
+        const int k = k0 + (e4 * 4) / BJ, j = j0 + (e4 * 4) % BJ;
+        if (k >= K || j >= J) continue;
+        float* d = dw + (long)k * J + j;
+        if (vec) {  // J % 4 == 0: the four columns are inside the row together
+            float4 o = sgx_ld4(d);
+            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+            sgx_st4(d, o);
+        } else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (j + t < J) d[t] += e[t];
+        }
+    }
+}
 
 template <int BNK, int BJ, int WK, int WC>
-__global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
     constexpr int NTH = WK * WC * 64;
     constexpr int TK = BNK / (WK * 32), TC = BJ / (WC * 32);
     static_assert(TK >= 1 && TC >= 1 && TK * WK * 32 == BNK && TC * WC * 32 == BJ, "bad tile");
@@ -1354,30 +1406,47 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgradParams p) {
     constexpr int DJ = (BNK / 4 + G - 1) / G, XJ = (BJ / 4 + G - 1) / G;
     __shared__ float Ds[2 * WG_BKP * BNK];
     __shared__ float Xs[2 * WG_BKP * BJ];
+    __shared__ int s_last;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave / WC, wc = wave % WC;
-    // blockIdx.x = (split * kt_tiles + ktile) * jt_tiles + jtile
-    int b = blockIdx.x;
-    const int jtile = b % p.jt_tiles; b /= p.jt_tiles;
-    const int ktile = b % p.kt_tiles; b /= p.kt_tiles;
-    const int split = b;
+    // which job: blocks [blk0, next blk0) belong to it
+    int ji = 0;
+    for (int i = 1; i < g.njobs; ++i)
+        if ((int)blockIdx.x >= g.jobs[i].blk0) ji = i;
+    const WgJob& p = g.jobs[ji];
+    const int T = p.kt_tiles * p.jt_tiles;
+    // (split, tile) of this workgroup.  XCD order: workgroup b runs on XCD b % 8; an XCD walks the tiles of split x, then of x + 8, ...
+    const int bl = (int)blockIdx.x - p.blk0;
+    int split, tile;
+    if (g.xcd_order) {
+        const int r = bl >> 3;
+        split = (bl & 7) + 8 * (r / T);
+        tile = r % T;
+    } else {
+        split = bl / T;
+        tile = bl % T;
+    }
+    if (split >= p.ksplit) return;  // whole workgroup leaves together (before any barrier)
+    const int ktile = tile / p.jt_tiles, jtile = tile - ktile * p.jt_tiles;
     const int k0 = ktile * BNK, j0 = jtile * BJ;
+    const int M = p.M, K = p.K, J = p.J, C = p.C, S = p.S, pad = p.pad, stride = p.stride, H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo;
+    const long x_ld_pix = p.x_ld_pix, x_ld_img = p.x_ld_img, y_ld_pix = p.y_ld_pix, y_ld_img = p.y_ld_img;
     const int mbeg = split * p.mchunk;
-    const int mend = min(p.M, mbeg + p.mchunk);
+    const int mend = min(M, mbeg + p.mchunk);
     const int nkt = (mend > mbeg) ? (mend - mbeg + WG_BKP - 1) / WG_BKP : 0;
-    const int hw = p.Ho * p.Wo;
+    const int hw = Ho * Wo;
 
     // descriptors re-based at the split's first image
     const int img0 = mbeg / hw;
-    const sgx_buf bufX = sgx_make_buf(p.X + (long)img0 * p.x_ld_img, p.x_bytes - (long)img0 * p.x_ld_img * 4);
-    const sgx_buf bufD = sgx_make_buf(p.DY + (long)img0 * p.y_ld_img, p.dy_bytes - (long)img0 * p.y_ld_img * 4);
+    const sgx_buf bufX = sgx_make_buf(p.X + (long)img0 * x_ld_img, p.x_bytes - (long)img0 * x_ld_img * 4);
+    const sgx_buf bufD = sgx_make_buf(p.DY + (long)img0 * y_ld_img, p.dy_bytes - (long)img0 * y_ld_img * 4);
 
     const int prow = tid / G, cg = tid % G;  // this lane's pixel row of the slab and first column group
     // pixel of slab 0
     int m = mbeg + prow;
     int img = m / hw, rem = m - img * hw;
-    int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    int ho = rem / Wo, wo = rem - ho * Wo;
     img -= img0;
 
     // fixed per column group: dY channel, X (tap, channel) -> byte delta and tap shift
@@ -1387,7 +1456,7 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgradParams p) {
     for (int q = 0; q < DJ; ++q) {
         const int c4 = (cg + q * G) * 4;
         dcol[q] = c4;
-        dok[q] = c4 < BNK && k0 + c4 < p.K;
+        dok[q] = c4 < BNK && k0 + c4 < K;
     }
     int xcol[XJ], xdelta[XJ], xdh[XJ], xdw[XJ];
     bool xok[XJ];
@@ -1396,45 +1465,45 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgradParams p) {
         const int c4 = (cg + q * G) * 4;
         const int j = j0 + c4;
         xcol[q] = c4;
-        xok[q] = c4 < BJ && j < p.J;
-        const int tap = xok[q] ? j / p.C : 0;
-        const int c = j - tap * p.C;
-        const int tr = tap / p.S, ts = tap - tr * p.S;
-        xdh[q] = tr - p.pad;
-        xdw[q] = ts - p.pad;
-        xdelta[q] = (int)((((long)xdh[q] * p.W + xdw[q]) * p.x_ld_pix + c) * 4);
+        xok[q] = c4 < BJ && j < J;
+        const int tap = xok[q] ? j / C : 0;
+        const int c = j - tap * C;
+        const int tr = tap / S, ts = tap - tr * S;
+        xdh[q] = tr - pad;
+        xdw[q] = ts - pad;
+        xdelta[q] = (int)((((long)xdh[q] * W + xdw[q]) * x_ld_pix + c) * 4);
     }
 
     float4 rd[DJ], rx[XJ];
     auto load_tile = [&]() {
         const bool pok = m < mend;
-        const int dbase = (int)(((long)img * p.y_ld_img + ((long)ho * p.Wo + wo) * p.y_ld_pix + k0) * 4);
-        const int hi0 = ho * p.stride, wi0 = wo * p.stride;
-        const int xbase = (int)(((long)img * p.x_ld_img + ((long)hi0 * p.W + wi0) * p.x_ld_pix) * 4);
+        const int dbase = (int)(((long)img * y_ld_img + ((long)ho * Wo + wo) * y_ld_pix + k0) * 4);
+        const int hi0 = ho * stride, wi0 = wo * stride;
+        const int xbase = (int)(((long)img * x_ld_img + ((long)hi0 * W + wi0) * x_ld_pix) * 4);
 #pragma unroll
         for (int q = 0; q < DJ; ++q) rd[q] = sgx_buf_ld4(bufD, (pok && dok[q]) ? (unsigned)(dbase + dcol[q] * 4) : SGX_BUF_OOB);
 #pragma unroll
         for (int q = 0; q < XJ; ++q) {
             const int hi = hi0 + xdh[q], wi = wi0 + xdw[q];
-            const bool ok = pok && xok[q] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+            const bool ok = pok && xok[q] && hi >= 0 && hi < H && wi >= 0 && wi < W;
             rx[q] = sgx_buf_ld4(bufX, ok ? (unsigned)(xbase + xdelta[q]) : SGX_BUF_OOB);
         }
         // advance this lane's pixel by one slab
         m += WG_BKP;
-        if (p.Wo >= WG_BKP) {
+        if (Wo >= WG_BKP) {
             wo += WG_BKP;
-            if (wo >= p.Wo) {
-                wo -= p.Wo;
-                if (++ho >= p.Ho) {
+            if (wo >= Wo) {
+                wo -= Wo;
+                if (++ho >= Ho) {
                     ho = 0;
                     ++img;
                 }
             }
         } else {
-            int mm = m < p.M ? m : p.M - 1;
+            int mm = m < M ? m : M - 1;
             int im = mm / hw, rm = mm - im * hw;
-            ho = rm / p.Wo;
-            wo = rm - ho * p.Wo;
+            ho = rm / Wo;
+            wo = rm - ho * Wo;
             img = im - img0;
         }
     };
@@ -1479,44 +1548,69 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgradParams p) {
         if (kt + 1 < nkt) store_tile(buf ^ 1);
         __syncthreads();
     }
-    // partial tile: part[split][k][j]
+    float* const dw = p.dw;
+    if (p.ksplit == 1) {  // the only split of its tile: straight into dW
 #pragma unroll
-    for (int i = 0; i < TK; ++i)
+        for (int i = 0; i < TK; ++i)
 #pragma unroll
-        for (int j = 0; j < TC; ++j) {
-            const int jj = j0 + wc * TC * 32 + j * 32 + (lane & 31);
+            for (int j = 0; j < TC; ++j) {
+                const int jj = j0 + wc * TC * 32 + j * 32 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = k0 + wk * TK * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (k < p.K && jj < p.J) p.part[((long)split * p.K + k) * p.J + jj] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int k = k0 + wk * TK * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (k < K && jj < J) dw[(long)k * J + jj] += acc[i][j][r];
+                }
             }
-        }
-}
-
-// dw[i] += sum_k part[k][i]: a workgroup owns EL consecutive elements and walks the split slabs with KL lanes per element
-// (KL * EL = 256), then folds the KL lane sums through LDS in a fixed order (deterministic, no atomics).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dw, long n, int ksplit, int KL) {
-    __shared__ float red[256];
-    const int EL = 256 / KL;
-    const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
-    const long i = (long)blockIdx.x * EL + el;
-    float s = 0.f;
-    if (i < n) {
-#pragma unroll 8
-        for (int k = kl; k < ksplit; k += KL) s += part[(long)k * n + i];
+        return;
     }
-    red[threadIdx.x] = s;
+    // partial tile (whole padded tile: rows / columns outside the filter are exact zeros)
+    constexpr int TE = BNK * BJ;
+    const int ksplit = p.ksplit, ngroups = p.ngroups, vec = p.vec;
+    {
+        float* const mine = p.part + ((long)tile * ksplit + split) * TE;
+#pragma unroll
+        for (int i = 0; i < TK; ++i)
+#pragma unroll
+            for (int j = 0; j < TC; ++j) {
+                const int jl = wc * TC * 32 + j * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(wk * TK * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BJ + jl] = acc[i][j][r];
+            }
+    }
+    // publish, take a ticket; the group's last arriver folds the group in split order
+    sgx_fence_release();
     __syncthreads();
-    if (kl == 0 && i < n) {
-        float t = 0.f;
-        for (int k = 0; k < KL; ++k) t += red[k * EL + el];
-        dw[i] += t;
+    const int grp = split / WG_GROUP, gbeg = grp * WG_GROUP;
+    const int gcnt = min(WG_GROUP, ksplit - gbeg);
+    int* const tk = p.tickets + (long)tile * (ngroups + 1);
+    if (tid == 0) {
+        const int old = atomicAdd(&tk[grp], 1);
+        s_last = old == gcnt - 1;
+        if (old == gcnt - 1) tk[grp] = 0;
     }
+    __syncthreads();
+    if (!s_last) return;
+    sgx_fence_acquire();
+    const float* const src = p.part + ((long)tile * ksplit + gbeg) * TE;
+    if (ngroups == 1) {
+        wg_fold<NTH, BNK, BJ>(src, TE, gcnt, nullptr, dw, K, J, k0, j0, vec);
+        return;
+    }
+    wg_fold<NTH, BNK, BJ>(src, TE, gcnt, p.gpart + ((long)tile * ngroups + grp) * TE, nullptr, K, J, k0, j0, vec);
+    sgx_fence_release();
+    __syncthreads();
+    if (tid == 0) {
+        const int old = atomicAdd(&tk[ngroups], 1);
+        s_last = old == ngroups - 1;
+        if (old == ngroups - 1) tk[ngroups] = 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    sgx_fence_acquire();
+    wg_fold<NTH, BNK, BJ>(p.gpart + (long)tile * ngroups * TE, TE, ngroups, nullptr, dw, K, J, k0, j0, vec);
 }
 
-struct WgradPlan {
-    int bnk, bj, waves, kt_tiles, jt_tiles, ksplit, mchunk;
-};
+// ---- host side: tile choice, group plan, launches ------------------------------------------------------------------------------------
 static int wg_tile(int n) {  // least padding among {32,64,96,128}, ties to the wider tile
     const int cand[4] = {32, 64, 96, 128};
     int b = 128, best = 1 << 30;
@@ -1542,10 +1636,25 @@ static int wg_waves(int bnk, int bj) {  // waves per workgroup of the instantiat
 }
 extern "C" int32_t sgx_stats_blocks(int64_t M);
 extern "C" int64_t sgx_colsum_workspace(int64_t M, int32_t C);
-static WgradPlan wgrad_plan(const sgx_conv_desc* d) {
-    WgradPlan pl;
+// grouped-launch knobs (measurement: sgx_debug_set_wgrad_group): rounds of work items a large group is cut into, the work of an item
+// below which a small group is not cut further (MFLOP), XCD-aware block order
+static std::atomic<int> g_wg_rounds{6}, g_wg_item_mflop{8}, g_wg_xcd{1};
+extern "C" int32_t sgx_debug_set_wgrad_group(int32_t rounds, int32_t item_mflop, int32_t xcd_order) {
+    SGX_CHECK_ARG(rounds >= 0 && item_mflop >= 0, "debug_set_wgrad_group: negative value");
+    g_wg_rounds = rounds ? rounds : 6;
+    g_wg_item_mflop = item_mflop ? item_mflop : 8;
+    g_wg_xcd = xcd_order ? 1 : 0;
+    return SGX_OK;
+}
+struct WgPlan {
+    int bnk, bj, waves, kt_tiles, jt_tiles, ksplit, mchunk, ngroups;
+    long part_off, gpart_off, ticket_off;  // floats, floats, ints
+};
+// tile choice from the exhaustive search: 64x64 where the channel count allows, 96x128 for 96-wide layers; a tuning-table entry (kind 2)
+// or the measurement override replaces it
+static void wgrad_tile(const sgx_conv_desc* d, WgPlan& pl) {
+    TuneScope tune(2, d);
     const int J = d->R * d->S * d->C;
-    // tile choice from the same exhaustive search: 64x64 where the channel count allows, 96x128 for 96-wide layers
     int bnk = wg_tile(d->K), bj;
     if (d->K % 128 == 0 && d->K >= 384) bnk = 128;
     else if (d->K % 64 == 0) bnk = 64;
@@ -1553,37 +1662,164 @@ static WgradPlan wgrad_plan(const sgx_conv_desc* d) {
     if (bnk == 96) bj = J >= 128 ? 128 : wg_tile(J);
     else if (bnk == 32) bj = J >= 128 ? 128 : wg_tile(J);
     else bj = J >= 64 ? 64 : wg_tile(J);
-    if (t_tune && t_tune->bm) bnk = t_tune->bm, bj = t_tune->bn;  // tuning table entry of this problem (kind 2)
-    const int owk = g_ovr_wk.load(std::memory_order_relaxed), owj = g_ovr_wj.load(std::memory_order_relaxed), osp = g_ovr_split.load(std::memory_order_relaxed);
+    if (t_tune && t_tune->bm) bnk = t_tune->bm, bj = t_tune->bn;
+    const int owk = g_ovr_wk.load(std::memory_order_relaxed), owj = g_ovr_wj.load(std::memory_order_relaxed);
     pl.bnk = owk ? owk : bnk;
     pl.bj = owj ? owj : bj;
     pl.waves = wg_waves(pl.bnk, pl.bj);
     pl.kt_tiles = sgx_cdiv(d->K, pl.bnk);
     pl.jt_tiles = sgx_cdiv(J, pl.bj);
-    long M = (long)d->N * d->Ho * d->Wo;
-    long tiles = (long)pl.kt_tiles * pl.jt_tiles;
-    const int tuned_split = t_tune ? t_tune->var : 0;
-    long target = (osp ? osp : tuned_split ? tuned_split : (pl.bnk == 64 && pl.bj == 64 ? 8192 : 4096)) / pl.waves;  // 4-8 waves per SIMD over the chip
-    long ks = (target + tiles - 1) / tiles;
-    long maxsplit = (M + 255) / 256;         // at least 256 pixels (16 slabs) per split
-    if (ks > maxsplit) ks = maxsplit;
-    // a split's lane offsets are 31-bit: keep every split under 1 GiB of either operand
-    long big = (long)d->N * (d->x_ld_img > d->y_ld_img ? d->x_ld_img : d->y_ld_img) * 4;
-    long need = big / (1L << 30) + 1;
-    if (ks < need) ks = need;
-    if (ks < 1) ks = 1;
-    long mchunk = (M + ks - 1) / ks;
-    mchunk = ((mchunk + WG_BKP - 1) / WG_BKP) * WG_BKP;
-    ks = (M + mchunk - 1) / mchunk;
-    pl.ksplit = (int)ks;
-    pl.mchunk = (int)mchunk;
-    return pl;
+}
+#define WG_SLOTS 1536  // workgroups the chip holds at once (256 CUs x ~6): the unit a group's work is cut against
+static int32_t wgrad_group_plan(const sgx_wgrad_job* jobs, int n, std::vector<WgPlan>& plans, long* part_floats, long* ticket_ints) {
+    plans.resize(n);
+    double work = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const sgx_conv_desc* d = &jobs[i].d;
+        int32_t rc = check_desc(d);
+        if (rc) return rc;
+        SGX_CHECK_ARG(d->K % 4 == 0 && d->y_ld_pix % 4 == 0, "conv bwd_weight: K and dy pixel stride must be multiples of 4");
+        wgrad_tile(d, plans[i]);
+        work += 2.0 * d->N * d->Ho * d->Wo * (double)plans[i].kt_tiles * plans[i].bnk * (double)plans[i].jt_tiles * plans[i].bj;
+    }
+    // work of one item: a large group is cut into `rounds` rounds of WG_SLOTS items; a small one into items of >= item_mflop (~100 us of
+    // one workgroup beside its co-residents) as long as that still leaves ~1.3 rounds
+    const double lo = 1e6 * g_wg_item_mflop.load(std::memory_order_relaxed);
+    double item = work / ((double)WG_SLOTS * g_wg_rounds.load(std::memory_order_relaxed));
+    if (item < lo) item = fmin(lo, work / (WG_SLOTS * 1.3));
+    const int osp = g_ovr_split.load(std::memory_order_relaxed);
+    long poff = 0, toff = 0;
+    for (int i = 0; i < n; ++i) {
+        const sgx_conv_desc* d = &jobs[i].d;
+        WgPlan& pl = plans[i];
+        const long M = (long)d->N * d->Ho * d->Wo;
+        const long tiles = (long)pl.kt_tiles * pl.jt_tiles;
+        long mchunk = (long)(item / (2.0 * pl.bnk * pl.bj));
+        if (osp) mchunk = M / sgx_cdiv(sgx_cdiv(osp, pl.waves), tiles);  // measurement: that many waves per job
+        if (mchunk < 256) mchunk = 256;  // at least 16 slabs per item
+        if (mchunk > M) mchunk = M;
+        long ks = (M + mchunk - 1) / mchunk;
+        if (ks > WG_GROUP * WG_GROUP) ks = WG_GROUP * WG_GROUP;  // two ticket levels
+        // a split's lane offsets are 31-bit: keep every split under 1 GiB of either operand
+        const long big = (long)d->N * (d->x_ld_img > d->y_ld_img ? d->x_ld_img : d->y_ld_img) * 4;
+        const long need = big / (1L << 30) + 1;
+        if (ks < need) ks = need;
+        if (ks > WG_GROUP * WG_GROUP) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv bwd_weight: operand too large (%ld pixel ranges of 1 GiB)", need);
+        mchunk = (M + ks - 1) / ks;
+        mchunk = ((mchunk + WG_BKP - 1) / WG_BKP) * WG_BKP;
+        ks = (M + mchunk - 1) / mchunk;
+        pl.ksplit = (int)ks;
+        pl.mchunk = (int)mchunk;
+        pl.ngroups = (int)((ks + WG_GROUP - 1) / WG_GROUP);
+        const long te = (long)pl.bnk * pl.bj;
+        pl.part_off = poff;
+        poff += ks > 1 ? tiles * ks * te : 0;
+        pl.gpart_off = poff;
+        poff += pl.ngroups > 1 ? tiles * pl.ngroups * te : 0;
+        pl.ticket_off = toff;
+        toff += ks > 1 ? tiles * (pl.ngroups + 1) : 0;
+    }
+    *part_floats = poff;
+    *ticket_ints = toff;
+    return SGX_OK;
+}
+extern "C" int32_t sgx_conv2d_bwd_weight_group_sizes(const sgx_wgrad_job* jobs, int32_t njobs, int64_t* ws_bytes, int64_t* ticket_ints) {
+    SGX_CHECK_ARG(jobs && njobs > 0 && ws_bytes && ticket_ints, "conv bwd_weight_group_sizes: bad args");
+    std::vector<WgPlan> plans;
+    long pf = 0, ti = 0;
+    int32_t rc = wgrad_group_plan(jobs, njobs, plans, &pf, &ti);
+    if (rc) return rc;
+    *ws_bytes = pf * 4 + 256;
+    *ticket_ints = ti + 1;
+    return SGX_OK;
+}
+template <int BNK, int BJ, int WK, int WC>
+static void launch_wgrad(const WgGroupParams& g, int nblk, void* stream) {
+    SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC>), dim3((unsigned)nblk), dim3(WK * WC * 64), 0, stream, g);
+}
+extern "C" int32_t sgx_conv2d_bwd_weight_group(const sgx_wgrad_job* jobs, int32_t njobs, void* ws, int64_t ws_bytes, int32_t* tickets,
+                                               int64_t ticket_ints, void* stream) {
+    SGX_CHECK_ARG(jobs && njobs > 0, "conv bwd_weight_group: bad args");
+    std::vector<WgPlan> plans;
+    long pf = 0, ti = 0;
+    int32_t rc = wgrad_group_plan(jobs, njobs, plans, &pf, &ti);
+    if (rc) return rc;
+    if (!ws || ws_bytes < pf * 4 + 256 || ((uintptr_t)ws % 16) != 0) SGX_FAIL(SGX_ERR_WORKSPACE, "conv bwd_weight_group: workspace too small / unaligned");
+    if (!tickets || ticket_ints < ti + 1) SGX_FAIL(SGX_ERR_WORKSPACE, "conv bwd_weight_group: ticket buffer too small");
+    std::vector<char> done(njobs, 0);
+    for (int first = 0; first < njobs; ++first) {
+        if (done[first]) continue;
+        // one launch per tile shape (and per WG_MAX_JOBS jobs of it)
+        WgGroupParams g;
+        memset(&g, 0, sizeof(g));
+        g.xcd_order = g_wg_xcd.load(std::memory_order_relaxed);
+        int nblk = 0;
+        double flops = 0.0, bytes = 0.0;
+        for (int i = first; i < njobs && g.njobs < WG_MAX_JOBS; ++i) {
+            if (done[i] || plans[i].bnk != plans[first].bnk || plans[i].bj != plans[first].bj) continue;
+            done[i] = 1;
+            const sgx_conv_desc* d = &jobs[i].d;
+            const WgPlan& pl = plans[i];
+            SGX_CHECK_ARG(jobs[i].x && jobs[i].dy && jobs[i].dw, "conv bwd_weight: null pointer");
+            WgJob& p = g.jobs[g.njobs++];
+            p.X = jobs[i].x; p.DY = jobs[i].dy; p.dw = jobs[i].dw;
+            p.part = (float*)ws + pl.part_off; p.gpart = (float*)ws + pl.gpart_off; p.tickets = tickets + pl.ticket_off;
+            p.x_ld_pix = d->x_ld_pix; p.x_ld_img = d->x_ld_img; p.y_ld_pix = d->y_ld_pix; p.y_ld_img = d->y_ld_img;
+            p.x_bytes = view_bytes(d->N, d->H, d->W, d->C, d->x_ld_pix, d->x_ld_img);
+            p.dy_bytes = view_bytes(d->N, d->Ho, d->Wo, d->K, d->y_ld_pix, d->y_ld_img);
+            p.H = d->H; p.W = d->W; p.C = d->C; p.K = d->K; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+            p.M = d->N * d->Ho * d->Wo; p.J = d->R * d->S * d->C;
+            p.ksplit = pl.ksplit; p.mchunk = pl.mchunk; p.kt_tiles = pl.kt_tiles; p.jt_tiles = pl.jt_tiles; p.ngroups = pl.ngroups;
+            p.blk0 = nblk;
+            p.vec = (p.J % 4 == 0 && ((uintptr_t)p.dw % 16) == 0) ? 1 : 0;
+            nblk += 8 * sgx_cdiv(pl.ksplit, 8) * pl.kt_tiles * pl.jt_tiles;
+            flops += 2.0 * (double)p.M * (double)d->K * (double)p.J;
+            bytes += 4.0 * ((double)d->N * d->H * d->W * d->C + (double)p.M * d->K + (double)d->K * p.J);
+        }
+        {
+            SGX_PROF(1, flops, bytes, stream);
+            const WgPlan& pl = plans[first];
+            bool launched = false;
+#define WG_CASE(BK_, BJ_, WK_, WC_)                              \
+    if (!launched && pl.bnk == BK_ && pl.bj == BJ_) {            \
+        launch_wgrad<BK_, BJ_, WK_, WC_>(g, nblk, stream);       \
+        launched = true;                                         \
+    }
+            WG_CASE(128, 128, 2, 2)
+            WG_CASE(128, 96, 4, 1)
+            WG_CASE(128, 64, 2, 2)
+            WG_CASE(128, 32, 4, 1)
+            WG_CASE(96, 128, 1, 4)
+            WG_CASE(96, 96, 3, 1)
+            WG_CASE(96, 64, 3, 1)
+            WG_CASE(96, 32, 3, 1)
+            WG_CASE(64, 128, 2, 2)
+            WG_CASE(64, 96, 2, 1)
+            WG_CASE(64, 64, 2, 2)
+            WG_CASE(64, 32, 2, 1)
+            WG_CASE(32, 128, 1, 4)
+            WG_CASE(32, 96, 1, 3)
+            WG_CASE(32, 64, 1, 2)
+            WG_CASE(32, 32, 1, 1)
+#undef WG_CASE
+            if (!launched) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv bwd_weight: no tile %dx%d", pl.bnk, pl.bj);
+        }
+        SGX_CHECK_LAUNCH("wgrad");
+    }
+    return SGX_OK;
 }
 
+// One weight gradient (a group of one).  ws holds the partial tiles, then the tickets (cleared here: the caller's workspace is scratch).
+static int64_t wgrad_single_sizes(const sgx_conv_desc* d, int64_t* part_bytes, int64_t* ticket_ints) {
+    sgx_wgrad_job job;
+    memset(&job, 0, sizeof(job));
+    job.d = *d;
+    return sgx_conv2d_bwd_weight_group_sizes(&job, 1, part_bytes, ticket_ints);
+}
 extern "C" int64_t sgx_conv2d_bwd_weight_workspace(const sgx_conv_desc* d) {
-    TuneScope tune(2, d);
-    WgradPlan pl = wgrad_plan(d);
-    int64_t slabs = (int64_t)pl.ksplit * d->K * d->R * d->S * d->C * sizeof(float);
+    int64_t pb = 0, ti = 0;
+    if (wgrad_single_sizes(d, &pb, &ti)) return -1;
+    int64_t slabs = ((pb + 255) / 256) * 256 + ti * 4;
     int64_t bias = sgx_colsum_workspace((int64_t)d->N * d->Ho * d->Wo, d->K);
     return (slabs > bias ? slabs : bias) + 256;
 }
@@ -1593,58 +1829,19 @@ extern "C" int32_t sgx_conv2d_bwd_weight(const sgx_conv_desc* d, const float* x,
     int32_t rc = check_desc(d);
     if (rc) return rc;
     SGX_CHECK_ARG(x && dy && dw, "conv bwd_weight: null pointer");
-    SGX_CHECK_ARG(d->K % 4 == 0 && d->y_ld_pix % 4 == 0, "conv bwd_weight: K and dy pixel stride must be multiples of 4");
+    int64_t pb = 0, ti = 0;
+    rc = wgrad_single_sizes(d, &pb, &ti);
+    if (rc) return rc;
     if (!ws || ws_bytes < sgx_conv2d_bwd_weight_workspace(d)) SGX_FAIL(SGX_ERR_WORKSPACE, "conv bwd_weight: workspace too small");
-    TuneScope tune(2, d);
-    WgradPlan pl = wgrad_plan(d);
-    WgradParams p;
-    p.X = x; p.DY = dy; p.part = (float*)ws;
-    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.K = d->K; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
-    p.Ho = d->Ho; p.Wo = d->Wo;
-    p.x_ld_pix = d->x_ld_pix; p.x_ld_img = d->x_ld_img; p.y_ld_pix = d->y_ld_pix; p.y_ld_img = d->y_ld_img;
-    p.x_bytes = view_bytes(d->N, d->H, d->W, d->C, d->x_ld_pix, d->x_ld_img);
-    p.dy_bytes = view_bytes(d->N, d->Ho, d->Wo, d->K, d->y_ld_pix, d->y_ld_img);
-    p.M = d->N * d->Ho * d->Wo; p.J = d->R * d->S * d->C;
-    p.ksplit = pl.ksplit; p.mchunk = pl.mchunk; p.kt_tiles = pl.kt_tiles; p.jt_tiles = pl.jt_tiles;
-    long nblk = (long)pl.ksplit * pl.kt_tiles * pl.jt_tiles;
-    dim3 grid((unsigned)nblk);
-    {
-    SGX_PROF(1, 2.0 * (double)p.M * (double)d->K * (double)p.J,
-             4.0 * ((double)d->N * d->H * d->W * d->C + (double)p.M * d->K + (double)d->K * p.J), stream);
-    bool launched = false;
-#define WG_CASE(BK_, BJ_, WK_, WC_)                                                                                  \
-    if (!launched && pl.bnk == BK_ && pl.bj == BJ_) {                                                                \
-        SGX_LAUNCH((wgrad_kernel<BK_, BJ_, WK_, WC_>), grid, dim3(WK_ * WC_ * 64), 0, stream, p);                    \
-        launched = true;                                                                                             \
-    }
-    WG_CASE(128, 128, 2, 2)
-    WG_CASE(128, 96, 4, 1)
-    WG_CASE(128, 64, 2, 2)
-    WG_CASE(128, 32, 4, 1)
-    WG_CASE(96, 128, 1, 4)
-    WG_CASE(96, 96, 3, 1)
-    WG_CASE(96, 64, 3, 1)
-    WG_CASE(96, 32, 3, 1)
-    WG_CASE(64, 128, 2, 2)
-    WG_CASE(64, 96, 2, 1)
-    WG_CASE(64, 64, 2, 2)
-    WG_CASE(64, 32, 2, 1)
-    WG_CASE(32, 128, 1, 4)
-    WG_CASE(32, 96, 1, 3)
-    WG_CASE(32, 64, 1, 2)
-    WG_CASE(32, 32, 1, 1)
-#undef WG_CASE
-    if (!launched) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv bwd_weight: no tile %dx%d", pl.bnk, pl.bj);
-    }
-    SGX_CHECK_LAUNCH("wgrad");
-    long n = (long)d->K * p.J;
-    int KL = 1;
-    while (KL < 16 && KL < pl.ksplit) KL *= 2;
-    const int EL = 256 / KL;
-    SGX_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n + EL - 1) / EL)), dim3(256), 0, stream, (const float*)ws, dw, n, pl.ksplit, KL);
-    SGX_CHECK_LAUNCH("wgrad_reduce");
+    const int64_t toff = ((pb + 255) / 256) * 256;
+    int32_t* tickets = (int32_t*)((char*)ws + toff);
+    SGX_MEMSET_ASYNC(tickets, 0, ti * 4, stream);
+    sgx_wgrad_job job;
+    job.d = *d; job.x = x; job.dy = dy; job.dw = dw;
+    rc = sgx_conv2d_bwd_weight_group(&job, 1, ws, toff, tickets, ti, stream);
+    if (rc) return rc;
     if (dbias) {
-        // column sum of dy; the workspace is free again once the slab reduce above has run (stream order)
+        // column sum of dy; the workspace is free again once the launch above has run (stream order)
         return sgx_colsum(dy, d->y_ld_pix, (int64_t)d->N * d->Ho * d->Wo, d->K, (int64_t)d->Ho * d->Wo, d->y_ld_img, dbias, 1, (float*)ws, stream);
     }
     return SGX_OK;

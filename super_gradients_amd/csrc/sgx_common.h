@@ -103,5 +103,16 @@ __device__ __forceinline__ float4 sgx_buf_ld4(sgx_buf b, unsigned off) {
 }
 #endif
 
+// ---- device-scope publish / observe fences (cross-workgroup hand-over through HBM: arrival tickets) ---------------------------------------
+// release: this thread's earlier stores are visible device-wide (L2 write-back across XCDs) before anything that follows;
+// acquire: loads that follow see what other workgroups released (non-local L2 lines invalidated).
+#ifdef SGX_EMU
+#define sgx_fence_release() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define sgx_fence_acquire() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#else
+#define sgx_fence_release() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define sgx_fence_acquire() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#endif
+
 __device__ __forceinline__ float4 sgx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void sgx_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -79,6 +79,7 @@ def clear_caches():
     """Everything this module remembers about the bound library (descriptors, size queries): for code that re-binds the library (the tests'
     host emulation / no-op builds)."""
     clear_desc_cache()
+    _TICKETS.clear()
     for f in (stats_blocks, _reduce_workspace, _qarep_workspace, _dot_workspace):
         f.cache_clear()
 
@@ -299,6 +300,39 @@ def conv2d_bwd_weight(x, dy, dw, dbias=None, stride=1, pad=0):
         d.wgrad_ws = lib().sgx_conv2d_bwd_weight_workspace(d.ref)
     ws = WORKSPACE.get(d.wgrad_ws, x.device)
     check(lib().sgx_conv2d_bwd_weight(d.ref, ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), stream()), "sgx_conv2d_bwd_weight")
+
+
+_TICKETS = {}
+
+
+def _ticket_buffer(n_ints: int, device) -> torch.Tensor:
+    """The arrival-ticket buffer of the grouped weight gradient on the current stream: int32, zero when handed to a launch and left zero by
+    it (include/sgx_hip.h: sgx_conv2d_bwd_weight_group), so it is cleared exactly once - when it is allocated."""
+    key = (device, stream() or 0)
+    b = _TICKETS.get(key)
+    if b is None or b.numel() < n_ints:
+        b = _TICKETS[key] = torch.zeros(max(2 * int(n_ints), 1 << 16), dtype=torch.int32, device=device)
+    return b
+
+
+def conv2d_bwd_weight_group(entries):
+    """entries: [(x, dy, dw, stride, pad), ...] - every dw (logical [K,C,R,S], OHWI memory) += its weight gradient, as ONE launch per tile
+    shape for the whole list (pixel splits sized for the group, partials folded inside the launch)."""
+    n = len(entries)
+    if n == 0:
+        return
+    jobs = (_lib.WgradJob * n)()
+    for j, (x, dy, dw, stride, pad) in zip(jobs, entries):
+        K, C, R, S = dw.shape
+        _chk_w(dw, K, R, S, x.shape[3])
+        j.d = conv_desc(x, K, R, S, stride, pad, dy)
+        j.x, j.dy, j.dw = ptr(x), ptr(dy), ptr(dw)
+    ws_bytes, t_ints = ctypes.c_int64(), ctypes.c_int64()
+    check(lib().sgx_conv2d_bwd_weight_group_sizes(jobs, n, ctypes.byref(ws_bytes), ctypes.byref(t_ints)), "sgx_conv2d_bwd_weight_group_sizes")
+    dev = entries[0][0].device
+    ws = WORKSPACE.get(ws_bytes.value, dev)
+    tk = _ticket_buffer(t_ints.value, dev)
+    check(lib().sgx_conv2d_bwd_weight_group(jobs, n, ptr(ws), ws.numel(), ptr(tk), tk.numel(), stream()), "sgx_conv2d_bwd_weight_group")
 
 
 def _chk_wt(wt, C, K):

@@ -195,6 +195,12 @@ class SgxNetwork(nn.Module):
         # under the side-stream weight gradients, so it stays off by default.
         self.aux_stream = torch.cuda.Stream(device=device) if (self.side_stream is not None and os.environ.get("SGX_AUX_STREAM", "0") == "1") else None
         self._wt_valid = False
+        # Weight gradients are mutually independent: blocks queue them (ConvLayer.wgrad) and the network launches a stretch of backward's
+        # worth together (kernels.conv2d_bwd_weight_group: one launch per tile shape, splits sized for the group, partials folded inside
+        # the launch) - whenever the queued work passes SGX_WGRAD_GROUP_GFLOP (default 40, ~0.5 ms of chip time: the stretch that is
+        # left un-overlapped at the end of backward), at every gradient-bucket boundary and at the end of backward.  0: one call per layer.
+        self.wg_group_flops = float(os.environ.get("SGX_WGRAD_GROUP_GFLOP", "40")) * 1e9
+        self._wg_pending, self._wg_flops = [], 0.0
         # The data-gradient weight transposes of ALL convolutions run as one launch at the start of every training forward (a job table
         # built once - the operands are arena views, their addresses never change) instead of one launch per convolution and parity class
         # inside backward (YOLO-NAS-S: 165 launches of ~10 us per step; SGX_WT_BATCH=0 restores the per-call form), and so do the
@@ -228,7 +234,7 @@ class SgxNetwork(nn.Module):
                         if v is not None:
                             m.__dict__[name] = v
 
-    _RUNTIME_ATTRS = ("side_stream", "aux_stream", "_wt_jobs", "_qp_jobs", "_dgrad_convs")
+    _RUNTIME_ATTRS = ("side_stream", "aux_stream", "_wt_jobs", "_qp_jobs", "_dgrad_convs", "_wg_pending")
 
     def __deepcopy__(self, memo):
         """copy.deepcopy(model) - what the reference's predict() pipeline does before fusing (pipelines.py:95-100): parameters, buffers and
@@ -289,8 +295,34 @@ class SgxNetwork(nn.Module):
                 t.record_stream(side)
         return out
 
+    def queue_wgrad(self, x, dy, gw, stride, pad):
+        self._wg_pending.append((x, dy, gw, stride, pad))
+        k, _, r, s_ = gw.shape
+        self._wg_flops += 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * k * r * s_ * x.shape[3]
+        if self._wg_flops >= self.wg_group_flops:
+            self.flush_wgrads()
+
+    def flush_wgrads(self):
+        """Launch the queued weight gradients (side stream).  The queue holds references to their operands until here."""
+        pending = getattr(self, "_wg_pending", None)
+        if not pending:
+            return
+        from .. import kernels as K
+
+        self._wg_pending, self._wg_flops = [], 0.0
+        self.fork_side(lambda: K.conv2d_bwd_weight_group(pending), *[t for e in pending for t in e[:2]])
+
+    def _bucket_ready(self, prefix: str):
+        """Backward of sub-network `prefix` is enqueued: its queued weight gradients go out, then the gradient exchange may start."""
+        self.flush_wgrads()
+        ready = getattr(self, "_grad_ready", None)
+        if ready is not None:
+            ready(prefix)
+
     def join_side(self):
-        """Make the current stream wait for the side stream (before anything consumes the weight gradients)."""
+        """Make the current stream wait for the side stream (before anything consumes the weight gradients); queued weight gradients go
+        out first."""
+        self.flush_wgrads()
         side = getattr(self, "side_stream", None)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
@@ -379,6 +411,7 @@ class NetFunction(torch.autograd.Function):
         net = ctx.net
         net.join_aux()
         net._bwd(*grads)
+        net.flush_wgrads()
         net._wt_valid = False
         net.join_side()
         hook = getattr(net, "_post_backward_hook", None)

@@ -75,8 +75,15 @@ class ConvLayer(SgxBlock):
 
     def wgrad(self, x, dy, bias_grad=True):
         """bias_grad=False: the caller knows sum(dy) is zero per channel (dy is a training-mode BatchNorm's input gradient)"""
-        self._net.fork_side(lambda: K.conv2d_bwd_weight(x, dy, self._gw, self.bias.grad if (self.bias is not None and bias_grad) else None,
-                                                        stride=self.stride, pad=self.padding), x, dy)
+        net = self._net
+        if net.wg_group_flops > 0:  # queued: the network launches the weight gradients of a stretch of backward together
+            if self.bias is not None and bias_grad:
+                gb = self.bias.grad
+                net.fork_side(lambda: K.colsum(dy, gb), dy)
+            net.queue_wgrad(x, dy, self._gw, self.stride, self.padding)
+            return
+        net.fork_side(lambda: K.conv2d_bwd_weight(x, dy, self._gw, self.bias.grad if (self.bias is not None and bias_grad) else None,
+                                                  stride=self.stride, pad=self.padding), x, dy)
 
     def dgrad(self, dy, x_shape, out=None, accumulate=False, addend=None):
         if self._wt is not None and self._net._wt_valid:  # transposed under the forward pass (engine.prefetch_dgrad_weights)

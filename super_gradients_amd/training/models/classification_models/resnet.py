@@ -199,7 +199,7 @@ class _ResNetBase(SgxNetwork):
     def _bwd(self, d_logits):
         d = self.linear.bwd(d_logits.contiguous())
         d = K.avgpool_bwd(d.contiguous(), self._feat_shape)
-        ready = getattr(self, "_grad_ready", None) or (lambda prefix: None)
+        ready = self._bucket_ready
         ready("linear.")
         for name in ("layer4", "layer3", "layer2", "layer1"):
             for blk in reversed(getattr(self, name).blocks()):

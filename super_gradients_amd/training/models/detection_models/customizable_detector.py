@@ -104,7 +104,7 @@ class CustomizableDetector(DetectionPredictMixin, SgxNetwork):
             d_logits = torch.zeros(like_l, device=dev)
         if d_distri is None:
             d_distri = torch.zeros(like_d, device=dev)
-        ready = getattr(self, "_grad_ready", None) or (lambda prefix: None)
+        ready = self._bucket_ready
         dps = self.heads.bwd(d_logits.contiguous(), d_distri.contiguous())
         ready("heads.")
         dcs = self.neck.bwd(*dps)

@@ -122,7 +122,7 @@ class PPYoloE(DetectionPredictMixin, SgxNetwork):
             d_logits = torch.zeros(like_l, device=dev)
         if d_distri is None:
             d_distri = torch.zeros(like_d, device=dev)
-        ready = getattr(self, "_grad_ready", None) or (lambda prefix: None)
+        ready = self._bucket_ready
         dps = self.head.bwd(d_logits.contiguous(), d_distri.contiguous())
         ready("head.")
         dcs = self.neck.bwd(*dps)

@@ -27,6 +27,17 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
         std::vector<WaveState> nv(nwaves);
         bs->waves.swap(nv);
     }
+    // SGX_EMU_SHUFFLE=<seed>: run the workgroups in a pseudo-random order (kernels that hand work between workgroups - arrival tickets -
+    // must not depend on the dispatch order)
+    std::vector<long> order(nblocks);
+    for (long b = 0; b < nblocks; ++b) order[b] = b;
+    if (const char* sh = getenv("SGX_EMU_SHUFFLE")) {
+        unsigned long long st = strtoull(sh, nullptr, 10) * 6364136223846793005ull + 1442695040888963407ull;
+        for (long b = nblocks - 1; b > 0; --b) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(order[b], order[(long)((st >> 33) % (unsigned long long)(b + 1))]);
+        }
+    }
     Barrier outer;
     outer.reset(nthreads);
     auto worker = [&](int tid) {
@@ -37,7 +48,8 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
         t_threadIdx.z = tid / (block.x * block.y);
         t_lane = tid & 63;
         t_wave = tid >> 6;
-        for (long b = 0; b < nblocks; ++b) {
+        for (long bi = 0; bi < nblocks; ++bi) {
+            const long b = order[bi];
             if (tid == 0) {
                 bs->bar.reset(nthreads);
                 for (int w = 0; w < nwaves; ++w) {

@@ -1055,3 +1055,60 @@ def test_conv_every_tile_shape(backend, math):
     finally:
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
         K.set_conv_math("fp32")
+
+
+def test_wgrad_group(backend, monkeypatch):
+    """sgx_conv2d_bwd_weight_group: several weight gradients of different shapes / tile shapes in one call, pixel splits folded inside the
+    launch by arrival tickets - one ticket level (<= 16 splits), two levels (> 16), the direct form (one split); dw accumulates; the
+    result does not depend on the order in which workgroups arrive (the emulation dispatches them in a shuffled order), the tickets are
+    left zero (a second call on the same buffers is correct) and the same call twice is bit-identical (fixed summation order)."""
+    from super_gradients_amd._lib import lib
+
+    gpu = backend.type == "cuda"
+    # (N, H, W, C, K, R, stride, pad)
+    cases = [(2, 80, 80, 64, 64, 3, 1, 1), (2, 80, 80, 96, 96, 1, 1, 0), (4, 40, 40, 32, 48, 3, 2, 1), (1, 20, 20, 128, 32, 1, 1, 0),
+             (2, 160, 160, 4, 48, 3, 2, 1)] if gpu else \
+            [(1, 72, 72, 4, 8, 1, 1, 0), (1, 9, 7, 8, 36, 3, 1, 1), (2, 12, 12, 8, 8, 3, 2, 1), (1, 20, 26, 4, 40, 1, 1, 0)]
+    ents, refs = [], []
+    for i, shape in enumerate(cases):
+        n, h, w, c, k, r, s, p = shape
+        x, wt, _ = _conv_case(shape, seed=10 + i)
+        wt.requires_grad_(True)
+        y = F.conv2d(x, wt, None, stride=s, padding=p)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(20 + i))
+        y.backward(dy)
+        refs.append(wt.grad)
+        dw = K.ohwi_empty(k, c, r, r, backend)
+        dw.fill_(0.25)
+        # operands as channel slices of wider buffers (explicit pixel strides), like the concat slices of the networks
+        ents.append((to_nhwc(x, backend, ld_pix=c + 8, c_off=4), to_nhwc(dy, backend, ld_pix=k + 4, c_off=0), dw, s, p))
+    if not gpu:
+        monkeypatch.setenv("SGX_EMU_SHUFFLE", "7")
+    try:
+        # small items: the first emu case (5184 pixels) is cut into 21 splits of 256 pixels -> two ticket levels
+        lib().sgx_debug_set_wgrad_group(6, 1, 1)
+        K.conv2d_bwd_weight_group(ents)
+        first = [e[2].clone() for e in ents]
+        for (shape, e, ref) in zip(cases, ents, refs):
+            assert_close(e[2].cpu(), ref + 0.25, TOL, f"grouped wgrad {shape}")
+        K.conv2d_bwd_weight_group(ents)  # accumulates; tickets were left zero
+        for (shape, e, ref) in zip(cases, ents, refs):
+            assert_close(e[2].cpu(), 2 * ref + 0.25, TOL, f"grouped wgrad, second call {shape}")
+        # same inputs, other arrival order / block order: bit-identical
+        if not gpu:
+            monkeypatch.setenv("SGX_EMU_SHUFFLE", "1234")
+        lib().sgx_debug_set_wgrad_group(6, 1, 0)
+        for e in ents:
+            e[2].fill_(0.25)
+        K.conv2d_bwd_weight_group(ents)
+        for a, e in zip(first, ents):
+            assert torch.equal(a.cpu(), e[2].cpu()), "grouped wgrad must not depend on the workgroup order"
+        # default item size: every small job is a single split (direct accumulate)
+        lib().sgx_debug_set_wgrad_group(0, 0, 1)
+        for e in ents:
+            e[2].zero_()
+        K.conv2d_bwd_weight_group(ents)
+        for (shape, e, ref) in zip(cases, ents, refs):
+            assert_close(e[2].cpu(), ref, TOL, f"grouped wgrad, default split {shape}")
+    finally:
+        lib().sgx_debug_set_wgrad_group(0, 0, 1)

@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variants", default="0")
     ap.add_argument("--tiles", default="0x0")
+    ap.add_argument("--math", default="fp32", help="comma list of fp32 | bf16x3 (kernels.set_conv_math) crossed with the variants / tiles")
     ap.add_argument("--problems", default=",".join(DEFAULT))
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
@@ -37,8 +38,9 @@ def main():
     dev = torch.device("cuda:0")
     variants = [int(v) for v in args.variants.split(",")]
     tiles = [tuple(int(a) for a in t.split("x")) for t in args.tiles.split(",")]
-    configs = [(v, t) for t in tiles for v in variants]
-    lines = [f"{'problem':<34}" + "".join(f"{f'v{v}/{t[0]}x{t[1]}':>14}" for v, t in configs) + "   (TFLOP/s, median of rounds; us below)"]
+    maths = args.math.split(",")
+    configs = [(v, t, m) for m in maths for t in tiles for v in variants]
+    lines = [f"{'problem':<34}" + "".join(f"{f'{m[:2]}{v}/{t[0]}x{t[1]}':>14}" for v, t, m in configs) + "   (TFLOP/s, median of rounds; us below)"]
     for spec in args.problems.split(","):
         kind, n, h, w, c, k, r, s = spec.split(":")
         n, h, w, c, k, r, s = (int(a) for a in (n, h, w, c, k, r, s))
@@ -58,7 +60,8 @@ def main():
         res = {cfg: [] for cfg in configs}
         for _ in range(args.rounds):
             for cfg in configs:
-                v, (bm, bn) = cfg
+                v, (bm, bn), m = cfg
+                K.set_conv_math(m)
                 lib().sgx_debug_set_variant(v)
                 lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
                 K.clear_desc_cache()
@@ -75,6 +78,7 @@ def main():
                     res[cfg].append(float("nan"))
         lib().sgx_debug_set_variant(0)
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
+        K.set_conv_math("fp32")
         K.clear_desc_cache()
         med = {cfg: statistics.median(v) for cfg, v in res.items()}
         lines.append(f"{spec:<34}" + "".join(f"{flops / med[cfg] / 1e6:>14.1f}" for cfg in configs))
