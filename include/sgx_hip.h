@@ -66,7 +66,11 @@ int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk, int32_t w
 /* Arithmetic of the forward / data-gradient GEMMs.  0 (default): fp32 matrix pipe, exact fp32 FMA chains.  1: "bf16x3" - every fp32
  * operand is split into three bf16 pieces (24 mantissa bits) and the six significant cross products run on the bf16 matrix pipe with
  * fp32 accumulation: fp32-accurate results (dropped terms <= 2^-24 of a product) at 2.7x fewer matrix-pipe cycles.  2: per problem -
- * bf16x3 where the reduction depth (taps x channels) is >= 192, fp32 MFMA for shallow ones.  Process-wide.                           */
+ * bf16x3 where the reduction depth (taps x channels) is >= 192, fp32 MFMA for shallow ones.  3: the 3x3 stride-1 pad-1 problems with
+ * C % 16 == 0 (forward, the QARepVGG two-branch forward, data gradient, two-source data gradient) run the PATCH kernel: a workgroup owns
+ * 8 x 16 output pixels of one image, stages their 10 x 18 input patch in LDS once per channel chunk (split into three bf16 planes) and
+ * reads all nine taps from it - bf16x3 arithmetic as in mode 1; statistics rows are then one per tile (sgx_conv2d_fwd_stat_blocks follows);
+ * every other problem stays on the fp32 pipe.  Process-wide.                                                                           */
 int32_t sgx_conv_set_math(int32_t mode);
 int32_t sgx_conv_get_math(void);
 int32_t sgx_debug_set_variant(int32_t wave_layout_variant);
@@ -169,7 +173,7 @@ int32_t sgx_conv2d_bwd_weight_group_sizes(const sgx_wgrad_job* jobs, int32_t njo
 int32_t sgx_conv2d_bwd_weight_group(const sgx_wgrad_job* jobs, int32_t njobs, void* ws, int64_t ws_bytes, int32_t* tickets,
                                     int64_t ticket_ints, void* stream);
 /* Measurement aid for the grouped weight gradient: rounds of work items a large group is cut into (0 = default 6), work of an item below
- * which a small group is not cut further (MFLOP, 0 = default 8), XCD-aware workgroup order (default 1).  Never set by the product.     */
+ * which a small group is not cut further (MFLOP, 0 = default 4; an item is never larger than twice that), XCD-aware workgroup order (default 1).  Never set by the product.     */
 int32_t sgx_debug_set_wgrad_group(int32_t rounds, int32_t item_mflop, int32_t xcd_order);
 
 /* ConvTranspose2d kernel 2, stride 2 (+bias): modules/sampling.py:72-73 via yolo_stages.py:292-294.

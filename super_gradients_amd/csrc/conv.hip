@@ -799,6 +799,422 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution (forward and data gradient) from an LDS-resident input PATCH, bf16x3 arithmetic ("pconv").
+//
+// Why a second kernel: on the bf16 matrix pipe the six cross products of a 16-deep step cost 192 cycles where the fp32 pipe needs 512,
+// and the slab-per-tap loop above cannot cash that in - every input element is staged (global -> VGPR -> split -> 3 LDS stores) once
+// PER TAP, and the VGPR->LDS store path (~80 B/clk/CU, MI355X_MICROARCH.md LDS table) plus the split's VALU work bound the loop at about
+// half the bf16x3 rate (measured r1y-r2: 1.15x over fp32 where the matrix pipe alone would give 2.7x).  Here a workgroup owns a 2-D tile
+// of 8 x 16 output pixels (one image) and stages the 10 x 18 input patch of a channel chunk ONCE, split into three bf16 planes; all nine
+// taps read their MFMA A-fragments from that patch (a tap is an LDS address offset), so input staging falls 9x and only the small
+// per-tap filter slab (BN x KC) still moves per tap (double-buffered, its global loads in flight under the previous tap's MFMAs).
+// Zero padding = the hardware bounds check of the patch loads (rows / columns outside the image arrive as zeros) - no per-tap masks.
+//
+// LDS image: plane[3][pixel][KC bf16]; the 16-byte chunks of a pixel are XOR-swizzled by pixel bits so that the ds_read_b128 of 16 lanes
+// with 16 distinct (pixel mod 16) hit 16 distinct 4-bank groups; MFMA row r of a 32-row sub-tile is output pixel (ty, tx) = (2s + r/16,
+// (r - 2 ty) mod 16): the rotation makes (patch pixel index mod 16) = (r mod 16) + const for every tap, i.e. conflict-free fragment
+// reads with the 18-pixel patch pitch.  Filter slab: plane[3][n][KC bf16], same swizzle by n.
+// Arithmetic: the bf16x3 scheme of igemm_kernel<MATH = 1> (round-to-nearest split, leading products and corrections in separate
+// accumulators).  PH2 as in igemm_kernel: 1 = second source (1x1, its own tensor) into the same accumulator - the QARepVGG data
+// gradient; 2 = second filter on the centre tap into a second output - the QARepVGG forward pair, with the five BatchNorm moments.
+// ------------------------------------------------------------------------------------------------
+#define PC_TH 8
+#define PC_TW 16
+#define PC_PW (PC_TW + 2)            // patch pitch (pixels)
+#define PC_NPIX ((PC_TH + 2) * PC_PW)  // 180 patch pixels
+template <int BN, int WM, int WN, int KC, int PH2>
+__global__ __launch_bounds__(WM * WN * 64) void pconv_kernel(IgemmParams p) {
+    static_assert(4 % WM == 0 && (KC == 16 || KC == 32), "WM divides the four 32-row sub-tiles; 16- or 32-channel chunks");
+    constexpr int NTH = WM * WN * 64;
+    constexpr int BM = PC_TH * PC_TW;           // 128 output pixels = 4 sub-tiles of 32 MFMA rows
+    constexpr int TM = 4 / WM, TN = BN / (32 * WN);
+    static_assert(TM >= 1 && TN >= 1 && TN * WN * 32 == BN, "bad tile");
+    constexpr int Q = KC / 8;                   // 16-byte chunks (8 bf16) per pixel and plane
+    constexpr int PPR = 16 / Q;                 // pixels per 256-byte bank row
+    constexpr int ROWB = KC * 2;                // bytes per pixel / filter row and plane
+    constexpr int A_PLANE = PC_NPIX * ROWB, B_PLANE = BN * ROWB;
+    constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 2 * 3 * B_PLANE;
+    constexpr int STAGE_BYTES = WM * WN * 32 * 32 * 4;
+    constexpr int SMEM_BYTES = (A_BYTES + B_BYTES) > STAGE_BYTES ? (A_BYTES + B_BYTES) : STAGE_BYTES;
+    constexpr int C4 = KC / 4;                  // float4 items per pixel / filter row
+    constexpr int AR = (PC_NPIX * C4 + NTH - 1) / NTH, BR = (BN * C4 + NTH - 1) / NTH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+    unsigned char* const As = smem_raw;
+    unsigned char* const Bs = smem_raw + A_BYTES;
+    float* const smem = reinterpret_cast<float*>(smem_raw);
+    __shared__ long long rowoff[BM];
+    __shared__ long long rowoff2[PH2 == 1 ? BM : 1];
+    __shared__ float red[(PH2 == 2 ? 5 : 2) * WM * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = blockIdx.x;
+    const int lin = (bid & 7) * p.chunk + (bid >> 3);
+    if (lin >= p.nblk) return;
+    const int mtile = lin / p.nt, ntile = lin - mtile * p.nt;
+    const int n0 = ntile * BN;
+    const int tiles_x = (p.Wa + PC_TW - 1) / PC_TW, tiles_y = (p.Ha + PC_TH - 1) / PC_TH;
+    const int img = mtile / (tiles_x * tiles_y);
+    const int trem = mtile - img * (tiles_x * tiles_y);
+    const int oy0 = (trem / tiles_x) * PC_TH, ox0 = (trem % tiles_x) * PC_TW;
+    const int cpt = p.C / KC;
+    auto swz = [](int q, int pix) { return q ^ ((pix / PPR) % Q); };
+
+    // output rows: MFMA row r of sub-tile s <-> pixel (oy0 + ty, ox0 + tx), ty = 2 s + (r >> 4), tx = (r - 2 ty) & 15
+    if (tid < BM) {
+        const int s = tid >> 5, r = tid & 31;
+        const int ty = 2 * s + (r >> 4), tx = (r - 2 * ty) & 15;
+        const int a = oy0 + ty, b = ox0 + tx;
+        long long off = -1;
+        if (a < p.Ha && b < p.Wa) {
+            off = (long long)img * p.y_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.y_ld_pix;
+            if (PH2 == 1 && p.addend2) rowoff2[tid] = (long long)img * p.a2d_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.a2d_ld_pix;
+        }
+        rowoff[tid] = off;
+    }
+
+    // ---- source state ------------------------------------------------------------------------------------------------------------
+    sgx_buf bufA, bufB;
+    int aoff[AR], alds[AR];   // global byte offset (chunk 0) and LDS byte offset (plane 0) of this thread's patch items; aoff < 0: padding
+    int boff[BR], blds[BR];
+    int w_ld_n_, taps_h, taps_w, dh0_, dw0_, dstep_, ntaps;
+    auto setup_src = [&](const float* A, const float* Wt, int Hin, int Win, int Th, int Tw, int dh0, int dw0, int dstep, long a_ld_pix, long a_ld_img,
+                         long w_ld_n, long a_bytes, long w_bytes) {
+        bufA = sgx_make_buf(A + (long)img * a_ld_img, a_bytes - (long)img * a_ld_img * 4);
+        bufB = sgx_make_buf(Wt, w_bytes);
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            const int idx = tid + NTH * r;
+            const int pp = idx / C4, c4 = (idx - pp * C4) * 4;
+            const int py = pp / PC_PW, px = pp - py * PC_PW;
+            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+            const bool ok = pp < PC_NPIX && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+            aoff[r] = ok ? (int)((((long)iy * Win + ix) * a_ld_pix + c4) * 4) : -1;
+            alds[r] = pp < PC_NPIX ? pp * ROWB + swz(c4 >> 3, pp) * 16 + ((c4 >> 2) & 1) * 8 : -1;
+        }
+#pragma unroll
+        for (int r = 0; r < BR; ++r) {
+            const int idx = tid + NTH * r;
+            const int n = idx / C4, c4 = (idx - n * C4) * 4;
+            const bool ok = n < BN && n0 + n < p.Nout;
+            boff[r] = ok ? (int)((((long)(n0 + n)) * w_ld_n + c4) * 4) : -1;
+            blds[r] = n < BN ? n * ROWB + swz(c4 >> 3, n) * 16 + ((c4 >> 2) & 1) * 8 : -1;
+        }
+        w_ld_n_ = (int)w_ld_n;
+        taps_h = Th; taps_w = Tw; dh0_ = dh0; dw0_ = dw0; dstep_ = dstep;
+        ntaps = Th * Tw;
+    };
+
+    float4 ra[AR], rb[BR];
+    auto load_patch = [&](int chunk) {
+#pragma unroll
+        for (int r = 0; r < AR; ++r) ra[r] = sgx_buf_ld4(bufA, aoff[r] >= 0 ? (unsigned)(aoff[r] + chunk * (KC * 4)) : SGX_BUF_OOB);
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            if (alds[r] < 0) continue;
+            uint2 h, m, l;
+            sgx_split3(ra[r], h, m, l);
+            *reinterpret_cast<uint2*>(As + alds[r]) = h;
+            *reinterpret_cast<uint2*>(As + A_PLANE + alds[r]) = m;
+            *reinterpret_cast<uint2*>(As + 2 * A_PLANE + alds[r]) = l;
+        }
+    };
+    // filter slab of (tap index in the weight row, channel chunk); wsel: 0 = the source's filter, 1 = the second filter of PH2 = 2 (Wt2, one tap)
+    sgx_buf bufB2 = bufB;
+    int boff2[PH2 == 2 ? BR : 1];
+    auto load_filter = [&](int wtap, int chunk, int wsel) {
+#pragma unroll
+        for (int r = 0; r < BR; ++r) {
+            if (PH2 == 2 && wsel == 1) rb[r] = sgx_buf_ld4(bufB2, boff2[PH2 == 2 ? r : 0] >= 0 ? (unsigned)(boff2[PH2 == 2 ? r : 0] + chunk * (KC * 4)) : SGX_BUF_OOB);
+            else rb[r] = sgx_buf_ld4(bufB, boff[r] >= 0 ? (unsigned)(boff[r] + (wtap * p.C + chunk * KC) * 4) : SGX_BUF_OOB);
+        }
+    };
+    auto store_filter = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < BR; ++r) {
+            if (blds[r] < 0) continue;
+            uint2 h, m, l;
+            sgx_split3(rb[r], h, m, l);
+            unsigned char* d = Bs + buf * 3 * B_PLANE + blds[r];
+            *reinterpret_cast<uint2*>(d) = h;
+            *reinterpret_cast<uint2*>(d + B_PLANE) = m;
+            *reinterpret_cast<uint2*>(d + 2 * B_PLANE) = l;
+        }
+    };
+
+    sgx_f32x16 acc[TM][TN], acc2[TM][TN];
+    constexpr bool DUAL = PH2 == 2;
+    sgx_f32x16 accu[DUAL ? TM : 1][DUAL ? TN : 1], accu2[DUAL ? TM : 1][DUAL ? TN : 1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                acc2[i][j][r] = 0.f;
+                if (DUAL) accu[DUAL ? i : 0][DUAL ? j : 0][r] = accu2[DUAL ? i : 0][DUAL ? j : 0][r] = 0.f;
+            }
+
+    // this lane's fragment rows: patch pixel of tap offset (0, 0) per sub-tile, filter row per N sub-tile
+    const int frow = lane & 31, khalf = lane >> 5;
+    int pbase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int s = wm * TM + i;
+        const int ty = 2 * s + (frow >> 4), tx = (frow - 2 * ty) & 15;
+        pbase[i] = ty * PC_PW + tx;
+    }
+    // one tap: KC / 16 steps of (TM + TN) x 3 fragment reads and 6 x TM x TN MFMAs into (c1 = leading products, c2 = corrections);
+    // products in "smallest first" order, each product across all sub-tiles before the next (independent accumulators back to back)
+    auto compute_tap = [&](int buf, int tapoff, sgx_f32x16 (&c1)[TM][TN], sgx_f32x16 (&c2)[TM][TN]) {
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const int q = ks * 2 + khalf;
+            uint4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int pix = pbase[i] + tapoff;
+                const unsigned char* s = As + pix * ROWB + swz(q, pix) * 16;
+                ah[i] = *reinterpret_cast<const uint4*>(s);
+                am[i] = *reinterpret_cast<const uint4*>(s + A_PLANE);
+                al[i] = *reinterpret_cast<const uint4*>(s + 2 * A_PLANE);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = wn * TN * 32 + j * 32 + frow;
+                const unsigned char* s = Bs + buf * 3 * B_PLANE + n * ROWB + swz(q, n) * 16;
+                bh[j] = *reinterpret_cast<const uint4*>(s);
+                bm[j] = *reinterpret_cast<const uint4*>(s + B_PLANE);
+                bl[j] = *reinterpret_cast<const uint4*>(s + 2 * B_PLANE);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(al[i], bh[j], c2[i][j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(ah[i], bl[j], c2[i][j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(am[i], bm[j], c2[i][j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(am[i], bh[j], c2[i][j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(ah[i], bm[j], c2[i][j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) c1[i][j] = sgx_mfma_bf16(ah[i], bh[j], c1[i][j]);
+        }
+    };
+
+#pragma unroll
+    for (int src = 0; src < (PH2 == 1 ? 2 : 1); ++src) {
+        if (src == 0) setup_src(p.A, p.Wt, p.Hin, p.Win, p.Th, p.Tw, p.dh0, p.dw0, p.dstep, p.a_ld_pix, p.a_ld_img, p.w_ld_n, p.a_bytes, p.w_bytes);
+        else {
+            if (!p.A2) break;
+            setup_src(p.A2, p.Wt2, p.Hin2, p.Win2, p.Th2, p.Tw2, p.dh02, p.dw02, p.dstep2, p.a2_ld_pix, p.a2_ld_img, p.w2_ld_n, p.a2_bytes, p.w2_bytes);
+        }
+        if (PH2 == 2) {
+            bufB2 = sgx_make_buf(p.Wt2, p.w2_bytes);
+#pragma unroll
+            for (int r = 0; r < BR; ++r) {
+                const int idx = tid + NTH * r;
+                const int n = idx / C4, c4 = (idx - n * C4) * 4;
+                boff2[PH2 == 2 ? r : 0] = (n < BN && n0 + n < p.Nout) ? (int)((((long)(n0 + n)) * p.w2_ld_n + c4) * 4) : -1;
+            }
+        }
+        load_patch(0);
+        for (int chunk = 0; chunk < cpt; ++chunk) {
+            // every wave is past its last read of the patch and of both filter buffers (barrier at the end of the previous tap)
+            store_patch();
+            load_filter(0, chunk, 0);
+            store_filter(0);
+            __syncthreads();
+            for (int t = 0; t < ntaps; ++t) {
+                const bool more = t + 1 < ntaps;
+                if (more) load_filter(t + 1, chunk, 0);
+                else if (DUAL) load_filter(0, chunk, 1);  // PH2 = 2: one more "tap" - the centre tap again, with the second filter
+                if (t == (ntaps > 4 ? ntaps - 4 : 0) && chunk + 1 < cpt) load_patch(chunk + 1);  // next chunk's patch travels in registers under the last taps
+                // patch offset of the tap: input pixel (a + dh0 + dstep * ti, b + dw0 + dstep * tj), patch origin (oy0 - 1, ox0 - 1)
+                const int ti = t / taps_w, tj = t - ti * taps_w;
+                compute_tap(t & 1, (dh0_ + dstep_ * ti + 1) * PC_PW + dw0_ + dstep_ * tj + 1, acc, acc2);
+                if (more || DUAL) store_filter((t + 1) & 1);
+                __syncthreads();
+            }
+            if constexpr (DUAL) {
+                compute_tap(ntaps & 1, PC_PW + 1, accu, accu2);
+                __syncthreads();
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] += acc2[i][j][r];
+                if (DUAL) accu[DUAL ? i : 0][DUAL ? j : 0][r] += accu2[DUAL ? i : 0][DUAL ? j : 0][r];
+            }
+    // ---- epilogues: as igemm_kernel's (32x32 accumulators transposed through a per-wave LDS patch -> 16-byte stores) ------------------------
+    float* const stage = smem + wave * (32 * 32);
+    const int sr = lane >> 3, sc4 = (lane & 7) * 4;
+    const bool full = oy0 + PC_TH <= p.Ha && ox0 + PC_TW <= p.Wa;
+    if constexpr (PH2 == 2) {
+        // y = acc -> Y, u = accu + bias2 -> Y2, and the five per-channel sums both BatchNorms of the block are finalised from (rows outside
+        // the image / columns outside the filter are exact zeros in both accumulators: no masks in the sums)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // (a 2-D tile that sticks out of the image computes real values for its outside pixels - their neighbours are inside - so
+                    // the sums take the rows of the image only)
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int ty = 2 * (wm * TM + i) + (row >> 4), tx = (row - 2 * ty) & 15;
+                    if (!full && (oy0 + ty >= p.Ha || ox0 + tx >= p.Wa)) continue;
+                    const float y = acc[i][j][r], u = accu[DUAL ? i : 0][DUAL ? j : 0][r];
+                    st[0] += y; st[1] += y * y; st[2] += u; st[3] += u * u; st[4] += y * u;
+                }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) st[t] += __shfl_xor(st[t], 32);
+            if (lane < 32) {
+#pragma unroll
+                for (int t = 0; t < 5; ++t) red[(t * WM + wm) * BN + wn * TN * 32 + j * 32 + lane] = st[t];
+            }
+            const int col = n0 + wn * TN * 32 + j * 32 + sc4;
+            const bool colok = col < p.Nout;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias2 && colok) bv = sgx_ld4(p.bias2 + col);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = o == 0 ? acc[i][j][r] : accu[DUAL ? i : 0][DUAL ? j : 0][r];
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rowl = q * 8 + sr;
+                        const long long off = rowoff[(wm * TM + i) * 32 + rowl];
+                        float4 v = sgx_ld4(stage + rowl * 32 + sc4);
+                        if (off >= 0 && colok) {
+                            if (o == 1) {
+                                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                            }
+                            sgx_st4((o == 0 ? p.Y : p.Y2) + off + col, v);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int col = n0 + tid;
+            if (col < p.Nout) {
+#pragma unroll
+                for (int pl = 0; pl < 5; ++pl) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) t += red[(pl * WM + w) * BN + tid];
+                    p.stat_partials[((long)pl * p.stat_nblk + mtile) * p.Nout + col] = t;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int coll = wn * TN * 32 + j * 32 + sc4;  // column inside the tile
+        const int col = n0 + coll;
+        const bool colok = col < p.Nout;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && colok) bv = sgx_ld4(p.bias + col);
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rowl = q * 8 + sr;
+                const long long off = rowoff[(wm * TM + i) * 32 + rowl];
+                float4 v = sgx_ld4(stage + rowl * 32 + sc4);
+                if (off >= 0 && colok) {
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    float* yp = p.Y + off + col;
+                    if (p.addend) {
+                        float4 u = sgx_ld4(p.addend + off + col);
+                        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                    }
+                    if (PH2 == 1 && p.addend2) {
+                        const float4 u = sgx_ld4(p.addend2 + rowoff2[(wm * TM + i) * 32 + rowl] + col);
+                        const float sc = p.addend2_scale * (p.addend2_scale_dev ? p.addend2_scale_dev[0] : 1.f);
+                        v.x += sc * u.x; v.y += sc * u.y; v.z += sc * u.z; v.w += sc * u.w;
+                    }
+                    if (p.accumulate) {
+                        float4 u = sgx_ld4(yp);
+                        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                    }
+                    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                    cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+                    sgx_st4(yp, make_float4(sgx_act(v.x, p.act), sgx_act(v.y, p.act), sgx_act(v.z, p.act), sgx_act(v.w, p.act)));
+                }
+            }
+            __syncthreads();
+        }
+        if (p.stat_partials) {
+            float vals[8] = {cs.x, cs.y, cs.z, cs.w, cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                vals[t] += __shfl_xor(vals[t], 8);
+                vals[t] += __shfl_xor(vals[t], 16);
+                vals[t] += __shfl_xor(vals[t], 32);
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    red[(0 * WM + wm) * BN + coll + t] = vals[t];
+                    red[(1 * WM + wm) * BN + coll + t] = vals[4 + t];
+                }
+            }
+        }
+    }
+    if (p.stat_partials) {
+        __syncthreads();
+        if (tid < BN) {
+            int col = n0 + tid;
+            if (col < p.Nout) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) {
+                    s += red[(0 * WM + w) * BN + tid];
+                    q += red[(1 * WM + w) * BN + tid];
+                }
+                p.stat_partials[(long)mtile * p.Nout + col] = s;
+                p.stat_partials[((long)p.stat_nblk + mtile) * p.Nout + col] = q;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // tile-shape selection
 // ------------------------------------------------------------------------------------------------
 struct TileCfg {
@@ -811,7 +1227,7 @@ static std::atomic<int> g_ovr_bm{0}, g_ovr_bn{0}, g_ovr_wk{0}, g_ovr_wj{0}, g_ov
 // arithmetic of the forward / data-gradient GEMMs: 0 = fp32 MFMA (exact fp32 FMA chains), 1 = bf16x3 split (see IG_LDP above)
 static std::atomic<int> g_conv_math{0};
 extern "C" int32_t sgx_conv_set_math(int32_t mode) {
-    SGX_CHECK_ARG(mode >= 0 && mode <= 2, "conv math mode %d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = per problem)", mode);
+    SGX_CHECK_ARG(mode >= 0 && mode <= 3, "conv math mode %d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = per problem, 3 = patch kernel for 3x3 stride-1)", mode);
     g_conv_math = mode;
     return SGX_OK;
 }
@@ -822,8 +1238,15 @@ extern "C" int32_t sgx_conv_get_math(void) { return g_conv_math; }
 #define SGX_BF3_MIN_DEPTH 192
 static int conv_math_for(int taps, int C) {
     const int m = g_conv_math.load(std::memory_order_relaxed);
+    if (m == 3) return 0;  // the patch kernel takes the 3x3 stride-1 problems (pconv_ok), everything else stays on the fp32 pipe
     return m == 2 ? ((long)taps * C >= SGX_BF3_MIN_DEPTH ? 1 : 0) : m;
 }
+// Mode 3: 3x3, stride 1, pad 1, channel counts in 16s -> pconv_kernel (bf16x3 from an LDS-resident patch).  Decidable from the descriptor,
+// so that the forward statistics rows (one per 8 x 16 pixel tile and image) are known before the launch.
+static bool pconv_shape_ok(int R, int S, int stride, int pad, int C, int K) {
+    return g_conv_math.load(std::memory_order_relaxed) == 3 && R == 3 && S == 3 && stride == 1 && pad == 1 && C % 16 == 0 && C >= 16 && K % 4 == 0;
+}
+static int pconv_tiles(int N, int H, int W) { return N * sgx_cdiv(H, PC_TH) * sgx_cdiv(W, PC_TW); }
 extern "C" int32_t sgx_debug_set_variant(int32_t v) {
     g_ovr_var = v;
     return SGX_OK;
@@ -957,6 +1380,41 @@ static void launch_igemm(IgemmParams& p, void* stream) {
     SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF, PH2>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
 }
 
+// ---- pconv dispatch ------------------------------------------------------------------------------------------------------------------
+static bool pconv_ok(const IgemmParams& p, int ph2) {
+    if (g_conv_math.load(std::memory_order_relaxed) != 3) return false;
+    if (p.Th != 3 || p.Tw != 3 || p.si != 1 || p.so != 1 || p.ph || p.pw || p.Hin != p.Ha || p.Win != p.Wa) return false;
+    if (!((p.dstep == 1 && p.dh0 == -1 && p.dw0 == -1) || (p.dstep == -1 && p.dh0 == 1 && p.dw0 == 1))) return false;  // forward / data-gradient taps
+    if (p.C % 16 || p.C < 16 || !p.vec) return false;
+    if (ph2 && p.A2 && !(p.Th2 == 1 && p.Tw2 == 1 && p.dh02 == 0 && p.dw02 == 0 && p.Hin2 == p.Ha && p.Win2 == p.Wa)) return false;
+    if (ph2 == 2 && (p.A2 != p.A || p.a2_ld_pix != p.a_ld_pix || p.a2_ld_img != p.a_ld_img)) return false;  // the second filter reads the same patch
+    if ((long)p.Hin * p.Win * p.a_ld_pix * 4 > SGX_BUF_MAX) return false;
+    return true;
+}
+template <int BN, int WM, int WN, int KC, int PH2>
+static void launch_pconv(IgemmParams& p, void* stream) {
+    p.mt = pconv_tiles(p.M / (p.Ha * p.Wa), p.Ha, p.Wa);
+    p.nt = sgx_cdiv(p.Nout, BN);
+    p.nblk = p.mt * p.nt;
+    p.chunk = sgx_cdiv(p.nblk, 8);
+    p.stat_nblk = p.mt;
+    SGX_LAUNCH((pconv_kernel<BN, WM, WN, KC, PH2>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
+}
+template <int KC, int PH2>
+static void launch_pconv_n(IgemmParams& p, void* stream) {
+    // N tile: 32 / 64 / 96 filters (one 32-wide accumulator column per wave; 96 runs six waves)
+    if (p.Nout <= 32) launch_pconv<32, 4, 1, KC, PH2>(p, stream);
+    else if (p.Nout % 96 == 0 || (p.Nout > 64 && p.Nout <= 96)) launch_pconv<96, 2, 3, KC, PH2>(p, stream);
+    else launch_pconv<64, 2, 2, KC, PH2>(p, stream);
+}
+static int32_t run_pconv(IgemmParams& p, void* stream, int ph2) {
+    const bool k32 = p.C % 32 == 0;
+    if (ph2 == 0 || !p.A2) k32 ? launch_pconv_n<32, 0>(p, stream) : launch_pconv_n<16, 0>(p, stream);
+    else if (ph2 == 1) k32 ? launch_pconv_n<32, 1>(p, stream) : launch_pconv_n<16, 1>(p, stream);
+    else k32 ? launch_pconv_n<32, 2>(p, stream) : launch_pconv_n<16, 2>(p, stream);
+    return SGX_OK;
+}
+
 // ph2: 0 = one source; 1 = second source into the same accumulator; 2 = second source into a second output (see IgemmParams)
 static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 = 0) {
     const int T = p.Th * p.Tw;
@@ -978,6 +1436,14 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
              4.0 * ((double)p.M / ((double)p.Ha * p.Wa) * p.Hin * p.Win * p.C * (ph2 == 1 && p.A2 ? 2.0 : 1.0) + (double)p.Nout * p.C * (T + T2) +
                     (double)p.M * p.Nout * (ph2 == 2 ? 2.0 : 1.0)), stream);
     const bool flat = p.C < IG_BK && T > 1;
+    if (!pconv_ok(p, ph2) && p.stat_partials && p.dstep == 1 && p.so == 1 && pconv_shape_ok(p.Th, p.Tw, p.si, -p.dh0, p.C, p.Nout))
+        SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (math mode 3): the statistics rows of this forward follow the patch kernel's tiles, which needs 16-byte aligned operands");
+    if (pconv_ok(p, ph2)) {
+        int32_t rc = run_pconv(p, stream, ph2);
+        if (rc) return rc;
+        SGX_CHECK_LAUNCH("pconv");
+        return SGX_OK;
+    }
     if (ph2) {
         if (flat || !p.vec) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (two sources): needs C >= 16 and 16-byte aligned outputs");
         if (p.C % 32 == 0) {
@@ -1031,6 +1497,7 @@ static long view_bytes(int N, int H, int W, int C, long ld_pix, long ld_img) {
 }
 
 extern "C" int32_t sgx_conv2d_fwd_stat_blocks(const sgx_conv_desc* d) {
+    if (pconv_shape_ok(d->R, d->S, d->stride, d->pad, d->C, d->K)) return pconv_tiles(d->N, d->Ho, d->Wo);
     TuneScope tune(0, d);
     long M = (long)d->N * d->Ho * d->Wo;
     TileCfg t = pick_tile(M, d->K, conv_math_for(d->R * d->S, d->C));
@@ -1065,6 +1532,7 @@ extern "C" int32_t sgx_conv2d_fwd(const sgx_conv_desc* d, const float* x, const 
 // tap of the RxS one (pad = R / 2), so the workgroup that owns an output tile walks the taps of w into one accumulator and then the
 // centre tap again with w1 into a second one.  stat5: [5][sgx_conv2d_fwd_dual_stat_blocks(d)][K] = sum y, y^2, u0, u0^2, y*u0 per row block (u0 = u - bias1).
 extern "C" int32_t sgx_conv2d_fwd_dual_stat_blocks(const sgx_conv_desc* d) {
+    if (pconv_shape_ok(d->R, d->S, d->stride, d->pad, d->C, d->K)) return pconv_tiles(d->N, d->Ho, d->Wo);
     long M = (long)d->N * d->Ho * d->Wo;
     return sgx_cdiv(M, pick_tile_heuristic(M, d->K).bm);
 }
@@ -1344,7 +1812,7 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
 // Tickets are zero on entry and are left zero (the last arriver resets its counter).
 // ------------------------------------------------------------------------------------------------
 #define WG_BKP 16
-#define WG_GROUP 16
+#define WG_GROUP 32
 #define WG_MAX_JOBS 20  // the job table travels as kernel arguments: 20 x 176 B + 8 B < 4 KB
 
 struct WgJob {
@@ -1372,13 +1840,13 @@ __device__ __forceinline__ void wg_fold(const float* src, long stride, int count
     constexpr int E4 = BNK * BJ / 4;
     for (int e4 = threadIdx.x; e4 < E4; e4 += NTH) {
         const float* s = src + (long)e4 * 4;
-        float4 v = sgx_ld4(s);
+        float4 v = sgx_ld4_dev(s);
         for (int q = 1; q < count; ++q) {
-            const float4 u = sgx_ld4(s + q * stride);
+            const float4 u = sgx_ld4_dev(s + q * stride);
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
         if (tile_dst) {
-            sgx_st4(tile_dst + (long)e4 * 4, v);
+            sgx_st4_dev(tile_dst + (long)e4 * 4, v);
             continue;
         }
         const int k = k0 + (e4 * 4) / BJ, j = j0 + (e4 * 4) % BJ;
@@ -1574,11 +2042,11 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
             for (int j = 0; j < TC; ++j) {
                 const int jl = wc * TC * 32 + j * 32 + (lane & 31);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mine[(wk * TK * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BJ + jl] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) sgx_st_dev(&mine[(wk * TK * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BJ + jl], acc[i][j][r]);
             }
     }
-    // publish, take a ticket; the group's last arriver folds the group in split order
-    sgx_fence_release();
+    // publish (device-scope stores, acknowledged), take a ticket; the group's last arriver folds the group in split order
+    sgx_wait_stores();
     __syncthreads();
     const int grp = split / WG_GROUP, gbeg = grp * WG_GROUP;
     const int gcnt = min(WG_GROUP, ksplit - gbeg);
@@ -1590,14 +2058,13 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
     }
     __syncthreads();
     if (!s_last) return;
-    sgx_fence_acquire();
     const float* const src = p.part + ((long)tile * ksplit + gbeg) * TE;
     if (ngroups == 1) {
         wg_fold<NTH, BNK, BJ>(src, TE, gcnt, nullptr, dw, K, J, k0, j0, vec);
         return;
     }
     wg_fold<NTH, BNK, BJ>(src, TE, gcnt, p.gpart + ((long)tile * ngroups + grp) * TE, nullptr, K, J, k0, j0, vec);
-    sgx_fence_release();
+    sgx_wait_stores();
     __syncthreads();
     if (tid == 0) {
         const int old = atomicAdd(&tk[ngroups], 1);
@@ -1606,7 +2073,6 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
     }
     __syncthreads();
     if (!s_last) return;
-    sgx_fence_acquire();
     wg_fold<NTH, BNK, BJ>(p.gpart + (long)tile * ngroups * TE, TE, ngroups, nullptr, dw, K, J, k0, j0, vec);
 }
 
@@ -1638,11 +2104,11 @@ extern "C" int32_t sgx_stats_blocks(int64_t M);
 extern "C" int64_t sgx_colsum_workspace(int64_t M, int32_t C);
 // grouped-launch knobs (measurement: sgx_debug_set_wgrad_group): rounds of work items a large group is cut into, the work of an item
 // below which a small group is not cut further (MFLOP), XCD-aware block order
-static std::atomic<int> g_wg_rounds{6}, g_wg_item_mflop{8}, g_wg_xcd{1};
+static std::atomic<int> g_wg_rounds{6}, g_wg_item_mflop{4}, g_wg_xcd{1};
 extern "C" int32_t sgx_debug_set_wgrad_group(int32_t rounds, int32_t item_mflop, int32_t xcd_order) {
     SGX_CHECK_ARG(rounds >= 0 && item_mflop >= 0, "debug_set_wgrad_group: negative value");
     g_wg_rounds = rounds ? rounds : 6;
-    g_wg_item_mflop = item_mflop ? item_mflop : 8;
+    g_wg_item_mflop = item_mflop ? item_mflop : 4;
     g_wg_xcd = xcd_order ? 1 : 0;
     return SGX_OK;
 }
@@ -1684,9 +2150,14 @@ static int32_t wgrad_group_plan(const sgx_wgrad_job* jobs, int n, std::vector<Wg
     }
     // work of one item: a large group is cut into `rounds` rounds of WG_SLOTS items; a small one into items of >= item_mflop (~100 us of
     // one workgroup beside its co-residents) as long as that still leaves ~1.3 rounds
+    // ... and never more than 2x that: an item is ONE sequential fp32 accumulation chain on the matrix pipe, and a weight gradient sums
+    // pixel products whose per-channel means cancel (dY is a BatchNorm input gradient) - short chains folded by the tickets are the blocked
+    // summation that keeps the result at the accuracy of ATen's CPU GEMM (r3a, flip-free check at 32 x 640^2: chains of ~1000-1700 pixels
+    // were 25x further from fp64 than the CPU path); the partial tile an item adds is ~6 % of the operand bytes it reads.
     const double lo = 1e6 * g_wg_item_mflop.load(std::memory_order_relaxed);
     double item = work / ((double)WG_SLOTS * g_wg_rounds.load(std::memory_order_relaxed));
     if (item < lo) item = fmin(lo, work / (WG_SLOTS * 1.3));
+    if (item > 2.0 * lo) item = 2.0 * lo;
     const int osp = g_ovr_split.load(std::memory_order_relaxed);
     long poff = 0, toff = 0;
     for (int i = 0; i < n; ++i) {

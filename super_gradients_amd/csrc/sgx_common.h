@@ -103,15 +103,37 @@ __device__ __forceinline__ float4 sgx_buf_ld4(sgx_buf b, unsigned off) {
 }
 #endif
 
-// ---- device-scope publish / observe fences (cross-workgroup hand-over through HBM: arrival tickets) ---------------------------------------
-// release: this thread's earlier stores are visible device-wide (L2 write-back across XCDs) before anything that follows;
-// acquire: loads that follow see what other workgroups released (non-local L2 lines invalidated).
+// ---- cross-workgroup hand-over through HBM (arrival tickets) ---------------------------------------------------------------------------
+// MI355X has one L2 per XCD and they are not coherent with each other for ordinary accesses.  A device-scope release FENCE makes a
+// workgroup's stores visible by writing back the WHOLE L2 (buffer_wbl2 sc1) and an acquire fence invalidates it (buffer_inv sc1):
+// measured (r3a) at ~3x the weight-gradient kernel's run time when every workgroup publishes a partial tile that way.  Instead the
+// hand-over data itself moves with device-scope accesses (sc1: written through to / read from the memory side, no cache walk):
+//   producer: sgx_st_dev* ... sgx_wait_stores() (stores acknowledged) ... __syncthreads() ... one atomicAdd on the ticket
+//   consumer: (sees the last ticket) ... sgx_ld4_dev
 #ifdef SGX_EMU
-#define sgx_fence_release() __atomic_thread_fence(__ATOMIC_SEQ_CST)
-#define sgx_fence_acquire() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+static inline void sgx_st_dev(float* p, float v) { *p = v; }
+static inline void sgx_st4_dev(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+static inline float4 sgx_ld4_dev(const float* p) { return *reinterpret_cast<const float4*>(p); }
+#define sgx_wait_stores() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #else
-#define sgx_fence_release() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
-#define sgx_fence_acquire() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+__device__ __forceinline__ void sgx_st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sgx_st4_dev(float* p, float4 v) {
+    unsigned long long a, b;
+    const float lo[2] = {v.x, v.y}, hi[2] = {v.z, v.w};
+    memcpy(&a, lo, 8);
+    memcpy(&b, hi, 8);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 sgx_ld4_dev(const float* p) {
+    const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float lo[2], hi[2];
+    memcpy(lo, &a, 8);
+    memcpy(hi, &b, 8);
+    return make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
+#define sgx_wait_stores() __builtin_amdgcn_s_waitcnt(0)  // vmcnt(0) expcnt(0) lgkmcnt(0): every store of this wave has been acknowledged
 #endif
 
 __device__ __forceinline__ float4 sgx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -885,13 +885,15 @@ def ema_update(ema, p, decay):
 
 
 # --------------------------------------------------------------------------------------------- conv arithmetic
-CONV_MATH = {"fp32": 0, "bf16x3": 1, "auto": 2}
+CONV_MATH = {"fp32": 0, "bf16x3": 1, "auto": 2, "patch": 3}
 
 
 def set_conv_math(mode: str):
     """"fp32": fp32 matrix pipe (exact fp32 FMA chains).  "bf16x3": fp32 operands split into three bf16 pieces, six cross products on the
     bf16 matrix pipe with fp32 accumulation - fp32-accurate, 2.7x fewer matrix-pipe cycles.  "auto": bf16x3 for reductions of depth
-    (taps x channels) >= 192, fp32 MFMA for shallow ones (include/sgx_hip.h: sgx_conv_set_math)."""
+    (taps x channels) >= 192, fp32 MFMA for shallow ones.  "patch": 3x3 stride-1 forward / data-gradient problems (channel counts in 16s) run
+    the patch kernel - bf16x3 arithmetic with the input patch of an 8 x 16 pixel tile staged in LDS once for all nine taps - everything
+    else stays on the fp32 pipe (include/sgx_hip.h: sgx_conv_set_math)."""
     check(lib().sgx_conv_set_math(CONV_MATH[mode]), "sgx_conv_set_math")
     clear_desc_cache()
 

@@ -1112,3 +1112,77 @@ def test_wgrad_group(backend, monkeypatch):
             assert_close(e[2].cpu(), ref, TOL, f"grouped wgrad, default split {shape}")
     finally:
         lib().sgx_debug_set_wgrad_group(0, 0, 1)
+
+
+# (N, H, W, C, K): 3x3 stride-1 pad-1 problems for the patch kernel - ragged 8 x 16 tiles in both directions, both chunk depths (C % 32),
+# every N tile (32 / 64 / 96 filters, ragged 40), several images
+PCONV_GPU = [(2, 40, 40, 96, 96), (1, 80, 80, 64, 64), (2, 20, 20, 192, 192), (2, 23, 37, 48, 40), (1, 160, 160, 32, 32), (3, 9, 20, 16, 128)]
+PCONV_EMU = [(1, 9, 20, 16, 32), (2, 8, 16, 32, 40), (1, 5, 7, 48, 96)]
+
+
+@pytest.mark.parametrize("idx", range(max(len(PCONV_GPU), len(PCONV_EMU))))
+def test_pconv(backend, idx):
+    """Conv math mode "patch" (pconv_kernel: bf16x3 from an LDS-resident input patch): forward with the fused epilogue and the BatchNorm
+    statistics rows, the QARepVGG two-branch forward with its five moments, the data gradient (accumulate + addend) and the two-source
+    data gradient with the scaled second addend - each against ATen's CPU convolution at the fp32 tolerance, and against the fp32-MFMA
+    kernels of the same library."""
+    shapes = _sizes(backend, PCONV_GPU, PCONV_EMU)
+    if idx >= len(shapes):
+        pytest.skip("no such case")
+    n, h, w, c, k = shapes[idx]
+    shape = (n, h, w, c, k, 3, 1, 1)
+    x, wt, b = _conv_case(shape)
+    g = torch.Generator().manual_seed(7)
+    w1 = torch.randn(k, c, 1, 1, generator=g) / c ** 0.5
+    x.requires_grad_(True)
+    y = F.conv2d(x, wt, b, padding=1)
+    u = F.conv2d(x, w1, b)
+    dy = torch.randn(y.shape, generator=g)
+    ds = torch.randn(y.shape, generator=g)
+    (y * dy).sum().backward(retain_graph=True)
+    gx3 = x.grad.clone()
+    x.grad = None
+    (u * ds).sum().backward()
+    gx1 = x.grad.clone()
+    xd, wd, w1d, dyd, dsd = to_nhwc(x.detach(), backend), K.to_ohwi(wt.to(backend)), K.to_ohwi(w1.to(backend)), to_nhwc(dy, backend), to_nhwc(ds, backend)
+    add = torch.randn(y.shape, generator=g)
+    K.set_conv_math("patch")
+    try:
+        # forward: bias + addend + relu into a channel slice of a wider buffer, input from a channel slice, statistics of the pre-activation
+        xs = to_nhwc(x.detach(), backend, ld_pix=c + 8, c_off=4)
+        out = empty_nhwc(n, h, w, k, backend, ld_pix=k + 12, c_off=8)
+        y2, parts = K.conv2d_fwd(xs, wd, bias=b.to(backend), addend=to_nhwc(add, backend, ld_pix=k + 12, c_off=8), out=out, act="relu", stride=1, pad=1,
+                                 stat_partials=True)
+        pre = (y + add).detach()
+        assert_close(to_nchw_cpu(y2), F.relu(pre), TOL, "pconv fwd fused")
+        M = n * h * w
+        assert parts.shape[1] == n * ((h + 7) // 8) * ((w + 15) // 16), "one statistics row per 8 x 16 tile and image"
+        assert_close(parts[0].sum(0).cpu() / M, pre.mean((0, 2, 3)), 1e-4, "pconv stat sum")
+        assert_close(parts[1].sum(0).cpu() / M, (pre * pre).mean((0, 2, 3)), 1e-4, "pconv stat sumsq")
+        yd = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=1, pad=1)
+        assert_close(to_nchw_cpu(yd), y.detach(), TOL, "pconv fwd")
+        # two-branch forward: y3 = conv3x3(x), u = conv1x1(x) + b, five moments
+        y3, ud, st5 = K.conv2d_fwd_dual(xd, wd, w1d, b.to(backend), stride=1)
+        y3r = F.conv2d(x.detach(), wt, None, padding=1)
+        assert_close(to_nchw_cpu(y3), y3r, TOL, "pconv dual y")
+        assert_close(to_nchw_cpu(ud), u.detach(), TOL, "pconv dual u")
+        u0 = u.detach() - b.view(1, -1, 1, 1)
+        for i, ref in enumerate((y3r, y3r * y3r, u0, u0 * u0, y3r * u0)):
+            assert_close(st5[i].sum(0).cpu() / M, ref.mean((0, 2, 3)), 1e-4, f"pconv dual moment {i}")
+        # data gradient, accumulate + addend
+        dx = K.conv2d_bwd_data(dyd, wd, (n, h, w, c), stride=1, pad=1)
+        assert_close(to_nchw_cpu(dx), gx3, TOL, "pconv dgrad")
+        addx = torch.randn(x.shape, generator=g)
+        dx2 = to_nhwc(torch.ones_like(x.detach()), backend)
+        K.conv2d_bwd_data(dyd, wd, (n, h, w, c), stride=1, pad=1, addend=to_nhwc(addx, backend), out=dx2, accumulate=True)
+        assert_close(to_nchw_cpu(dx2), gx3 + addx + 1.0, TOL, "pconv dgrad acc")
+        # two-source data gradient: dx = dgrad3x3(dy) + dgrad1x1(ds) + addend + 0.5 * addend2 (its own strides)
+        wtb = K.conv2d_wt_buffer(wd, backend)
+        K.conv2d_transpose_weights(wd, wtb, stride=1, pad=1)
+        w1t = w1d.reshape(k, c).t().contiguous()
+        a2 = torch.randn(x.shape, generator=g)
+        dxd = K.conv2d_bwd_data_dual(dyd, wd, wtb, dsd, w1t, (n, h, w, c), stride=1, addend=to_nhwc(addx, backend),
+                                     addend2=to_nhwc(a2, backend, ld_pix=c + 4, c_off=0), addend2_scale=0.5)
+        assert_close(to_nchw_cpu(dxd), gx3 + gx1 + addx + 0.5 * a2, TOL, "pconv dual dgrad")
+    finally:
+        K.set_conv_math("fp32")

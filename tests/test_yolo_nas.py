@@ -3,6 +3,8 @@ reference's own modules by tests/test_oracle_vs_reference.py) on identical weigh
 Checks: state_dict key/shape identity, forward outputs (decoded + raw), PPYoloELoss value, EVERY parameter gradient,
 BatchNorm running statistics.  Tolerance: the north star's 1e-4 relative (fp32 both sides, different summation order).
 """
+import os
+
 import pytest
 import torch
 
@@ -253,6 +255,15 @@ def _backward_exact_without_relu_flips(variant, B, size, gpu_device, lazy_fp64=F
             if e_hip > max(bar(n), 2.0 * e_cpu):
                 bad.append(f"{n}: hip-cpu32 {e:.2e}, hip-fp64 {e_hip:.2e}, cpu32-fp64 {e_cpu:.2e}")
     errs.sort(reverse=True)
+    dump = os.environ.get("SGX_TEST_DUMP")
+    if dump:  # diagnosis aid: the whole list, worst first (hip vs cpu32; the fp64 columns for the parameters that needed the tie-break)
+        with open(dump, "a") as f:
+            f.write(f"# {variant} {B}x{size} conv_math={os.environ.get('SGX_CONV_MATH')} tuning={os.environ.get('SGX_CONV_TUNING')} "
+                    f"group={os.environ.get('SGX_WGRAD_GROUP_GFLOP')}\n")
+            for e, n in errs:
+                f.write(f"{e:.3e} {n}\n")
+            for b_ in bad:
+                f.write(f"BAD {b_}\n")
     assert not bad, f"{len(bad)} parameter gradients off by more than 1e-4 of their largest element (and further from fp64 than 2x the CPU fp32 path): {bad[:8]}"
     assert tie <= 8, f"{tie} parameters needed the fp64 tie-break (more than 8)"
     print(f"[exact {variant} {B}x{size}] worst parameter gradient error {errs[0][0]:.2e} ({errs[0][1]}); fp64 tie-breaks: {tie}")
