@@ -132,26 +132,9 @@ class SgxNetwork(nn.Module):
             slot.start = self.p_arena.reserve(name, slot.numel)
             self.g_arena.reserve(name, slot.numel)
             self.slots.append(slot)
-        pbuf = self.p_arena.allocate(device)
-        gbuf = self.g_arena.allocate(device)
-        for s in self.slots:
-            flat, gflat = pbuf[s.start: s.start + s.numel], gbuf[s.start: s.start + s.numel]
-            old = s.param.data
-            if s.kind == "conv":
-                K_, C_, R_, S_ = old.shape
-                view, s.kernel_view = _conv_weight_view(flat, K_, C_, R_, S_)
-                gview, s.grad_kernel_view = _conv_weight_view(gflat, K_, C_, R_, S_)
-            elif s.kind == "convT":  # logical [C,K,2,2], stored [C][2][2][K]
-                C_, K_ = old.shape[:2]
-                view = flat.view(C_, 2, 2, K_).permute(0, 3, 1, 2)
-                gview = gflat.view(C_, 2, 2, K_).permute(0, 3, 1, 2)
-                s.kernel_view, s.grad_kernel_view = view, gview
-            else:
-                view, gview = flat.view(old.shape), gflat.view(old.shape)
-                s.kernel_view, s.grad_kernel_view = view, gview
-            view.copy_(old.to(device))
-            s.param.data = view
-            s.param.grad = gview
+        self.p_arena.allocate(device)
+        self.g_arena.allocate(device)
+        self._bind_slots(copy_in=True)
         # buffers: BN running stats -> buffer arena (fp32); num_batches_tracked -> one int64 arena
         fbufs, ibufs = [], []
         for mname, m in self.named_modules():
@@ -177,6 +160,31 @@ class SgxNetwork(nn.Module):
                 object.__setattr__(m, "_net", self)  # plain attribute: must not register the network as a child module
         self._build_runtime()
         return self
+
+    def _bind_slots(self, copy_in: bool):
+        """Make every live parameter a strided view of the parameter arena (its .grad a view of the gradient arena) and rebuild the kernel
+        views.  copy_in: the parameter's current values move into the arena (materialize); otherwise the arena already holds them (a
+        deep copy: nn.Parameter.__deepcopy__ clones .data and drops .grad, so the copy's parameters must be re-attached to ITS arenas)."""
+        pbuf, gbuf = self.p_arena.buf, self.g_arena.buf
+        for s in self.slots:
+            flat, gflat = pbuf[s.start: s.start + s.numel], gbuf[s.start: s.start + s.numel]
+            old = s.param.data
+            if s.kind == "conv":
+                K_, C_, R_, S_ = old.shape
+                view, s.kernel_view = _conv_weight_view(flat, K_, C_, R_, S_)
+                gview, s.grad_kernel_view = _conv_weight_view(gflat, K_, C_, R_, S_)
+            elif s.kind == "convT":  # logical [C,K,2,2], stored [C][2][2][K]
+                C_, K_ = old.shape[:2]
+                view = flat.view(C_, 2, 2, K_).permute(0, 3, 1, 2)
+                gview = gflat.view(C_, 2, 2, K_).permute(0, 3, 1, 2)
+                s.kernel_view, s.grad_kernel_view = view, gview
+            else:
+                view, gview = flat.view(old.shape), gflat.view(old.shape)
+                s.kernel_view, s.grad_kernel_view = view, gview
+            if copy_in:
+                view.copy_(old.to(pbuf.device))
+            s.param.data = view
+            s.param.grad = gview
 
     def _build_runtime(self):
         """Everything that refers to this instance's device memory by address or lives outside tensors: the HIP streams, and the per-step
@@ -247,6 +255,25 @@ class SgxNetwork(nn.Module):
             if k not in self._RUNTIME_ATTRS:
                 new.__dict__[k] = copy.deepcopy(v, memo)
         if self._materialized:
+            # the copied arenas hold the values; the copied Parameters are detached clones without .grad: re-attach them (and the BatchNorm
+            # buffers, which deepcopy also cloned out of the buffer arena), then rebuild everything that refers to device addresses
+            new._bind_slots(copy_in=False)
+            fb, ib = 0, 0
+            for _, m in new.named_modules():
+                for bname, b in list(m._buffers.items()):
+                    if b is None:
+                        continue
+                    if b.dtype == torch.float32:
+                        _, start, n = new.b_arena.segments[fb]
+                        fb += 1
+                        m._buffers[bname] = new.b_arena.buf[start: start + n].view(b.shape)
+                    else:
+                        m._buffers[bname] = new.i_arena[ib]
+                        ib += 1
+                    m.__dict__.pop(bname, None)
+            for m in new.modules():
+                if isinstance(m, SgxBlock):
+                    object.__setattr__(m, "_net", new)
             new._build_runtime()
         return new
 
@@ -346,6 +373,20 @@ class SgxNetwork(nn.Module):
             if m is not self and hasattr(m, "prep_model_for_conversion"):
                 m.prep_model_for_conversion(input_size, **kwargs)
         return self
+
+    def weights_changed(self):
+        """Anything that rewrites parameters or BatchNorm statistics outside a training step (load_state_dict, an EMA swap, a broadcast)
+        calls this: eval-mode caches derived from the weights - the folded conv+BN filters of prep_model_for_conversion - are dropped and
+        rebuilt on demand, instead of silently serving the old weights."""
+        for m in self.modules():
+            if getattr(m, "_folded", None) is not None:
+                m._folded = None
+        self._wt_valid = False
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.weights_changed()
+        return out
 
     def zero_grad(self, set_to_none: bool = False):
         if self._materialized:

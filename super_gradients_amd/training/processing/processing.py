@@ -79,6 +79,14 @@ class _ImagePlan:
         """-> True when the stage repeats the previous one (only a rescale may: dataset-derived lists hold e.g. DetectionLongestMaxSize
         followed by DetectionPaddedRescale's own rescale, preprocessing_unit_test.py:119-123 - the second one is then a no-op)."""
         i = _STAGES.index(stage)
+        if stage == "reverse" and not self.reverse and self._stage == _STAGES.index("pad"):
+            # Channel reversal commutes with padding (the reference's skip_image_resizing compose puts its auto-padding FIRST, processing.py:
+            # 186-202, and dataset-derived / PP-YOLOE pipelines start with ReverseImageChannels): reverse-then-pad with the per-channel pad
+            # value reversed is the same image.  The stage pointer stays at 'pad'.
+            pv = np.asarray(self.pad_value)
+            if pv.ndim:
+                self.pad_value = tuple(pv.reshape(-1)[::-1].tolist())
+            return False
         if i < self._stage or (i == self._stage and stage != "rescale"):
             raise NotImplementedError(f"{type(who).__name__} after '{_STAGES[self._stage]}': the fused device pre-processing covers the stage order "
                                       f"{' -> '.join(_STAGES)} (each at most once; a repeated rescale only when it leaves the size unchanged)")

@@ -78,11 +78,13 @@ class ModelEMA:
         keep_p, keep_b = m.p_arena.buf.clone(), m.b_arena.buf.clone()
         m.p_arena.buf.copy_(self.p_ema)
         m.b_arena.buf.copy_(self.b_ema)
+        m.weights_changed()  # folded eval filters (prep_model_for_conversion) must not outlive the swap
         try:
             yield m
         finally:
             m.p_arena.buf.copy_(keep_p)
             m.b_arena.buf.copy_(keep_b)
+            m.weights_changed()
 
     def state_dict(self):
         """state_dict of the averaged network (same keys as the model's), e.g. for the checkpoint's `ema_net` entry."""

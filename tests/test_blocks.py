@@ -218,6 +218,18 @@ def test_conv_block_folded_eval_form(backend, k, s):
     blk._folded = ("stale",)  # e.g. prepared while in training mode
     blk.fwd(to_nhwc(x, backend))
     assert blk._folded is None
+    # new weights arriving in eval mode (load_state_dict, an EMA swap) must drop the folded copy too - not serve the old filter
+    net.eval()
+    net.prep_model_for_conversion(input_size=(h, w))
+    assert blk._folded is not None
+    sd = {kk: (v * 1.5 if kk.endswith("conv.weight") else v) for kk, v in blk.state_dict().items()}
+    net.load_state_dict({"b." + kk: v for kk, v in sd.items()})
+    assert blk._folded is None
+    with torch.no_grad():
+        y3 = to_nchw_cpu(blk.fwd(to_nhwc(x, backend)))
+    ref.load_state_dict(sd)
+    with torch.no_grad():
+        assert_close(y3, ref(x), 2e-5, "eval forward after load_state_dict on a prepared model")
 
 
 @pytest.mark.parametrize("two_branch", [False, True])
@@ -494,3 +506,53 @@ def test_experiment_switches_compose(backend, monkeypatch):
         lib().sgx_debug_set_variant(0)
         lib().sgx_bn_set_fused_finalize(0)
         load_conv_tuning([])
+
+
+def test_deepcopy_of_a_materialised_network_trains(backend):
+    """copy.deepcopy(net) after materialisation - nn.Parameter.__deepcopy__ clones .data and drops .grad, so the copy's parameters
+    must be re-attached to the COPIED arenas: parameters / gradients are views of the copy's arenas (not of the original's), one training
+    step of the copy produces the gradients the original produces, writes them into the copy's gradient arena only, and load_state_dict
+    on the copy reaches the weights its kernels read."""
+    import copy
+
+    from super_gradients_amd.modules import QARepVGGBlock
+
+    blk = QARepVGGBlock(16, 16, stride=1, use_residual_connection=True)
+    net = _wrap(blk, backend)
+    net.train()
+    x = torch.randn(2, 16, 6, 5, generator=torch.Generator().manual_seed(0)) + 0.5
+    dy = torch.randn(2, 16, 6, 5, generator=torch.Generator().manual_seed(1))
+
+    def step(n):
+        n.zero_grad()
+        n.prefetch_dgrad_weights()
+        y = n.b.fwd(to_nhwc(x, backend))
+        n.b.bwd(to_nhwc(dy, backend))
+        n.join_side()
+        return to_nchw_cpu(y)
+
+    y0 = step(net)
+    g0 = net.g_arena.buf.clone()
+    cp = copy.deepcopy(net)
+
+    def inside(t, arena):
+        return arena.buf.data_ptr() <= t.data_ptr() < arena.buf.data_ptr() + arena.buf.numel() * 4
+
+    assert cp.p_arena.buf.data_ptr() != net.p_arena.buf.data_ptr()
+    for name, p in cp.named_parameters():
+        if "rbr_reparam" in name:
+            continue
+        assert inside(p.data, cp.p_arena) and p.grad is not None and inside(p.grad, cp.g_arena), name
+    for b in cp.buffers():
+        assert not inside(b, net.b_arena) and (b.dtype != torch.float32 or inside(b, cp.b_arena))
+    net.zero_grad()
+    y1 = step(cp)
+    assert torch.equal(y1, y0) and torch.equal(cp.g_arena.buf, g0)
+    assert float(net.g_arena.buf.abs().max()) == 0.0, "the copy's step must not touch the original's gradient arena"
+    # load_state_dict on the copy reaches the arena its convolutions read
+    sd = {k: (v + 0.25 if v.dtype == torch.float32 and "rbr_reparam" not in k else v) for k, v in net.state_dict().items()}
+    cp.load_state_dict(sd)
+    y2 = step(cp)
+    assert not torch.equal(y2, y0)
+    net.load_state_dict(sd)
+    assert torch.equal(step(net), y2)

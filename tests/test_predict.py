@@ -412,3 +412,30 @@ def test_reference_unit_test_vectors_for_processing_helpers():
     want = np.array([[[1, 2, 3], [4, 5, 6], [0, 0, 0], [0, 0, 0]], [[7, 8, 9], [10, 11, 12], [0, 0, 0], [0, 0, 0]], [[0, 0, 0]] * 4], dtype=np.uint8)
     assert np.array_equal(O.pad(img, (0, 1, 0, 2), 0), want)
     assert np.array_equal(O.pad(img, (0, 0, 0, 0), 114), img)
+
+
+def test_skip_image_resizing_with_reversed_channels(backend):
+    """the reference's skip_image_resizing compose puts the auto-padding FIRST (processing.py:186-202), and the PP-YOLOE /
+    dataset-derived pipelines start with ReverseImageChannels - so the reversal arrives after a padding stage.  It commutes with the padding
+    (per-channel pad value reversed): the fused launch must take it, bit-exact against the stage-by-stage oracle, for a scalar and for a
+    per-channel pad value."""
+    from super_gradients_amd.training.processing import (ComposeProcessing, DetectionAutoPadding, DetectionRescale, ImagePermute, NormalizeImage,
+                                                         ReverseImageChannels, StandardizeImage, default_ppyoloe_coco_processing_params)
+
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (45, 70, 3), dtype=np.uint8)
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    for pad_value in (0, (10, 20, 30)):
+        cp = ComposeProcessing([ReverseImageChannels(), DetectionRescale((64, 64)), NormalizeImage(mean, std), ImagePermute()])
+        skip = cp.get_equivalent_compose_without_resizing(DetectionAutoPadding(shape_multiple=(32, 32), pad_value=pad_value))
+        batch, metas = skip.preprocess_batch([img], device=backend)
+        x = O.pad(img, O.auto_padding(img.shape[:2], (32, 32)), pad_value)[..., ::-1]
+        want = np.ascontiguousarray(O.normalize(x, mean, std).transpose(2, 0, 1))
+        assert tuple(batch.shape) == (1, 3, 64, 96)
+        assert np.array_equal(batch[0].cpu().numpy(), want), f"pad_value {pad_value}"
+    # the reference's default PP-YOLOE processing, as predict(skip_image_resizing=True) builds it
+    params = default_ppyoloe_coco_processing_params()
+    proc = params["image_processor"]
+    skip = proc.get_equivalent_compose_without_resizing(DetectionAutoPadding(shape_multiple=(32, 32), pad_value=0))
+    batch, _ = skip.preprocess_batch([img], device=backend)
+    assert tuple(batch.shape)[2:] == (64, 96)
