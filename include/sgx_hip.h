@@ -274,7 +274,8 @@ int32_t sgx_bn_bwd_reduce(const float* dy, int64_t dy_ld, const float* x, int64_
                           const float* shift, const float* save_mean, int64_t M, int32_t C, int32_t act, float* partials,
                           void* stream);
 /* stage 2 (tiny): dgamma += sum g*xhat, dbeta += sum g; coefficients for stage 3:
- * dx = c1[c] * ((g - mg[c]) - (x - mean[c]) * k[c]).  coef: [4][C] = c1, mg, k, mean.               */
+ * dx = c1[c] * ((g - mg[c] - mg_lo[c]) - (x - mean[c]) * k[c]).  coef: [5][C] = c1, mg, k, mean, mg_lo (the mean of g travels as hi + lo
+ * floats: its rounding would otherwise be a constant per-channel offset in every dx element, see csrc/bn.hip).                          */
 int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma,
                             const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                             float* coef, void* ws, int64_t ws_bytes, void* stream);
@@ -293,7 +294,7 @@ int32_t sgx_bn_bwd_apply(const float* dy, int64_t dy_ld, const float* x, int64_t
  *   sgx_qarep_bwd_reduce    ONE sweep over (dout, y, u): partials4[4][sgx_stats_blocks(M)][C] = sum g, g*(s-mean_s), g*(y-mean3),
  *                           (s-mean_s)*(y-mean3), g = dout * act'(pre-activation recomputed with the forward's roundings).
  *   sgx_qarep_bwd_finalize  d gamma / d beta of post_bn and d gamma of bn3 accumulated in place (d beta3 is analytically zero: a BatchNorm's
- *                           input gradient sums to zero per channel), cb[5][C] = coefficients of the apply sweep.
+ *                           input gradient sums to zero per channel), cb[6][C] = coefficients of the apply sweep.
  *   sgx_qarep_bwd_apply     ONE sweep over (dout, y, u) writing ds (gradient of u; may alias u) and dy (gradient of y; may alias y).     */
 int64_t sgx_qarep_workspace(int32_t nblk, int32_t C);
 int32_t sgx_qarep_fwd_finalize(const float* stat5, int32_t nblk, int64_t M, int32_t C, const float* bias1, const float* gamma3, const float* beta3,

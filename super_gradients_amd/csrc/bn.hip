@@ -78,17 +78,19 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_kernel(F f, SweepGeom g, flo
         if (NQ > 1) red[NQ > 1 ? 1 : 0][tid] = q1;
         __syncthreads();
         if (live && rl == 0) {
-            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+            // the lane sums meet in double: the partial row carries ONE fp32 rounding (random sign), not a chain of them - the per-channel
+            // means the finalize kernels form from these rows (mean of g in the BatchNorm backward above all) are then good to ~1e-9 relative
+            double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
             for (int k = 0; k < g.RL; ++k) {
                 float4 a = red[0][k * g.CG + cg];
-                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+                s0[0] += a.x; s0[1] += a.y; s0[2] += a.z; s0[3] += a.w;
                 if (NQ > 1) {
                     float4 b = red[NQ > 1 ? 1 : 0][k * g.CG + cg];
-                    s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+                    s1[0] += b.x; s1[1] += b.y; s1[2] += b.z; s1[3] += b.w;
                 }
             }
-            sgx_st4(partials + (long)blockIdx.x * g.C + c, s0);
-            if (NQ > 1) sgx_st4(partials + ((long)g.nblk + blockIdx.x) * g.C + c, s1);
+            sgx_st4(partials + (long)blockIdx.x * g.C + c, make_float4((float)s0[0], (float)s0[1], (float)s0[2], (float)s0[3]));
+            if (NQ > 1) sgx_st4(partials + ((long)g.nblk + blockIdx.x) * g.C + c, make_float4((float)s1[0], (float)s1[1], (float)s1[2], (float)s1[3]));
         }
     }
 }
@@ -410,9 +412,17 @@ __global__ void bn_bwd_finalize_kernel(ColSrc src, ColSrc loc, long M, int C, co
     // dx = c1 * ((g - mg) - (x - mean) * k): differences first, then the scale - the order ATen's CPU kernel uses, so a
     // nearly constant upstream gradient does not lose its small remainder to cancellation between large products
     coef[c] = (float)(g * invstd);
-    coef[C + c] = (float)(sg / (double)M);
+    // The mean of g as TWO floats (hi + lo): (g - mean g) must sum to zero over the pixels to ~2^-48, not 2^-24.  With one float the
+    // rounding of the mean is a constant per-channel offset in every element of dx; the weight gradient of the producing convolution sums
+    // dx against activations whose per-channel mean need not be small, so M * offset * mean(x) competes with a sum that grows like
+    // sqrt(M): measured (r3b, 32 x 640^2, activations at mean 4) as a 60x larger distance from fp64 than ATen's CPU kernel, which forms
+    // (g - mean g) in double.  The x-hat coefficient and the scale are relative factors: their rounding is harmless.
+    const double mgd = sg / (double)M;
+    const float mg_hi = (float)mgd;
+    coef[C + c] = mg_hi;
     coef[2 * C + c] = (float)(invstd * invstd * sgx / (double)M);
     coef[3 * C + c] = (float)mean;
+    coef[4 * C + c] = (float)(mgd - (double)mg_hi);
 }
 extern "C" int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int64_t M, int32_t C, const float* gamma, const float* save_mean,
                                        const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* ws, int64_t ws_bytes,
@@ -444,11 +454,11 @@ struct BnBwdApplyF {
         (void)q0; (void)q1;
         const float4 d = in.d, v = in.v;
         float4 s = sgx_ld4(scale + c), t = sgx_ld4(shift + c);
-        float4 c1 = sgx_ld4(coef + c), mg = sgx_ld4(coef + C + c), k = sgx_ld4(coef + 2 * C + c), mu = sgx_ld4(coef + 3 * C + c);
+        float4 c1 = sgx_ld4(coef + c), mg = sgx_ld4(coef + C + c), k = sgx_ld4(coef + 2 * C + c), mu = sgx_ld4(coef + 3 * C + c), ml = sgx_ld4(coef + 4 * C + c);
         float4 g = make_float4(bn_masked(d.x, v.x, s.x, t.x, act), bn_masked(d.y, v.y, s.y, t.y, act),
                                bn_masked(d.z, v.z, s.z, t.z, act), bn_masked(d.w, v.w, s.w, t.w, act));
-        float4 o = make_float4(c1.x * ((g.x - mg.x) - (v.x - mu.x) * k.x), c1.y * ((g.y - mg.y) - (v.y - mu.y) * k.y),
-                               c1.z * ((g.z - mg.z) - (v.z - mu.z) * k.z), c1.w * ((g.w - mg.w) - (v.w - mu.w) * k.w));
+        float4 o = make_float4(c1.x * (((g.x - mg.x) - ml.x) - (v.x - mu.x) * k.x), c1.y * (((g.y - mg.y) - ml.y) - (v.y - mu.y) * k.y),
+                               c1.z * (((g.z - mg.z) - ml.z) - (v.z - mu.z) * k.z), c1.w * (((g.w - mg.w) - ml.w) - (v.w - mu.w) * k.w));
         sgx_st4(dx + r * dx_ld + c, o);
         if (g_out) sgx_st4(g_out + r * g_ld + c, g);
     }
@@ -695,12 +705,12 @@ __global__ __launch_bounds__(SW_THREADS) void sweepq_kernel(F f, SweepGeom g, fl
     if (live && rl == 0) {
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            double t[4] = {0.0, 0.0, 0.0, 0.0};  // (lane sums meet in double: see sweep_kernel)
             for (int j = 0; j < g.RL; ++j) {
                 const float4 a = red[k][j * g.CG + cg];
-                t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+                t[0] += a.x; t[1] += a.y; t[2] += a.z; t[3] += a.w;
             }
-            sgx_st4(partials + ((long)k * g.nblk + blockIdx.x) * g.C + c, t);
+            sgx_st4(partials + ((long)k * g.nblk + blockIdx.x) * g.C + c, make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]));
         }
     }
 }
@@ -817,10 +827,13 @@ __global__ void qarep_bwd_finalize_kernel(ColSrc src, long M, int C, const float
     if (dgamma3) dgamma3[c] += (float)(invstd3 * Sdy);
     // (d beta3 = sum ds = 0: the input gradient of post_bn sums to zero per channel)
     cb[c] = (float)cp;
-    cb[C + c] = (float)(Sg / m);
+    const double mgd = Sg / m;  // mean g as hi + lo floats: see bn_bwd_finalize_kernel
+    const float mg_hi = (float)mgd;
+    cb[C + c] = mg_hi;
     cb[2 * C + c] = (float)kp;
     cb[3 * C + c] = (float)(g3 * invstd3);
     cb[4 * C + c] = (float)(invstd3 * invstd3 * Sdy / m);
+    cb[5 * C + c] = (float)(mgd - (double)mg_hi);
 }
 extern "C" int32_t sgx_qarep_bwd_finalize(const float* partials4, int32_t nblk, int64_t M, int32_t C, const float* gamma3, const float* gammap,
                                           const float* sv, float* dgamma3, float* dgammap, float* dbetap, float* cb, void* ws, int64_t ws_bytes,
@@ -842,10 +855,11 @@ struct QarepBwdApplyF {
         float4 g, sc, yc;
         b.terms(c, in, g, sc, yc);
         const int C = b.C;
-        const float4 cp = sgx_ld4(cb + c), mg = sgx_ld4(cb + C + c), kp = sgx_ld4(cb + 2 * C + c), c3 = sgx_ld4(cb + 3 * C + c), k3 = sgx_ld4(cb + 4 * C + c);
+        const float4 cp = sgx_ld4(cb + c), mg = sgx_ld4(cb + C + c), kp = sgx_ld4(cb + 2 * C + c), c3 = sgx_ld4(cb + 3 * C + c), k3 = sgx_ld4(cb + 4 * C + c),
+                     ml = sgx_ld4(cb + 5 * C + c);
         // differences first, then the scale (the order ATen's CPU batch-norm backward uses)
-        const float4 s = make_float4(cp.x * ((g.x - mg.x) - sc.x * kp.x), cp.y * ((g.y - mg.y) - sc.y * kp.y), cp.z * ((g.z - mg.z) - sc.z * kp.z),
-                                     cp.w * ((g.w - mg.w) - sc.w * kp.w));
+        const float4 s = make_float4(cp.x * (((g.x - mg.x) - ml.x) - sc.x * kp.x), cp.y * (((g.y - mg.y) - ml.y) - sc.y * kp.y),
+                                     cp.z * (((g.z - mg.z) - ml.z) - sc.z * kp.z), cp.w * (((g.w - mg.w) - ml.w) - sc.w * kp.w));
         sgx_st4(ds + r * ds_ld + c, s);
         sgx_st4(dy + r * dy_ld + c, make_float4(c3.x * (s.x - yc.x * k3.x), c3.y * (s.y - yc.y * k3.y), c3.z * (s.z - yc.z * k3.z), c3.w * (s.w - yc.w * k3.w)));
     }

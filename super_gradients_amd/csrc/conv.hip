@@ -823,7 +823,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #define PC_PW (PC_TW + 2)            // patch pitch (pixels)
 #define PC_NPIX ((PC_TH + 2) * PC_PW)  // 180 patch pixels
 template <int BN, int WM, int WN, int KC, int PH2>
-__global__ __launch_bounds__(WM * WN * 64) void pconv_kernel(IgemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
     static_assert(4 % WM == 0 && (KC == 16 || KC == 32), "WM divides the four 32-row sub-tiles; 16- or 32-channel chunks");
     constexpr int NTH = WM * WN * 64;
     constexpr int BM = PC_TH * PC_TW;           // 128 output pixels = 4 sub-tiles of 32 MFMA rows
@@ -1034,16 +1034,18 @@ __global__ __launch_bounds__(WM * WN * 64) void pconv_kernel(IgemmParams p) {
             }
         }
         load_patch(0);
+        load_filter(0, 0, 0);
         for (int chunk = 0; chunk < cpt; ++chunk) {
-            // every wave is past its last read of the patch and of both filter buffers (barrier at the end of the previous tap)
+            // every wave is past its last read of the patch and of both filter buffers (barrier at the end of the previous tap); the patch and
+            // the first filter slab of this chunk have been travelling in registers since the last taps of the previous one
             store_patch();
-            load_filter(0, chunk, 0);
             store_filter(0);
             __syncthreads();
             for (int t = 0; t < ntaps; ++t) {
                 const bool more = t + 1 < ntaps;
                 if (more) load_filter(t + 1, chunk, 0);
                 else if (DUAL) load_filter(0, chunk, 1);  // PH2 = 2: one more "tap" - the centre tap again, with the second filter
+                else if (chunk + 1 < cpt) load_filter(0, chunk + 1, 0);
                 if (t == (ntaps > 4 ? ntaps - 4 : 0) && chunk + 1 < cpt) load_patch(chunk + 1);  // next chunk's patch travels in registers under the last taps
                 // patch offset of the tap: input pixel (a + dh0 + dstep * ti, b + dw0 + dstep * tj), patch origin (oy0 - 1, ox0 - 1)
                 const int ti = t / taps_w, tj = t - ti * taps_w;
@@ -1052,6 +1054,7 @@ __global__ __launch_bounds__(WM * WN * 64) void pconv_kernel(IgemmParams p) {
                 __syncthreads();
             }
             if constexpr (DUAL) {
+                if (chunk + 1 < cpt) load_filter(0, chunk + 1, 0);
                 compute_tap(ntaps & 1, PC_PW + 1, accu, accu2);
                 __syncthreads();
             }
@@ -1383,10 +1386,15 @@ static void launch_igemm(IgemmParams& p, void* stream) {
 // ---- pconv dispatch ------------------------------------------------------------------------------------------------------------------
 static bool pconv_ok(const IgemmParams& p, int ph2) {
     if (g_conv_math.load(std::memory_order_relaxed) != 3) return false;
-    if (p.Th != 3 || p.Tw != 3 || p.si != 1 || p.so != 1 || p.ph || p.pw || p.Hin != p.Ha || p.Win != p.Wa) return false;
-    if (!((p.dstep == 1 && p.dh0 == -1 && p.dw0 == -1) || (p.dstep == -1 && p.dh0 == 1 && p.dw0 == 1))) return false;  // forward / data-gradient taps
+    // dense taps whose input offsets all lie in [-1, +1]: the 3x3 stride-1 forward / data gradient, and the output-parity classes of a 3x3
+    // stride-2 data gradient (2x2 / 2x1 / 1x2 taps at offsets {0, +1}; the output grid is then written with stride `so`)
+    if (p.si != 1 || p.Th > 3 || p.Tw > 3 || p.Th * p.Tw < 2 || (p.dstep != 1 && p.dstep != -1)) return false;
+    for (int i = 0; i < p.Th; ++i)
+        if (p.dh0 + p.dstep * i < -1 || p.dh0 + p.dstep * i > 1) return false;
+    for (int j = 0; j < p.Tw; ++j)
+        if (p.dw0 + p.dstep * j < -1 || p.dw0 + p.dstep * j > 1) return false;
     if (p.C % 16 || p.C < 16 || !p.vec) return false;
-    if (ph2 && p.A2 && !(p.Th2 == 1 && p.Tw2 == 1 && p.dh02 == 0 && p.dw02 == 0 && p.Hin2 == p.Ha && p.Win2 == p.Wa)) return false;
+    if (ph2 && p.A2 && !(p.Th2 == 1 && p.Tw2 == 1 && p.dh02 == 0 && p.dw02 == 0)) return false;
     if (ph2 == 2 && (p.A2 != p.A || p.a2_ld_pix != p.a_ld_pix || p.a2_ld_img != p.a_ld_img)) return false;  // the second filter reads the same patch
     if ((long)p.Hin * p.Win * p.a_ld_pix * 4 > SGX_BUF_MAX) return false;
     return true;
@@ -1805,65 +1813,31 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
 // GROUP fills the chip, not each layer on its own: fewer, longer work items -> fewer partial tiles in HBM, ~8x fewer
 // launches, no per-layer tail.  Workgroup -> (job, split, tile) is XCD-aware: the (k, j) tiles of one pixel range run
 // back to back on ONE XCD, so the range is fetched from HBM once and re-read from that XCD's L2 by the other tiles.
-// The split partials are folded INSIDE the launch, deterministically: a workgroup publishes its partial tile, bumps an
-// arrival ticket, and the LAST arriver of a group of <= WG_GROUP splits adds the group's partials in split order (a
-// second ticket level folds the group sums the same way when a job has more than WG_GROUP splits) and accumulates the
-// result into dW - fixed summation order whatever the arrival order, no float atomics, no separate reduce launch.
-// Tickets are zero on entry and are left zero (the last arriver resets its counter).
+// The split partials are folded INSIDE the launch, deterministically, by a fixed binary tree over the split index that the workgroups walk
+// in arrival order (see the kernel's tail): fixed association whatever the arrival order, pairwise summation, no float atomics, no
+// separate reduce launch, no workgroup folding more than one partner tile per level.  The hand-over moves with device-scope stores /
+// loads (sc1), not with L2 write-back fences.  Tickets are zero on entry and are left zero (the second arriver of a pair resets it).
 // ------------------------------------------------------------------------------------------------
 #define WG_BKP 16
-#define WG_GROUP 32
+#define WG_MAX_SPLIT 4096
 #define WG_MAX_JOBS 20  // the job table travels as kernel arguments: 20 x 176 B + 8 B < 4 KB
 
 struct WgJob {
     const float* X;
     const float* DY;
     float* dw;
-    float* part;    // [tile][ksplit][BNK * BJ]
-    float* gpart;   // [tile][ngroups][BNK * BJ]   (ksplit > WG_GROUP)
-    int* tickets;   // [tile][ngroups + 1]
+    float* part;    // [tile][ksplit][BNK * BJ]: node values of the fold tree, in place (a node lives in its leftmost leaf's slot)
+    int* tickets;   // [tile][ksplit]: one per sibling pair
     long x_ld_pix, x_ld_img, y_ld_pix, y_ld_img;
     long x_bytes, dy_bytes;
     int H, W, C, K, S, stride, pad, Ho, Wo;
-    int M, J, ksplit, mchunk, kt_tiles, jt_tiles, ngroups;
+    int M, J, ksplit, mchunk, kt_tiles, jt_tiles;
     int blk0;  // first workgroup of the job in its launch (a multiple of 8: XCD phase 0)
-    int vec;   // dW rows are 16-byte aligned
 };
 struct WgGroupParams {
     int njobs, xcd_order;
     WgJob jobs[WG_MAX_JOBS];
 };
-
-// dst (+)= src[0] + src[1] + ... + src[count - 1] (tiles `stride` floats apart), added in index order
-template <int NTH, int BNK, int BJ>
-__device__ __forceinline__ void wg_fold(const float* src, long stride, int count, float* tile_dst, float* dw, int K, int J, int k0, int j0, int vec) {
-    constexpr int E4 = BNK * BJ / 4;
-    for (int e4 = threadIdx.x; e4 < E4; e4 += NTH) {
-        const float* s = src + (long)e4 * 4;
-        float4 v = sgx_ld4_dev(s);
-        for (int q = 1; q < count; ++q) {
-            const float4 u = sgx_ld4_dev(s + q * stride);
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-        }
-        if (tile_dst) {
-            sgx_st4_dev(tile_dst + (long)e4 * 4, v);
-            continue;
-        }
-        const int k = k0 + (e4 * 4) / BJ, j = j0 + (e4 * 4) % BJ;
-        if (k >= K || j >= J) continue;
-        float* d = dw + (long)k * J + j;
-        if (vec) {  // J % 4 == 0: the four columns are inside the row together
-            float4 o = sgx_ld4(d);
-            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-            sgx_st4(d, o);
-        } else {
-            const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (j + t < J) d[t] += e[t];
-        }
-    }
-}
 
 template <int BNK, int BJ, int WK, int WC>
 __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
@@ -2016,64 +1990,66 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
         if (kt + 1 < nkt) store_tile(buf ^ 1);
         __syncthreads();
     }
+    // ---- fold the pixel splits of this tile: a fixed binary tree over the split index, walked by arrival -------------------------------------
+    // Level L pairs node i = split >> L with its sibling i ^ 1.  A workgroup holding a node's value publishes it (device-scope stores into
+    // the slot of the node's leftmost leaf), takes the pair's ticket, and leaves if it is the FIRST of the pair; the second one adds the
+    // sibling's value to its registers and carries the parent one level up.  Whoever arrives last, every node is left + right of the same
+    // two children (fp32 addition commutes), so the result is bit-reproducible - and it is a pairwise summation: ~log2(ksplit) roundings
+    // on top of the chains.  No workgroup ever folds more than one partner tile per level (the serial "last arriver folds them all" form
+    // measured r3b: 55 TFLOP/s against 88 for the two-launch kernel it replaced).  Tickets: one per pair, at the right child's
+    // leftmost-leaf index (odd x 2^L: unique over the tree), reset by the second arriver.
+    const int ksplit = p.ksplit;
+    if (ksplit > 1) {
+        constexpr int TE = BNK * BJ;
+        float* const base = p.part + (long)tile * ksplit * TE;
+        int* const tk = p.tickets + (long)tile * ksplit;
+        const int lrow = (lane >> 5) * 4, lcol = lane & 31;
+        for (int L = 0; (1 << L) < ksplit; ++L) {
+            const int i = split >> L, sib = i ^ 1;
+            if (((long)sib << L) >= ksplit) continue;  // no sibling on this level: the value passes up as it is
+            float* const mine = base + ((long)i << L) * TE;
+#pragma unroll
+            for (int a = 0; a < TK; ++a)
+#pragma unroll
+                for (int b = 0; b < TC; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sgx_st_dev(&mine[(wk * TK * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + lrow) * BJ + wc * TC * 32 + b * 32 + lcol], acc[a][b][r]);
+            sgx_wait_stores();
+            __syncthreads();
+            if (tid == 0) {
+                int* const t = &tk[((long)(i | 1)) << L];
+                const int old = atomicAdd(t, 1);
+                s_last = old;
+                if (old) *t = 0;
+            }
+            __syncthreads();
+            const int second = s_last;
+            __syncthreads();  // (s_last is rewritten on the next level)
+            if (!second) return;
+            const float* const other = base + ((long)sib << L) * TE;
+#pragma unroll
+            for (int a = 0; a < TK; ++a)
+#pragma unroll
+                for (int b = 0; b < TC; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[a][b][r] += sgx_ld_dev(&other[(wk * TK * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + lrow) * BJ + wc * TC * 32 + b * 32 + lcol]);
+        }
+    }
+    // the root of the tile: into dW
     float* const dw = p.dw;
-    if (p.ksplit == 1) {  // the only split of its tile: straight into dW
 #pragma unroll
-        for (int i = 0; i < TK; ++i)
+    for (int i = 0; i < TK; ++i)
 #pragma unroll
-            for (int j = 0; j < TC; ++j) {
-                const int jj = j0 + wc * TC * 32 + j * 32 + (lane & 31);
+        for (int j = 0; j < TC; ++j) {
+            const int jj = j0 + wc * TC * 32 + j * 32 + (lane & 31);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = k0 + wk * TK * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (k < K && jj < J) dw[(long)k * J + jj] += acc[i][j][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wk * TK * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (k < K && jj < J) dw[(long)k * J + jj] += acc[i][j][r];
             }
-        return;
-    }
-    // partial tile (whole padded tile: rows / columns outside the filter are exact zeros)
-    constexpr int TE = BNK * BJ;
-    const int ksplit = p.ksplit, ngroups = p.ngroups, vec = p.vec;
-    {
-        float* const mine = p.part + ((long)tile * ksplit + split) * TE;
-#pragma unroll
-        for (int i = 0; i < TK; ++i)
-#pragma unroll
-            for (int j = 0; j < TC; ++j) {
-                const int jl = wc * TC * 32 + j * 32 + (lane & 31);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sgx_st_dev(&mine[(wk * TK * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BJ + jl], acc[i][j][r]);
-            }
-    }
-    // publish (device-scope stores, acknowledged), take a ticket; the group's last arriver folds the group in split order
-    sgx_wait_stores();
-    __syncthreads();
-    const int grp = split / WG_GROUP, gbeg = grp * WG_GROUP;
-    const int gcnt = min(WG_GROUP, ksplit - gbeg);
-    int* const tk = p.tickets + (long)tile * (ngroups + 1);
-    if (tid == 0) {
-        const int old = atomicAdd(&tk[grp], 1);
-        s_last = old == gcnt - 1;
-        if (old == gcnt - 1) tk[grp] = 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const float* const src = p.part + ((long)tile * ksplit + gbeg) * TE;
-    if (ngroups == 1) {
-        wg_fold<NTH, BNK, BJ>(src, TE, gcnt, nullptr, dw, K, J, k0, j0, vec);
-        return;
-    }
-    wg_fold<NTH, BNK, BJ>(src, TE, gcnt, p.gpart + ((long)tile * ngroups + grp) * TE, nullptr, K, J, k0, j0, vec);
-    sgx_wait_stores();
-    __syncthreads();
-    if (tid == 0) {
-        const int old = atomicAdd(&tk[ngroups], 1);
-        s_last = old == ngroups - 1;
-        if (old == ngroups - 1) tk[ngroups] = 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    wg_fold<NTH, BNK, BJ>(p.gpart + (long)tile * ngroups * TE, TE, ngroups, nullptr, dw, K, J, k0, j0, vec);
+        }
 }
 
 // ---- host side: tile choice, group plan, launches ------------------------------------------------------------------------------------
@@ -2113,8 +2089,8 @@ extern "C" int32_t sgx_debug_set_wgrad_group(int32_t rounds, int32_t item_mflop,
     return SGX_OK;
 }
 struct WgPlan {
-    int bnk, bj, waves, kt_tiles, jt_tiles, ksplit, mchunk, ngroups;
-    long part_off, gpart_off, ticket_off;  // floats, floats, ints
+    int bnk, bj, waves, kt_tiles, jt_tiles, ksplit, mchunk;
+    long part_off, ticket_off;  // floats, ints
 };
 // tile choice from the exhaustive search: 64x64 where the channel count allows, 96x128 for 96-wide layers; a tuning-table entry (kind 2)
 // or the measurement override replaces it
@@ -2170,25 +2146,22 @@ static int32_t wgrad_group_plan(const sgx_wgrad_job* jobs, int n, std::vector<Wg
         if (mchunk < 256) mchunk = 256;  // at least 16 slabs per item
         if (mchunk > M) mchunk = M;
         long ks = (M + mchunk - 1) / mchunk;
-        if (ks > WG_GROUP * WG_GROUP) ks = WG_GROUP * WG_GROUP;  // two ticket levels
+        if (ks > WG_MAX_SPLIT) ks = WG_MAX_SPLIT;
         // a split's lane offsets are 31-bit: keep every split under 1 GiB of either operand
         const long big = (long)d->N * (d->x_ld_img > d->y_ld_img ? d->x_ld_img : d->y_ld_img) * 4;
         const long need = big / (1L << 30) + 1;
         if (ks < need) ks = need;
-        if (ks > WG_GROUP * WG_GROUP) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv bwd_weight: operand too large (%ld pixel ranges of 1 GiB)", need);
+        if (ks > WG_MAX_SPLIT) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv bwd_weight: operand too large (%ld pixel ranges of 1 GiB)", need);
         mchunk = (M + ks - 1) / ks;
         mchunk = ((mchunk + WG_BKP - 1) / WG_BKP) * WG_BKP;
         ks = (M + mchunk - 1) / mchunk;
         pl.ksplit = (int)ks;
         pl.mchunk = (int)mchunk;
-        pl.ngroups = (int)((ks + WG_GROUP - 1) / WG_GROUP);
         const long te = (long)pl.bnk * pl.bj;
         pl.part_off = poff;
         poff += ks > 1 ? tiles * ks * te : 0;
-        pl.gpart_off = poff;
-        poff += pl.ngroups > 1 ? tiles * pl.ngroups * te : 0;
         pl.ticket_off = toff;
-        toff += ks > 1 ? tiles * (pl.ngroups + 1) : 0;
+        toff += ks > 1 ? tiles * ks : 0;
     }
     *part_floats = poff;
     *ticket_ints = toff;
@@ -2234,15 +2207,14 @@ extern "C" int32_t sgx_conv2d_bwd_weight_group(const sgx_wgrad_job* jobs, int32_
             SGX_CHECK_ARG(jobs[i].x && jobs[i].dy && jobs[i].dw, "conv bwd_weight: null pointer");
             WgJob& p = g.jobs[g.njobs++];
             p.X = jobs[i].x; p.DY = jobs[i].dy; p.dw = jobs[i].dw;
-            p.part = (float*)ws + pl.part_off; p.gpart = (float*)ws + pl.gpart_off; p.tickets = tickets + pl.ticket_off;
+            p.part = (float*)ws + pl.part_off; p.tickets = tickets + pl.ticket_off;
             p.x_ld_pix = d->x_ld_pix; p.x_ld_img = d->x_ld_img; p.y_ld_pix = d->y_ld_pix; p.y_ld_img = d->y_ld_img;
             p.x_bytes = view_bytes(d->N, d->H, d->W, d->C, d->x_ld_pix, d->x_ld_img);
             p.dy_bytes = view_bytes(d->N, d->Ho, d->Wo, d->K, d->y_ld_pix, d->y_ld_img);
             p.H = d->H; p.W = d->W; p.C = d->C; p.K = d->K; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
             p.M = d->N * d->Ho * d->Wo; p.J = d->R * d->S * d->C;
-            p.ksplit = pl.ksplit; p.mchunk = pl.mchunk; p.kt_tiles = pl.kt_tiles; p.jt_tiles = pl.jt_tiles; p.ngroups = pl.ngroups;
+            p.ksplit = pl.ksplit; p.mchunk = pl.mchunk; p.kt_tiles = pl.kt_tiles; p.jt_tiles = pl.jt_tiles;
             p.blk0 = nblk;
-            p.vec = (p.J % 4 == 0 && ((uintptr_t)p.dw % 16) == 0) ? 1 : 0;
             nblk += 8 * sgx_cdiv(pl.ksplit, 8) * pl.kt_tiles * pl.jt_tiles;
             flops += 2.0 * (double)p.M * (double)d->K * (double)p.J;
             bytes += 4.0 * ((double)d->N * d->H * d->W * d->C + (double)p.M * d->K + (double)d->K * p.J);

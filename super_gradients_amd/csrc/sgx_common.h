@@ -112,11 +112,13 @@ __device__ __forceinline__ float4 sgx_buf_ld4(sgx_buf b, unsigned off) {
 //   consumer: (sees the last ticket) ... sgx_ld4_dev
 #ifdef SGX_EMU
 static inline void sgx_st_dev(float* p, float v) { *p = v; }
+static inline float sgx_ld_dev(const float* p) { return *p; }
 static inline void sgx_st4_dev(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 static inline float4 sgx_ld4_dev(const float* p) { return *reinterpret_cast<const float4*>(p); }
 #define sgx_wait_stores() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #else
 __device__ __forceinline__ void sgx_st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float sgx_ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sgx_st4_dev(float* p, float4 v) {
     unsigned long long a, b;
     const float lo[2] = {v.x, v.y}, hi[2] = {v.z, v.w};

@@ -282,7 +282,7 @@ def qarep_bwd(dout, y, u, cf, sv, bn3, pbn, act):
     nblk = stats_blocks(M)
     parts = torch.empty(4, nblk, C, device=y.device, dtype=torch.float32)
     check(lib().sgx_qarep_bwd_reduce(ptr(dout), dl, ptr(y), yl, ptr(u), ul, ptr(cf), ptr(sv), M, C, a, ptr(parts), stream()), "sgx_qarep_bwd_reduce")
-    cb = torch.empty(5, C, device=y.device, dtype=torch.float32)
+    cb = torch.empty(6, C, device=y.device, dtype=torch.float32)
     ws = WORKSPACE.get(_qarep_workspace(nblk, C), y.device)
     check(lib().sgx_qarep_bwd_finalize(ptr(parts), nblk, M, C, ptr(bn3.weight), ptr(pbn.weight), ptr(sv), ptr(bn3.weight.grad), ptr(pbn.weight.grad),
                                        ptr(pbn.bias.grad), ptr(cb), ptr(ws), ws.numel(), stream()), "sgx_qarep_bwd_finalize")
@@ -556,7 +556,7 @@ def bn_bwd(dy, x, scale, shift, gamma, save_mean, save_invstd, dgamma, dbeta, ac
     if parts is None:
         parts = torch.empty(2, stats_blocks(M), C, device=x.device, dtype=torch.float32)
         check(lib().sgx_bn_bwd_reduce(ptr(dy), dl, ptr(x), ld, ptr(scale), ptr(shift), ptr(save_mean), M, C, a, ptr(parts), stream()), "sgx_bn_bwd_reduce")
-    coef = torch.empty(4, C, device=x.device, dtype=torch.float32)
+    coef = torch.empty(5, C, device=x.device, dtype=torch.float32)
     ws = WORKSPACE.get(_reduce_workspace(parts.shape[1], C), x.device)
     if sync:
         local = torch.empty(2, C, device=x.device, dtype=torch.float64)

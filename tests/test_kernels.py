@@ -975,7 +975,7 @@ def test_fused_finalize(backend, nblk, C):
             lib().sgx_bn_set_fused_finalize(fused)
             rm, rv = torch.zeros(C, device=backend), torch.ones(C, device=backend)
             fwd = K.bn_finalize(parts, M, gamma, beta, 1e-3, 0.03, rm, rv)
-            coef, dg, db = torch.empty(4, C, device=backend), torch.zeros(C, device=backend), torch.zeros(C, device=backend)
+            coef, dg, db = torch.empty(5, C, device=backend), torch.zeros(C, device=backend), torch.zeros(C, device=backend)
             ws = K.WORKSPACE.get(lib().sgx_reduce_workspace(nblk, C), parts.device)
             K.check(lib().sgx_bn_bwd_finalize(K.ptr(parts), nblk, M, C, K.ptr(gamma), K.ptr(mean), K.ptr(invstd), K.ptr(dg), K.ptr(db), K.ptr(coef), K.ptr(ws),
                                               ws.numel(), K.stream()), "sgx_bn_bwd_finalize")
@@ -1186,3 +1186,28 @@ def test_pconv(backend, idx):
         assert_close(to_nchw_cpu(dxd), gx3 + gx1 + addx + 0.5 * a2, TOL, "pconv dual dgrad")
     finally:
         K.set_conv_math("fp32")
+
+
+def test_bn_backward_input_gradient_sums_to_zero(backend):
+    """A training-mode BatchNorm's input gradient sums to zero per channel.  The weight gradient of the convolution in front of it is
+    sum_pixels dx * activation, and activations have per-channel means - so a constant offset in dx as small as the fp32 rounding of
+    mean(g) (2^-24 |mean g| in EVERY element) is amplified by M * mean(activation) against a sum that only grows like sqrt(M).  Found by
+    the flip-free gradient check at 32 x 640^2 (r3b: 60x further from fp64 than ATen's CPU kernel, which forms g - mean g in double).
+    The apply sweeps therefore take mean(g) as hi + lo floats: |sum dx| must stay at the random-rounding level, far below the
+    single-float offset bound M * 2^-24 * |mean g| * c1 (both the plain BatchNorm backward and the QARepVGG pair's)."""
+    n, h, w, c = _sizes(backend, (8, 80, 80, 16), (1, 150, 150, 4))
+    M = n * h * w
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, c, h, w, generator=g) * 0.3 + 4.0
+    dy = torch.randn(n, c, h, w, generator=g) * 0.01 + torch.tensor([3.1, -2.7, 5.3, 1.9] * (c // 4)).view(1, c, 1, 1)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    xd = to_nhwc(x, backend)
+    parts = K.channel_stats_partial(xd)
+    rm, rv = torch.zeros(c, device=backend), torch.ones(c, device=backend)
+    scale, shift, mean, invstd = K.bn_finalize(parts, M, gamma.to(backend), beta.to(backend), 1e-3, 0.03, rm, rv)
+    dgamma, dbeta = torch.zeros(c, device=backend), torch.zeros(c, device=backend)
+    dx = K.bn_bwd(to_nhwc(dy, backend), xd, scale, shift, gamma.to(backend), mean, invstd, dgamma, dbeta, act=None)
+    s = to_nchw_cpu(dx).double().sum((0, 2, 3)).abs()
+    c1 = (gamma.double() * invstd.cpu().double()).abs()
+    single_float_offset = M * 2.0 ** -24 * dy.double().mean((0, 2, 3)).abs() * c1
+    assert bool((s <= 0.05 * single_float_offset).all()), f"sum dx {s.tolist()} vs single-float offset bound {single_float_offset.tolist()}"
