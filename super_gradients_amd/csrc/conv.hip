@@ -837,7 +837,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
     constexpr int STAGE_BYTES = WM * WN * 32 * 32 * 4;
     constexpr int SMEM_BYTES = (A_BYTES + B_BYTES) > STAGE_BYTES ? (A_BYTES + B_BYTES) : STAGE_BYTES;
     constexpr int C4 = KC / 4;                  // float4 items per pixel / filter row
-    constexpr int AR = (PC_NPIX * C4 + NTH - 1) / NTH, BR = (BN * C4 + NTH - 1) / NTH;
+    // Staging roles: the first half of the waves fetches / splits / stores the per-tap FILTER slabs, the second half the input PATCH.  A
+    // wave's global loads return in issue order (one vmcnt counter): were every wave to carry both streams, each wait for a filter slab
+    // (short, L2) would also wait for the patch prefetch behind it (long, HBM) - measured r3c as 30 % of the wave cycles parked in
+    // s_waitcnt.  Every wave runs the same MFMA work.
+    constexpr int GTH = NTH / 2;                // threads per staging role
+    constexpr int AR = (PC_NPIX * C4 + GTH - 1) / GTH, BR = (BN * C4 + GTH - 1) / GTH;
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
     unsigned char* const As = smem_raw;
     unsigned char* const Bs = smem_raw + A_BYTES;
@@ -875,26 +880,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
 
     // ---- source state ------------------------------------------------------------------------------------------------------------
     sgx_buf bufA, bufB;
-    int aoff[AR], alds[AR];   // global byte offset (chunk 0) and LDS byte offset (plane 0) of this thread's patch items; aoff < 0: padding
+    // (patch items are addressed on the fly - once per chunk -, filter items from cached offsets - once per tap)
+    int Hin_, Win_;
+    long a_ld_pix_;
     int boff[BR], blds[BR];
     int w_ld_n_, taps_h, taps_w, dh0_, dw0_, dstep_, ntaps;
     auto setup_src = [&](const float* A, const float* Wt, int Hin, int Win, int Th, int Tw, int dh0, int dw0, int dstep, long a_ld_pix, long a_ld_img,
                          long w_ld_n, long a_bytes, long w_bytes) {
         bufA = sgx_make_buf(A + (long)img * a_ld_img, a_bytes - (long)img * a_ld_img * 4);
         bufB = sgx_make_buf(Wt, w_bytes);
-#pragma unroll
-        for (int r = 0; r < AR; ++r) {
-            const int idx = tid + NTH * r;
-            const int pp = idx / C4, c4 = (idx - pp * C4) * 4;
-            const int py = pp / PC_PW, px = pp - py * PC_PW;
-            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-            const bool ok = pp < PC_NPIX && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
-            aoff[r] = ok ? (int)((((long)iy * Win + ix) * a_ld_pix + c4) * 4) : -1;
-            alds[r] = pp < PC_NPIX ? pp * ROWB + swz(c4 >> 3, pp) * 16 + ((c4 >> 2) & 1) * 8 : -1;
-        }
+        Hin_ = Hin; Win_ = Win; a_ld_pix_ = a_ld_pix;
 #pragma unroll
         for (int r = 0; r < BR; ++r) {
-            const int idx = tid + NTH * r;
+            const int idx = tid + GTH * r;  // (filter role: threads 0 .. GTH - 1)
             const int n = idx / C4, c4 = (idx - n * C4) * 4;
             const bool ok = n < BN && n0 + n < p.Nout;
             boff[r] = ok ? (int)((((long)(n0 + n)) * w_ld_n + c4) * 4) : -1;
@@ -906,25 +904,39 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
     };
 
     float4 ra[AR], rb[BR];
+    const bool filter_role = tid < GTH;
     auto load_patch = [&](int chunk) {
-#pragma unroll
-        for (int r = 0; r < AR; ++r) ra[r] = sgx_buf_ld4(bufA, aoff[r] >= 0 ? (unsigned)(aoff[r] + chunk * (KC * 4)) : SGX_BUF_OOB);
-    };
-    auto store_patch = [&]() {
+        if (filter_role) return;
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
-            if (alds[r] < 0) continue;
+            const int idx = (tid - GTH) + GTH * r;  // (patch role: threads GTH .. NTH - 1)
+            const int pp = idx / C4, c4 = (idx - pp * C4) * 4;
+            const int py = pp / PC_PW, px = pp - py * PC_PW;
+            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+            const bool ok = pp < PC_NPIX && iy >= 0 && iy < Hin_ && ix >= 0 && ix < Win_;
+            ra[r] = sgx_buf_ld4(bufA, ok ? (unsigned)((((long)iy * Win_ + ix) * a_ld_pix_ + c4 + chunk * KC) * 4) : SGX_BUF_OOB);
+        }
+    };
+    auto store_patch = [&]() {
+        if (filter_role) return;
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            const int idx = (tid - GTH) + GTH * r;
+            const int pp = idx / C4, c4 = (idx - pp * C4) * 4;
+            if (pp >= PC_NPIX) continue;
+            unsigned char* const d = As + pp * ROWB + swz(c4 >> 3, pp) * 16 + ((c4 >> 2) & 1) * 8;
             uint2 h, m, l;
             sgx_split3(ra[r], h, m, l);
-            *reinterpret_cast<uint2*>(As + alds[r]) = h;
-            *reinterpret_cast<uint2*>(As + A_PLANE + alds[r]) = m;
-            *reinterpret_cast<uint2*>(As + 2 * A_PLANE + alds[r]) = l;
+            *reinterpret_cast<uint2*>(d) = h;
+            *reinterpret_cast<uint2*>(d + A_PLANE) = m;
+            *reinterpret_cast<uint2*>(d + 2 * A_PLANE) = l;
         }
     };
     // filter slab of (tap index in the weight row, channel chunk); wsel: 0 = the source's filter, 1 = the second filter of PH2 = 2 (Wt2, one tap)
     sgx_buf bufB2 = bufB;
     int boff2[PH2 == 2 ? BR : 1];
     auto load_filter = [&](int wtap, int chunk, int wsel) {
+        if (!filter_role) return;
 #pragma unroll
         for (int r = 0; r < BR; ++r) {
             if (PH2 == 2 && wsel == 1) rb[r] = sgx_buf_ld4(bufB2, boff2[PH2 == 2 ? r : 0] >= 0 ? (unsigned)(boff2[PH2 == 2 ? r : 0] + chunk * (KC * 4)) : SGX_BUF_OOB);
@@ -932,6 +944,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
         }
     };
     auto store_filter = [&](int buf) {
+        if (!filter_role) return;
 #pragma unroll
         for (int r = 0; r < BR; ++r) {
             if (blds[r] < 0) continue;
@@ -1028,7 +1041,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
             bufB2 = sgx_make_buf(p.Wt2, p.w2_bytes);
 #pragma unroll
             for (int r = 0; r < BR; ++r) {
-                const int idx = tid + NTH * r;
+                const int idx = tid + GTH * r;  // (filter role: threads 0 .. GTH - 1)
                 const int n = idx / C4, c4 = (idx - n * C4) * 4;
                 boff2[PH2 == 2 ? r : 0] = (n < BN && n0 + n < p.Nout) ? (int)((((long)(n0 + n)) * p.w2_ld_n + c4) * 4) : -1;
             }
@@ -1416,7 +1429,10 @@ static void launch_pconv_n(IgemmParams& p, void* stream) {
     else launch_pconv<64, 2, 2, KC, PH2>(p, stream);
 }
 static int32_t run_pconv(IgemmParams& p, void* stream, int ph2) {
-    const bool k32 = p.C % 32 == 0;
+    // 32-channel chunks where the registers allow them (one source / one output); the two-source and two-output forms carry twice the
+    // accumulators and run 16-channel chunks.  Measurement: variant 8 forces 16, variant 9 forces 32 (where C % 32 == 0).
+    const int var = conv_variant();
+    const bool k32 = p.C % 32 == 0 && var != 8 && (var == 9 || ph2 == 0 || !p.A2);
     if (ph2 == 0 || !p.A2) k32 ? launch_pconv_n<32, 0>(p, stream) : launch_pconv_n<16, 0>(p, stream);
     else if (ph2 == 1) k32 ? launch_pconv_n<32, 1>(p, stream) : launch_pconv_n<16, 1>(p, stream);
     else k32 ? launch_pconv_n<32, 2>(p, stream) : launch_pconv_n<16, 2>(p, stream);

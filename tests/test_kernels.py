@@ -1211,3 +1211,36 @@ def test_bn_backward_input_gradient_sums_to_zero(backend):
     c1 = (gamma.double() * invstd.cpu().double()).abs()
     single_float_offset = M * 2.0 ** -24 * dy.double().mean((0, 2, 3)).abs() * c1
     assert bool((s <= 0.05 * single_float_offset).all()), f"sum dx {s.tolist()} vs single-float offset bound {single_float_offset.tolist()}"
+
+
+@pytest.mark.parametrize("case", [(1, 12, 14, 16, 32), (2, 9, 11, 32, 16)])
+def test_pconv_stride2_data_gradient(backend, case):
+    """Conv math mode "patch" on the output-parity classes of a 3x3 stride-2 data gradient (2x2 / 2x1 / 1x2 / 1x1 taps at input offsets
+    {0, +1}, outputs written with stride 2; odd sizes give the classes different extents) and its two-source form (the QARepVGG downsample
+    blocks: the 1x1 branch reaches parity class (0, 0) only)."""
+    n, h, w, c, k = case if backend.type != "cuda" else (case[0] * 4, case[1] * 8 + 1, case[2] * 8, case[3] * 2, case[4] * 2)
+    shape = (n, h, w, c, k, 3, 2, 1)
+    x, wt, b = _conv_case(shape)
+    g = torch.Generator().manual_seed(9)
+    w1 = torch.randn(k, c, 1, 1, generator=g) / c ** 0.5
+    x.requires_grad_(True)
+    y = F.conv2d(x, wt, None, stride=2, padding=1)
+    u = F.conv2d(x, w1, None, stride=2)
+    dy, ds = torch.randn(y.shape, generator=g), torch.randn(y.shape, generator=g)
+    (y * dy).sum().backward(retain_graph=True)
+    gx3 = x.grad.clone()
+    x.grad = None
+    (u * ds).sum().backward()
+    gx1 = x.grad.clone()
+    wd, w1d, dyd, dsd = K.to_ohwi(wt.to(backend)), K.to_ohwi(w1.to(backend)), to_nhwc(dy, backend), to_nhwc(ds, backend)
+    K.set_conv_math("patch")
+    try:
+        dx = K.conv2d_bwd_data(dyd, wd, (n, h, w, c), stride=2, pad=1)
+        assert_close(to_nchw_cpu(dx), gx3, TOL, "pconv stride-2 dgrad")
+        wtb = K.conv2d_wt_buffer(wd, backend)
+        K.conv2d_transpose_weights(wd, wtb, stride=2, pad=1)
+        addx = torch.randn(x.shape, generator=g)
+        dxd = K.conv2d_bwd_data_dual(dyd, wd, wtb, dsd, w1d.reshape(k, c).t().contiguous(), (n, h, w, c), stride=2, addend=to_nhwc(addx, backend))
+        assert_close(to_nchw_cpu(dxd), gx3 + gx1 + addx, TOL, "pconv stride-2 dual dgrad")
+    finally:
+        K.set_conv_math("fp32")

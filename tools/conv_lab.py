@@ -51,7 +51,19 @@ def main():
         wt = K.to_ohwi(torch.randn(k, c, r, r, device=dev) / (c * r * r) ** 0.5)
         dw = torch.zeros_like(wt)
         flops = 2.0 * n * ho * wo * k * c * r * r
-        if kind == "fwd":
+        if kind in ("fwd2", "dgrad2"):  # the QARepVGG pair: 3x3 + 1x1 branch per launch (two outputs / two sources)
+            w1 = K.to_ohwi(torch.randn(k, c, 1, 1, device=dev) / c ** 0.5)
+            b1 = torch.randn(k, device=dev)
+            wtb = K.conv2d_wt_buffer(wt, dev)
+            K.conv2d_transpose_weights(wt, wtb, stride=s, pad=pad)
+            w1t = w1.reshape(k, c).t().contiguous()
+            ds = torch.randn(n, ho, wo, k, device=dev)
+            flops += 2.0 * n * ho * wo * k * c
+        if kind == "fwd2":
+            fn = lambda: K.conv2d_fwd_dual(x, wt, w1, b1, stride=s)
+        elif kind == "dgrad2":
+            fn = lambda: K.conv2d_bwd_data_dual(y, wt, wtb, ds, w1t, (n, h, w, c), stride=s, out=x)
+        elif kind == "fwd":
             fn = lambda: K.conv2d_fwd(x, wt, out=y, stride=s, pad=pad, stat_partials=True)
         elif kind == "dgrad":
             fn = lambda: K.conv2d_bwd_data(y, wt, (n, h, w, c), stride=s, pad=pad, out=x)
