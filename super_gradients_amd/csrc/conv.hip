@@ -799,50 +799,52 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3x3 stride-1 convolution (forward and data gradient) from an LDS-resident input PATCH, bf16x3 arithmetic ("pconv").
+// 3x3 convolution (stride-1 forward and data gradient, and the parity classes of a stride-2 data gradient) from an LDS-resident input
+// PATCH, bf16x3 arithmetic ("pconv").
 //
 // Why a second kernel: on the bf16 matrix pipe the six cross products of a 16-deep step cost 192 cycles where the fp32 pipe needs 512,
 // and the slab-per-tap loop above cannot cash that in - every input element is staged (global -> VGPR -> split -> 3 LDS stores) once
 // PER TAP, and the VGPR->LDS store path (~80 B/clk/CU, MI355X_MICROARCH.md LDS table) plus the split's VALU work bound the loop at about
 // half the bf16x3 rate (measured r1y-r2: 1.15x over fp32 where the matrix pipe alone would give 2.7x).  Here a workgroup owns a 2-D tile
-// of 8 x 16 output pixels (one image) and stages the 10 x 18 input patch of a channel chunk ONCE, split into three bf16 planes; all nine
-// taps read their MFMA A-fragments from that patch (a tap is an LDS address offset), so input staging falls 9x and only the small
-// per-tap filter slab (BN x KC) still moves per tap (double-buffered, its global loads in flight under the previous tap's MFMAs).
+// of 8 x 16 output pixels (one image) and, per 16-channel chunk, stages the 10 x 18 input patch ONCE (split into three bf16 planes)
+// together with the filter slabs of ALL taps of the chunk; the taps then read their MFMA A-fragments from the patch (a tap is an LDS
+// address offset) and run back to back - one barrier pair per CHUNK (108 MFMAs per wave for 3x3), none per tap, and no global-memory
+// wait inside a chunk: the next chunk's patch and filters travel in registers from the start of this chunk's MFMAs.
+// (r3b-r3d measured the first form - a double-buffered filter slab per tap, one barrier per tap, 32-channel chunks - at 35 % matrix-pipe
+// utilisation: 30-50 % of the wave cycles parked in s_waitcnt / s_barrier.  A wave's loads return in issue order, so every per-tap wait
+// for a short filter load also waited for the long patch prefetch issued behind it.)
 // Zero padding = the hardware bounds check of the patch loads (rows / columns outside the image arrive as zeros) - no per-tap masks.
 //
-// LDS image: plane[3][pixel][KC bf16]; the 16-byte chunks of a pixel are XOR-swizzled by pixel bits so that the ds_read_b128 of 16 lanes
-// with 16 distinct (pixel mod 16) hit 16 distinct 4-bank groups; MFMA row r of a 32-row sub-tile is output pixel (ty, tx) = (2s + r/16,
-// (r - 2 ty) mod 16): the rotation makes (patch pixel index mod 16) = (r mod 16) + const for every tap, i.e. conflict-free fragment
-// reads with the 18-pixel patch pitch.  Filter slab: plane[3][n][KC bf16], same swizzle by n.
+// LDS image: plane[3][pixel][16 bf16]; the two 16-byte halves of a pixel are swapped on pixels with bit 3 set, so that the ds_read_b128
+// of 16 lanes with 16 distinct (pixel mod 16) hit 16 distinct 4-bank groups; MFMA row r of a 32-row sub-tile is output pixel (ty, tx) =
+// (2s + r/16, (r - 2 ty) mod 16): the rotation makes (patch pixel index mod 16) = (r mod 16) + const for every tap, i.e. conflict-free
+// fragment reads with the 18-pixel patch pitch (measured: SQ_LDS_BANK_CONFLICT = 0).  Filter slabs: plane[3][tap][n][16 bf16], same swap by n.
 // Arithmetic: the bf16x3 scheme of igemm_kernel<MATH = 1> (round-to-nearest split, leading products and corrections in separate
 // accumulators).  PH2 as in igemm_kernel: 1 = second source (1x1, its own tensor) into the same accumulator - the QARepVGG data
 // gradient; 2 = second filter on the centre tap into a second output - the QARepVGG forward pair, with the five BatchNorm moments.
 // ------------------------------------------------------------------------------------------------
 #define PC_TH 8
 #define PC_TW 16
-#define PC_PW (PC_TW + 2)            // patch pitch (pixels)
+#define PC_PW (PC_TW + 2)              // patch pitch (pixels)
 #define PC_NPIX ((PC_TH + 2) * PC_PW)  // 180 patch pixels
-template <int BN, int WM, int WN, int KC, int PH2>
+#define PC_KC 16                       // channels per chunk
+template <int BN, int WM, int WN, int PH2>
 __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
-    static_assert(4 % WM == 0 && (KC == 16 || KC == 32), "WM divides the four 32-row sub-tiles; 16- or 32-channel chunks");
+    static_assert(4 % WM == 0, "WM divides the four 32-row sub-tiles");
     constexpr int NTH = WM * WN * 64;
     constexpr int BM = PC_TH * PC_TW;           // 128 output pixels = 4 sub-tiles of 32 MFMA rows
     constexpr int TM = 4 / WM, TN = BN / (32 * WN);
     static_assert(TM >= 1 && TN >= 1 && TN * WN * 32 == BN, "bad tile");
-    constexpr int Q = KC / 8;                   // 16-byte chunks (8 bf16) per pixel and plane
-    constexpr int PPR = 16 / Q;                 // pixels per 256-byte bank row
-    constexpr int ROWB = KC * 2;                // bytes per pixel / filter row and plane
-    constexpr int A_PLANE = PC_NPIX * ROWB, B_PLANE = BN * ROWB;
-    constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 2 * 3 * B_PLANE;
+    constexpr int KC = PC_KC, ROWB = KC * 2, C4 = KC / 4;   // bytes per pixel / filter row and plane; float4 items per row
+    constexpr int NF = PH2 == 2 ? 10 : 9;                    // filter slabs per chunk (nine taps [+ the second filter])
+    // staging items: every thread takes AR patch items and BR filter items per chunk; slots past the real data are padding (branch-free)
+    constexpr int AR = (PC_NPIX * C4 + NTH - 1) / NTH, BR = (NF * BN * C4 + NTH - 1) / NTH;
+    constexpr int NPIXP = AR * NTH / C4;                     // patch pixel slots incl. padding (192)
+    constexpr int NROWP = BR * NTH / C4;                     // filter row slots incl. padding
+    constexpr int A_PLANE = NPIXP * ROWB, B_PLANE = NROWP * ROWB;
+    constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 3 * B_PLANE;
     constexpr int STAGE_BYTES = WM * WN * 32 * 32 * 4;
     constexpr int SMEM_BYTES = (A_BYTES + B_BYTES) > STAGE_BYTES ? (A_BYTES + B_BYTES) : STAGE_BYTES;
-    constexpr int C4 = KC / 4;                  // float4 items per pixel / filter row
-    // Staging roles: the first half of the waves fetches / splits / stores the per-tap FILTER slabs, the second half the input PATCH.  A
-    // wave's global loads return in issue order (one vmcnt counter): were every wave to carry both streams, each wait for a filter slab
-    // (short, L2) would also wait for the patch prefetch behind it (long, HBM) - measured r3c as 30 % of the wave cycles parked in
-    // s_waitcnt.  Every wave runs the same MFMA work.
-    constexpr int GTH = NTH / 2;                // threads per staging role
-    constexpr int AR = (PC_NPIX * C4 + GTH - 1) / GTH, BR = (BN * C4 + GTH - 1) / GTH;
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
     unsigned char* const As = smem_raw;
     unsigned char* const Bs = smem_raw + A_BYTES;
@@ -863,7 +865,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
     const int trem = mtile - img * (tiles_x * tiles_y);
     const int oy0 = (trem / tiles_x) * PC_TH, ox0 = (trem % tiles_x) * PC_TW;
     const int cpt = p.C / KC;
-    auto swz = [](int q, int pix) { return q ^ ((pix / PPR) % Q); };
+    auto swz = [](int q, int row) { return q ^ ((row >> 3) & 1); };  // which 16-byte half of a 32-byte row holds k-half q
 
     // output rows: MFMA row r of sub-tile s <-> pixel (oy0 + ty, ox0 + tx), ty = 2 s + (r >> 4), tx = (r - 2 ty) & 15
     if (tid < BM) {
@@ -879,51 +881,55 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
     }
 
     // ---- source state ------------------------------------------------------------------------------------------------------------
-    sgx_buf bufA, bufB;
-    // (patch items are addressed on the fly - once per chunk -, filter items from cached offsets - once per tap)
-    int Hin_, Win_;
-    long a_ld_pix_;
-    int boff[BR], blds[BR];
-    int w_ld_n_, taps_h, taps_w, dh0_, dw0_, dstep_, ntaps;
+    sgx_buf bufA, bufB, bufB2;
+    int aoff[AR];   // byte offset of this thread's patch items at chunk 0 (-1: outside the image / padding slot)
+    int boff[BR];   // byte offset of this thread's filter items at chunk 0 (-1: no such filter row / tap); bit 30 set: second filter (bufB2)
+    int taps_w, dh0_, dw0_, dstep_, ntaps;
     auto setup_src = [&](const float* A, const float* Wt, int Hin, int Win, int Th, int Tw, int dh0, int dw0, int dstep, long a_ld_pix, long a_ld_img,
                          long w_ld_n, long a_bytes, long w_bytes) {
         bufA = sgx_make_buf(A + (long)img * a_ld_img, a_bytes - (long)img * a_ld_img * 4);
         bufB = sgx_make_buf(Wt, w_bytes);
-        Hin_ = Hin; Win_ = Win; a_ld_pix_ = a_ld_pix;
-#pragma unroll
-        for (int r = 0; r < BR; ++r) {
-            const int idx = tid + GTH * r;  // (filter role: threads 0 .. GTH - 1)
-            const int n = idx / C4, c4 = (idx - n * C4) * 4;
-            const bool ok = n < BN && n0 + n < p.Nout;
-            boff[r] = ok ? (int)((((long)(n0 + n)) * w_ld_n + c4) * 4) : -1;
-            blds[r] = n < BN ? n * ROWB + swz(c4 >> 3, n) * 16 + ((c4 >> 2) & 1) * 8 : -1;
-        }
-        w_ld_n_ = (int)w_ld_n;
-        taps_h = Th; taps_w = Tw; dh0_ = dh0; dw0_ = dw0; dstep_ = dstep;
+        if (PH2 == 2) bufB2 = sgx_make_buf(p.Wt2, p.w2_bytes);
         ntaps = Th * Tw;
-    };
-
-    float4 ra[AR], rb[BR];
-    const bool filter_role = tid < GTH;
-    auto load_patch = [&](int chunk) {
-        if (filter_role) return;
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
-            const int idx = (tid - GTH) + GTH * r;  // (patch role: threads GTH .. NTH - 1)
+            const int idx = tid + NTH * r;
             const int pp = idx / C4, c4 = (idx - pp * C4) * 4;
             const int py = pp / PC_PW, px = pp - py * PC_PW;
             const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-            const bool ok = pp < PC_NPIX && iy >= 0 && iy < Hin_ && ix >= 0 && ix < Win_;
-            ra[r] = sgx_buf_ld4(bufA, ok ? (unsigned)((((long)iy * Win_ + ix) * a_ld_pix_ + c4 + chunk * KC) * 4) : SGX_BUF_OOB);
+            const bool ok = pp < PC_NPIX && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+            aoff[r] = ok ? (int)((((long)iy * Win + ix) * a_ld_pix + c4) * 4) : -1;
+        }
+#pragma unroll
+        for (int r = 0; r < BR; ++r) {
+            const int idx = tid + NTH * r;
+            const int row = idx / C4, c4 = (idx - row * C4) * 4;
+            const int slab = row / BN, n = row - slab * BN;
+            const bool nok = n0 + n < p.Nout;
+            int o = -1;
+            if (nok && slab < ntaps) o = (int)(((long)(n0 + n) * w_ld_n + (long)slab * p.C + c4) * 4);
+            if (PH2 == 2 && nok && slab == NF - 1) o = (int)(((long)(n0 + n) * p.w2_ld_n + c4) * 4) | (1 << 30);
+            boff[r] = o;
+        }
+        taps_w = Tw; dh0_ = dh0; dw0_ = dw0; dstep_ = dstep;
+    };
+
+    float4 ra[AR], rb[BR];
+    auto load_chunk = [&](int chunk) {
+#pragma unroll
+        for (int r = 0; r < AR; ++r) ra[r] = sgx_buf_ld4(bufA, aoff[r] >= 0 ? (unsigned)(aoff[r] + chunk * (KC * 4)) : SGX_BUF_OOB);
+#pragma unroll
+        for (int r = 0; r < BR; ++r) {
+            const unsigned o = boff[r] >= 0 ? (unsigned)((boff[r] & ~(1 << 30)) + chunk * (KC * 4)) : SGX_BUF_OOB;
+            if (PH2 == 2 && boff[r] >= 0 && (boff[r] & (1 << 30))) rb[r] = sgx_buf_ld4(bufB2, o);
+            else rb[r] = sgx_buf_ld4(bufB, o);
         }
     };
-    auto store_patch = [&]() {
-        if (filter_role) return;
+    auto store_chunk = [&]() {
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
-            const int idx = (tid - GTH) + GTH * r;
+            const int idx = tid + NTH * r;
             const int pp = idx / C4, c4 = (idx - pp * C4) * 4;
-            if (pp >= PC_NPIX) continue;
             unsigned char* const d = As + pp * ROWB + swz(c4 >> 3, pp) * 16 + ((c4 >> 2) & 1) * 8;
             uint2 h, m, l;
             sgx_split3(ra[r], h, m, l);
@@ -931,26 +937,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
             *reinterpret_cast<uint2*>(d + A_PLANE) = m;
             *reinterpret_cast<uint2*>(d + 2 * A_PLANE) = l;
         }
-    };
-    // filter slab of (tap index in the weight row, channel chunk); wsel: 0 = the source's filter, 1 = the second filter of PH2 = 2 (Wt2, one tap)
-    sgx_buf bufB2 = bufB;
-    int boff2[PH2 == 2 ? BR : 1];
-    auto load_filter = [&](int wtap, int chunk, int wsel) {
-        if (!filter_role) return;
 #pragma unroll
         for (int r = 0; r < BR; ++r) {
-            if (PH2 == 2 && wsel == 1) rb[r] = sgx_buf_ld4(bufB2, boff2[PH2 == 2 ? r : 0] >= 0 ? (unsigned)(boff2[PH2 == 2 ? r : 0] + chunk * (KC * 4)) : SGX_BUF_OOB);
-            else rb[r] = sgx_buf_ld4(bufB, boff[r] >= 0 ? (unsigned)(boff[r] + (wtap * p.C + chunk * KC) * 4) : SGX_BUF_OOB);
-        }
-    };
-    auto store_filter = [&](int buf) {
-        if (!filter_role) return;
-#pragma unroll
-        for (int r = 0; r < BR; ++r) {
-            if (blds[r] < 0) continue;
+            const int idx = tid + NTH * r;
+            const int row = idx / C4, c4 = (idx - row * C4) * 4;
+            unsigned char* const d = Bs + row * ROWB + swz(c4 >> 3, row) * 16 + ((c4 >> 2) & 1) * 8;
             uint2 h, m, l;
             sgx_split3(rb[r], h, m, l);
-            unsigned char* d = Bs + buf * 3 * B_PLANE + blds[r];
             *reinterpret_cast<uint2*>(d) = h;
             *reinterpret_cast<uint2*>(d + B_PLANE) = m;
             *reinterpret_cast<uint2*>(d + 2 * B_PLANE) = l;
@@ -980,54 +973,50 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
         const int ty = 2 * s + (frow >> 4), tx = (frow - 2 * ty) & 15;
         pbase[i] = ty * PC_PW + tx;
     }
-    // one tap: KC / 16 steps of (TM + TN) x 3 fragment reads and 6 x TM x TN MFMAs into (c1 = leading products, c2 = corrections);
-    // products in "smallest first" order, each product across all sub-tiles before the next (independent accumulators back to back)
-    auto compute_tap = [&](int buf, int tapoff, sgx_f32x16 (&c1)[TM][TN], sgx_f32x16 (&c2)[TM][TN]) {
+    // one tap: (TM + TN) x 3 fragment reads and 6 x TM x TN MFMAs into (c1 = leading products, c2 = corrections); products in "smallest
+    // first" order, each product across all sub-tiles before the next (independent accumulators back to back)
+    auto compute_tap = [&](int slab, int tapoff, sgx_f32x16 (&c1)[TM][TN], sgx_f32x16 (&c2)[TM][TN]) {
+        uint4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
-        for (int ks = 0; ks < KC / 16; ++ks) {
-            const int q = ks * 2 + khalf;
-            uint4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int pix = pbase[i] + tapoff;
-                const unsigned char* s = As + pix * ROWB + swz(q, pix) * 16;
-                ah[i] = *reinterpret_cast<const uint4*>(s);
-                am[i] = *reinterpret_cast<const uint4*>(s + A_PLANE);
-                al[i] = *reinterpret_cast<const uint4*>(s + 2 * A_PLANE);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = wn * TN * 32 + j * 32 + frow;
-                const unsigned char* s = Bs + buf * 3 * B_PLANE + n * ROWB + swz(q, n) * 16;
-                bh[j] = *reinterpret_cast<const uint4*>(s);
-                bm[j] = *reinterpret_cast<const uint4*>(s + B_PLANE);
-                bl[j] = *reinterpret_cast<const uint4*>(s + 2 * B_PLANE);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(al[i], bh[j], c2[i][j]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(ah[i], bl[j], c2[i][j]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(am[i], bm[j], c2[i][j]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(am[i], bh[j], c2[i][j]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(ah[i], bm[j], c2[i][j]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) c1[i][j] = sgx_mfma_bf16(ah[i], bh[j], c1[i][j]);
+        for (int i = 0; i < TM; ++i) {
+            const int pix = pbase[i] + tapoff;
+            const unsigned char* s = As + pix * ROWB + swz(khalf, pix) * 16;
+            ah[i] = *reinterpret_cast<const uint4*>(s);
+            am[i] = *reinterpret_cast<const uint4*>(s + A_PLANE);
+            al[i] = *reinterpret_cast<const uint4*>(s + 2 * A_PLANE);
         }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = wn * TN * 32 + j * 32 + frow;
+            const unsigned char* s = Bs + (slab * BN + n) * ROWB + swz(khalf, slab * BN + n) * 16;
+            bh[j] = *reinterpret_cast<const uint4*>(s);
+            bm[j] = *reinterpret_cast<const uint4*>(s + B_PLANE);
+            bl[j] = *reinterpret_cast<const uint4*>(s + 2 * B_PLANE);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(al[i], bh[j], c2[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(ah[i], bl[j], c2[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(am[i], bm[j], c2[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(am[i], bh[j], c2[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(ah[i], bm[j], c2[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) c1[i][j] = sgx_mfma_bf16(ah[i], bh[j], c1[i][j]);
     };
 
 #pragma unroll
@@ -1037,40 +1026,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
             if (!p.A2) break;
             setup_src(p.A2, p.Wt2, p.Hin2, p.Win2, p.Th2, p.Tw2, p.dh02, p.dw02, p.dstep2, p.a2_ld_pix, p.a2_ld_img, p.w2_ld_n, p.a2_bytes, p.w2_bytes);
         }
-        if (PH2 == 2) {
-            bufB2 = sgx_make_buf(p.Wt2, p.w2_bytes);
-#pragma unroll
-            for (int r = 0; r < BR; ++r) {
-                const int idx = tid + GTH * r;  // (filter role: threads 0 .. GTH - 1)
-                const int n = idx / C4, c4 = (idx - n * C4) * 4;
-                boff2[PH2 == 2 ? r : 0] = (n < BN && n0 + n < p.Nout) ? (int)((((long)(n0 + n)) * p.w2_ld_n + c4) * 4) : -1;
-            }
-        }
-        load_patch(0);
-        load_filter(0, 0, 0);
+        load_chunk(0);
         for (int chunk = 0; chunk < cpt; ++chunk) {
-            // every wave is past its last read of the patch and of both filter buffers (barrier at the end of the previous tap); the patch and
-            // the first filter slab of this chunk have been travelling in registers since the last taps of the previous one
-            store_patch();
-            store_filter(0);
+            // every wave is past its last fragment read of the previous chunk (barrier below); this chunk has been travelling in registers
+            store_chunk();
             __syncthreads();
+            if (chunk + 1 < cpt) load_chunk(chunk + 1);
             for (int t = 0; t < ntaps; ++t) {
-                const bool more = t + 1 < ntaps;
-                if (more) load_filter(t + 1, chunk, 0);
-                else if (DUAL) load_filter(0, chunk, 1);  // PH2 = 2: one more "tap" - the centre tap again, with the second filter
-                else if (chunk + 1 < cpt) load_filter(0, chunk + 1, 0);
-                if (t == (ntaps > 4 ? ntaps - 4 : 0) && chunk + 1 < cpt) load_patch(chunk + 1);  // next chunk's patch travels in registers under the last taps
                 // patch offset of the tap: input pixel (a + dh0 + dstep * ti, b + dw0 + dstep * tj), patch origin (oy0 - 1, ox0 - 1)
                 const int ti = t / taps_w, tj = t - ti * taps_w;
-                compute_tap(t & 1, (dh0_ + dstep_ * ti + 1) * PC_PW + dw0_ + dstep_ * tj + 1, acc, acc2);
-                if (more || DUAL) store_filter((t + 1) & 1);
-                __syncthreads();
+                compute_tap(t, (dh0_ + dstep_ * ti + 1) * PC_PW + dw0_ + dstep_ * tj + 1, acc, acc2);
             }
-            if constexpr (DUAL) {
-                if (chunk + 1 < cpt) load_filter(0, chunk + 1, 0);
-                compute_tap(ntaps & 1, PC_PW + 1, accu, accu2);
-                __syncthreads();
-            }
+            if constexpr (DUAL) compute_tap(NF - 1, PC_PW + 1, accu, accu2);  // the centre tap again, with the second filter
+            __syncthreads();
         }
     }
 
@@ -1412,30 +1380,26 @@ static bool pconv_ok(const IgemmParams& p, int ph2) {
     if ((long)p.Hin * p.Win * p.a_ld_pix * 4 > SGX_BUF_MAX) return false;
     return true;
 }
-template <int BN, int WM, int WN, int KC, int PH2>
+template <int BN, int WM, int WN, int PH2>
 static void launch_pconv(IgemmParams& p, void* stream) {
     p.mt = pconv_tiles(p.M / (p.Ha * p.Wa), p.Ha, p.Wa);
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
     p.chunk = sgx_cdiv(p.nblk, 8);
     p.stat_nblk = p.mt;
-    SGX_LAUNCH((pconv_kernel<BN, WM, WN, KC, PH2>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
+    SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
 }
-template <int KC, int PH2>
+template <int PH2>
 static void launch_pconv_n(IgemmParams& p, void* stream) {
-    // N tile: 32 / 64 / 96 filters (one 32-wide accumulator column per wave; 96 runs six waves)
-    if (p.Nout <= 32) launch_pconv<32, 4, 1, KC, PH2>(p, stream);
-    else if (p.Nout % 96 == 0 || (p.Nout > 64 && p.Nout <= 96)) launch_pconv<96, 2, 3, KC, PH2>(p, stream);
-    else launch_pconv<64, 2, 2, KC, PH2>(p, stream);
+    // N tile: 64 filters (two 32-wide accumulator columns x two 64-row halves) where that wastes nothing, else 32 (four 32-row waves)
+    // (two outputs: ten filter slabs of 64 rows would leave room for one workgroup per CU only - 32-filter tiles, three per CU)
+    if (PH2 != 2 && (p.Nout % 64 == 0 || (p.Nout > 32 && p.Nout % 32 != 0))) launch_pconv<64, 2, 2, PH2>(p, stream);
+    else launch_pconv<32, 4, 1, PH2>(p, stream);
 }
 static int32_t run_pconv(IgemmParams& p, void* stream, int ph2) {
-    // 32-channel chunks where the registers allow them (one source / one output); the two-source and two-output forms carry twice the
-    // accumulators and run 16-channel chunks.  Measurement: variant 8 forces 16, variant 9 forces 32 (where C % 32 == 0).
-    const int var = conv_variant();
-    const bool k32 = p.C % 32 == 0 && var != 8 && (var == 9 || ph2 == 0 || !p.A2);
-    if (ph2 == 0 || !p.A2) k32 ? launch_pconv_n<32, 0>(p, stream) : launch_pconv_n<16, 0>(p, stream);
-    else if (ph2 == 1) k32 ? launch_pconv_n<32, 1>(p, stream) : launch_pconv_n<16, 1>(p, stream);
-    else k32 ? launch_pconv_n<32, 2>(p, stream) : launch_pconv_n<16, 2>(p, stream);
+    if (ph2 == 0 || !p.A2) launch_pconv_n<0>(p, stream);
+    else if (ph2 == 1) launch_pconv_n<1>(p, stream);
+    else launch_pconv_n<2>(p, stream);
     return SGX_OK;
 }
 
