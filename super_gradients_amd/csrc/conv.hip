@@ -828,7 +828,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
 #define PC_PW (PC_TW + 2)              // patch pitch (pixels)
 #define PC_NPIX ((PC_TH + 2) * PC_PW)  // 180 patch pixels
 #define PC_KC 16                       // channels per chunk
-template <int BN, int WM, int WN, int PH2>
+template <int BN, int WM, int WN, int PH2, bool FPIPE = true>
 __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
     static_assert(4 % WM == 0, "WM divides the four 32-row sub-tiles");
     constexpr int NTH = WM * WN * 64;
@@ -973,50 +973,62 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
         const int ty = 2 * s + (frow >> 4), tx = (frow - 2 * ty) & 15;
         pbase[i] = ty * PC_PW + tx;
     }
-    // one tap: (TM + TN) x 3 fragment reads and 6 x TM x TN MFMAs into (c1 = leading products, c2 = corrections); products in "smallest
-    // first" order, each product across all sub-tiles before the next (independent accumulators back to back)
-    auto compute_tap = [&](int slab, int tapoff, sgx_f32x16 (&c1)[TM][TN], sgx_f32x16 (&c2)[TM][TN]) {
+    // One tap = (TM + TN) x 3 fragment reads (16 bytes each) and 6 x TM x TN MFMAs.  The fragments of tap t + 1 are read from LDS BEFORE the
+    // MFMAs of tap t are issued (two fragment register sets): with two waves per SIMD nothing else hides the LDS latency, and the first
+    // form - read, wait, multiply, per tap - left 30 % of the wave cycles in s_waitcnt lgkmcnt (r3e counters).
+    struct Frags {
         uint4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+    };
+    auto load_frags = [&](Frags& f, int slab, int tapoff) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int pix = pbase[i] + tapoff;
             const unsigned char* s = As + pix * ROWB + swz(khalf, pix) * 16;
-            ah[i] = *reinterpret_cast<const uint4*>(s);
-            am[i] = *reinterpret_cast<const uint4*>(s + A_PLANE);
-            al[i] = *reinterpret_cast<const uint4*>(s + 2 * A_PLANE);
+            f.ah[i] = *reinterpret_cast<const uint4*>(s);
+            f.am[i] = *reinterpret_cast<const uint4*>(s + A_PLANE);
+            f.al[i] = *reinterpret_cast<const uint4*>(s + 2 * A_PLANE);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = wn * TN * 32 + j * 32 + frow;
             const unsigned char* s = Bs + (slab * BN + n) * ROWB + swz(khalf, slab * BN + n) * 16;
-            bh[j] = *reinterpret_cast<const uint4*>(s);
-            bm[j] = *reinterpret_cast<const uint4*>(s + B_PLANE);
-            bl[j] = *reinterpret_cast<const uint4*>(s + 2 * B_PLANE);
+            f.bh[j] = *reinterpret_cast<const uint4*>(s);
+            f.bm[j] = *reinterpret_cast<const uint4*>(s + B_PLANE);
+            f.bl[j] = *reinterpret_cast<const uint4*>(s + 2 * B_PLANE);
         }
+    };
+    // products in "smallest first" order into (c1 = leading products, c2 = corrections), each product across all sub-tiles before the next
+    // (independent accumulators back to back)
+    auto mfma_tap = [&](const Frags& f, sgx_f32x16 (&c1)[TM][TN], sgx_f32x16 (&c2)[TM][TN]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(al[i], bh[j], c2[i][j]);
+            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(f.al[i], f.bh[j], c2[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(ah[i], bl[j], c2[i][j]);
+            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(f.ah[i], f.bl[j], c2[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(am[i], bm[j], c2[i][j]);
+            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(f.am[i], f.bm[j], c2[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(am[i], bh[j], c2[i][j]);
+            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(f.am[i], f.bh[j], c2[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(ah[i], bm[j], c2[i][j]);
+            for (int j = 0; j < TN; ++j) c2[i][j] = sgx_mfma_bf16(f.ah[i], f.bm[j], c2[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) c1[i][j] = sgx_mfma_bf16(ah[i], bh[j], c1[i][j]);
+            for (int j = 0; j < TN; ++j) c1[i][j] = sgx_mfma_bf16(f.ah[i], f.bh[j], c1[i][j]);
+    };
+    // patch offset of tap t: input pixel (a + dh0 + dstep * ti, b + dw0 + dstep * tj), patch origin (oy0 - 1, ox0 - 1)
+    auto tap_off = [&](int t) {
+        const int ti = t / taps_w, tj = t - ti * taps_w;
+        return (dh0_ + dstep_ * ti + 1) * PC_PW + dw0_ + dstep_ * tj + 1;
     };
 
 #pragma unroll
@@ -1032,12 +1044,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
             store_chunk();
             __syncthreads();
             if (chunk + 1 < cpt) load_chunk(chunk + 1);
-            for (int t = 0; t < ntaps; ++t) {
-                // patch offset of the tap: input pixel (a + dh0 + dstep * ti, b + dw0 + dstep * tj), patch origin (oy0 - 1, ox0 - 1)
-                const int ti = t / taps_w, tj = t - ti * taps_w;
-                compute_tap(t, (dh0_ + dstep_ * ti + 1) * PC_PW + dw0_ + dstep_ * tj + 1, acc, acc2);
+            if constexpr (!FPIPE) {  // measurement variant 8: read - wait - multiply per tap (one fragment set: fewer registers)
+                Frags f;
+                for (int t = 0; t < ntaps; ++t) {
+                    load_frags(f, t, tap_off(t));
+                    mfma_tap(f, acc, acc2);
+                }
+                if constexpr (DUAL) {
+                    load_frags(f, NF - 1, PC_PW + 1);
+                    mfma_tap(f, accu, accu2);
+                }
+                __syncthreads();
+                continue;
             }
-            if constexpr (DUAL) compute_tap(NF - 1, PC_PW + 1, accu, accu2);  // the centre tap again, with the second filter
+            Frags fa, fb;
+            load_frags(fa, 0, tap_off(0));
+            int t = 0;
+            for (; t + 1 < ntaps; t += 2) {
+                load_frags(fb, t + 1, tap_off(t + 1));
+                mfma_tap(fa, acc, acc2);
+                if (t + 2 < ntaps) load_frags(fa, t + 2, tap_off(t + 2));
+                else if (DUAL) load_frags(fa, NF - 1, PC_PW + 1);
+                mfma_tap(fb, acc, acc2);
+            }
+            if (t < ntaps) {  // odd tap count: the last tap is in fa
+                if (DUAL) load_frags(fb, NF - 1, PC_PW + 1);
+                mfma_tap(fa, acc, acc2);
+                if constexpr (DUAL) mfma_tap(fb, accu, accu2);  // the centre tap again, with the second filter
+            } else if constexpr (DUAL) {
+                mfma_tap(fa, accu, accu2);
+            }
             __syncthreads();
         }
     }
@@ -1382,12 +1418,14 @@ static bool pconv_ok(const IgemmParams& p, int ph2) {
 }
 template <int BN, int WM, int WN, int PH2>
 static void launch_pconv(IgemmParams& p, void* stream) {
+    const bool fpipe = conv_variant() != 8;
     p.mt = pconv_tiles(p.M / (p.Ha * p.Wa), p.Ha, p.Wa);
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
     p.chunk = sgx_cdiv(p.nblk, 8);
     p.stat_nblk = p.mt;
-    SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
+    if (fpipe) SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, true>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
+    else SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, false>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
 }
 template <int PH2>
 static void launch_pconv_n(IgemmParams& p, void* stream) {

@@ -87,6 +87,34 @@ def main():
         return dx
 
     blk.bwd, conv.dgrad = bwd, dgrad
+    # the two terms of neck2's g_inter: upsample.bwd(dcat[..., :oc]) and the axpy of neck3's skip gradient
+    up = net.neck.neck2.upsample
+    orig_up = up.bwd
+
+    def up_bwd(dy, **kw):
+        cap["up_dy"] = dy.detach().clone()
+        cap["up_dy_meta"] = (tuple(dy.shape), dy.stride())
+        dx = orig_up(dy, **kw)
+        cap["up_dx"] = dx.detach().clone()
+        return dx
+
+    up.bwd = up_bwd
+    orig_axpy = K.axpy
+    axpys = []
+
+    def axpy(xx, a=1.0, a_dev=None, out=None, accumulate=False):
+        rec = None
+        if tuple(xx.shape) == (args.batch, args.size // 16, args.size // 16, 96) and accumulate:
+            rec = dict(x=xx.detach().clone(), x_meta=(tuple(xx.shape), xx.stride()), before=out.detach().clone())
+        r = orig_axpy(xx, a=a, a_dev=a_dev, out=out, accumulate=accumulate)
+        if rec is not None:
+            rec["after"] = r.detach().clone()
+            axpys.append(rec)
+        return r
+
+    K.axpy = axpy
+    import super_gradients_amd.training.models.detection_models.yolo_nas.yolo_stages as YS
+    YS.K.axpy = axpy
     out = net(x.to(dev))
     lg, ds = out[1][:2]
     torch.autograd.backward([lg, ds], [up_l.to(dev), up_d.to(dev)])
@@ -103,6 +131,18 @@ def main():
     print("     error per-channel mean / rms:", float(e.mean((0, 2, 3)).abs().max()), float(e.pow(2).mean().sqrt()), " dx rms", float(dx64.pow(2).mean().sqrt()))
     eo = nchw(cap["dx"]).double() - grads["neck1_out"].double()
     print("     vs oracle: error per-channel mean max", float(eo.mean((0, 2, 3)).abs().max()), "rms", float(eo.pow(2).mean().sqrt()))
+    wt = up.weight.detach().cpu().double()  # ConvTranspose2d weight [C_in, C_out, 2, 2]: d/dx = conv2d(dy, W, stride 2)
+    updx64 = F.conv2d(nchw(cap["up_dy"]).double(), wt, stride=2)
+    print("upsample.bwd: operand", cap["up_dy_meta"], " hip vs float64 conv of ITS OWN dy:", rel(nchw(cap["up_dx"]), updx64))
+    for i, r in enumerate(axpys):
+        want = r["before"].double() + r["x"].double()
+        print(f"axpy[{i}] x {r['x_meta']}: after vs before + x:", rel(r["after"], want), " |x| max", float(r["x"].abs().max()))
+    if axpys:
+        tot = nchw(axpys[-1]["after"])
+        print("g_inter after the axpy vs oracle:", rel(tot, grads["n2conv_y"]), "   upsample term alone vs oracle total:", rel(nchw(cap["up_dx"]), grads["n2conv_y"]))
+        e = (tot.double() - grads["n2conv_y"].double()).abs()
+        idx = torch.nonzero(e > 0.25 * e.max())
+        print("   large-error elements:", idx.shape[0], "first", idx[:8].tolist(), " of shape", tuple(e.shape))
     # the same kernel again, stand-alone, on the captured operand
     dx2 = K.conv2d_bwd_data(cap["dt"], conv._w, tuple(cap["dx"].shape), stride=1, pad=0)
     print("dx   stand-alone kernel call vs float64:", rel(nchw(dx2), dx64))
