@@ -173,7 +173,7 @@ int32_t sgx_conv2d_bwd_weight_group_sizes(const sgx_wgrad_job* jobs, int32_t njo
 int32_t sgx_conv2d_bwd_weight_group(const sgx_wgrad_job* jobs, int32_t njobs, void* ws, int64_t ws_bytes, int32_t* tickets,
                                     int64_t ticket_ints, void* stream);
 /* Measurement aid for the grouped weight gradient: rounds of work items a large group is cut into (0 = default 6), work of an item below
- * which a small group is not cut further (MFLOP, 0 = default 4; an item is never larger than twice that), XCD-aware workgroup order (default 1).  Never set by the product.     */
+ * which a small group is not cut further (MFLOP, 0 = default 8; an item is never larger than twice that), XCD-aware workgroup order (default 1).  Never set by the product.     */
 int32_t sgx_debug_set_wgrad_group(int32_t rounds, int32_t item_mflop, int32_t xcd_order);
 
 /* ConvTranspose2d kernel 2, stride 2 (+bias): modules/sampling.py:72-73 via yolo_stages.py:292-294.

@@ -1418,7 +1418,10 @@ static bool pconv_ok(const IgemmParams& p, int ph2) {
 }
 template <int BN, int WM, int WN, int PH2>
 static void launch_pconv(IgemmParams& p, void* stream) {
-    const bool fpipe = conv_variant() != 8;
+    // two fragment sets where they do not cost a wave of occupancy (r3f lab: the 64-filter tile gains 4-6 %, the 32-filter tiles - three
+    // workgroups per CU with one set, two with two - lose 5-15 %); measurement: variant 8 = never, 9 = always
+    const int var = conv_variant();
+    const bool fpipe = var == 9 || (var != 8 && BN == 64);
     p.mt = pconv_tiles(p.M / (p.Ha * p.Wa), p.Ha, p.Wa);
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
@@ -2098,11 +2101,11 @@ extern "C" int32_t sgx_stats_blocks(int64_t M);
 extern "C" int64_t sgx_colsum_workspace(int64_t M, int32_t C);
 // grouped-launch knobs (measurement: sgx_debug_set_wgrad_group): rounds of work items a large group is cut into, the work of an item
 // below which a small group is not cut further (MFLOP), XCD-aware block order
-static std::atomic<int> g_wg_rounds{6}, g_wg_item_mflop{4}, g_wg_xcd{1};
+static std::atomic<int> g_wg_rounds{6}, g_wg_item_mflop{8}, g_wg_xcd{1};
 extern "C" int32_t sgx_debug_set_wgrad_group(int32_t rounds, int32_t item_mflop, int32_t xcd_order) {
     SGX_CHECK_ARG(rounds >= 0 && item_mflop >= 0, "debug_set_wgrad_group: negative value");
     g_wg_rounds = rounds ? rounds : 6;
-    g_wg_item_mflop = item_mflop ? item_mflop : 4;
+    g_wg_item_mflop = item_mflop ? item_mflop : 8;
     g_wg_xcd = xcd_order ? 1 : 0;
     return SGX_OK;
 }
@@ -2144,10 +2147,8 @@ static int32_t wgrad_group_plan(const sgx_wgrad_job* jobs, int n, std::vector<Wg
     }
     // work of one item: a large group is cut into `rounds` rounds of WG_SLOTS items; a small one into items of >= item_mflop (~100 us of
     // one workgroup beside its co-residents) as long as that still leaves ~1.3 rounds
-    // ... and never more than 2x that: an item is ONE sequential fp32 accumulation chain on the matrix pipe, and a weight gradient sums
-    // pixel products whose per-channel means cancel (dY is a BatchNorm input gradient) - short chains folded by the tickets are the blocked
-    // summation that keeps the result at the accuracy of ATen's CPU GEMM (r3a, flip-free check at 32 x 640^2: chains of ~1000-1700 pixels
-    // were 25x further from fp64 than the CPU path); the partial tile an item adds is ~6 % of the operand bytes it reads.
+    // ... and never more than 2x that: an item is ONE sequential fp32 accumulation chain on the matrix pipe; short chains folded pairwise
+    // by the tree keep the sum a blocked summation, and the partial tile an item adds is ~6 % of the operand bytes it reads.
     const double lo = 1e6 * g_wg_item_mflop.load(std::memory_order_relaxed);
     double item = work / ((double)WG_SLOTS * g_wg_rounds.load(std::memory_order_relaxed));
     if (item < lo) item = fmin(lo, work / (WG_SLOTS * 1.3));

@@ -183,7 +183,7 @@ def test_yolo_nas_s_train_step_parity(gpu_device):
     assert abs(l - lr) <= 2e-4 * abs(lr)
 
 
-def _backward_exact_without_relu_flips(variant, B, size, gpu_device, lazy_fp64=False, threads=None):
+def _backward_exact_without_relu_flips(variant, B, size, gpu_device, lazy_fp64=False, threads=None, certify=False):
     """The strict form of the whole-model backward check.  At random init a handful of ReLU pre-activations change sign between any two
     fp32 implementations, and every flip is an O(1) local gradient error - which is why the three-way checks can only bound the aggregate.
     Here every BatchNorm that feeds an activation gets bias +4 (weights in [0.5, 1]): all pre-activations stay positive on both paths, the
@@ -202,12 +202,36 @@ def _backward_exact_without_relu_flips(variant, B, size, gpu_device, lazy_fp64=F
             p.data.uniform_(0.5, 1.0, generator=g)
         elif (name.endswith("bn.bias") and "branch_3x3" not in name) or name.endswith("post_bn.bias"):
             p.data.fill_(4.0)
-    net.load_state_dict(ref.state_dict(), strict=True)
     if threads:
         torch.set_num_threads(threads)
     ref.train()
-    net.train()
     x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(8))
+    if certify:
+        # "+4" is not flip-free at 32 x 640^2: BatchNorm outputs are heavy-tailed and with ~1e8 elements per layer the minima reach -5 (r3f:
+        # backbone.stage1 ... post_bn -4.98; the HIP and CPU paths then clip DIFFERENT elements and a whole sub-network's gradients differ by
+        # 1e-3 - a property of the probe, not of either implementation).  So the premise is CERTIFIED: every activation-feeding BatchNorm whose
+        # smallest output on this very batch is below +0.5 gets its bias raised by the shortfall, until no pre-activation is below +0.5.
+        feeds = {n: m for n, m in ref.named_modules() if isinstance(m, torch.nn.BatchNorm2d) and not n.endswith("branch_3x3.bn")}
+        mins = {}
+        hooks = [m.register_forward_hook(lambda mod, inp, out, n=n: mins.__setitem__(n, float(out.min()))) for n, m in feeds.items()]
+        state = {n: (m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone()) for n, m in ref.named_modules()
+                 if isinstance(m, torch.nn.BatchNorm2d)}
+        for _ in range(10):
+            with torch.no_grad():
+                ref(x)
+            low = {n: v for n, v in mins.items() if v < 0.5}
+            if not low:
+                break
+            for n, v in low.items():
+                feeds[n].bias.data += 1.5 * (0.5 - v)
+        for h in hooks:
+            h.remove()
+        assert not low, f"could not certify the flip-free premise: {sorted(low.items(), key=lambda kv: kv[1])[:4]}"
+        for n, m in ref.named_modules():  # the probing forwards must not count as training steps
+            if n in state:
+                m.running_mean.copy_(state[n][0]); m.running_var.copy_(state[n][1]); m.num_batches_tracked.copy_(state[n][2])
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net.train()
     out_ref = ref(x)
     out = net(x.to(gpu_device))
     (lg, ds), (lg_r, ds_r) = out[1][:2], out_ref[1][:2]
@@ -284,9 +308,10 @@ def test_yolo_nas_m_backward_exact_without_relu_flips(gpu_device):
 @pytest.mark.gpu
 def test_yolo_nas_s_headline_config_backward_exact(gpu_device):
     """BASELINE.json configs[2] at FULL size (YOLO-NAS-S, 32 x 640^2): the conv problems, pixel splits and tuning-table entries the
-    benchmark runs - element-wise gradient check of every parameter against the CPU fp32 oracle (flip-free form, see the helper); the
-    fp64 oracle runs only if a parameter needs the tie-break."""
-    _backward_exact_without_relu_flips("s", 32, 640, gpu_device, lazy_fp64=True, threads=min(64, torch.get_num_threads() * 4))
+    benchmark runs - element-wise gradient check of every parameter against the CPU fp32 oracle (flip-free form, see the helper, with the
+    premise certified on this batch: no activation-feeding BatchNorm output below +0.5); the fp64 oracle runs only if a parameter needs
+    the tie-break."""
+    _backward_exact_without_relu_flips("s", 32, 640, gpu_device, lazy_fp64=True, threads=min(64, torch.get_num_threads() * 4), certify=True)
 
 
 @pytest.mark.gpu

@@ -61,8 +61,8 @@ def record_problems(model, batch, size, dev):
         rec[k] = rec.get(k, 0) + 1
         return r
 
-    def dgrad2(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, out=None, accumulate=False):
-        o = orig[4](dy, w, wt, ds, w1pt, x_shape, stride=stride, addend=addend, out=out, accumulate=accumulate)
+    def dgrad2(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, out=None, accumulate=False, addend2=None, addend2_scale=None):
+        o = orig[4](dy, w, wt, ds, w1pt, x_shape, stride=stride, addend=addend, out=out, accumulate=accumulate, addend2=addend2, addend2_scale=addend2_scale)
         k = key_of("dgrad2", x_shape, w.shape[0], w.shape[2], stride, w.shape[2] // 2, o.stride(2), dy.stride(2), (addend is not None, bool(accumulate)))
         rec[k] = rec.get(k, 0) + 1
         return o
