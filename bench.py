@@ -32,6 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 TRAIN_GFLOP_PER_IMG = {"s": 101.634, "m": 282.556, "l": 386.959}  # 3 x forward conv FLOPs @640^2
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md; the headline figures with 2:1 sparsity are not used)
 HBM_ACHIEVABLE_TBS = 6.3  # MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable
 
 
@@ -181,7 +182,9 @@ def nms_leg(device, iters=100, warmup=10):
     stream_bytes = 3.0 * B * L * C * 4
     return {"value": round(ncand / (ms * 1e-3), 1), "unit": "boxes/s", "ms_per_batch": round(ms, 4), "candidates": ncand, "kept": kept, "batch": B,
             "roofline": {"bound": "hbm", "achieved": round(stream_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(stream_bytes / (ms * 1e-3) / 8e12, 4), "traffic": None,
+                         "frac": round(stream_bytes / (ms * 1e-3) / 8e12, 4), "traffic": measured_nms_traffic().get("nms_bytes_per_call"),
+                         "traffic_unit": "bytes/call (HBM, PMC: FETCH_SIZE x2 + WRITE_SIZE over the kernels of one post-prediction call)",
+                         "algorithmic_bytes_per_call": round(stream_bytes),
                          "note": "algorithmic bytes = 3 passes over the fp32 scores (258 MB per batch) / time of the WHOLE post-prediction call "
                                  "(selection + per-image sort + suppression scan, which are latency-bound and move no HBM bytes)"},
             "config": "B=32 L=8400 C=80 multi-label, score>0.01, top-k 1000, IoU 0.7, max 300, class-agnostic",
@@ -220,13 +223,18 @@ def predict_leg(device, model="s", batch=32, batches=10):
 
 
 def measured_traffic():
-    """HBM bytes per igemm launch from the committed rocprofv3 PMC passes of this same command (profiles/igemm_traffic.json,
-    written by tools/pmc_traffic.py from the FETCH_SIZE / WRITE_SIZE passes, with MI355X_MICROARCH.md's gfx950 correction)."""
+    """HBM bytes per conv-kernel launch (forward / data gradient, and weight gradient) and the loaded shader clock, from the committed
+    rocprofv3 PMC passes of this same command (profiles/igemm_traffic.json, written by tools/pmc_traffic.py from the FETCH_SIZE /
+    WRITE_SIZE / GRBM_GUI_ACTIVE passes, with MI355X_MICROARCH.md's gfx950 correction).  -> dict (empty when no pass is committed)"""
     f = os.path.join(ROOT, "profiles", "igemm_traffic.json")
     if not os.path.exists(f):
-        return None, None
-    d = json.load(open(f))
-    return d.get("bytes_per_launch"), d.get("source")
+        return {}
+    return json.load(open(f))
+
+
+def measured_nms_traffic():
+    f = os.path.join(ROOT, "profiles", "nms_traffic.json")
+    return json.load(open(f)) if os.path.exists(f) else {}
 
 
 def resnet50_main(args):
@@ -280,11 +288,18 @@ def main():
     ap.add_argument("--no-ema", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--no-predict", action="store_true", help="skip the predict() leg (YOLO-NAS only)")
+    ap.add_argument("--only-nms", type=int, default=0, metavar="CALLS", help="run ONLY the NMS leg with that many timed calls and print its object "
+                    "(what the rocprofv3 passes of the post-prediction kernels trace: tools/gpu_round.sh nms stage)")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the 3 extra untimed steps that time the conv kernels without the side stream")
     ap.add_argument("--sync-bn", action="store_true", help="synchronised BatchNorm across ranks (recipe setting; off in the reference's own benchmark)")
     ap.add_argument("--workload", default="yolo_nas", choices=["yolo_nas", "resnet50", "ppyoloe"],
                     help="yolo_nas = BASELINE.json's headline config; resnet50 = configs[1]; ppyoloe = SURVEY 8f-1 (same loss / step, CSPResNet model)")
     args = ap.parse_args()
+    if args.only_nms:
+        import torch
+
+        print(json.dumps(nms_leg(torch.device("cuda:0"), iters=args.only_nms, warmup=0)), flush=True)
+        return
     if args.workload == "resnet50":
         if args.gpus != 1:
             raise RuntimeError("the ResNet-50 workload (BASELINE.json configs[1]) is single-GPU")
@@ -363,11 +378,13 @@ def main():
     for _ in range(args.steps):
         step()
     fence()
-    ig_bytes, wg_bytes = K.prof_bytes(0), K.prof_bytes(1)
-    ig_ms, ig_fl, ig_n = K.prof_summary(0)
+    # class 0 = fp32-MFMA implicit GEMM, class 2 = the bf16x3 patch kernel (conv math "patch"): forward / data gradient together
+    pc_ms, pc_fl, pc_n = K.prof_summary(2)
+    ig_bytes, wg_bytes = K.prof_bytes(0) + K.prof_bytes(2), K.prof_bytes(1)
+    ig_ms, ig_fl, ig_n = (a + b for a, b in zip(K.prof_summary(0), (pc_ms, pc_fl, pc_n)))
     wg_ms, wg_fl, wg_n = K.prof_summary(1)
     # per-launch roofline time: max(FLOPs / MFMA peak, algorithmic bytes / achievable HBM rate) summed over the same launches
-    ig_bound_ms = K.prof_bound_ms(0, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
+    ig_bound_ms = K.prof_bound_ms(0, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12) + K.prof_bound_ms(2, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
     wg_bound_ms = K.prof_bound_ms(1, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
     K.prof_enable(False)
     # The per-launch figures above are taken while the weight-gradient kernels run concurrently on the side HIP stream (they share the
@@ -379,9 +396,10 @@ def main():
     for _ in range(0 if args.no_exclusive else 3):
         step()
     fence()
-    ex_ms, ex_fl, ex_n = K.prof_summary(0)
+    expc_ms, expc_fl, expc_n = K.prof_summary(2)
+    ex_ms, ex_fl, ex_n = (a + b for a, b in zip(K.prof_summary(0), (expc_ms, expc_fl, expc_n)))
     exw_ms, exw_fl, exw_n = K.prof_summary(1)
-    ex_bound_ms = K.prof_bound_ms(0, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
+    ex_bound_ms = K.prof_bound_ms(0, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12) + K.prof_bound_ms(2, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
     K.prof_enable(False)
     net.side_stream = side
     # host side of one step: enqueue time of a step with the device idle at the start (no sync inside)
@@ -404,7 +422,8 @@ def main():
         wg_tf = wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
         per_gpu = value / world
         # the committed PMC passes were taken on the headline workload only
-        traffic, traffic_src = measured_traffic() if (args.workload == "yolo_nas" and args.model == "s") else (None, "no PMC pass committed for this workload")
+        pmc = measured_traffic() if (args.workload == "yolo_nas" and args.model == "s") else {}
+        traffic, traffic_src = pmc.get("bytes_per_launch"), pmc.get("source", "no PMC pass committed for this workload")
         rec = {
             "metric": f"images/sec/node {family}-{args.model.upper()} {args.size}x{args.size} train-step",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -419,7 +438,9 @@ def main():
                        "conv_tuning_entries": int(lib().sgx_conv_tuning_size()),
                        "allreduce_from_side_stream": bool(reducer.from_side) if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data gradient, "
-                                                    + ("v_mfma_f32_32x32x2_f32)" if K.get_conv_math() == "fp32" else "v_mfma_f32_32x32x16_bf16 x6 / v_mfma_f32_32x32x2_f32 per problem)"),
+                                                    + ("v_mfma_f32_32x32x2_f32)" if K.get_conv_math() == "fp32" else
+                                                       "v_mfma_f32_32x32x2_f32) + pconv_kernel (3x3 problems from an LDS patch, v_mfma_f32_32x32x16_bf16 x6)" if K.get_conv_math() == "patch"
+                                                       else "v_mfma_f32_32x32x16_bf16 x6 / v_mfma_f32_32x32x2_f32 per problem)"),
                          "achieved": round(ig_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                          "timed_over": f"{args.steps} further steps of the same loop with a HIP event pair around every launch of the kernel on its launch stream",
                          "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_src,
@@ -437,7 +458,16 @@ def main():
                                                "3 extra untimed steps after the timed region"},
                          "wgrad": {"achieved": round(wg_tf, 2), "frac": round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4), "launches_per_step": wg_n // max(args.steps, 1),
                                    "kernel_ms_per_step": round(wg_ms / args.steps, 3),
+                                   "traffic": pmc.get("wgrad_bytes_per_launch"), "traffic_unit": "bytes/launch (HBM, PMC; a launch = one group of weight gradients)",
                                    "algorithmic_bytes_per_launch": round(wg_bytes / max(wg_n, 1)), "gflop_per_launch": round(wg_fl / max(wg_n, 1) / 1e9, 3)},
+                         # the patch kernel alone, priced against BOTH pipes: algorithmic (fp32-equivalent) FLOPs against the fp32 matrix peak, and the
+                         # bf16 MFMA FLOPs it actually executes (six products per algorithmic one) against the dense bf16 peak
+                         "patch_kernel": None if pc_n == 0 else {
+                             "launches_per_step": pc_n // max(args.steps, 1), "kernel_ms_per_step": round(pc_ms / args.steps, 3),
+                             "algorithmic_tflops": round(pc_fl / (pc_ms * 1e-3) / 1e12, 2), "frac_of_fp32_mfma_peak": round(pc_fl / (pc_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                             "executed_bf16_tflops": round(6.0 * pc_fl / (pc_ms * 1e-3) / 1e12, 1), "frac_of_bf16_mfma_peak": round(6.0 * pc_fl / (pc_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                             "exclusive_algorithmic_tflops": round(expc_fl / (expc_ms * 1e-3) / 1e12, 2) if expc_ms > 0 else None},
+                         "loaded_clock_ghz": pmc.get("loaded_clock_ghz"),
                          # whole-step MFMA utilisation: algorithmic conv FLOPs of one step (model table; measured launches for PP-YOLOE) / step time
                          "step_mfma_frac": round((per_gpu * TRAIN_GFLOP_PER_IMG[args.model] * (args.size / 640.0) ** 2 / 1e3 if args.workload == "yolo_nas"
                                                   else (ig_fl + wg_fl) / args.steps / (dt / args.steps) / 1e12) / PEAK_FP32_MFMA_TFLOPS, 4)},

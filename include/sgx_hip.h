@@ -43,7 +43,8 @@ const char* sgx_last_error(void);
 
 /* Measurement aid (bench.py roofline leg).  While enabled, every launch of the two MFMA kernel classes is bracketed by
  * HIP events on its own launch stream and its algorithmic FLOPs (2*M*N*K of the real, unpadded problem) are tallied.
- * cls 0 = implicit-GEMM kernel (conv forward and data gradient), cls 1 = weight-gradient kernel.
+ * cls 0 = implicit-GEMM kernel (conv forward and data gradient, fp32 matrix pipe), cls 1 = weight-gradient kernel (one record per
+ * grouped launch), cls 2 = the patch kernel (conv forward and data gradient of 3x3 problems on the bf16 matrix pipe, conv math mode 3).
  * sgx_prof_summary synchronises on the recorded events and returns the sums since the last sgx_prof_enable().      */
 int32_t sgx_prof_enable(int32_t on);
 int32_t sgx_prof_summary(int32_t cls, double* ms, double* flops, int64_t* launches);

@@ -1461,7 +1461,8 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
                 : 0;
     // algorithmic work: every input element, weight and output element once (fp32); the second source adds its taps
     const double T2 = (ph2 && p.A2) ? (double)p.Th2 * p.Tw2 : 0.0;
-    SGX_PROF(0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * ((double)T + T2),
+    // (profiling class 0 = fp32-MFMA implicit GEMM, 2 = the bf16x3 patch kernel: same algorithmic FLOPs, priced separately by bench.py)
+    SGX_PROF(pconv_ok(p, ph2) ? 2 : 0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * ((double)T + T2),
              4.0 * ((double)p.M / ((double)p.Ha * p.Wa) * p.Hin * p.Win * p.C * (ph2 == 1 && p.A2 ? 2.0 : 1.0) + (double)p.Nout * p.C * (T + T2) +
                     (double)p.M * p.Nout * (ph2 == 2 ? 2.0 : 1.0)), stream);
     const bool flat = p.C < IG_BK && T > 1;

@@ -240,7 +240,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
     const int n = count < K ? count : K;
     // ---- radix select of the n-th largest composite key (only when count > K) ----
     u64 thr_key = 0;  // select keys >= thr_key
-    if (count > K) {
+    // (a list that fits the sort buffer needs no selection: it is a superset of the top K, sorting it whole puts the top n first - the
+    // usual case, the list being the top K plus the few ties of the boundary bin; five histogram passes and ~25 barriers saved)
+    if (count > K && !(use_list && m_list <= NMS_MAXK)) {
         const int total_bits = 31 + NMS_IDXBITS;  // 53
         const int widths[5] = {11, 11, 11, 11, total_bits - 44};
         if (tid == 0) {
@@ -279,7 +281,31 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
         }
     });
     __syncthreads();
-    for (int size = 2; size <= NMS_MAXK; size <<= 1) {
+    if constexpr (NMS_MAXK == NMS_THREADS) {
+        // one key per thread: the compare-exchange steps with a partner inside the wave (stride < 64: 45 of the 55 steps of a 1024-key
+        // bitonic network) run on wave shuffles in registers - only the ten wide steps go through LDS and barriers
+        u64 k = keys[tid];
+        for (int size = 2; size <= NMS_MAXK; size <<= 1) {
+            const bool desc = (tid & size) == 0;
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                u64 other;
+                if (stride >= 64) {
+                    keys[tid] = k;
+                    __syncthreads();
+                    other = keys[tid ^ stride];
+                    __syncthreads();
+                } else {
+                    other = __shfl_xor(k, stride);
+                }
+                const bool lower = (tid & stride) == 0;
+                const u64 hi = k > other ? k : other, lo = k > other ? other : k;
+                k = (lower == desc) ? hi : lo;
+            }
+        }
+        keys[tid] = k;
+        __syncthreads();
+    }
+    for (int size = 2; size <= (NMS_MAXK == NMS_THREADS ? 0 : NMS_MAXK); size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int i = tid; i < NMS_MAXK; i += NMS_THREADS) {
                 int j = i ^ stride;

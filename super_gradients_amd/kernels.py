@@ -908,7 +908,7 @@ def prof_enable(on: bool):
 
 
 def prof_summary(cls: int):
-    """-> (total ms, algorithmic FLOPs, launches) of kernel class cls (0 = implicit GEMM fwd/dgrad, 1 = weight gradient)."""
+    """-> (total ms, algorithmic FLOPs, launches) of kernel class cls (0 = fp32-MFMA implicit GEMM fwd/dgrad, 1 = weight gradient, 2 = the bf16x3 patch kernel fwd/dgrad)."""
     ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     check(lib().sgx_prof_summary(cls, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "sgx_prof_summary")
     return ms.value, fl.value, n.value

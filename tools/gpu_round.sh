@@ -49,9 +49,23 @@ if has pmc; then
     python tools/prof_summary.py pmc "$OUT/pmc$i" > "$OUT/pmc${i}_summary.txt" 2>&1
     head -12 "$OUT/pmc${i}_summary.txt"
   done
-  python tools/pmc_traffic.py "$OUT/pmc1" "$OUT/pmc2" "$OUT/igemm_traffic.json" > "$OUT/pmc_traffic.log" 2>&1
+  python tools/pmc_traffic.py "$OUT/pmc1" "$OUT/pmc2" "$OUT/igemm_traffic.json" "$OUT/pmc3" > "$OUT/pmc_traffic.log" 2>&1
   cat "$OUT/pmc_traffic.log" | head -5
   for i in 1 2 3; do find "$OUT/pmc$i" -name "*.csv" -size +8M -delete; done
+fi
+if has nms; then
+  # the post-prediction kernels alone: kernel stats + FETCH_SIZE / WRITE_SIZE passes of 20 calls -> profiles/nms_traffic.json
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/nms_stats" -o nms -- bash -c "cd $REPO && python bench.py --only-nms 20" > "$OUT/nms_stats.log" 2>&1
+  cd "$REPO"; python tools/prof_summary.py stats "$OUT/nms_stats" > "$OUT/nms_kernel_stats_summary.txt" 2>&1; head -12 "$OUT/nms_kernel_stats_summary.txt"
+  i=0
+  for set in "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1)); cd /tmp
+    timeout 300 rocprofv3 --pmc $set --kernel-trace -f csv -d "$OUT/nms_pmc$i" -o nms -- bash -c "cd $REPO && python bench.py --only-nms 20" > "$OUT/nms_pmc$i.log" 2>&1
+    cd "$REPO"
+  done
+  python tools/pmc_traffic.py "$OUT/nms_pmc1" "$OUT/nms_pmc2" "$OUT/nms_traffic.json" - 20 > "$OUT/nms_traffic.log" 2>&1; head -4 "$OUT/nms_traffic.json"
+  find "$OUT" -name "*.csv" -size +8M -delete
 fi
 if has tests; then
   timeout 600 python -m pytest tests -m gpu -x -q --durations=15 > "$OUT/pytest_gpu.log" 2>&1
