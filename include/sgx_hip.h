@@ -64,14 +64,15 @@ int32_t sgx_conv_tuning_size(void);
 
 /* Measurement aid (tools/conv_tune.py): force the conv tile shapes (0 = built-in heuristic).  Not thread-safe; never set by the product. */
 int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk, int32_t wgrad_bj, int32_t wgrad_split_target);
-/* Arithmetic of the forward / data-gradient GEMMs.  0 (default): fp32 matrix pipe, exact fp32 FMA chains.  1: "bf16x3" - every fp32
+/* Arithmetic of the forward / data-gradient GEMMs.  0: fp32 matrix pipe, exact fp32 FMA chains.  1: "bf16x3" - every fp32
  * operand is split into three bf16 pieces (24 mantissa bits) and the six significant cross products run on the bf16 matrix pipe with
  * fp32 accumulation: fp32-accurate results (dropped terms <= 2^-24 of a product) at 2.7x fewer matrix-pipe cycles.  2: per problem -
- * bf16x3 where the reduction depth (taps x channels) is >= 192, fp32 MFMA for shallow ones.  3: the 3x3 stride-1 pad-1 problems with
- * C % 16 == 0 (forward, the QARepVGG two-branch forward, data gradient, two-source data gradient) run the PATCH kernel: a workgroup owns
- * 8 x 16 output pixels of one image, stages their 10 x 18 input patch in LDS once per channel chunk (split into three bf16 planes) and
- * reads all nine taps from it - bf16x3 arithmetic as in mode 1; statistics rows are then one per tile (sgx_conv2d_fwd_stat_blocks follows);
- * every other problem stays on the fp32 pipe.  Process-wide.                                                                           */
+ * bf16x3 where the reduction depth (taps x channels) is >= 192, fp32 MFMA for shallow ones.  3 (DEFAULT): the 3x3 stride-1 pad-1
+ * problems with C % 16 == 0 on output maps of 40 x 40 and larger (forward, the QARepVGG two-branch forward, data gradient, two-source
+ * data gradient) run the PATCH kernel: a workgroup owns 8 x 16 output pixels of one image, stages their 10 x 18 input patch and the
+ * filter slabs of all nine taps in LDS once per 16-channel chunk (split into three bf16 planes) and reads the taps from there - bf16x3
+ * arithmetic as in mode 1; statistics rows are then one per tile (sgx_conv2d_fwd_stat_blocks follows); every other problem stays on the
+ * fp32 pipe.  Process-wide.                                                                                                            */
 int32_t sgx_conv_set_math(int32_t mode);
 int32_t sgx_conv_get_math(void);
 int32_t sgx_debug_set_variant(int32_t wave_layout_variant);
@@ -448,6 +449,9 @@ typedef struct sgx_nms_desc {
     int32_t nms_top_k, max_predictions;
     float score_threshold, iou_threshold;
 } sgx_nms_desc;
+/* Measurement aid: 0 keeps the suppression stage inside the per-image kernel (the round-2 form); default 1 = the bit matrix is built by
+ * a chip-wide launch and walked by one wave per image (top-k <= 1024, with a workspace).  Same rows either way.                       */
+int32_t sgx_debug_set_nms_split(int32_t on);
 int64_t sgx_nms_workspace(const sgx_nms_desc* d);
 int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const float* scores, float* out, int32_t* out_count,
                 int32_t* out_index, int32_t* num_candidates, void* ws, int64_t ws_bytes, void* stream);

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "sgx_conv2d_bwd_weight_group_sizes": (_i32, [POINTER(WgradJob), _i32, POINTER(c_int64), POINTER(c_int64)]),
     "sgx_conv2d_bwd_weight_group": (_i32, [POINTER(WgradJob), _i32, _P, _i64, _P, _i64, _P]),
     "sgx_debug_set_wgrad_group": (_i32, [_i32] * 3),
+    "sgx_debug_set_nms_split": (_i32, [_i32]),
     "sgx_convT2x2_workspace": (_i64, [_i32] * 5),
     "sgx_convT2x2_fwd": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _P, _i64, _i64, _P, _i64, _P]),
     "sgx_convT2x2_bwd_data": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _i64, _i64, _P]),

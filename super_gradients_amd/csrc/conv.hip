@@ -1245,7 +1245,9 @@ struct TileCfg {
 // the library stays re-entrant, as include/sgx_hip.h promises)
 static std::atomic<int> g_ovr_bm{0}, g_ovr_bn{0}, g_ovr_wk{0}, g_ovr_wj{0}, g_ovr_split{0}, g_ovr_var{0};
 // arithmetic of the forward / data-gradient GEMMs: 0 = fp32 MFMA (exact fp32 FMA chains), 1 = bf16x3 split (see IG_LDP above)
-static std::atomic<int> g_conv_math{0};
+// default 3: fp32 matrix pipe everywhere except the 3x3 stride-1 problems on maps of 40 x 40 and larger, which run pconv_kernel (bf16x3 from
+// an LDS-resident patch): 1.25-1.6x on those launches, every GPU parity test green in that mode (r3g)
+static std::atomic<int> g_conv_math{3};
 extern "C" int32_t sgx_conv_set_math(int32_t mode) {
     SGX_CHECK_ARG(mode >= 0 && mode <= 3, "conv math mode %d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = per problem, 3 = patch kernel for 3x3 stride-1)", mode);
     g_conv_math = mode;
@@ -1263,8 +1265,10 @@ static int conv_math_for(int taps, int C) {
 }
 // Mode 3: 3x3, stride 1, pad 1, channel counts in 16s -> pconv_kernel (bf16x3 from an LDS-resident patch).  Decidable from the descriptor,
 // so that the forward statistics rows (one per 8 x 16 pixel tile and image) are known before the launch.
-static bool pconv_shape_ok(int R, int S, int stride, int pad, int C, int K) {
-    return g_conv_math.load(std::memory_order_relaxed) == 3 && R == 3 && S == 3 && stride == 1 && pad == 1 && C % 16 == 0 && C >= 16 && K % 4 == 0;
+static int conv_variant();
+static bool pconv_shape_ok(int R, int S, int stride, int pad, int C, int K, long HoWo) {
+    return g_conv_math.load(std::memory_order_relaxed) == 3 && R == 3 && S == 3 && stride == 1 && pad == 1 && C % 16 == 0 && C >= 16 && K % 4 == 0 &&
+           (HoWo >= 1600 || conv_variant() == 9);
 }
 static int pconv_tiles(int N, int H, int W) { return N * sgx_cdiv(H, PC_TH) * sgx_cdiv(W, PC_TW); }
 extern "C" int32_t sgx_debug_set_variant(int32_t v) {
@@ -1411,6 +1415,10 @@ static bool pconv_ok(const IgemmParams& p, int ph2) {
     for (int j = 0; j < p.Tw; ++j)
         if (p.dw0 + p.dstep * j < -1 || p.dw0 + p.dstep * j > 1) return false;
     if (p.C % 16 || p.C < 16 || !p.vec) return false;
+    // Where it pays (r3g, replay of every conv problem of a YOLO-NAS-S step): the stride-1 problems on maps of 40 x 40 and larger (1.25-1.6x
+    // over the fp32 pipe).  20 x 20 maps fill their 8 x 16 tiles to 52 %, and the parity classes of a stride-2 data gradient carry
+    // 2x2 / 2x1 taps only - a quarter of the reuse the patch is staged for, and 0.65x on the 768-channel layer.  Variant 9 lifts both.
+    if (conv_variant() != 9 && (p.so != 1 || (long)p.Ha * p.Wa < 1600)) return false;
     if (ph2 && p.A2 && !(p.Th2 == 1 && p.Tw2 == 1 && p.dh02 == 0 && p.dw02 == 0)) return false;
     if (ph2 == 2 && (p.A2 != p.A || p.a2_ld_pix != p.a_ld_pix || p.a2_ld_img != p.a_ld_img)) return false;  // the second filter reads the same patch
     if ((long)p.Hin * p.Win * p.a_ld_pix * 4 > SGX_BUF_MAX) return false;
@@ -1466,7 +1474,7 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
              4.0 * ((double)p.M / ((double)p.Ha * p.Wa) * p.Hin * p.Win * p.C * (ph2 == 1 && p.A2 ? 2.0 : 1.0) + (double)p.Nout * p.C * (T + T2) +
                     (double)p.M * p.Nout * (ph2 == 2 ? 2.0 : 1.0)), stream);
     const bool flat = p.C < IG_BK && T > 1;
-    if (!pconv_ok(p, ph2) && p.stat_partials && p.dstep == 1 && p.so == 1 && pconv_shape_ok(p.Th, p.Tw, p.si, -p.dh0, p.C, p.Nout))
+    if (!pconv_ok(p, ph2) && p.stat_partials && p.dstep == 1 && p.so == 1 && pconv_shape_ok(p.Th, p.Tw, p.si, -p.dh0, p.C, p.Nout, (long)p.Ha * p.Wa))
         SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (math mode 3): the statistics rows of this forward follow the patch kernel's tiles, which needs 16-byte aligned operands");
     if (pconv_ok(p, ph2)) {
         int32_t rc = run_pconv(p, stream, ph2);
@@ -1527,7 +1535,7 @@ static long view_bytes(int N, int H, int W, int C, long ld_pix, long ld_img) {
 }
 
 extern "C" int32_t sgx_conv2d_fwd_stat_blocks(const sgx_conv_desc* d) {
-    if (pconv_shape_ok(d->R, d->S, d->stride, d->pad, d->C, d->K)) return pconv_tiles(d->N, d->Ho, d->Wo);
+    if (pconv_shape_ok(d->R, d->S, d->stride, d->pad, d->C, d->K, (long)d->Ho * d->Wo)) return pconv_tiles(d->N, d->Ho, d->Wo);
     TuneScope tune(0, d);
     long M = (long)d->N * d->Ho * d->Wo;
     TileCfg t = pick_tile(M, d->K, conv_math_for(d->R * d->S, d->C));
@@ -1562,7 +1570,7 @@ extern "C" int32_t sgx_conv2d_fwd(const sgx_conv_desc* d, const float* x, const 
 // tap of the RxS one (pad = R / 2), so the workgroup that owns an output tile walks the taps of w into one accumulator and then the
 // centre tap again with w1 into a second one.  stat5: [5][sgx_conv2d_fwd_dual_stat_blocks(d)][K] = sum y, y^2, u0, u0^2, y*u0 per row block (u0 = u - bias1).
 extern "C" int32_t sgx_conv2d_fwd_dual_stat_blocks(const sgx_conv_desc* d) {
-    if (pconv_shape_ok(d->R, d->S, d->stride, d->pad, d->C, d->K)) return pconv_tiles(d->N, d->Ho, d->Wo);
+    if (pconv_shape_ok(d->R, d->S, d->stride, d->pad, d->C, d->K, (long)d->Ho * d->Wo)) return pconv_tiles(d->N, d->Ho, d->Wo);
     long M = (long)d->N * d->Ho * d->Wo;
     return sgx_cdiv(M, pick_tile_heuristic(M, d->K).bm);
 }
@@ -1842,7 +1850,7 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
 // ------------------------------------------------------------------------------------------------
 #define WG_BKP 16
 #define WG_MAX_SPLIT 4096
-#define WG_MAX_JOBS 20  // the job table travels as kernel arguments: 20 x 176 B + 8 B < 4 KB
+#define WG_MAX_JOBS 24  // the job table travels as kernel arguments: 24 x (152 + 4) B + 8 B < 4 KB
 
 struct WgJob {
     const float* X;
@@ -1858,6 +1866,7 @@ struct WgJob {
 };
 struct WgGroupParams {
     int njobs, xcd_order;
+    int blk0[WG_MAX_JOBS];  // first workgroup of every job, together: the job lookup is a handful of scalar loads, not one per job
     WgJob jobs[WG_MAX_JOBS];
 };
 
@@ -1876,8 +1885,9 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
     const int wk = wave / WC, wc = wave % WC;
     // which job: blocks [blk0, next blk0) belong to it
     int ji = 0;
-    for (int i = 1; i < g.njobs; ++i)
-        if ((int)blockIdx.x >= g.jobs[i].blk0) ji = i;
+#pragma unroll
+    for (int i = 1; i < WG_MAX_JOBS; ++i)
+        if (i < g.njobs && (int)blockIdx.x >= g.blk0[i]) ji = i;
     const WgJob& p = g.jobs[ji];
     const int T = p.kt_tiles * p.jt_tiles;
     // (split, tile) of this workgroup.  XCD order: workgroup b runs on XCD b % 8; an XCD walks the tiles of split x, then of x + 8, ...
@@ -2235,6 +2245,7 @@ extern "C" int32_t sgx_conv2d_bwd_weight_group(const sgx_wgrad_job* jobs, int32_
             p.M = d->N * d->Ho * d->Wo; p.J = d->R * d->S * d->C;
             p.ksplit = pl.ksplit; p.mchunk = pl.mchunk; p.kt_tiles = pl.kt_tiles; p.jt_tiles = pl.jt_tiles;
             p.blk0 = nblk;
+            g.blk0[g.njobs - 1] = nblk;
             nblk += 8 * sgx_cdiv(pl.ksplit, 8) * pl.kt_tiles * pl.jt_tiles;
             flops += 2.0 * (double)p.M * (double)d->K * (double)p.J;
             bytes += 4.0 * ((double)d->N * d->H * d->W * d->C + (double)p.M * d->K + (double)d->K * p.J);

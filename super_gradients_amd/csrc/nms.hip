@@ -28,11 +28,24 @@
 #define NMS_S1_THREADS 256
 
 typedef unsigned long long u64;
+#include <atomic>
+static std::atomic<int> g_nms_split{1};
+extern "C" int32_t sgx_debug_set_nms_split(int32_t on) {
+    g_nms_split = on != 0;
+    return SGX_OK;
+}
 
 // workspace layout (ints unless noted): hist1 [B][2048] | hist2 [B][2048] | list_count [B] | total [B] | list (u64) [B][NMS_LIST_CAP]
+// ... | per image (split suppression, top-k <= 1024): sorted candidates (keys u64[1024], boxes f32[1024][4], boxes as the IoU test sees them
+// f32[1024][4], areas f32[1024], classes int[1024], {n, class mode} int[16]) and the triangular suppression bit matrix u64[8704]
+#define NMS_SPLIT_K 1024
+#define NMS_CAND_BYTES (NMS_SPLIT_K * (8 + 16 + 16 + 4 + 4) + 64)
+#define NMS_MASK_WORDS_1024 8704
+#define NMS_SPLIT_BYTES (NMS_CAND_BYTES + NMS_MASK_WORDS_1024 * 8)
+static int64_t nms_ws_head(const sgx_nms_desc* d) { return (((int64_t)d->B * (2 * NMS_HBINS + 2) * 4 + 255) & ~255L) + (int64_t)d->B * NMS_LIST_CAP * 8; }
 extern "C" int64_t sgx_nms_workspace(const sgx_nms_desc* d) {
     if (!d || !d->multi_label) return 256;
-    return (int64_t)d->B * (2 * NMS_HBINS + 2) * 4 + 256 + (int64_t)d->B * NMS_LIST_CAP * 8;
+    return nms_ws_head(d) + 256 + (int64_t)d->B * NMS_SPLIT_BYTES;
 }
 
 __device__ __forceinline__ bool nms_candidate(const sgx_nms_desc& d, const float* sc, long e, float& score, int& cls) {
@@ -184,7 +197,7 @@ __device__ __forceinline__ int nms_mask_row(int i) {
 }
 template <int NMS_MAXK>
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const float* boxes, const float* scores, float* out, int* out_count,
-                                                          int* out_index, int* num_candidates, const int* ws) {
+                                                          int* out_index, int* num_candidates, const int* ws, char* split) {
     constexpr bool MASK = NMS_MAXK == 1024;
     __shared__ int hist[NMS_HBINS];
     __shared__ u64 keys[NMS_MAXK];
@@ -373,6 +386,36 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
     }
     if (tid == 0) s_kept = 0;
     __syncthreads();
+    if (MASK && split && d.iou_threshold < 2.0f) {
+        // Split suppression: this workgroup hands the sorted candidates over; the bit matrix is then built by the WHOLE chip (grid = 64-row
+        // strips x images, nms_mask_kernel) and walked by one wave per image (nms_walk_kernel).  Inside this kernel the matrix build ran on
+        // 32 of 256 CUs and was the larger half of the 170-190 us the call took (r2z profile).
+        char* const o = split + (long)b * NMS_SPLIT_BYTES;
+        u64* okeys = reinterpret_cast<u64*>(o);
+        float* obx = reinterpret_cast<float*>(o + NMS_SPLIT_K * 8);
+        float* onb = obx + NMS_SPLIT_K * 4;
+        float* oarea = onb + NMS_SPLIT_K * 4;
+        int* ocls = reinterpret_cast<int*>(oarea + NMS_SPLIT_K);
+        int* ometa = ocls + NMS_SPLIT_K;
+        for (int t = tid; t < NMS_SPLIT_K; t += NMS_THREADS) {
+            okeys[t] = keys[t];
+            if (t < n) {
+                float nb[4];
+                nbox(t, nb);
+                for (int q = 0; q < 4; ++q) {
+                    obx[t * 4 + q] = bx[t][q];
+                    onb[t * 4 + q] = nb[q];
+                }
+                oarea[t] = area[t];
+                ocls[t] = cls_s[t];
+            }
+        }
+        if (tid == 0) {
+            ometa[0] = n;
+            ometa[1] = class_mode;
+        }
+        return;
+    }
     // does box i (kept) suppress box t?  (the arithmetic order of torchvision's nms kernel)
     auto suppresses = [&](const float* ci, float ai, int t) {
         float nb[4];
@@ -485,6 +528,121 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
     }
 }
 
+// ---- split suppression (top-k <= 1024) ---------------------------------------------------------------------------------------------------
+// nms_mask_kernel: grid = (16 strips of 64 candidates, images).  Row i of the triangular matrix: bit j of word w - c = "i suppresses
+// 64 w + j" for the words w >= c = i / 64; a wave owns a row, a lane one column, the word is the ballot of 64 IoU tests (the arithmetic
+// order of torchvision's kernel, as above).  Every row of the strip is built (the in-kernel form skipped rows already suppressed: about
+// three times the tests, on sixteen times the workgroups of a chip that was 7/8 idle).
+#define NMS_MASK_THREADS 256
+__global__ __launch_bounds__(NMS_MASK_THREADS) void nms_mask_kernel(sgx_nms_desc d, char* split) {
+    __shared__ float nb[NMS_SPLIT_K][4];
+    __shared__ float area[NMS_SPLIT_K];
+    __shared__ int cls_s[NMS_SPLIT_K];
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* const o = split + (long)b * NMS_SPLIT_BYTES;
+    const float* gnb = reinterpret_cast<const float*>(o + NMS_SPLIT_K * 8) + NMS_SPLIT_K * 4;
+    const float* garea = gnb + NMS_SPLIT_K * 4;
+    const int* gcls = reinterpret_cast<const int*>(garea + NMS_SPLIT_K);
+    const int* meta = gcls + NMS_SPLIT_K;
+    u64* const mask = reinterpret_cast<u64*>(o + NMS_CAND_BYTES);
+    const int n = meta[0], class_mode = meta[1];
+    if (64 * c >= n) return;  // whole workgroup
+    const int nw = (n + 63) >> 6;
+    for (int t = 64 * c + tid; t < n; t += NMS_MASK_THREADS) {  // this strip's rows and every later column
+        for (int q = 0; q < 4; ++q) nb[t][q] = gnb[t * 4 + q];
+        area[t] = garea[t];
+        cls_s[t] = gcls[t];
+    }
+    __syncthreads();
+    for (int r = wave; r < 64; r += NMS_MASK_THREADS / 64) {
+        const int i = 64 * c + r;
+        if (i >= n) break;  // wave-uniform
+        const float ci0 = nb[i][0], ci1 = nb[i][1], ci2 = nb[i][2], ci3 = nb[i][3], ai = area[i];
+        const int ic = cls_s[i], base = nms_mask_row(i);
+        for (int w = c; w < nw; ++w) {
+            const int t = 64 * w + lane;
+            bool hit = false;
+            if (t > i && t < n && (class_mode != 2 || cls_s[t] == ic)) {
+                const float xx1 = fmaxf(ci0, nb[t][0]), yy1 = fmaxf(ci1, nb[t][1]);
+                const float xx2 = fminf(ci2, nb[t][2]), yy2 = fminf(ci3, nb[t][3]);
+                float ww = xx2 - xx1; ww = ww < 0.f ? 0.f : ww;
+                float hh = yy2 - yy1; hh = hh < 0.f ? 0.f : hh;
+                const float inter = ww * hh;
+                const float ovr = inter / (ai + area[t] - inter);
+                hit = ovr > d.iou_threshold;
+            }
+            const u64 bits = __ballot(hit);
+            if (lane == 0) mask[base + (w - c)] = bits;
+        }
+    }
+}
+// nms_walk_kernel: one workgroup per image loads the matrix into LDS (68 KB, coalesced), ONE wave walks it - the kept candidates of a word
+// are the flags that are still clear, found with ffs; every kept candidate ORs its row into the flags (its own word through a same-address
+// LDS read, the later words lane by lane) - then the rows are written.
+#define NMS_WALK_THREADS 256
+__global__ __launch_bounds__(NMS_WALK_THREADS) void nms_walk_kernel(sgx_nms_desc d, const char* split, float* out, int* out_count, int* out_index,
+                                                                    int* num_candidates) {
+    __shared__ u64 mask[NMS_MASK_WORDS_1024];
+    __shared__ int keep_list[NMS_SPLIT_K];
+    __shared__ int s_kept;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const char* const o = split + (long)b * NMS_SPLIT_BYTES;
+    const u64* keys = reinterpret_cast<const u64*>(o);
+    const float* bx = reinterpret_cast<const float*>(o + NMS_SPLIT_K * 8);
+    const int* cls = reinterpret_cast<const int*>(bx + 2 * NMS_SPLIT_K * 4 + NMS_SPLIT_K);
+    const int* meta = cls + NMS_SPLIT_K;
+    const u64* gmask = reinterpret_cast<const u64*>(o + NMS_CAND_BYTES);
+    const int n = meta[0];
+    const int nw = (n + 63) >> 6;
+    // only the rows of existing candidates were written: strip g holds 64 rows of (16 - g) words
+    const int used = n > 0 ? nms_mask_row(n - 1) + (NMS_MW - ((n - 1) >> 6)) : 0;
+    for (int q = tid; q < used; q += NMS_WALK_THREADS) mask[q] = gmask[q];
+    __syncthreads();
+    if (wave == 0) {
+        int kept = 0;
+        u64 rem = 0;  // lane w: suppression flags of word w
+        for (int c = 0; c < nw && kept < d.max_predictions; ++c) {
+            u64 cur = __shfl(rem, c);
+            if (c == nw - 1 && (n & 63)) cur |= ~0ull << (n & 63);  // slots past the last candidate
+            u64 avail = ~cur;
+            u64 later = 0;
+            while (avail && kept < d.max_predictions) {  // wave-uniform
+                const int bit = __ffsll(avail) - 1;
+                const int i = 64 * c + bit;
+                if (lane == 0) keep_list[kept] = i;
+                ++kept;
+                const int base = nms_mask_row(i);
+                cur |= mask[base];
+                if (lane > c && lane < nw) later |= mask[base + (lane - c)];
+                avail = ~cur & ~((2ull << bit) - 1ull);
+            }
+            rem |= later;
+        }
+        if (lane == 0) s_kept = kept;
+    }
+    __syncthreads();
+    const int kept = s_kept < d.max_predictions ? s_kept : d.max_predictions;
+    if (tid == 0) {
+        out_count[b] = kept;
+        if (num_candidates) num_candidates[b] = n;
+    }
+    for (int r = tid; r < d.max_predictions; r += NMS_WALK_THREADS) {
+        float* q = out + ((long)b * d.max_predictions + r) * 6;
+        if (r < kept) {
+            const int i = keep_list[r];
+            const u64 k = keys[i];
+            const unsigned e = ((1u << NMS_IDXBITS) - 1u) - (unsigned)(k & ((1u << NMS_IDXBITS) - 1u));
+            q[0] = bx[i * 4 + 0]; q[1] = bx[i * 4 + 1]; q[2] = bx[i * 4 + 2]; q[3] = bx[i * 4 + 3];
+            q[4] = __uint_as_float((unsigned)(k >> NMS_IDXBITS));
+            q[5] = (float)cls[i];
+            if (out_index) out_index[(long)b * d.max_predictions + r] = (int)e;
+        } else {
+            for (int z = 0; z < 6; ++z) q[z] = 0.f;
+            if (out_index) out_index[(long)b * d.max_predictions + r] = -1;
+        }
+    }
+}
+
 extern "C" int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const float* scores, float* out, int32_t* out_count, int32_t* out_index,
                            int32_t* num_candidates, void* ws, int64_t ws_bytes, void* stream) {
     SGX_CHECK_ARG(d && boxes && scores && out && out_count, "nms: null pointer");
@@ -513,9 +671,15 @@ extern "C" int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const floa
         }
     }
     const int need = d->nms_top_k > d->max_predictions ? d->nms_top_k : d->max_predictions;
-    if (need <= 1024) SGX_LAUNCH(nms_kernel<1024>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates, wsi);
-    else if (need <= 2048) SGX_LAUNCH(nms_kernel<2048>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates, wsi);
-    else SGX_LAUNCH(nms_kernel<4096>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates, wsi);
+    // split suppression (matrix build on the whole chip): needs the workspace; sgx_debug_set_nms_split(0) keeps everything in nms_kernel
+    char* split = (wsi && need <= 1024 && d->iou_threshold < 2.0f && g_nms_split.load(std::memory_order_relaxed)) ? (char*)ws + nms_ws_head(d) + 256 - ((nms_ws_head(d) + 256) & 255) : nullptr;
+    if (need <= 1024) SGX_LAUNCH(nms_kernel<1024>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates, wsi, split);
+    else if (need <= 2048) SGX_LAUNCH(nms_kernel<2048>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates, wsi, (char*)nullptr);
+    else SGX_LAUNCH(nms_kernel<4096>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates, wsi, (char*)nullptr);
+    if (split) {
+        SGX_LAUNCH(nms_mask_kernel, dim3(NMS_MW, (unsigned)d->B), dim3(NMS_MASK_THREADS), 0, stream, *d, split);
+        SGX_LAUNCH(nms_walk_kernel, dim3(d->B), dim3(NMS_WALK_THREADS), 0, stream, *d, (const char*)split, out, out_count, out_index, num_candidates);
+    }
     SGX_CHECK_LAUNCH("nms");
     return SGX_OK;
 }

@@ -90,7 +90,7 @@ def main():
                     res[cfg].append(float("nan"))
         lib().sgx_debug_set_variant(0)
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
-        K.set_conv_math("fp32")
+        K.set_conv_math(K.DEFAULT_CONV_MATH)
         K.clear_desc_cache()
         med = {cfg: statistics.median(v) for cfg, v in res.items()}
         lines.append(f"{spec:<34}" + "".join(f"{flops / med[cfg] / 1e6:>14.1f}" for cfg in configs))
