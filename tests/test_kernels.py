@@ -1061,16 +1061,17 @@ def test_conv_every_tile_shape(backend, math):
 
 def test_wgrad_group(backend, monkeypatch):
     """sgx_conv2d_bwd_weight_group: several weight gradients of different shapes / tile shapes in one call, pixel splits folded inside the
-    launch by arrival tickets - one ticket level (<= 16 splits), two levels (> 16), the direct form (one split); dw accumulates; the
-    result does not depend on the order in which workgroups arrive (the emulation dispatches them in a shuffled order), the tickets are
-    left zero (a second call on the same buffers is correct) and the same call twice is bit-identical (fixed summation order)."""
+    launch by the arrival-walked binary tree - an odd split count (nodes without a sibling pass up), several levels, the direct form
+    (one split); dw accumulates; the result does not depend on the order in which workgroups arrive (the emulation dispatches them in a
+    shuffled order), the tickets are left zero (a second call on the same buffers is correct) and the same call under another arrival
+    order is bit-identical (fixed association)."""
     from super_gradients_amd._lib import lib
 
     gpu = backend.type == "cuda"
     # (N, H, W, C, K, R, stride, pad)
     cases = [(2, 80, 80, 64, 64, 3, 1, 1), (2, 80, 80, 96, 96, 1, 1, 0), (4, 40, 40, 32, 48, 3, 2, 1), (1, 20, 20, 128, 32, 1, 1, 0),
              (2, 160, 160, 4, 48, 3, 2, 1)] if gpu else \
-            [(1, 72, 72, 4, 8, 1, 1, 0), (1, 9, 7, 8, 36, 3, 1, 1), (2, 12, 12, 8, 8, 3, 2, 1), (1, 20, 26, 4, 40, 1, 1, 0)]
+            [(1, 42, 42, 4, 8, 1, 1, 0), (1, 9, 7, 8, 36, 3, 1, 1), (2, 12, 12, 8, 8, 3, 2, 1), (1, 20, 26, 4, 40, 1, 1, 0)]
     ents, refs = [], []
     for i, shape in enumerate(cases):
         n, h, w, c, k, r, s, p = shape
@@ -1087,7 +1088,7 @@ def test_wgrad_group(backend, monkeypatch):
     if not gpu:
         monkeypatch.setenv("SGX_EMU_SHUFFLE", "7")
     try:
-        # small items: the first emu case (5184 pixels) is cut into 21 splits of 256 pixels -> two ticket levels
+        # small items: the first emu case (1764 pixels) is cut into 7 splits of 256 pixels -> a three-level tree with sibling-less nodes
         lib().sgx_debug_set_wgrad_group(6, 1, 1)
         K.conv2d_bwd_weight_group(ents)
         first = [e[2].clone() for e in ents]
