@@ -106,6 +106,7 @@ PROTOTYPES = {
     "sgx_conv2d_bwd_weight_group_sizes": (_i32, [POINTER(WgradJob), _i32, POINTER(c_int64), POINTER(c_int64)]),
     "sgx_conv2d_bwd_weight_group": (_i32, [POINTER(WgradJob), _i32, _P, _i64, _P, _i64, _P]),
     "sgx_debug_set_wgrad_group": (_i32, [_i32] * 3),
+    "sgx_debug_set_wgrad_loop": (_i32, [_i32] * 2),
     "sgx_debug_set_nms_split": (_i32, [_i32]),
     "sgx_convT2x2_workspace": (_i64, [_i32] * 5),
     "sgx_convT2x2_fwd": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _P, _i64, _i64, _P, _i64, _P]),
@@ -207,6 +208,12 @@ def lib():
         wgg = os.environ.get("SGX_WGRAD_GROUP")  # measurement switch of the grouped weight gradient: "rounds,item_mflop,xcd_order" (0 = default)
         if wgg:
             _LIB.sgx_debug_set_wgrad_group(*[int(v) for v in wgg.split(",")])
+        # measurement switches of the weight-gradient loop: 32-pixel slabs (small tiles); ablation bits (honoured by -DSGX_WGRAD_LAB builds only);
+        # one tile shape for every layer "bnk,bj"
+        if os.environ.get("SGX_WGRAD_SLAB") == "32" or os.environ.get("SGX_WGRAD_ABLATE"):
+            _LIB.sgx_debug_set_wgrad_loop(int(os.environ.get("SGX_WGRAD_SLAB") == "32"), int(os.environ.get("SGX_WGRAD_ABLATE", "0")))
+        if os.environ.get("SGX_WGRAD_TILE"):
+            _LIB.sgx_debug_set_tiles(0, 0, *[int(v) for v in os.environ["SGX_WGRAD_TILE"].split(",")], 0)
         if os.environ.get("SGX_FUSED_FINALIZE") == "0":  # measurement switch: two-launch BatchNorm / column-sum finalize (default: one launch)
             _LIB.sgx_bn_set_fused_finalize(0)
         # per-problem (tile, variant) table measured by tools/conv_tune.py --emit-table: SGX_CONV_TUNING=<json> ("" / "0" = none),

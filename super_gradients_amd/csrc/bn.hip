@@ -140,11 +140,14 @@ struct ColSrc {  // what a finalize kernel sums over: either the fp32 partials o
     int coop;  // 1: the finalize kernel is launched with CO_CH x CO_RL threads per workgroup and folds the fp32 partial rows itself
 };
 // ---- one-launch finalize (default; sgx_bn_set_fused_finalize(0) restores the two-launch form): instead of a pre-reduction
-// launch + a finalize launch, the finalize kernel runs with 32 channels x 32 row lanes per workgroup; every lane folds its rows
-// (b = lane, lane + 32, ...) in fp64, the 32 lane sums meet in LDS and are added in lane order (deterministic, no atomics).  Worth it
-// while one workgroup can stream the partial rows of its 32 channels faster than a second launch costs: nblk <= CR_COOP_MAX.
+// launch + a finalize launch, the finalize kernel runs with CO_CH channels x CO_RL row lanes per workgroup; every lane folds its rows
+// (b = lane, lane + CO_RL, ...) in fp64, the lane sums meet in LDS and are added in lane order (deterministic, no atomics).  Worth it
+// while one workgroup can stream the partial rows of its channels faster than a second launch costs: nblk <= CR_COOP_MAX.
+// These kernels are a handful of workgroups on an otherwise idle chip (they sit between a convolution and the sweep that needs its
+// statistics), so their time is load LATENCY x dependent rounds, not bytes: all planes of FOUR rows are loaded before the first add
+// (r3: the per-plane form measured 27 us for the five-moment finalize of an 80 x 80 map - 500 loads per lane, eight in flight).
 #ifndef CO_CH
-#define CO_CH 32
+#define CO_CH 16
 #endif
 #define CO_RL (1024 / CO_CH)
 #define CR_COOP_MAX 4096
@@ -174,24 +177,71 @@ __device__ __forceinline__ double colsrc_sum(const ColSrc& s, int plane, int C, 
     }
     return acc;
 }
-// column total of one plane; in coop mode EVERY thread of the workgroup must call it (barriers), all lanes return the total
-__device__ __forceinline__ double col_total(const ColSrc& s, int plane, int C, int c, bool cok) {
-    if (!s.coop) return cok ? colsrc_sum(s, plane, C, c) : 0.0;
-    __shared__ double red[CO_RL][CO_CH + 1];
-    const int cl = threadIdx.x % CO_CH, rl = threadIdx.x / CO_CH;
-    double acc = 0.0;
-    if (cok) {
-        const float* p = s.f + (long)plane * s.n * C + c;
-#pragma unroll 8
-        for (int b = rl; b < s.n; b += CO_RL) acc += (double)p[(long)b * C];
-    }
-    __syncthreads();  // the previous plane's totals have been read
-    red[rl][cl] = acc;
-    __syncthreads();
-    double t = 0.0;
+// this lane's rows of P planes, ascending (a fixed order), FOUR rows x P planes of loads in flight
+template <int P, typename T>
+__device__ __forceinline__ void col_lane_sums(const T* p0, long plane_ld, int n, int C, int rl, double (&acc)[P]) {
+    int b = rl;
+    for (; b + 3 * CO_RL < n; b += 4 * CO_RL) {
+        T v[4][P];
 #pragma unroll
-    for (int k = 0; k < CO_RL; ++k) t += red[k][cl];
-    return t;
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < P; ++q) v[u][q] = p0[q * plane_ld + (long)(b + u * CO_RL) * C];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < P; ++q) acc[q] += (double)v[u][q];
+    }
+    for (; b < n; b += CO_RL)
+#pragma unroll
+        for (int q = 0; q < P; ++q) acc[q] += (double)p0[q * plane_ld + (long)b * C];
+}
+// column totals of the first P planes; in coop mode EVERY thread of the workgroup must call it (barriers); the totals are valid in the
+// writer lanes (SGX_FIN_THREAD) - the only ones that use them
+template <int P>
+__device__ __forceinline__ void col_totals(const ColSrc& s, int C, int c, bool cok, double (&out)[P]) {
+    if (!s.coop) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) out[q] = cok ? colsrc_sum(s, q, C, c) : 0.0;
+        return;
+    }
+    __shared__ double red[P][CO_RL][CO_CH + 1];
+    const int cl = threadIdx.x % CO_CH, rl = threadIdx.x / CO_CH;
+    double acc[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) acc[q] = 0.0;
+    if (cok) {
+        if (s.d) col_lane_sums<P>(s.d + c, (long)s.n * C, s.n, C, rl, acc);
+        else col_lane_sums<P>(s.f + c, (long)s.n * C, s.n, C, rl, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q) red[q][rl][cl] = acc[q];
+    __syncthreads();
+    // lane sums -> totals in two fixed steps: row lanes 0..7 each add eight consecutive lane sums, the writer lane adds those eight.
+    // (All 1024 threads adding all CO_RL sums, as this was first written, is 2.6 MB of LDS reads for five planes: ~8 us on its own.)
+    constexpr int F1 = 8, F2 = CO_RL / F1;
+    if (rl < F1) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < F2; ++k) t += red[q][rl * F2 + k][cl];
+            acc[q] = t;
+        }
+    }
+    __syncthreads();
+    if (rl < F1)
+#pragma unroll
+        for (int q = 0; q < P; ++q) red[q][rl][cl] = acc[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        double t = 0.0;
+        if (rl == 0)
+#pragma unroll
+            for (int k = 0; k < F1; ++k) t += red[q][k][cl];
+        out[q] = t;  // valid in the writer lanes (row lane 0) only
+    }
 }
 static int cr_slices(int nblk) {
     if (nblk <= CR_DIRECT) return 0;
@@ -241,7 +291,7 @@ static int32_t col_prereduce(const float* partials, int nblk, int C, void* ws, i
     const int chunk = (nblk + S - 1) / S;
     SGX_LAUNCH((colreduce_kernel<PLANES>), dim3(sgx_cdiv(C, 64), S), dim3(256), 0, stream, partials, nblk, C, S, chunk, (double*)ws);
     SGX_CHECK_LAUNCH("colreduce");
-    *src = ColSrc{nullptr, (const double*)ws, S, 0};
+    *src = ColSrc{nullptr, (const double*)ws, S, g_fused_finalize ? 1 : 0};  // the fp64 slices are folded by row lanes as well
     return SGX_OK;
 }
 
@@ -249,8 +299,10 @@ __global__ void bn_finalize_kernel(ColSrc src, long M, int C, const float* gamma
                                    float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                                    float* scale, float* shift) {
     SGX_FIN_THREAD(src, C);
-    double s = col_total(src, 0, C, c, cok), q = col_total(src, 1, C, c, cok);
+    double tot[2];
+    col_totals<2>(src, C, c, cok, tot);
     if (!writer) return;
+    const double s = tot[0], q = tot[1];
     double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -282,19 +334,21 @@ extern "C" int32_t sgx_bn_finalize(const float* partials, int32_t nblk, int64_t 
 
 // ---- cross-rank (synchronised) BatchNorm: the per-channel sums leave the library as fp64 [planes][C] so that the host can
 // all-reduce them over RCCL (ONE small collective per BN layer and direction), then come back for the finalisation.
-__global__ void colsum_f64_kernel(ColSrc src, int planes, int C, double* out) {
+template <int P>
+__global__ void colsum_f64_kernel(ColSrc src, int C, double* out) {
     SGX_FIN_THREAD(src, C);
-    for (int p = 0; p < planes; ++p) {
-        const double t = col_total(src, p, C, c, cok);
-        if (writer) out[(long)p * C + c] = t;
-    }
+    double tot[P];
+    col_totals<P>(src, C, c, cok, tot);
+    if (writer)
+#pragma unroll
+        for (int p = 0; p < P; ++p) out[(long)p * C + c] = tot[p];
 }
 extern "C" int32_t sgx_bn_reduce_sums(const float* partials, int32_t nblk, int32_t C, double* sums, void* ws, int64_t ws_bytes, void* stream) {
     SGX_CHECK_ARG(partials && sums && nblk > 0, "bn_reduce_sums: bad args");
     ColSrc src;
     int32_t rc = col_prereduce<2>(partials, nblk, C, ws, ws_bytes, stream, &src);
     if (rc) return rc;
-    SGX_LAUNCH(colsum_f64_kernel, fin_grid(src, C), fin_block(src), 0, stream, src, 2, C, sums);
+    SGX_LAUNCH(colsum_f64_kernel<2>, fin_grid(src, C), fin_block(src), 0, stream, src, C, sums);
     SGX_CHECK_LAUNCH("bn_reduce_sums");
     return SGX_OK;
 }
@@ -401,7 +455,9 @@ extern "C" int32_t sgx_bn_bwd_reduce(const float* dy, int64_t dy_ld, const float
 __global__ void bn_bwd_finalize_kernel(ColSrc src, ColSrc loc, long M, int C, const float* gamma, const float* save_mean,
                                        const float* save_invstd, float* dgamma, float* dbeta, float* coef) {
     SGX_FIN_THREAD(src, C);
-    double sg = col_total(src, 0, C, c, cok), sgx = col_total(src, 1, C, c, cok);
+    double tot[2];
+    col_totals<2>(src, C, c, cok, tot);
+    const double sg = tot[0], sgx = tot[1];
     // (loc: the synchronised-BatchNorm path, one fp64 row per plane, never cooperative - read by the writer lanes only)
     if (!writer) return;
     double mean = save_mean[c], invstd = save_invstd[c], g = gamma ? (double)gamma[c] : 1.0;
@@ -723,9 +779,10 @@ __global__ void qarep_fwd_finalize_kernel(ColSrc src, long M, int C, const float
                                           float* rm3, float* rv3, const float* gp, const float* bp, float epsp, float momp, float* rmp, float* rvp,
                                           float* cf, float* sv) {
     SGX_FIN_THREAD(src, C);
-    const double Sy = col_total(src, 0, C, c, cok), Syy = col_total(src, 1, C, c, cok), Su = col_total(src, 2, C, c, cok),
-                 Suu = col_total(src, 3, C, c, cok), Syu = col_total(src, 4, C, c, cok);
+    double tot[5];
+    col_totals<5>(src, C, c, cok, tot);
     if (!writer) return;
+    const double Sy = tot[0], Syy = tot[1], Su = tot[2], Suu = tot[3], Syu = tot[4];
     const double m = (double)M, unb = M > 1 ? m / (m - 1.0) : 1.0;
     const double mean3 = Sy / m;
     double var3 = Syy / m - mean3 * mean3;
@@ -814,9 +871,10 @@ extern "C" int32_t sgx_qarep_bwd_reduce(const float* dout, int64_t d_ld, const f
 __global__ void qarep_bwd_finalize_kernel(ColSrc src, long M, int C, const float* gamma3, const float* gammap, const float* sv, float* dgamma3,
                                           float* dgammap, float* dbetap, float* cb) {
     SGX_FIN_THREAD(src, C);
-    const double Sg = col_total(src, 0, C, c, cok), Sgs = col_total(src, 1, C, c, cok), Sgy = col_total(src, 2, C, c, cok),
-                 Ssy = col_total(src, 3, C, c, cok);
+    double tot[4];
+    col_totals<4>(src, C, c, cok, tot);
     if (!writer) return;
+    const double Sg = tot[0], Sgs = tot[1], Sgy = tot[2], Ssy = tot[3];
     const double m = (double)M, invstd3 = sv[C + c], invstdp = sv[5 * C + c];
     const double gp = gammap ? (double)gammap[c] : 1.0, g3 = gamma3 ? (double)gamma3[c] : 1.0;
     if (dgammap) dgammap[c] += (float)(invstdp * Sgs);
@@ -893,8 +951,10 @@ struct ColsumF {
 };
 __global__ void colsum_finalize_kernel(ColSrc src, int C, float* out, int accumulate) {
     SGX_FIN_THREAD(src, C);
-    double s = col_total(src, 0, C, c, cok);
+    double tot[1];
+    col_totals<1>(src, C, c, cok, tot);
     if (!writer) return;
+    const double s = tot[0];
     out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 extern "C" int64_t sgx_colsum_workspace(int64_t M, int32_t C) {

@@ -1848,8 +1848,14 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
 // separate reduce launch, no workgroup folding more than one partner tile per level.  The hand-over moves with device-scope stores /
 // loads (sc1), not with L2 write-back fences.  Tickets are zero on entry and are left zero (the second arriver of a pair resets it).
 // ------------------------------------------------------------------------------------------------
-#define WG_BKP 16
+#define WG_BKP 16      // pixels per slab (template parameter BKP of the kernel: 16, or WG_BKP_DEEP for the tiles whose two slabs stay <= 32 KB)
+#define WG_BKP_DEEP 32
 #define WG_MAX_SPLIT 4096
+#ifdef SGX_WGRAD_LAB
+#define WG_AB(bit) (g.lab & (bit))
+#else
+#define WG_AB(bit) false
+#endif
 #define WG_MAX_JOBS 24  // the job table travels as kernel arguments: 24 x (152 + 4) B + 8 B < 4 KB
 
 struct WgJob {
@@ -1866,19 +1872,23 @@ struct WgJob {
 };
 struct WgGroupParams {
     int njobs, xcd_order;
+    int lab;  // measurement builds (-DSGX_WGRAD_LAB) only: ablation bits - 1 no global loads, 2 no LDS stores (after the first slab), 4 no MFMAs, 8 no fold / dW
     int blk0[WG_MAX_JOBS];  // first workgroup of every job, together: the job lookup is a handful of scalar loads, not one per job
     WgJob jobs[WG_MAX_JOBS];
 };
 
-template <int BNK, int BJ, int WK, int WC>
-__global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
+// waves per SIMD the register budget is held to: accumulators (16 per 32x32 block of the wave's sub-tile) + 48 for the loop
+// (one-block sub-tiles fit 64 registers unprompted: no request)
+constexpr int wg_min_waves(int acc_regs) { return acc_regs <= 16 ? 1 : 512 / (acc_regs + 48); }
+template <int BNK, int BJ, int WK, int WC, int BKP>
+__global__ __launch_bounds__(WK * WC * 64, wg_min_waves((BNK / (WK * 32)) * (BJ / (WC * 32)) * 16)) void wgrad_kernel(WgGroupParams g) {
     constexpr int NTH = WK * WC * 64;
     constexpr int TK = BNK / (WK * 32), TC = BJ / (WC * 32);
     static_assert(TK >= 1 && TC >= 1 && TK * WK * 32 == BNK && TC * WC * 32 == BJ, "bad tile");
-    constexpr int G = NTH / WG_BKP;  // lanes per pixel row
+    constexpr int G = NTH / BKP;  // lanes per pixel row
     constexpr int DJ = (BNK / 4 + G - 1) / G, XJ = (BJ / 4 + G - 1) / G;
-    __shared__ float Ds[2 * WG_BKP * BNK];
-    __shared__ float Xs[2 * WG_BKP * BJ];
+    __shared__ float Ds[2 * BKP * BNK];
+    __shared__ float Xs[2 * BKP * BJ];
     __shared__ int s_last;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1908,7 +1918,7 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
     const long x_ld_pix = p.x_ld_pix, x_ld_img = p.x_ld_img, y_ld_pix = p.y_ld_pix, y_ld_img = p.y_ld_img;
     const int mbeg = split * p.mchunk;
     const int mend = min(M, mbeg + p.mchunk);
-    const int nkt = (mend > mbeg) ? (mend - mbeg + WG_BKP - 1) / WG_BKP : 0;
+    const int nkt = (mend > mbeg) ? (mend - mbeg + BKP - 1) / BKP : 0;
     const int hw = Ho * Wo;
 
     // descriptors re-based at the split's first image
@@ -1963,9 +1973,9 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
             rx[q] = sgx_buf_ld4(bufX, ok ? (unsigned)(xbase + xdelta[q]) : SGX_BUF_OOB);
         }
         // advance this lane's pixel by one slab
-        m += WG_BKP;
-        if (Wo >= WG_BKP) {
-            wo += WG_BKP;
+        m += BKP;
+        if (Wo >= BKP) {
+            wo += BKP;
             if (wo >= Wo) {
                 wo -= Wo;
                 if (++ho >= Ho) {
@@ -1984,10 +1994,10 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < DJ; ++q)
-            if (dcol[q] < BNK) sgx_st4(&Ds[buf * WG_BKP * BNK + prow * BNK + dcol[q]], rd[q]);
+            if (dcol[q] < BNK) sgx_st4(&Ds[buf * BKP * BNK + prow * BNK + dcol[q]], rd[q]);
 #pragma unroll
         for (int q = 0; q < XJ; ++q)
-            if (xcol[q] < BJ) sgx_st4(&Xs[buf * WG_BKP * BJ + prow * BJ + xcol[q]], rx[q]);
+            if (xcol[q] < BJ) sgx_st4(&Xs[buf * BKP * BJ + prow * BJ + xcol[q]], rx[q]);
     };
 
     sgx_f32x16 acc[TK][TC];
@@ -2006,21 +2016,26 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
     const int fcol = lane & 31, fkh = lane >> 5;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile();
+        if (kt + 1 < nkt && !WG_AB(1)) load_tile();
+        if (!WG_AB(4))
 #pragma unroll
-        for (int kk = 0; kk < WG_BKP / 2; ++kk) {
+        for (int kk = 0; kk < BKP / 2; ++kk) {
             float af[TK], bf[TC];
 #pragma unroll
-            for (int i = 0; i < TK; ++i) af[i] = Ds[buf * WG_BKP * BNK + (2 * kk + fkh) * BNK + wk * TK * 32 + i * 32 + fcol];
+            for (int i = 0; i < TK; ++i) af[i] = Ds[buf * BKP * BNK + (2 * kk + fkh) * BNK + wk * TK * 32 + i * 32 + fcol];
 #pragma unroll
-            for (int j = 0; j < TC; ++j) bf[j] = Xs[buf * WG_BKP * BJ + (2 * kk + fkh) * BJ + wc * TC * 32 + j * 32 + fcol];
+            for (int j = 0; j < TC; ++j) bf[j] = Xs[buf * BKP * BJ + (2 * kk + fkh) * BJ + wc * TC * 32 + j * 32 + fcol];
 #pragma unroll
             for (int i = 0; i < TK; ++i)
 #pragma unroll
                 for (int j = 0; j < TC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        if (kt + 1 < nkt && !WG_AB(2)) store_tile(buf ^ 1);
         __syncthreads();
+    }
+    if (WG_AB(8)) {  // main loop only (the accumulators stay observable)
+        if (acc[0][0][0] == 1.2345e-30f) p.dw[0] = 1.f;
+        return;
     }
     // ---- fold the pixel splits of this tile: a fixed binary tree over the split index, walked by arrival -------------------------------------
     // Level L pairs node i = split >> L with its sibling i ^ 1.  A workgroup holding a node's value publishes it (device-scope stores into
@@ -2035,7 +2050,7 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
         constexpr int TE = BNK * BJ;
         float* const base = p.part + (long)tile * ksplit * TE;
         int* const tk = p.tickets + (long)tile * ksplit;
-        const int lrow = (lane >> 5) * 4, lcol = lane & 31;
+        const int foff = (wk * TK * 32 + (lane >> 5) * 4) * BJ + wc * TC * 32 + (lane & 31);  // this lane's corner of the wave's sub-tile
         for (int L = 0; (1 << L) < ksplit; ++L) {
             const int i = split >> L, sib = i ^ 1;
             if (((long)sib << L) >= ksplit) continue;  // no sibling on this level: the value passes up as it is
@@ -2043,10 +2058,12 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
 #pragma unroll
             for (int a = 0; a < TK; ++a)
 #pragma unroll
-                for (int b = 0; b < TC; ++b)
+                for (int b = 0; b < TC; ++b) {
+                    float* const q = mine + foff + (a * 32) * BJ + b * 32;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        sgx_st_dev(&mine[(wk * TK * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + lrow) * BJ + wc * TC * 32 + b * 32 + lcol], acc[a][b][r]);
+                    for (int r = 0; r < 16; ++r) sgx_st_dev(&q[((r & 3) + 8 * (r >> 2)) * BJ], acc[a][b][r]);
+                    sgx_sched_fence();
+                }
             sgx_wait_stores();
             __syncthreads();
             if (tid == 0) {
@@ -2063,10 +2080,15 @@ __global__ __launch_bounds__(WK * WC * 64) void wgrad_kernel(WgGroupParams g) {
 #pragma unroll
             for (int a = 0; a < TK; ++a)
 #pragma unroll
-                for (int b = 0; b < TC; ++b)
+                for (int b = 0; b < TC; ++b) {  // one 32x32 block at a time: 16 loads in flight per lane, 16 registers - not TK*TC*16
+                    const float* const q = other + foff + (a * 32) * BJ + b * 32;
+                    float v[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[a][b][r] += sgx_ld_dev(&other[(wk * TK * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + lrow) * BJ + wc * TC * 32 + b * 32 + lcol]);
+                    for (int r = 0; r < 16; ++r) v[r] = sgx_ld_dev(&q[((r & 3) + 8 * (r >> 2)) * BJ]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] += v[r];
+                    sgx_sched_fence();
+                }
         }
     }
     // the root of the tile: into dW
@@ -2112,12 +2134,18 @@ extern "C" int32_t sgx_stats_blocks(int64_t M);
 extern "C" int64_t sgx_colsum_workspace(int64_t M, int32_t C);
 // grouped-launch knobs (measurement: sgx_debug_set_wgrad_group): rounds of work items a large group is cut into, the work of an item
 // below which a small group is not cut further (MFLOP), XCD-aware block order
-static std::atomic<int> g_wg_rounds{6}, g_wg_item_mflop{8}, g_wg_xcd{1};
+static std::atomic<int> g_wg_rounds{6}, g_wg_item_mflop{8}, g_wg_xcd{1}, g_wg_deep{0};
 extern "C" int32_t sgx_debug_set_wgrad_group(int32_t rounds, int32_t item_mflop, int32_t xcd_order) {
     SGX_CHECK_ARG(rounds >= 0 && item_mflop >= 0, "debug_set_wgrad_group: negative value");
     g_wg_rounds = rounds ? rounds : 6;
     g_wg_item_mflop = item_mflop ? item_mflop : 8;
     g_wg_xcd = xcd_order ? 1 : 0;
+    return SGX_OK;
+}
+static std::atomic<int> g_wg_lab{0};
+extern "C" int32_t sgx_debug_set_wgrad_loop(int32_t deep_slab, int32_t ablate) {
+    g_wg_deep = deep_slab ? 1 : 0;
+    g_wg_lab = ablate;
     return SGX_OK;
 }
 struct WgPlan {
@@ -2183,7 +2211,7 @@ static int32_t wgrad_group_plan(const sgx_wgrad_job* jobs, int n, std::vector<Wg
         if (ks < need) ks = need;
         if (ks > WG_MAX_SPLIT) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv bwd_weight: operand too large (%ld pixel ranges of 1 GiB)", need);
         mchunk = (M + ks - 1) / ks;
-        mchunk = ((mchunk + WG_BKP - 1) / WG_BKP) * WG_BKP;
+        mchunk = ((mchunk + WG_BKP_DEEP - 1) / WG_BKP_DEEP) * WG_BKP_DEEP;
         ks = (M + mchunk - 1) / mchunk;
         pl.ksplit = (int)ks;
         pl.mchunk = (int)mchunk;
@@ -2209,7 +2237,13 @@ extern "C" int32_t sgx_conv2d_bwd_weight_group_sizes(const sgx_wgrad_job* jobs, 
 }
 template <int BNK, int BJ, int WK, int WC>
 static void launch_wgrad(const WgGroupParams& g, int nblk, void* stream) {
-    SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC>), dim3((unsigned)nblk), dim3(WK * WC * 64), 0, stream, g);
+    if constexpr (BNK + BJ <= 128) {  // 32-pixel slabs (half the barriers, twice the bytes in flight per lane) where two of them fit 32 KB
+        if (g_wg_deep.load(std::memory_order_relaxed)) {
+            SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP_DEEP>), dim3((unsigned)nblk), dim3(WK * WC * 64), 0, stream, g);
+            return;
+        }
+    }
+    SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP>), dim3((unsigned)nblk), dim3(WK * WC * 64), 0, stream, g);
 }
 extern "C" int32_t sgx_conv2d_bwd_weight_group(const sgx_wgrad_job* jobs, int32_t njobs, void* ws, int64_t ws_bytes, int32_t* tickets,
                                                int64_t ticket_ints, void* stream) {
@@ -2227,6 +2261,7 @@ extern "C" int32_t sgx_conv2d_bwd_weight_group(const sgx_wgrad_job* jobs, int32_
         WgGroupParams g;
         memset(&g, 0, sizeof(g));
         g.xcd_order = g_wg_xcd.load(std::memory_order_relaxed);
+        g.lab = g_wg_lab.load(std::memory_order_relaxed);
         int nblk = 0;
         double flops = 0.0, bytes = 0.0;
         for (int i = first; i < njobs && g.njobs < WG_MAX_JOBS; ++i) {

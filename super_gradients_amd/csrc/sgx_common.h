@@ -116,7 +116,11 @@ static inline float sgx_ld_dev(const float* p) { return *p; }
 static inline void sgx_st4_dev(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 static inline float4 sgx_ld4_dev(const float* p) { return *reinterpret_cast<const float4*>(p); }
 #define sgx_wait_stores() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define sgx_sched_fence() ((void)0)
 #else
+// no instruction moves across this point in the scheduler: bounds how many independent loads an unrolled loop keeps in flight (and with
+// them the registers a kernel's tail claims for the WHOLE kernel: the allocation of a kernel is its hungriest region's)
+#define sgx_sched_fence() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ void sgx_st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float sgx_ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sgx_st4_dev(float* p, float4 v) {

@@ -205,9 +205,10 @@ class SgxNetwork(nn.Module):
         self._wt_valid = False
         # Weight gradients are mutually independent: blocks queue them (ConvLayer.wgrad) and the network launches a stretch of backward's
         # worth together (kernels.conv2d_bwd_weight_group: one launch per tile shape, splits sized for the group, partials folded inside
-        # the launch) - whenever the queued work passes SGX_WGRAD_GROUP_GFLOP (default 40, ~0.5 ms of chip time: the stretch that is
-        # left un-overlapped at the end of backward), at every gradient-bucket boundary and at the end of backward.  0: one call per layer.
-        self.wg_group_flops = float(os.environ.get("SGX_WGRAD_GROUP_GFLOP", "40")) * 1e9
+        # the launch) - whenever the queued work passes SGX_WGRAD_GROUP_GFLOP (default 160, ~2 ms of chip time; measured r3i/r3j on
+        # YOLO-NAS-S: 40 -> 613, 160 -> 633, 400 -> 629 images/s - every launch ends in a fold chain that nothing of its own fills), at every
+        # gradient-bucket boundary and at the end of backward.  0: one call per layer.
+        self.wg_group_flops = float(os.environ.get("SGX_WGRAD_GROUP_GFLOP", "160")) * 1e9
         self._wg_pending, self._wg_flops = [], 0.0
         # The data-gradient weight transposes of ALL convolutions run as one launch at the start of every training forward (a job table
         # built once - the operands are arena views, their addresses never change) instead of one launch per convolution and parity class

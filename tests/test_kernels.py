@@ -1113,8 +1113,17 @@ def test_wgrad_group(backend, monkeypatch):
         K.conv2d_bwd_weight_group(ents)
         for (shape, e, ref) in zip(cases, ents, refs):
             assert_close(e[2].cpu(), ref, TOL, f"grouped wgrad, default split {shape}")
+        # 32-pixel slabs (the small-tile variants of the loop), small items again
+        lib().sgx_debug_set_wgrad_group(6, 1, 1)
+        lib().sgx_debug_set_wgrad_loop(1, 0)
+        for e in ents:
+            e[2].zero_()
+        K.conv2d_bwd_weight_group(ents)
+        for (shape, e, ref) in zip(cases, ents, refs):
+            assert_close(e[2].cpu(), ref, TOL, f"grouped wgrad, 32-pixel slabs {shape}")
     finally:
         lib().sgx_debug_set_wgrad_group(0, 0, 1)
+        lib().sgx_debug_set_wgrad_loop(0, 0)
 
 
 # (N, H, W, C, K): 3x3 stride-1 pad-1 problems for the patch kernel - ragged 8 x 16 tiles in both directions, both chunk depths (C % 32),
