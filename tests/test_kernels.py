@@ -1113,14 +1113,15 @@ def test_wgrad_group(backend, monkeypatch):
         K.conv2d_bwd_weight_group(ents)
         for (shape, e, ref) in zip(cases, ents, refs):
             assert_close(e[2].cpu(), ref, TOL, f"grouped wgrad, default split {shape}")
-        # 32-pixel slabs (the small-tile variants of the loop), small items again
+        # the loop's variants: 32-pixel slabs (small tiles), one slab of loads in flight instead of two; small items again
         lib().sgx_debug_set_wgrad_group(6, 1, 1)
-        lib().sgx_debug_set_wgrad_loop(1, 0)
-        for e in ents:
-            e[2].zero_()
-        K.conv2d_bwd_weight_group(ents)
-        for (shape, e, ref) in zip(cases, ents, refs):
-            assert_close(e[2].cpu(), ref, TOL, f"grouped wgrad, 32-pixel slabs {shape}")
+        for loop, what in ((1, "32-pixel slabs"), (2, "one slab in flight")):
+            lib().sgx_debug_set_wgrad_loop(loop, 0)
+            for e in ents:
+                e[2].zero_()
+            K.conv2d_bwd_weight_group(ents)
+            for (shape, e, ref) in zip(cases, ents, refs):
+                assert_close(e[2].cpu(), ref, TOL, f"grouped wgrad, {what} {shape}")
     finally:
         lib().sgx_debug_set_wgrad_group(0, 0, 1)
         lib().sgx_debug_set_wgrad_loop(0, 0)

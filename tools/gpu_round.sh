@@ -1,7 +1,8 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, smoke, bench, rocprofv3 kernel stats + PMC passes.  Outputs under gpurun_out/$TAG/.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round.sh r1a'
-# Stages are individually time-boxed so that one hang cannot eat the box budget.  STAGES env selects a subset.
+# Stages are individually time-boxed so that one hang cannot eat the box budget (rocprofv3 gets SIGKILL 10 s after SIGTERM: after an
+# aborted counter configuration it catches SIGTERM and never exits - r3o lost 25 GPU-minutes that way).  STAGES env selects a subset.
 TAG=${1:-r1}
 STAGES=${STAGES:-"bench stats pmc tests smoke"}
 REPO=$(pwd)
@@ -27,7 +28,7 @@ fi
 PROF_CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-nms --no-predict --no-exclusive"
 if has stats; then
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o bench -- bash -c "cd $REPO && $PROF_CMD" > "$OUT/stats.log" 2>&1
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o bench -- bash -c "cd $REPO && $PROF_CMD" > "$OUT/stats.log" 2>&1
   echo "stats rc=$?" >> "$OUT/stats.log"
   cd "$REPO"
   python tools/prof_summary.py stats "$OUT/stats" > "$OUT/kernel_stats_summary.txt" 2>&1
@@ -43,7 +44,7 @@ if has pmc; then
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
     i=$((i+1))
     cd /tmp
-    timeout 420 rocprofv3 --pmc $set --kernel-trace -f csv -d "$OUT/pmc$i" -o bench -- bash -c "cd $REPO && $PMC_CMD" > "$OUT/pmc$i.log" 2>&1
+    timeout -k 10 420 rocprofv3 --pmc $set --kernel-trace -f csv -d "$OUT/pmc$i" -o bench -- bash -c "cd $REPO && $PMC_CMD" > "$OUT/pmc$i.log" 2>&1
     echo "pmc$i ($set) rc=$?" >> "$OUT/pmc$i.log"
     cd "$REPO"
     python tools/prof_summary.py pmc "$OUT/pmc$i" > "$OUT/pmc${i}_summary.txt" 2>&1
@@ -56,12 +57,12 @@ fi
 if has nms; then
   # the post-prediction kernels alone: kernel stats + FETCH_SIZE / WRITE_SIZE passes of 20 calls -> profiles/nms_traffic.json
   cd /tmp
-  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/nms_stats" -o nms -- bash -c "cd $REPO && python bench.py --only-nms 20" > "$OUT/nms_stats.log" 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/nms_stats" -o nms -- bash -c "cd $REPO && python bench.py --only-nms 20" > "$OUT/nms_stats.log" 2>&1
   cd "$REPO"; python tools/prof_summary.py stats "$OUT/nms_stats" > "$OUT/nms_kernel_stats_summary.txt" 2>&1; head -12 "$OUT/nms_kernel_stats_summary.txt"
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1)); cd /tmp
-    timeout 300 rocprofv3 --pmc $set --kernel-trace -f csv -d "$OUT/nms_pmc$i" -o nms -- bash -c "cd $REPO && python bench.py --only-nms 20" > "$OUT/nms_pmc$i.log" 2>&1
+    timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace -f csv -d "$OUT/nms_pmc$i" -o nms -- bash -c "cd $REPO && python bench.py --only-nms 20" > "$OUT/nms_pmc$i.log" 2>&1
     cd "$REPO"
   done
   python tools/pmc_traffic.py "$OUT/nms_pmc1" "$OUT/nms_pmc2" "$OUT/nms_traffic.json" - 20 > "$OUT/nms_traffic.log" 2>&1; head -4 "$OUT/nms_traffic.json"
