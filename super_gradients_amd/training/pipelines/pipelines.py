@@ -60,6 +60,21 @@ def load_images(images) -> List[Union[np.ndarray, torch.Tensor]]:
     return [_load_image(images)]
 
 
+_FP16_NOTED = False
+
+
+def _note_fp16_once():
+    """fp16=True is the reference's default (pipelines.py:76: torch.autocast around the forward).  This build has no half-precision
+    kernels: the forward runs in fp32 - results are at least as precise, throughput is the fp32 path's.  Said once per process."""
+    global _FP16_NOTED
+    if not _FP16_NOTED:
+        _FP16_NOTED = True
+        import logging
+
+        logging.getLogger(__name__).warning("predict(fp16=True): no half-precision kernels on this build - the forward runs in fp32 "
+                                            "(pass fp16=False to silence this note)")
+
+
 class Pipeline(ABC):
     def __init__(self, model, image_processor: Union[Processing, List[Processing]], class_names: List[str], device: Optional[str] = None,
                  fuse_model: bool = True, dtype: Optional[torch.dtype] = None, fp16: bool = True):
@@ -81,6 +96,8 @@ class Pipeline(ABC):
         self.image_processor = image_processor
         self.fuse_model = fuse_model  # fused on the first batch, like the reference (pipelines.py:91,95-100)
         self.fp16 = fp16
+        if fp16:
+            _note_fp16_once()
 
     def _fuse_model(self, input_size):
         cache, self.model._pipeline_cache = getattr(self.model, "_pipeline_cache", None), None  # (it holds this pipeline: not part of the copy)
