@@ -8,6 +8,7 @@ import torch
 
 from ...common.factories import UnknownTypeException
 from ...common.registry import ARCHITECTURES
+from ..utils.checkpoint_utils import contains_opaque, read_checkpoint
 from ..utils.utils import HpmStruct, get_param
 
 
@@ -80,6 +81,10 @@ def _maybe_load_preprocessing_params(net, ckpt) -> bool:
     (Processing.to_config) so the file stays loadable with weights_only=True."""
     if not (isinstance(ckpt, dict) and "processing_params" in ckpt and hasattr(net, "set_dataset_processing_params")):
         return False
+    if contains_opaque(ckpt["processing_params"]):  # a reference-written file: its image processor is a pickled object, not a config
+        warnings.warn("The checkpoint stores its preprocessing pipeline as pickled objects, which are not constructed from a file. Before calling "
+                      "predict make sure to call set_dataset_processing_params.")
+        return False
     try:
         net.set_dataset_processing_params(**ckpt["processing_params"])
         return True
@@ -97,7 +102,7 @@ def get(model_name: str, arch_params: Optional[dict] = None, num_classes: Option
     if load_backbone and not checkpoint_path:
         raise ValueError("Please set checkpoint_path when load_backbone=True")
     if checkpoint_path:
-        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)  # tensors and plain containers only: never runs pickled code
+        ckpt = read_checkpoint(checkpoint_path)  # tensors and plain containers only: never runs pickled code (objects come back as placeholders)
         sd = ckpt.get("ema_net", ckpt.get("net", ckpt)) if isinstance(ckpt, dict) else ckpt
         adaptive_load_state_dict(net, sd, strict_load)
         _maybe_load_preprocessing_params(net, ckpt)

@@ -24,6 +24,7 @@ from ...common.registry import LOSSES, LR_SCHEDULERS_CLS_DICT, LR_WARMUP_CLS_DIC
 from ...modules.engine import SgxNetwork
 from ..utils import distributed_training_utils as dtu
 from ..utils.callbacks import Callback, CallbackHandler, LRCallbackBase, PhaseContext
+from ..utils.checkpoint_utils import read_checkpoint
 from ..utils.ema import ModelEMA
 from ..utils.optimizers import build_optimizer
 from ..utils.utils import HpmStruct
@@ -57,12 +58,22 @@ class AverageMeter:
         self.sum = v.clone() if self.sum is None else self.sum + v
         self.n += batch_size
 
-    def all_reduce(self):
-        """Sum the meter over the data-parallel ranks, so that every rank reports - and selects its best checkpoint by - the same numbers."""
-        if self.sum is not None and dtu.get_world_size() > 1:
-            t = torch.cat([self.sum.double(), torch.tensor([float(self.n)], device=self.sum.device, dtype=torch.float64)])
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
-            self.sum, self.n = t[:-1].float(), int(round(float(t[-1])))
+    def all_reduce(self, device=None):
+        """Sum the meter over the data-parallel ranks, so that every rank reports - and selects its best checkpoint by - the same numbers.
+        EVERY rank takes part, also one that saw no batch (an empty shard, max_valid_batches): it learns the item count from the others
+        (one MAX reduction of the length) and contributes zeros - a rank that skipped the collective would leave the others waiting."""
+        if dtu.get_world_size() <= 1:
+            return
+        dev = self.sum.device if self.sum is not None else torch.device(device if device is not None else "cpu")
+        k = torch.tensor([0 if self.sum is None else self.sum.numel()], device=dev, dtype=torch.int64)
+        torch.distributed.all_reduce(k, op=torch.distributed.ReduceOp.MAX)
+        k = int(k.item())
+        if k == 0:
+            return
+        mine = self.sum.double() if self.sum is not None else torch.zeros(k, device=dev, dtype=torch.float64)
+        t = torch.cat([mine, torch.tensor([float(self.n)], device=dev, dtype=torch.float64)])
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+        self.sum, self.n = t[:-1].float(), int(round(float(t[-1])))
 
     @property
     def average(self):
@@ -401,7 +412,7 @@ class Trainer:
         else:
             run(self.net)
         self.net.train()
-        meter.all_reduce()  # ranks validate different shards: _track_best must see one value everywhere
+        meter.all_reduce(device=device)  # ranks validate different shards: _track_best must see one value everywhere
         out = dict(zip(self.loss_logging_items_names or [], meter.average))
         for m in metrics:
             out.update(_metric_results(m))
@@ -450,8 +461,11 @@ class Trainer:
             state["ema_net"] = {k: v.cpu() for k, v in self.ema_model.state_dict().items()}
         if getattr(self, "_processing_params", None) is not None:  # sg_trainer.py:710-712, with the image processor as a plain config
             pp = dict(self._processing_params)
-            if hasattr(pp.get("image_processor"), "to_config"):
-                pp["image_processor"] = pp["image_processor"].to_config()
+            ip = pp.get("image_processor")
+            if hasattr(ip, "to_config"):
+                pp["image_processor"] = ip.to_config()
+            elif isinstance(ip, (list, tuple)) and all(hasattr(q, "to_config") for q in ip):  # a list of Processing objects = their composition
+                pp["image_processor"] = {"ComposeProcessing": {"processings": [q.to_config() for q in ip]}}
             if pp.get("class_names") is not None:
                 pp["class_names"] = list(pp["class_names"])
             state["processing_params"] = pp
@@ -466,7 +480,7 @@ class Trainer:
         return st
 
     def _load_checkpoint(self, path, load_opt):
-        ckpt = torch.load(path, map_location="cpu", weights_only=True)  # tensors, numbers, strings and plain containers only (same rule as models.get)
+        ckpt = read_checkpoint(path)  # tensors, numbers, strings and plain containers only (same rule as models.get)
         self.net.load_state_dict(ckpt["net"], strict=True)
         if self.ema_model is not None and "ema_net" in ckpt:
             with self.ema_model.averaged() as net:

@@ -134,6 +134,15 @@ def _worker(rank, world, port, outdir):
     out["buffers_before"] = (net.b_arena.buf.clone(), net.i_arena.clone())
     reducer.broadcast_buffers(0)
     out["buffers_after"] = (net.b_arena.buf.clone(), net.i_arena.clone())
+    # ---- validation meters: a rank that saw no batch still takes part in the exchange (and learns the item count from the others) ---------
+    from super_gradients_amd.training.sg_trainer.sg_trainer import AverageMeter
+
+    meter = AverageMeter()
+    if rank == 0:
+        meter.update(torch.tensor([1.0, 2.0, 3.0]), 4)
+        meter.update(torch.tensor([3.0, 2.0, 1.0]), 4)
+    meter.all_reduce(device=dev)
+    out["meter"] = (meter.average, meter.n)
     if rank == 0:
         ref.train()
         yf = ref(xfull)
@@ -199,6 +208,8 @@ def test_world_size_2_gloo(tmp_path):
     assert not torch.equal(r[0]["buffers_before"][0], r[1]["buffers_before"][0])
     for i in range(world):
         assert torch.equal(r[i]["buffers_after"][0], r[0]["buffers_before"][0]) and torch.equal(r[i]["buffers_after"][1], r[0]["buffers_before"][1])
+        # both ranks report rank 0's two batches (rank 1 had none): mean over 8 samples
+        assert r[i]["meter"][1] == 8 and r[i]["meter"][0] == pytest.approx((2.0, 2.0, 2.0))
 
 
 def _worker_rccl(rank, world, port, outdir):
