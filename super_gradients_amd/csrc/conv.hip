@@ -2014,8 +2014,8 @@ __global__ __launch_bounds__(WK * WC * 64, wg_min_waves((BNK / (WK * 32)) * (BJ 
         load_tile(rdA, rxA);
         store_tile(0, rdA, rxA);
         if (PF == 2) {
-            if (nkt > 1) load_tile(rdA, rxA);
-            if (nkt > 2) load_tile(rdB, rxB);
+            load_tile(rdA, rxA);
+            load_tile(rdB, rxB);
         }
     }
     __syncthreads();
@@ -2045,17 +2045,23 @@ __global__ __launch_bounds__(WK * WC * 64, wg_min_waves((BNK / (WK * 32)) * (BJ 
     } else {
         // step kt: the other LDS buffer is free (its readers passed the barrier): store slab kt+1 (requested two steps ago), re-issue the
         // set for slab kt+3, then the MFMAs of slab kt
+        // Store and re-issue are UNCONDITIONAL: past the end of the range the lanes' offsets are out of bounds (no memory access, zeros) and
+        // the slab stored last is never read.  With `if (kt + 3 < nkt)` around the loads hipcc's wait-count pass has a path on which the
+        // younger set was never requested, takes the minimum over paths and waits for vmcnt(0) before the store - i.e. for the set requested
+        // ONE step ago as well, which makes the second register set pointless (r3n's build: read off the ISA afterwards).
         auto step = [&](int kt, float4* rd, float4* rx) {
             const int buf = kt & 1;
-            if (kt + 1 < nkt && !WG_AB(2)) store_tile(buf ^ 1, rd, rx);
-            if (kt + 3 < nkt && !WG_AB(1)) load_tile(rd, rx);
+            if (!WG_AB(2)) store_tile(buf ^ 1, rd, rx);
+            if (!WG_AB(1)) load_tile(rd, rx);
             if (!WG_AB(4)) mfma_slab(buf);
             __syncthreads();
         };
-        for (int kt = 0; kt < nkt; kt += 2) {
+        int kt = 0;
+        for (; kt + 1 < nkt; kt += 2) {
             step(kt, rdA, rxA);
-            if (kt + 1 < nkt) step(kt + 1, rdB, rxB);
+            step(kt + 1, rdB, rxB);
         }
+        if (kt < nkt) step(kt, rdA, rxA);
     }
     if (WG_AB(8)) {  // main loop only (the accumulators stay observable)
         if (acc[0][0][0] == 1.2345e-30f) p.dw[0] = 1.f;
@@ -2263,6 +2269,14 @@ template <int BNK, int BJ, int WK, int WC>
 static void launch_wgrad(const WgGroupParams& g, int nblk, void* stream) {
     const int loop = g_wg_deep.load(std::memory_order_relaxed);  // bit 0: 32-pixel slabs, bit 1: ONE slab in flight (default: two)
     const dim3 grid((unsigned)nblk), block(WK * WC * 64);
+    if constexpr (BNK == 64 && BJ == 64 && WK == 2 && WC == 2) {
+        // bit 2 (measurement, not yet measured): the 64x64 tile on TWO waves - two 32x32 blocks per wave, half the address arithmetic /
+        // LDS traffic per MFMA (r3o: 5.9 VALU + 3.7 SALU instructions per MFMA with one block per wave)
+        if (loop & 4) {
+            launch_wgrad<64, 64, 1, 2>(g, nblk, stream);
+            return;
+        }
+    }
     if constexpr (BNK + BJ <= 128) {  // 32-pixel slabs (half the barriers, twice the bytes in flight per lane) where two of them fit 32 KB
         if (loop & 1) {
             SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP_DEEP, 1>), grid, block, 0, stream, g);

@@ -1115,7 +1115,7 @@ def test_wgrad_group(backend, monkeypatch):
             assert_close(e[2].cpu(), ref, TOL, f"grouped wgrad, default split {shape}")
         # the loop's variants: 32-pixel slabs (small tiles), one slab of loads in flight instead of two; small items again
         lib().sgx_debug_set_wgrad_group(6, 1, 1)
-        for loop, what in ((1, "32-pixel slabs"), (2, "one slab in flight")):
+        for loop, what in ((1, "32-pixel slabs"), (2, "one slab in flight"), (4, "64x64 tile on two waves")):
             lib().sgx_debug_set_wgrad_loop(loop, 0)
             for e in ents:
                 e[2].zero_()
