@@ -1961,36 +1961,52 @@ __global__ __launch_bounds__(WK * WC * 64, wg_min_waves((BNK / (WK * 32)) * (BJ 
     // PF register sets of one slab each: PF = 1 loads slab kt+1 under the MFMAs of slab kt (a round trip to HBM has ONE slab's MFMA time);
     // PF = 2 keeps two slabs in flight - the set stored at the top of step kt was requested two steps earlier
     float4 rdA[DJ], rxA[XJ], rdB[PF == 2 ? DJ : 1], rxB[PF == 2 ? XJ : 1];
+    // Running byte offsets of this lane's pixel into dY (+ k0) and X (tap (0,0), before the padding shift) and its input coordinates: a slab
+    // step is additions - dY is linear in the pixel index inside an image; X moves BKP * stride pixels along the row, one constant more at
+    // a row wrap, another at an image wrap (r3o: 5.9 VALU instructions per MFMA with the offsets recomputed from (img, ho, wo) through
+    // 64-bit multiplies every slab).  31-bit by the split rule of the plan (every split under 1 GiB of either operand).
+    auto d_offset = [&](int im, int h, int w) { return (int)(((long)im * y_ld_img + ((long)h * Wo + w) * y_ld_pix + k0) * 4); };
+    auto x_offset = [&](int im, int h, int w) { return (int)(((long)im * x_ld_img + ((long)h * stride * W + w * stride) * x_ld_pix) * 4); };
+    int d_off = d_offset(img, ho, wo), x_off = x_offset(img, ho, wo);
+    int hi0 = ho * stride, wi0 = wo * stride;  // the lane's state from here on: m, hi0, wi0, d_off, x_off
+    const int d_step = (int)(BKP * y_ld_pix * 4), d_img_fix = (int)((y_ld_img - (long)hw * y_ld_pix) * 4);
+    const int x_step = (int)((long)BKP * stride * x_ld_pix * 4), x_row_fix = (int)((long)stride * (W - Wo) * x_ld_pix * 4);
+    const int x_img_fix = (int)((x_ld_img - (long)Ho * stride * W * x_ld_pix) * 4);
+    const int w_span = Wo * stride, h_span = Ho * stride;
     auto load_tile = [&](float4* rd, float4* rx) {
         const bool pok = m < mend;
-        const int dbase = (int)(((long)img * y_ld_img + ((long)ho * Wo + wo) * y_ld_pix + k0) * 4);
-        const int hi0 = ho * stride, wi0 = wo * stride;
-        const int xbase = (int)(((long)img * x_ld_img + ((long)hi0 * W + wi0) * x_ld_pix) * 4);
 #pragma unroll
-        for (int q = 0; q < DJ; ++q) rd[q] = sgx_buf_ld4(bufD, (pok && dok[q]) ? (unsigned)(dbase + dcol[q] * 4) : SGX_BUF_OOB);
+        for (int q = 0; q < DJ; ++q) rd[q] = sgx_buf_ld4(bufD, (pok && dok[q]) ? (unsigned)(d_off + dcol[q] * 4) : SGX_BUF_OOB);
 #pragma unroll
         for (int q = 0; q < XJ; ++q) {
             const int hi = hi0 + xdh[q], wi = wi0 + xdw[q];
             const bool ok = pok && xok[q] && hi >= 0 && hi < H && wi >= 0 && wi < W;
-            rx[q] = sgx_buf_ld4(bufX, ok ? (unsigned)(xbase + xdelta[q]) : SGX_BUF_OOB);
+            rx[q] = sgx_buf_ld4(bufX, ok ? (unsigned)(x_off + xdelta[q]) : SGX_BUF_OOB);
         }
         // advance this lane's pixel by one slab
         m += BKP;
         if (Wo >= BKP) {
-            wo += BKP;
-            if (wo >= Wo) {
-                wo -= Wo;
-                if (++ho >= Ho) {
-                    ho = 0;
-                    ++img;
+            wi0 += BKP * stride;
+            d_off += d_step;
+            x_off += x_step;
+            if (wi0 >= w_span) {  // next output row
+                wi0 -= w_span;
+                hi0 += stride;
+                x_off += x_row_fix;
+                if (hi0 >= h_span) {  // next image
+                    hi0 = 0;
+                    d_off += d_img_fix;
+                    x_off += x_img_fix;
                 }
             }
         } else {
-            int mm = m < M ? m : M - 1;
-            int im = mm / hw, rm = mm - im * hw;
-            ho = rm / Wo;
-            wo = rm - ho * Wo;
-            img = im - img0;
+            const int mm = m < M ? m : M - 1;
+            const int im = mm / hw, rm = mm - im * hw;
+            const int h = rm / Wo, w = rm - h * Wo;
+            d_off = d_offset(im - img0, h, w);
+            x_off = x_offset(im - img0, h, w);
+            hi0 = h * stride;
+            wi0 = w * stride;
         }
     };
     auto store_tile = [&](int buf, const float4* rd, const float4* rx) {

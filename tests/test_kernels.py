@@ -1071,7 +1071,9 @@ def test_wgrad_group(backend, monkeypatch):
     # (N, H, W, C, K, R, stride, pad)
     cases = [(2, 80, 80, 64, 64, 3, 1, 1), (2, 80, 80, 96, 96, 1, 1, 0), (4, 40, 40, 32, 48, 3, 2, 1), (1, 20, 20, 128, 32, 1, 1, 0),
              (2, 160, 160, 4, 48, 3, 2, 1)] if gpu else \
-            [(1, 42, 42, 4, 8, 1, 1, 0), (1, 9, 7, 8, 36, 3, 1, 1), (2, 12, 12, 8, 8, 3, 2, 1), (1, 20, 26, 4, 40, 1, 1, 0)]
+            [(1, 42, 42, 4, 8, 1, 1, 0), (1, 9, 7, 8, 36, 3, 1, 1), (2, 12, 12, 8, 8, 3, 2, 1), (1, 20, 26, 4, 40, 1, 1, 0),
+             # rows of >= 16 pixels with row AND image wraps inside a split (the incremental lane offsets), stride 1 and 2
+             (2, 17, 18, 4, 8, 3, 1, 1), (2, 34, 36, 4, 8, 3, 2, 1)]
     ents, refs = [], []
     for i, shape in enumerate(cases):
         n, h, w, c, k, r, s, p = shape

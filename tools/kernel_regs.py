@@ -2,14 +2,19 @@
 
     python tools/kernel_regs.py super_gradients_amd/csrc/conv.hip [filter-substring]
 """
+import os
 import re
 import subprocess
 import sys
 
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-Wno-unused-result",
-       "-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", src, "-o", "/dev/null"]
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "super_gradients_amd", "csrc"))
+import build as product_build  # noqa: E402  (the product's per-file flags: the report must describe the code objects that ship)
+
+base = os.path.basename(src)
+extra = (["-ffp-contract=off"] if base in product_build.NO_CONTRACT else []) + product_build.EXTRA.get(base, [])
+cmd = [product_build.HIPCC] + product_build.COMMON + extra + ["-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", src, "-o", "/dev/null"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rec, rows = {}, []
 for line in out.splitlines():
