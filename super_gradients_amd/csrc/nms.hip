@@ -529,16 +529,27 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
 }
 
 // ---- split suppression (top-k <= 1024) ---------------------------------------------------------------------------------------------------
-// nms_mask_kernel: grid = (16 strips of 64 candidates, images).  Row i of the triangular matrix: bit j of word w - c = "i suppresses
-// 64 w + j" for the words w >= c = i / 64; a wave owns a row, a lane one column, the word is the ballot of 64 IoU tests (the arithmetic
-// order of torchvision's kernel, as above).  Every row of the strip is built (the in-kernel form skipped rows already suppressed: about
-// three times the tests, on sixteen times the workgroups of a chip that was 7/8 idle).
+// nms_mask_kernel: Row i of the triangular matrix: bit j of word w - c = "i suppresses 64 w + j" for the words w >= c = i / 64; a wave owns
+// a row, a lane one column, the word is the ballot of 64 IoU tests (the arithmetic order of torchvision's kernel, as above).  Every row is
+// built (the in-kernel form skipped rows already suppressed: about three times the tests, on a chip that was 7/8 idle).
+// Work items = (strip c of 64 rows, group g of NMS_MASK_WG words): 40 per image instead of one workgroup per strip - strip 0 alone was 16
+// words x 64 rows on four waves (the r3z trace: 68 us per call, the longest kernel of the post-prediction call, bound by its longest
+// workgroup); an item is at most 4 words x 64 rows = 64 ballots per wave, and stages only its own 64 rows and 256 columns.
 #define NMS_MASK_THREADS 256
+#define NMS_MASK_WG 4                                        // words per work item
+#define NMS_MASK_ITEMS 40                                    // sum over strips c of ceil((NMS_MW - c) / NMS_MASK_WG) for NMS_MW = 16
 __global__ __launch_bounds__(NMS_MASK_THREADS) void nms_mask_kernel(sgx_nms_desc d, char* split) {
-    __shared__ float nb[NMS_SPLIT_K][4];
-    __shared__ float area[NMS_SPLIT_K];
-    __shared__ int cls_s[NMS_SPLIT_K];
-    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static_assert(NMS_MW == 16 && NMS_MASK_WG == 4, "NMS_MASK_ITEMS and the item table are written for 16 words in groups of 4");
+    __shared__ float rnb[64][4], cnb[64 * NMS_MASK_WG][4];
+    __shared__ float rarea[64], carea[64 * NMS_MASK_WG];
+    __shared__ int rcls[64], ccls[64 * NMS_MASK_WG];
+    // item -> (strip, group): strips 0-3 have 4 groups, 4-7 three, 8-11 two, 12-15 one
+    int item = blockIdx.x, c, g;
+    if (item < 16) { c = item >> 2; g = item & 3; }
+    else if (item < 28) { c = 4 + (item - 16) / 3; g = (item - 16) % 3; }
+    else if (item < 36) { c = 8 + ((item - 28) >> 1); g = (item - 28) & 1; }
+    else { c = 12 + (item - 36); g = 0; }
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     char* const o = split + (long)b * NMS_SPLIT_BYTES;
     const float* gnb = reinterpret_cast<const float*>(o + NMS_SPLIT_K * 8) + NMS_SPLIT_K * 4;
     const float* garea = gnb + NMS_SPLIT_K * 4;
@@ -546,29 +557,42 @@ __global__ __launch_bounds__(NMS_MASK_THREADS) void nms_mask_kernel(sgx_nms_desc
     const int* meta = gcls + NMS_SPLIT_K;
     u64* const mask = reinterpret_cast<u64*>(o + NMS_CAND_BYTES);
     const int n = meta[0], class_mode = meta[1];
-    if (64 * c >= n) return;  // whole workgroup
     const int nw = (n + 63) >> 6;
-    for (int t = 64 * c + tid; t < n; t += NMS_MASK_THREADS) {  // this strip's rows and every later column
-        for (int q = 0; q < 4; ++q) nb[t][q] = gnb[t * 4 + q];
-        area[t] = garea[t];
-        cls_s[t] = gcls[t];
+    const int w0 = c + NMS_MASK_WG * g;                                   // first word of the item
+    if (64 * c >= n || w0 >= nw) return;                                 // whole workgroup
+    const int w1 = w0 + NMS_MASK_WG < nw ? w0 + NMS_MASK_WG : nw;        // one past its last word
+    if (tid < 64) {
+        const int t = 64 * c + tid;
+        if (t < n) {
+            for (int q = 0; q < 4; ++q) rnb[tid][q] = gnb[t * 4 + q];
+            rarea[tid] = garea[t];
+            rcls[tid] = gcls[t];
+        }
+    }
+    for (int j = tid; j < 64 * (w1 - w0); j += NMS_MASK_THREADS) {
+        const int t = 64 * w0 + j;
+        if (t < n) {
+            for (int q = 0; q < 4; ++q) cnb[j][q] = gnb[t * 4 + q];
+            carea[j] = garea[t];
+            ccls[j] = gcls[t];
+        }
     }
     __syncthreads();
     for (int r = wave; r < 64; r += NMS_MASK_THREADS / 64) {
         const int i = 64 * c + r;
         if (i >= n) break;  // wave-uniform
-        const float ci0 = nb[i][0], ci1 = nb[i][1], ci2 = nb[i][2], ci3 = nb[i][3], ai = area[i];
-        const int ic = cls_s[i], base = nms_mask_row(i);
-        for (int w = c; w < nw; ++w) {
-            const int t = 64 * w + lane;
+        const float ci0 = rnb[r][0], ci1 = rnb[r][1], ci2 = rnb[r][2], ci3 = rnb[r][3], ai = rarea[r];
+        const int ic = rcls[r], base = nms_mask_row(i);
+        for (int w = w0; w < w1; ++w) {
+            const int j = 64 * (w - w0) + lane, t = 64 * w + lane;
             bool hit = false;
-            if (t > i && t < n && (class_mode != 2 || cls_s[t] == ic)) {
-                const float xx1 = fmaxf(ci0, nb[t][0]), yy1 = fmaxf(ci1, nb[t][1]);
-                const float xx2 = fminf(ci2, nb[t][2]), yy2 = fminf(ci3, nb[t][3]);
+            if (t > i && t < n && (class_mode != 2 || ccls[j] == ic)) {
+                const float xx1 = fmaxf(ci0, cnb[j][0]), yy1 = fmaxf(ci1, cnb[j][1]);
+                const float xx2 = fminf(ci2, cnb[j][2]), yy2 = fminf(ci3, cnb[j][3]);
                 float ww = xx2 - xx1; ww = ww < 0.f ? 0.f : ww;
                 float hh = yy2 - yy1; hh = hh < 0.f ? 0.f : hh;
                 const float inter = ww * hh;
-                const float ovr = inter / (ai + area[t] - inter);
+                const float ovr = inter / (ai + carea[j] - inter);
                 hit = ovr > d.iou_threshold;
             }
             const u64 bits = __ballot(hit);
@@ -596,7 +620,20 @@ __global__ __launch_bounds__(NMS_WALK_THREADS) void nms_walk_kernel(sgx_nms_desc
     const int nw = (n + 63) >> 6;
     // only the rows of existing candidates were written: strip g holds 64 rows of (16 - g) words
     const int used = n > 0 ? nms_mask_row(n - 1) + (NMS_MW - ((n - 1) >> 6)) : 0;
-    for (int q = tid; q < used; q += NMS_WALK_THREADS) mask[q] = gmask[q];
+    // (eight 8-byte loads in flight per lane: written as `mask[q] = gmask[q]` the copy of the 68 KB was ~34 dependent round trips per lane)
+    for (int q0 = 0; q0 < used; q0 += 8 * NMS_WALK_THREADS) {
+        u64 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + u * NMS_WALK_THREADS + tid;
+            v[u] = q < used ? gmask[q] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + u * NMS_WALK_THREADS + tid;
+            if (q < used) mask[q] = v[u];
+        }
+    }
     __syncthreads();
     if (wave == 0) {
         int kept = 0;
@@ -604,19 +641,31 @@ __global__ __launch_bounds__(NMS_WALK_THREADS) void nms_walk_kernel(sgx_nms_desc
         for (int c = 0; c < nw && kept < d.max_predictions; ++c) {
             u64 cur = __shfl(rem, c);
             if (c == nw - 1 && (n & 63)) cur |= ~0ull << (n & 63);  // slots past the last candidate
-            u64 avail = ~cur;
-            u64 later = 0;
+            // the chunk's own words (row r of the chunk, word c) one per lane: the serial chain kept -> flags -> next kept then runs on
+            // scalar reads of a register (two v_readlane), not on one LDS round trip per kept candidate
+            const u64 diag = 64 * c + lane < n ? mask[nms_mask_row(64 * c + lane)] : 0ull;
+            // The chain kept -> flags -> next kept on the SCALAR unit: the flags are wave-uniform, so they move to scalar registers once per
+            // chunk and every step is s_ff1 / two v_readlane / a few 64-bit scalar ops (as vector code a step was ~25 dependent VALU
+            // instructions: 300 kept candidates x ~320 cycles = the 45-50 us the kernel took whatever its memory side did, r3zf)
+            u64 cur_s = sgx_uniform_u64(cur);
+            u64 avail = ~cur_s;
+            u64 kept_bits = 0;  // the chunk's kept candidates
             while (avail && kept < d.max_predictions) {  // wave-uniform
                 const int bit = __ffsll(avail) - 1;
-                const int i = 64 * c + bit;
-                if (lane == 0) keep_list[kept] = i;
+                if (lane == 0) keep_list[kept] = 64 * c + bit;
                 ++kept;
-                const int base = nms_mask_row(i);
-                cur |= mask[base];
-                if (lane > c && lane < nw) later |= mask[base + (lane - c)];
-                avail = ~cur & ~((2ull << bit) - 1ull);
+                kept_bits |= 1ull << bit;
+                cur_s |= sgx_readlane_u64(diag, bit);
+                avail = ~cur_s & ~((2ull << bit) - 1ull);
             }
-            rem |= later;
+            // what the chunk's kept candidates suppress in the LATER words: lane w ORs word w of their rows - independent LDS reads after
+            // the chain, not one read (and its wait) inside every step of it
+            if (lane > c && lane < nw) {
+                u64 later = 0;
+                const int stride_w = NMS_MW - c, off = nms_mask_row(64 * c) + (lane - c);  // rows of a strip are (NMS_MW - c) words apart
+                for (u64 kb = kept_bits; kb; kb &= kb - 1ull) later |= mask[off + (__ffsll(kb) - 1) * stride_w];
+                rem |= later;
+            }
         }
         if (lane == 0) s_kept = kept;
     }
@@ -677,7 +726,7 @@ extern "C" int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const floa
     else if (need <= 2048) SGX_LAUNCH(nms_kernel<2048>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates, wsi, (char*)nullptr);
     else SGX_LAUNCH(nms_kernel<4096>, dim3(d->B), dim3(NMS_THREADS), 0, stream, *d, boxes, scores, out, out_count, out_index, num_candidates, wsi, (char*)nullptr);
     if (split) {
-        SGX_LAUNCH(nms_mask_kernel, dim3(NMS_MW, (unsigned)d->B), dim3(NMS_MASK_THREADS), 0, stream, *d, split);
+        SGX_LAUNCH(nms_mask_kernel, dim3(NMS_MASK_ITEMS, (unsigned)d->B), dim3(NMS_MASK_THREADS), 0, stream, *d, split);
         SGX_LAUNCH(nms_walk_kernel, dim3(d->B), dim3(NMS_WALK_THREADS), 0, stream, *d, (const char*)split, out, out_count, out_index, num_candidates);
     }
     SGX_CHECK_LAUNCH("nms");

@@ -142,5 +142,22 @@ __device__ __forceinline__ float4 sgx_ld4_dev(const float* p) {
 #define sgx_wait_stores() __builtin_amdgcn_s_waitcnt(0)  // vmcnt(0) expcnt(0) lgkmcnt(0): every store of this wave has been acknowledged
 #endif
 
+// value of a 64-bit register in lane `src` - `src` must be the same in every lane (a scalar read: two v_readlane, no LDS crossbar)
+#ifdef SGX_EMU
+static inline unsigned long long sgx_readlane_u64(unsigned long long v, int src) { return __shfl(v, src); }
+static inline unsigned long long sgx_uniform_u64(unsigned long long v) { return v; }
+#else
+// a value that IS the same in every lane, moved to scalar registers: what is computed from it afterwards runs on the scalar unit
+__device__ __forceinline__ unsigned long long sgx_uniform_u64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long sgx_readlane_u64(unsigned long long v, int src) {
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, s), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), s);
+    return ((unsigned long long)hi << 32) | lo;
+}
+#endif
+
 __device__ __forceinline__ float4 sgx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void sgx_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
