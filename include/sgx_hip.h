@@ -178,7 +178,8 @@ int32_t sgx_conv2d_bwd_weight_group(const sgx_wgrad_job* jobs, int32_t njobs, vo
  * which a small group is not cut further (MFLOP, 0 = default 8; an item is never larger than twice that), XCD-aware workgroup order (default 1).  Never set by the product.     */
 int32_t sgx_debug_set_wgrad_group(int32_t rounds, int32_t item_mflop, int32_t xcd_order);
 /* Measurement aid: deep_slab bit 0 = 32-pixel slabs in the weight-gradient loop for the tiles whose two slabs fit 32 KB of LDS, bit 1 = ONE
- * slab of global loads in flight instead of two (one register set), bit 2 = the 64x64 tile on two waves instead of four; `ablate` is
+ * slab of global loads in flight instead of two (one register set), bit 2 = the 64x64 tile on two waves instead of four, bit 3 = the
+ * bf16x3 loop (three bf16 planes per slab, operands through the LDS transpose read, six bf16 MFMAs per product; the main tile shapes); `ablate` is
  * honoured only by a library built with -DSGX_WGRAD_LAB (tools/wgrad_lab.py: loop ablations, results are wrong by design).          */
 int32_t sgx_debug_set_wgrad_loop(int32_t deep_slab, int32_t ablate);
 

@@ -210,9 +210,9 @@ def lib():
             _LIB.sgx_debug_set_wgrad_group(*[int(v) for v in wgg.split(",")])
         # measurement switches of the weight-gradient loop: 32-pixel slabs (small tiles); ablation bits (honoured by -DSGX_WGRAD_LAB builds only);
         # one tile shape for every layer "bnk,bj"
-        if os.environ.get("SGX_WGRAD_SLAB") == "32" or os.environ.get("SGX_WGRAD_ABLATE") or os.environ.get("SGX_WGRAD_PF"):
-            _LIB.sgx_debug_set_wgrad_loop(int(os.environ.get("SGX_WGRAD_SLAB") == "32") + 2 * int(os.environ.get("SGX_WGRAD_PF") == "1"),
-                                          int(os.environ.get("SGX_WGRAD_ABLATE", "0")))
+        if os.environ.get("SGX_WGRAD_SLAB") == "32" or os.environ.get("SGX_WGRAD_ABLATE") or os.environ.get("SGX_WGRAD_PF") or os.environ.get("SGX_WGRAD_MATH"):
+            _LIB.sgx_debug_set_wgrad_loop(int(os.environ.get("SGX_WGRAD_SLAB") == "32") + 2 * int(os.environ.get("SGX_WGRAD_PF") == "1")
+                                          + 8 * int(os.environ.get("SGX_WGRAD_MATH") == "bf16x3"), int(os.environ.get("SGX_WGRAD_ABLATE", "0")))
         if os.environ.get("SGX_WGRAD_TILE"):
             _LIB.sgx_debug_set_tiles(0, 0, *[int(v) for v in os.environ["SGX_WGRAD_TILE"].split(",")], 0)
         if os.environ.get("SGX_FUSED_FINALIZE") == "0":  # measurement switch: two-launch BatchNorm / column-sum finalize (default: one launch)

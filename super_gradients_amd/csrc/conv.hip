@@ -272,6 +272,36 @@ __device__ __forceinline__ sgx_f32x16 sgx_mfma_bf16(const uint4& a, const uint4&
 }
 #endif
 
+// ds_read_b64_tr_b16 (gfx950's LDS transpose read): every lane reads the four 16-bit elements at its own 8-byte-aligned LDS address; inside
+// each group of 16 lanes the 16 x 4 matrix In[lane][e] comes back transposed in 4 x 4 blocks - lane i receives In[(i >> 2) + 4 j][i & 3],
+// j = 0..3 (measured on the chip: tools/probe_tr_read.hip, profiles/r3zi_probe_ds_read_tr_b16.txt).  If the 16 lanes address a
+// [4 rows][16 columns] block of a row-major bf16 image (lane q: row q >> 2, columns 4 (q & 3) .. + 3), lane i gets column i of the four
+// rows: an MFMA operand whose reduction index runs along the ROWS of the LDS image (pixels of a weight gradient) without a transposing
+// store.  All 64 lanes take part (the host emulation exchanges through the wave buffer).
+#ifdef SGX_EMU
+static inline uint2 sgx_lds_tr_read(const unsigned short* p) {
+    uint64_t u;
+    memcpy(&u, p, 8);
+    auto x = sgx_emu::xchg_put(&u, 1);
+    const int l = sgx_emu::t_lane, g = l & ~15, i = l & 15;
+    unsigned short o[4];
+    for (int j = 0; j < 4; ++j) {
+        unsigned short in[4];
+        memcpy(in, &x.w->xbuf[x.buf][g + (i >> 2) + 4 * j][0], 8);
+        o[j] = in[i & 3];
+    }
+    uint2 r;
+    memcpy(&r, o, 8);
+    return r;
+}
+#else
+typedef short sgx_i16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 sgx_lds_tr_read(const unsigned short* p) {
+    const sgx_i16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sgx_i16x4*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+#endif
+
 // KD = slab depth, NBUF = LDS buffers.  (16, 2): one barrier per slab (the round-1 loop).  KD = 32 (fp32 arithmetic, C % 32 == 0;
 // experiment switches sgx_debug_set_variant(5 | 6), see run_igemm): every global load instruction covers whole 128-byte lines (8 lanes
 // x 16 B per slab row instead of 4 x 16 B = half a line - MI355X's load path handles half-line "fragment-shaped" requests at about half
@@ -1880,15 +1910,26 @@ struct WgGroupParams {
 // waves per SIMD the register budget is held to: accumulators (16 per 32x32 block of the wave's sub-tile) + 48 for the loop
 // (one-block sub-tiles fit 64 registers unprompted: no request)
 constexpr int wg_min_waves(int acc_regs, int pf) { return acc_regs <= 16 ? 1 : 512 / (acc_regs + (pf == 2 ? 64 : 48)); }
-template <int BNK, int BJ, int WK, int WC, int BKP, int PF>
-__global__ __launch_bounds__(WK * WC * 64, wg_min_waves((BNK / (WK * 32)) * (BJ / (WC * 32)) * 16, PF)) void wgrad_kernel(WgGroupParams g) {
+// MATH = 1 (measurement switch, NOT yet measured on the chip - written against the host emulation in round 3 after the transpose read's
+// lane mapping had been probed): the bf16x3 arithmetic of the patch kernel for the weight gradient.  A slab is staged as three bf16 planes
+// [plane][pixel][channel] (the split happens once per element, at the LDS store); the MFMA operands - eight consecutive PIXELS of one channel
+// per lane - come out of that pixel-major image through ds_read_b64_tr_b16, two reads per plane and 32-row block; six v_mfma_f32_32x32x16_bf16
+// per block pair and 16 pixels (hi*hi into the accumulator, the five cross terms into a second one that is added at the end).  Pixel rows are
+// pitched at 16 or 48 banks mod 64 so that the four rows a 16-lane group reads fall on distinct banks.
+constexpr int wg_bf16_pitch(int row) { return row + (row % 64 == 0 ? 32 : 0); }  // bf16 elements per pixel row
+template <int BNK, int BJ, int WK, int WC, int BKP, int PF, int MATH = 0>
+__global__ __launch_bounds__(WK * WC * 64, MATH ? 1 : wg_min_waves((BNK / (WK * 32)) * (BJ / (WC * 32)) * 16, PF)) void wgrad_kernel(WgGroupParams g) {
     constexpr int NTH = WK * WC * 64;
     constexpr int TK = BNK / (WK * 32), TC = BJ / (WC * 32);
     static_assert(TK >= 1 && TC >= 1 && TK * WK * 32 == BNK && TC * WC * 32 == BJ, "bad tile");
+    static_assert(MATH == 0 || BKP == 16, "bf16x3 loop: 16-pixel slabs (one K step of the bf16 MFMA)");
     constexpr int G = NTH / BKP;  // lanes per pixel row
     constexpr int DJ = (BNK / 4 + G - 1) / G, XJ = (BJ / 4 + G - 1) / G;
-    __shared__ float Ds[2 * BKP * BNK];
-    __shared__ float Xs[2 * BKP * BJ];
+    constexpr int DP = wg_bf16_pitch(BNK), XP = wg_bf16_pitch(BJ);
+    __shared__ float Ds[MATH ? 4 : 2 * BKP * BNK];
+    __shared__ float Xs[MATH ? 4 : 2 * BKP * BJ];
+    __shared__ unsigned short Dh[MATH ? 2 * 3 * BKP * DP : 4];  // [buffer][plane][pixel][DP]
+    __shared__ unsigned short Xh[MATH ? 2 * 3 * BKP * XP : 4];
     __shared__ int s_last;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2010,6 +2051,29 @@ __global__ __launch_bounds__(WK * WC * 64, wg_min_waves((BNK / (WK * 32)) * (BJ 
         }
     };
     auto store_tile = [&](int buf, const float4* rd, const float4* rx) {
+        if constexpr (MATH == 1) {
+#pragma unroll
+            for (int q = 0; q < DJ; ++q)
+                if (dcol[q] < BNK) {
+                    uint2 h, m, l;
+                    sgx_split3(rd[q], h, m, l);
+                    unsigned short* const b = &Dh[((buf * 3) * BKP + prow) * DP + dcol[q]];
+                    *reinterpret_cast<uint2*>(b) = h;
+                    *reinterpret_cast<uint2*>(b + BKP * DP) = m;
+                    *reinterpret_cast<uint2*>(b + 2 * BKP * DP) = l;
+                }
+#pragma unroll
+            for (int q = 0; q < XJ; ++q)
+                if (xcol[q] < BJ) {
+                    uint2 h, m, l;
+                    sgx_split3(rx[q], h, m, l);
+                    unsigned short* const b = &Xh[((buf * 3) * BKP + prow) * XP + xcol[q]];
+                    *reinterpret_cast<uint2*>(b) = h;
+                    *reinterpret_cast<uint2*>(b + BKP * XP) = m;
+                    *reinterpret_cast<uint2*>(b + 2 * BKP * XP) = l;
+                }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < DJ; ++q)
             if (dcol[q] < BNK) sgx_st4(&Ds[buf * BKP * BNK + prow * BNK + dcol[q]], rd[q]);
@@ -2036,7 +2100,46 @@ __global__ __launch_bounds__(WK * WC * 64, wg_min_waves((BNK / (WK * 32)) * (BJ 
     }
     __syncthreads();
     const int fcol = lane & 31, fkh = lane >> 5;
+    sgx_f32x16 acc2[MATH ? TK : 1][MATH ? TC : 1];  // bf16x3: the five cross terms
+    if constexpr (MATH == 1) {
+#pragma unroll
+        for (int i = 0; i < TK; ++i)
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+    }
+    // bf16x3 operand of a 32-row block: lane l ends up with the eight pixels 8 (l / 32) .. + 7 of column blk0 + l % 32 (two transpose reads)
+    auto frag = [&](const unsigned short* img, int pitch, int buf, int pl, int blk0) {
+        const int gq = lane >> 4, q = lane & 15;
+        const unsigned short* const ptr = img + ((buf * 3 + pl) * BKP + 8 * (gq >> 1) + (q >> 2)) * pitch + blk0 + 16 * (gq & 1) + 4 * (q & 3);
+        const uint2 lo = sgx_lds_tr_read(ptr), hi = sgx_lds_tr_read(ptr + 4 * pitch);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    };
     auto mfma_slab = [&](int buf) {
+        if constexpr (MATH == 1) {
+            uint4 b[TC][3];
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[j][pl] = frag(Xh, XP, buf, pl, wc * TC * 32 + j * 32);
+#pragma unroll
+            for (int i = 0; i < TK; ++i) {
+                uint4 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = frag(Dh, DP, buf, pl, wk * TK * 32 + i * 32);
+#pragma unroll
+                for (int j = 0; j < TC; ++j) {
+                    acc[i][j] = sgx_mfma_bf16(a[0], b[j][0], acc[i][j]);
+                    acc2[i][j] = sgx_mfma_bf16(a[0], b[j][1], acc2[i][j]);
+                    acc2[i][j] = sgx_mfma_bf16(a[1], b[j][0], acc2[i][j]);
+                    acc2[i][j] = sgx_mfma_bf16(a[1], b[j][1], acc2[i][j]);
+                    acc2[i][j] = sgx_mfma_bf16(a[0], b[j][2], acc2[i][j]);
+                    acc2[i][j] = sgx_mfma_bf16(a[2], b[j][0], acc2[i][j]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < BKP / 2; ++kk) {
             float af[TK], bf[TC];
@@ -2078,6 +2181,14 @@ __global__ __launch_bounds__(WK * WC * 64, wg_min_waves((BNK / (WK * 32)) * (BJ 
             step(kt + 1, rdB, rxB);
         }
         if (kt < nkt) step(kt, rdA, rxA);
+    }
+    if constexpr (MATH == 1) {
+#pragma unroll
+        for (int i = 0; i < TK; ++i)
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
     }
     if (WG_AB(8)) {  // main loop only (the accumulators stay observable)
         if (acc[0][0][0] == 1.2345e-30f) p.dw[0] = 1.f;
@@ -2296,6 +2407,13 @@ static void launch_wgrad(const WgGroupParams& g, int nblk, void* stream) {
     if constexpr (BNK + BJ <= 128) {  // 32-pixel slabs (half the barriers, twice the bytes in flight per lane) where two of them fit 32 KB
         if (loop & 1) {
             SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP_DEEP, 1>), grid, block, 0, stream, g);
+            return;
+        }
+    }
+    // bit 3 (measurement, not yet measured): the bf16x3 loop for the tile shapes that carry most of a YOLO-NAS step
+    if constexpr ((BNK == 64 && BJ == 64 && WK == 2) || (BNK == 96 && BJ == 128) || (BNK == 128 && BJ == 64) || (BNK == 32 && BJ == 128)) {
+        if (loop & 8) {
+            SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP, 2, 1>), grid, block, 0, stream, g);
             return;
         }
     }

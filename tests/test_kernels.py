@@ -1117,7 +1117,7 @@ def test_wgrad_group(backend, monkeypatch):
             assert_close(e[2].cpu(), ref, TOL, f"grouped wgrad, default split {shape}")
         # the loop's variants: 32-pixel slabs (small tiles), one slab of loads in flight instead of two; small items again
         lib().sgx_debug_set_wgrad_group(6, 1, 1)
-        for loop, what in ((1, "32-pixel slabs"), (2, "one slab in flight"), (4, "64x64 tile on two waves")):
+        for loop, what in ((1, "32-pixel slabs"), (2, "one slab in flight"), (4, "64x64 tile on two waves"), (8, "bf16x3 loop")):
             lib().sgx_debug_set_wgrad_loop(loop, 0)
             for e in ents:
                 e[2].zero_()
@@ -1125,6 +1125,43 @@ def test_wgrad_group(backend, monkeypatch):
             for (shape, e, ref) in zip(cases, ents, refs):
                 assert_close(e[2].cpu(), ref, TOL, f"grouped wgrad, {what} {shape}")
     finally:
+        lib().sgx_debug_set_wgrad_group(0, 0, 1)
+        lib().sgx_debug_set_wgrad_loop(0, 0)
+
+
+def test_wgrad_bf16x3_loop(backend):
+    """The weight gradient's bf16x3 loop (sgx_debug_set_wgrad_loop bit 3: three bf16 planes per slab, MFMA operands through the LDS transpose
+    read) on each tile shape it is instantiated for, against ATen's fp32 gradient: fp32-level agreement (the six-product scheme drops terms
+    <= 2^-24 of a product), i.e. much tighter than the conv tolerance; pixel splits + several images + stride 2 + channel-slice operands."""
+    from super_gradients_amd._lib import lib
+
+    gpu = backend.type == "cuda"
+    shapes = [(2, 40, 40, 32, 48, 3, 1, 1), (2, 40, 40, 16, 40, 3, 2, 1)] if gpu else [(2, 9, 18, 4, 12, 3, 1, 1), (1, 10, 36, 8, 8, 1, 2, 0)]
+    try:
+        for bnk, bj in ((64, 64), (96, 128), (128, 64), (32, 128)):
+            lib().sgx_debug_set_tiles(0, 0, bnk, bj, 0)
+            lib().sgx_debug_set_wgrad_group(6, 1, 1)  # small items: several splits -> the fold tail runs too
+            for i, shape in enumerate(shapes):
+                n, h, w, c, k, r, s_, p_ = shape
+                x, wt, _ = _conv_case(shape, seed=40 + i)
+                wt.requires_grad_(True)
+                y = F.conv2d(x, wt, None, stride=s_, padding=p_)
+                dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(50 + i))
+                y.backward(dy)
+                ent = (to_nhwc(x, backend, ld_pix=c + 4, c_off=4), to_nhwc(dy, backend, ld_pix=k + 4, c_off=0), K.ohwi_empty(k, c, r, r, backend), s_, p_)
+                got = {}
+                for loop in (0, 8):
+                    lib().sgx_debug_set_wgrad_loop(loop, 0)
+                    ent[2].zero_()
+                    K.conv2d_bwd_weight_group([ent])
+                    got[loop] = ent[2].cpu().clone()
+                scale = float(wt.grad.abs().max())
+                e_fp32 = float((got[0] - wt.grad).abs().max()) / scale
+                e_bf = float((got[8] - wt.grad).abs().max()) / scale
+                assert e_bf <= max(2e-6, 4.0 * e_fp32), f"tile {bnk}x{bj} {shape}: bf16x3 {e_bf:.2e}, fp32 loop {e_fp32:.2e}"
+                wt.grad = None
+    finally:
+        lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
         lib().sgx_debug_set_wgrad_group(0, 0, 1)
         lib().sgx_debug_set_wgrad_loop(0, 0)
 

@@ -3,7 +3,7 @@ the loop / the grouping - interleaved in ONE process (rounds x configs, median).
 
     python tools/wgrad_lab.py [--model s] [--batch 32] [--size 640] [--configs base,slab32,ab1,ab3,ab7,ab8,ab15] [--rounds 3] [--iters 5]
 
-A config is a '+'-joined list of:  base | slab32 | pf1 (one slab of loads in flight instead of two) | w2 (64x64 tile on two waves) | abN (ablation bits, needs a library built with -DSGX_WGRAD_LAB: 1 no global loads,
+A config is a '+'-joined list of:  base | slab32 | pf1 (one slab of loads in flight instead of two) | w2 (64x64 tile on two waves) | bf16 (the bf16x3 loop) | abN (ablation bits, needs a library built with -DSGX_WGRAD_LAB: 1 no global loads,
 2 no LDS stores, 4 no MFMAs, 8 no fold / dW) | gR.I.X (sgx_debug_set_wgrad_group rounds.item_mflop.xcd) | tBxJ (tile override).
 Per group (= one K.conv2d_bwd_weight_group call of the step): jobs, GFLOP, then microseconds per config; last line: ms per step and
 algorithmic TFLOP/s.  Measurement tool: product library only.
@@ -63,6 +63,8 @@ def apply_config(cfg, lib):
             deep |= 2
         elif part == "w2":
             deep |= 4
+        elif part == "bf16":
+            deep |= 8
         elif part.startswith("ab"):
             ab = int(part[2:])
         elif part.startswith("g"):
