@@ -1131,14 +1131,14 @@ def test_wgrad_group(backend, monkeypatch):
 
 def test_wgrad_bf16x3_loop(backend):
     """The weight gradient's bf16x3 loop (sgx_debug_set_wgrad_loop bit 3: three bf16 planes per slab, MFMA operands through the LDS transpose
-    read) on each tile shape it is instantiated for, against ATen's fp32 gradient: fp32-level agreement (the six-product scheme drops terms
+    read) on tile shapes of every wave layout, against ATen's fp32 gradient: fp32-level agreement (the six-product scheme drops terms
     <= 2^-24 of a product), i.e. much tighter than the conv tolerance; pixel splits + several images + stride 2 + channel-slice operands."""
     from super_gradients_amd._lib import lib
 
     gpu = backend.type == "cuda"
     shapes = [(2, 40, 40, 32, 48, 3, 1, 1), (2, 40, 40, 16, 40, 3, 2, 1)] if gpu else [(2, 9, 18, 4, 12, 3, 1, 1), (1, 10, 36, 8, 8, 1, 2, 0)]
     try:
-        for bnk, bj in ((64, 64), (96, 128), (128, 64), (32, 128)):
+        for bnk, bj in ((64, 64), (96, 128), (128, 64), (32, 128), (96, 96), (64, 32), (32, 32), (128, 128)):
             lib().sgx_debug_set_tiles(0, 0, bnk, bj, 0)
             lib().sgx_debug_set_wgrad_group(6, 1, 1)  # small items: several splits -> the fold tail runs too
             for i, shape in enumerate(shapes):
