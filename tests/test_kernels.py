@@ -1117,7 +1117,9 @@ def test_wgrad_group(backend, monkeypatch):
             assert_close(e[2].cpu(), ref, TOL, f"grouped wgrad, default split {shape}")
         # the loop's variants: 32-pixel slabs (small tiles), one slab of loads in flight instead of two; small items again
         lib().sgx_debug_set_wgrad_group(6, 1, 1)
-        for loop, what in ((1, "32-pixel slabs"), (2, "one slab in flight"), (4, "64x64 tile on two waves"), (8, "bf16x3 loop")):
+        # (the bf16x3 loop has its own test; here it runs on the emulation only - on the chip this case list would reach tile shapes of it
+        # that have not met hardware yet)
+        for loop, what in ((1, "32-pixel slabs"), (2, "one slab in flight"), (4, "64x64 tile on two waves")) + (() if gpu else ((8, "bf16x3 loop"),)):
             lib().sgx_debug_set_wgrad_loop(loop, 0)
             for e in ents:
                 e[2].zero_()
