@@ -580,6 +580,31 @@ def test_nms(backend, multi_label, class_mode):
         assert torch.equal(out[b, :n], ref[b]), f"image {b}: rows differ"  # bit-exact boxes/scores/classes
 
 
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 128, 129, 200])
+def test_nms_candidate_count_boundaries(backend, n):
+    """Candidate counts around the 64-candidate flag words of the suppression matrix (empty list, one candidate, a full word, one past it,
+    two words, ...): the split suppression's work items, the walk's register-resident diagonal words and its tail mask all change shape
+    there.  Three images with different counts in one call (n, n + 1 clamped, 0), class-agnostic, against the oracle bit for bit."""
+    from oracle import nms as onms
+
+    L = max(n + 1, 2)
+    g = np.random.RandomState(100 + n)
+    c = g.uniform(100, 540, (3, L, 2)) + g.normal(0, 4, (3, L, 2))
+    wh = g.uniform(40, 160, (3, L, 2))
+    boxes = torch.from_numpy(np.concatenate([c - wh / 2, c + wh / 2], -1).astype(np.float32))
+    scores = torch.from_numpy(g.uniform(0.2, 0.9, (3, L, 1)).astype(np.float32))
+    scores[0, n:] = 0.0       # image 0: exactly n candidates
+    scores[2] = 0.0           # image 2: none
+    kw = dict(score_threshold=0.1, nms_threshold=0.5, nms_top_k=max(L, 1), max_predictions=max(L, 1), multi_label_per_box=True)
+    ref = onms.post_prediction(boxes, scores, class_agnostic_nms=True, **kw)
+    out, cnt, idx, ncand = K.nms(boxes.to(backend), scores.to(backend), 0.1, 0.5, max(L, 1), max(L, 1), multi_label=True, class_mode=0)
+    assert int(ncand[0]) == n and int(ncand[1]) == L and int(ncand[2]) == 0
+    for b in range(3):
+        k = int(cnt[b])
+        assert k == ref[b].shape[0], f"n={n} image {b}: kept {k} vs oracle {ref[b].shape[0]}"
+        assert torch.equal(out[b, :k].cpu(), ref[b]), f"n={n} image {b}: rows differ"
+
+
 def test_nms_per_class_case_is_reproducible(backend):
     """A per-class case (detections of a random-init YOLO-NAS on two 64x64 images: 252 candidates, scores within 0.0093..0.0106, boxes far
     larger than the image) on which the chunked suppression walk keeps candidates in all four flag words.  Under the host emulation - one OS
