@@ -72,7 +72,7 @@ int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk, int32_t w
  * data gradient) run the PATCH kernel: a workgroup owns 8 x 16 output pixels of one image, stages their 10 x 18 input patch and the
  * filter slabs of all nine taps in LDS once per 16-channel chunk (split into three bf16 planes) and reads the taps from there - bf16x3
  * arithmetic as in mode 1; statistics rows are then one per tile (sgx_conv2d_fwd_stat_blocks follows); every other problem stays on the
- * fp32 pipe.  Process-wide.                                                                                                            */
+ * fp32 pipe.  4 (measurement): mode 3's patch kernel on its problems, mode 2's per-problem rule for the rest.  Process-wide.            */
 int32_t sgx_conv_set_math(int32_t mode);
 int32_t sgx_conv_get_math(void);
 int32_t sgx_debug_set_variant(int32_t wave_layout_variant);

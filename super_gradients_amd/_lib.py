@@ -199,9 +199,9 @@ def lib():
         _check_single_runtime()
         mode = os.environ.get("SGX_CONV_MATH")   # "fp32" | "bf16x3" | "auto" (kernels.set_conv_math); unset = the library default
         if mode:
-            if mode not in ("fp32", "bf16x3", "auto", "patch"):
-                raise RuntimeError(f"SGX_CONV_MATH={mode!r}: expected 'fp32', 'bf16x3', 'auto' or 'patch'")
-            _LIB.sgx_conv_set_math({"fp32": 0, "bf16x3": 1, "auto": 2, "patch": 3}[mode])
+            if mode not in ("fp32", "bf16x3", "auto", "patch", "patch_auto"):
+                raise RuntimeError(f"SGX_CONV_MATH={mode!r}: expected 'fp32', 'bf16x3', 'auto', 'patch' or 'patch_auto'")
+            _LIB.sgx_conv_set_math({"fp32": 0, "bf16x3": 1, "auto": 2, "patch": 3, "patch_auto": 4}[mode])
         var = os.environ.get("SGX_CONV_VARIANT")  # measurement switch of the conv kernels (sgx_debug_set_variant; 7 = the 16-deep loop)
         if var:
             _LIB.sgx_debug_set_variant(int(var))

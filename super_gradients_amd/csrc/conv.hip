@@ -1279,7 +1279,7 @@ static std::atomic<int> g_ovr_bm{0}, g_ovr_bn{0}, g_ovr_wk{0}, g_ovr_wj{0}, g_ov
 // an LDS-resident patch): 1.25-1.6x on those launches, every GPU parity test green in that mode (r3g)
 static std::atomic<int> g_conv_math{3};
 extern "C" int32_t sgx_conv_set_math(int32_t mode) {
-    SGX_CHECK_ARG(mode >= 0 && mode <= 3, "conv math mode %d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = per problem, 3 = patch kernel for 3x3 stride-1)", mode);
+    SGX_CHECK_ARG(mode >= 0 && mode <= 4, "conv math mode %d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = per problem, 3 = patch kernel for 3x3 stride-1, 4 = 3 + 2)", mode);
     g_conv_math = mode;
     return SGX_OK;
 }
@@ -1291,13 +1291,14 @@ extern "C" int32_t sgx_conv_get_math(void) { return g_conv_math; }
 static int conv_math_for(int taps, int C) {
     const int m = g_conv_math.load(std::memory_order_relaxed);
     if (m == 3) return 0;  // the patch kernel takes the 3x3 stride-1 problems (pconv_ok), everything else stays on the fp32 pipe
-    return m == 2 ? ((long)taps * C >= SGX_BF3_MIN_DEPTH ? 1 : 0) : m;
+    // mode 4 (measurement, not yet measured): the patch kernel on its problems AND the per-problem rule of mode 2 for the rest
+    return (m == 2 || m == 4) ? ((long)taps * C >= SGX_BF3_MIN_DEPTH ? 1 : 0) : m;
 }
 // Mode 3: 3x3, stride 1, pad 1, channel counts in 16s -> pconv_kernel (bf16x3 from an LDS-resident patch).  Decidable from the descriptor,
 // so that the forward statistics rows (one per 8 x 16 pixel tile and image) are known before the launch.
 static int conv_variant();
 static bool pconv_shape_ok(int R, int S, int stride, int pad, int C, int K, long HoWo) {
-    return g_conv_math.load(std::memory_order_relaxed) == 3 && R == 3 && S == 3 && stride == 1 && pad == 1 && C % 16 == 0 && C >= 16 && K % 4 == 0 &&
+    return g_conv_math.load(std::memory_order_relaxed) >= 3 && R == 3 && S == 3 && stride == 1 && pad == 1 && C % 16 == 0 && C >= 16 && K % 4 == 0 &&
            (HoWo >= 1600 || conv_variant() == 9);
 }
 static int pconv_tiles(int N, int H, int W) { return N * sgx_cdiv(H, PC_TH) * sgx_cdiv(W, PC_TW); }
@@ -1436,7 +1437,7 @@ static void launch_igemm(IgemmParams& p, void* stream) {
 
 // ---- pconv dispatch ------------------------------------------------------------------------------------------------------------------
 static bool pconv_ok(const IgemmParams& p, int ph2) {
-    if (g_conv_math.load(std::memory_order_relaxed) != 3) return false;
+    if (g_conv_math.load(std::memory_order_relaxed) < 3) return false;
     // dense taps whose input offsets all lie in [-1, +1]: the 3x3 stride-1 forward / data gradient, and the output-parity classes of a 3x3
     // stride-2 data gradient (2x2 / 2x1 / 1x2 taps at offsets {0, +1}; the output grid is then written with stride `so`)
     if (p.si != 1 || p.Th > 3 || p.Tw > 3 || p.Th * p.Tw < 2 || (p.dstep != 1 && p.dstep != -1)) return false;

@@ -1156,6 +1156,40 @@ def test_wgrad_group(backend, monkeypatch):
         lib().sgx_debug_set_wgrad_loop(0, 0)
 
 
+def test_conv_math_patch_auto(backend):
+    """Conv math mode 4 ("patch_auto", a measurement mode): the patch kernel on the 3x3 stride-1 problems, the per-problem bf16x3 / fp32 rule
+    on the rest - forward (with the statistics rows, whose count follows the dispatch) and data gradient against ATen on a problem of each
+    kind.  Emulation only this round: the dispatch combination has not met the chip yet (its two kernels have)."""
+    from super_gradients_amd._lib import lib
+
+    if backend.type == "cuda":
+        pytest.skip("mode 4 has only met the emulation so far")
+    cases = [(1, 9, 20, 16, 32, 3, 1, 1),    # 3x3 stride 1 -> patch kernel (variant 9 lifts the 40 x 40 floor for the small map)
+             (1, 6, 6, 192, 16, 1, 1, 0),    # depth 192 -> bf16x3 GEMM
+             (1, 8, 8, 8, 16, 1, 1, 0),      # shallow -> fp32 pipe
+             (1, 10, 10, 32, 16, 3, 2, 1)]   # 3x3 stride 2, depth 288 -> bf16x3 GEMM
+    K.set_conv_math("patch_auto")
+    lib().sgx_debug_set_variant(9)
+    try:
+        assert K.get_conv_math() == "patch_auto"
+        for i, shape in enumerate(cases):
+            n, h, w, c, k, r, s_, p_ = shape
+            x, wt, b = _conv_case(shape, seed=60 + i)
+            x.requires_grad_(True)
+            y = F.conv2d(x, wt, b, stride=s_, padding=p_)
+            dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(70 + i))
+            y.backward(dy)
+            xd, wd = to_nhwc(x.detach(), backend), K.to_ohwi(wt.to(backend))
+            yd, parts = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s_, pad=p_, stat_partials=True)
+            assert_close(to_nchw_cpu(yd), y.detach(), TOL, f"patch_auto fwd {shape}")
+            assert_close(parts[0].sum(0).cpu() / (y.numel() // k), y.detach().mean((0, 2, 3)), 1e-4, f"patch_auto stats {shape}")
+            dx = K.conv2d_bwd_data(to_nhwc(dy, backend), wd, (n, h, w, c), stride=s_, pad=p_)
+            assert_close(to_nchw_cpu(dx), x.grad, TOL, f"patch_auto dgrad {shape}")
+    finally:
+        lib().sgx_debug_set_variant(0)
+        K.set_conv_math(K.DEFAULT_CONV_MATH)
+
+
 def test_wgrad_bf16x3_loop(backend):
     """The weight gradient's bf16x3 loop (sgx_debug_set_wgrad_loop bit 3: three bf16 planes per slab, MFMA operands through the LDS transpose
     read) on tile shapes of every wave layout, against ATen's fp32 gradient: fp32-level agreement (the six-product scheme drops terms
