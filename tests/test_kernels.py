@@ -1154,6 +1154,10 @@ def test_wgrad_group(backend, monkeypatch):
     finally:
         lib().sgx_debug_set_wgrad_group(0, 0, 1)
         lib().sgx_debug_set_wgrad_loop(0, 0)
+        if gpu:  # the next use re-binds the library and re-applies the SGX_* environment switches (a gate run sets SGX_WGRAD_MATH suite-wide)
+            from super_gradients_amd import _lib as _l
+
+            _l._LIB = None
 
 
 def test_conv_math_patch_auto(backend):
@@ -1227,6 +1231,10 @@ def test_wgrad_bf16x3_loop(backend):
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
         lib().sgx_debug_set_wgrad_group(0, 0, 1)
         lib().sgx_debug_set_wgrad_loop(0, 0)
+        if gpu:  # (as in test_wgrad_group)
+            from super_gradients_amd import _lib as _l
+
+            _l._LIB = None
 
 
 # (N, H, W, C, K): 3x3 stride-1 pad-1 problems for the patch kernel - ragged 8 x 16 tiles in both directions, both chunk depths (C % 32),
