@@ -115,6 +115,35 @@ int32_t sgx_conv2d_bwd_data(const sgx_conv_desc* d, const float* dy, const float
 int32_t sgx_conv2d_transpose_weights(const sgx_conv_desc* d, const float* w, float* wt, int64_t wt_bytes, void* stream);
 int32_t sgx_conv2d_bwd_data_wt(const sgx_conv_desc* d, const float* dy, const float* wt, const float* addend, float* dx,
                                int32_t accumulate, void* stream);
+/* BatchNorm-backward REDUCE inside the data gradient that finalises a layer's output gradient (round 4).  The reference runs
+ * aten::native_batch_norm_backward per BatchNorm2d (modules/conv_bn_act_block.py:88-93 under sg_trainer.py:611-647): a reduction over dy and
+ * the saved conv output, then the input gradient.  When the LAST writer of a layer's dy is a data-gradient launch, its epilogue holds every
+ * dy value in registers: given the layer's saved pre-BatchNorm conv output t and scale / shift / mean it leaves the per-channel partial sums
+ * sum g, sum g (t - mean) with g = dy * act'(scale t + shift) - exactly the rows sgx_bn_bwd_reduce produces with its own pass over dy and t
+ * (same fp32 arithmetic per element; the rows regroup with the launch's tile rows, the fp64 finalize is unchanged).
+ * A request covers a channel range [c_lo, c_hi) of dx (multiples of 4): a data gradient that writes a concat gradient can serve the
+ * layers behind two of its slices.  partials: [2][rows][c_hi - c_lo] with rows = sgx_conv2d_bwd_data_stat_blocks(d, two_source) (0: this
+ * problem cannot carry requests - unaligned rows, fewer than 16 filters ...).  t is indexed like dx: [N, H, W] pixels, its own strides.    */
+#define SGX_MAX_BN_REQ 2
+typedef struct sgx_bn_reduce_req {
+    int32_t c_lo, c_hi;
+    const float* t;
+    int64_t t_ld_pix, t_ld_img;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    int32_t act;
+    int32_t rows;     /* rows the partials were allocated for: must equal sgx_conv2d_bwd_data_stat_blocks */
+    float* partials;
+} sgx_bn_reduce_req;
+int32_t sgx_conv2d_bwd_data_stat_blocks(const sgx_conv_desc* d, int32_t two_source);
+int32_t sgx_conv2d_bwd_data_wt_req(const sgx_conv_desc* d, const float* dy, const float* wt, const float* addend, float* dx,
+                                   int32_t accumulate, const sgx_bn_reduce_req* reqs, int32_t nreq, void* stream);
+/* (the two-source form, sgx_conv2d_bwd_data_dual below, with requests) */
+int32_t sgx_conv2d_bwd_data_dual_req(const sgx_conv_desc* d, const float* dy, const float* wt, const float* ds, int64_t ds_ld_pix,
+                                     int64_t ds_ld_img, const float* w1t, const float* addend, const float* addend2, int64_t a2_ld_pix,
+                                     int64_t a2_ld_img, float a2_scale, const float* a2_scale_dev, float* dx, int32_t accumulate,
+                                     const sgx_bn_reduce_req* reqs, int32_t nreq, void* stream);
 /* All of a network's data-gradient weight transposes as ONE launch per step instead of one per convolution and parity class
  * (YOLO-NAS-S: 165 launches of ~10 us): sgx_conv2d_transpose_jobs appends the jobs of convolution d (weights w -> buffer wt of
  * sgx_conv2d_bwd_data_workspace(d) bytes; pointers must stay valid - they are arena views) to a HOST array; the caller uploads the
@@ -182,6 +211,17 @@ int32_t sgx_debug_set_wgrad_group(int32_t rounds, int32_t item_mflop, int32_t xc
  * bf16x3 loop (three bf16 planes per slab, operands through the LDS transpose read, six bf16 MFMAs per product; the main tile shapes); `ablate` is
  * honoured only by a library built with -DSGX_WGRAD_LAB (tools/wgrad_lab.py: loop ablations, results are wrong by design).          */
 int32_t sgx_debug_set_wgrad_loop(int32_t deep_slab, int32_t ablate);
+/* Arithmetic of the weight gradient (aten::convolution_backward's weight half under sg_trainer.py:611-647), process-wide.
+ * 0: the fp32 matrix pipe.  1: the bf16x3 slab loop (three bf16 planes per slab, operands through the LDS transpose read, six bf16 MFMAs per
+ * product: fp32-accurate).  2 (DEFAULT): mode 1, and the 3x3 pad-1 problems (stride 1 and 2) run the PATCH kernel - a workgroup owns a
+ * (32 / 64 / 96 filters) x (32 channels) x (nine taps) block of dW, walks tiles of 32 output pixels, stages the dY tile and the input patch
+ * of a tile ONCE (one bf16x3 split per element instead of one per tap) and the taps read their operands from the patch (a tap is an LDS
+ * address offset).  sgx_debug_set_wgrad_loop bit 4 keeps the patch kernel out, bit 5 forces the fp32 loop (measurement / parity tests).   */
+int32_t sgx_conv_set_wgrad_math(int32_t mode);
+int32_t sgx_conv_get_wgrad_math(void);
+/* Measurement aid for the patch kernel: largest work item (MFLOP, 0 = default 48), filter blocks per workgroup (1..3, 0 = by padding), least
+ * share of useful matrix work (filters x channels x pixels over their padded tiles, percent, 0 = default 60) for a job to take the kernel. */
+int32_t sgx_debug_set_wgrad_patch(int32_t item_mflop, int32_t kb, int32_t min_fill_pct);
 
 /* ConvTranspose2d kernel 2, stride 2 (+bias): modules/sampling.py:72-73 via yolo_stages.py:292-294.
  * x [N,H,W,C] -> y [N,2H,2W,K].  It is the adjoint of a 2x2 stride-2 convolution, so it runs on the same

@@ -46,6 +46,12 @@ class WgradJob(ctypes.Structure):  # == sgx_wgrad_job
     _fields_ = [("d", ConvDesc), ("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p)]
 
 
+class BnReduceReq(ctypes.Structure):  # == sgx_bn_reduce_req
+    _fields_ = [("c_lo", c_int32), ("c_hi", c_int32), ("t", ctypes.c_void_p), ("t_ld_pix", ctypes.c_int64), ("t_ld_img", ctypes.c_int64),
+                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("act", c_int32), ("rows", c_int32),
+                ("partials", ctypes.c_void_p)]
+
+
 class QarepPrepJob(ctypes.Structure):  # == sgx_qarep_prep_job
     _fields_ = [("w1", ctypes.c_void_p), ("w1p", ctypes.c_void_p), ("w1pt", ctypes.c_void_p), ("alpha", ctypes.c_void_p), ("K", c_int32), ("C", c_int32),
                 ("identity", c_int32), ("pad_", c_int32)]
@@ -90,6 +96,9 @@ PROTOTYPES = {
     "sgx_conv2d_bwd_data": (_i32, [_CD, _P, _P, _P, _P, _i32, _P, _i64, _P]),
     "sgx_conv2d_transpose_weights": (_i32, [_CD, _P, _P, _i64, _P]),
     "sgx_conv2d_bwd_data_wt": (_i32, [_CD, _P, _P, _P, _P, _i32, _P]),
+    "sgx_conv2d_bwd_data_stat_blocks": (_i32, [_CD, _i32]),
+    "sgx_conv2d_bwd_data_wt_req": (_i32, [_CD, _P, _P, _P, _P, _i32, POINTER(BnReduceReq), _i32, _P]),
+    "sgx_conv2d_bwd_data_dual_req": (_i32, [_CD, _P, _P, _P, _i64, _i64, _P, _P, _P, _i64, _i64, _f, _P, _P, _i32, POINTER(BnReduceReq), _i32, _P]),
     "sgx_conv2d_transpose_jobs": (_i32, [_CD, _P, _P, _i64, POINTER(WtransJob), _i32, POINTER(c_int32)]),
     "sgx_wtrans_batch": (_i32, [_P, _i32, _P]),
     "sgx_conv2d_fwd_dual_stat_blocks": (_i32, [_CD]),
@@ -107,6 +116,9 @@ PROTOTYPES = {
     "sgx_conv2d_bwd_weight_group": (_i32, [POINTER(WgradJob), _i32, _P, _i64, _P, _i64, _P]),
     "sgx_debug_set_wgrad_group": (_i32, [_i32] * 3),
     "sgx_debug_set_wgrad_loop": (_i32, [_i32] * 2),
+    "sgx_conv_set_wgrad_math": (_i32, [_i32]),
+    "sgx_conv_get_wgrad_math": (_i32, []),
+    "sgx_debug_set_wgrad_patch": (_i32, [_i32] * 3),
     "sgx_debug_set_nms_split": (_i32, [_i32]),
     "sgx_convT2x2_workspace": (_i64, [_i32] * 5),
     "sgx_convT2x2_fwd": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _P, _i64, _i64, _P, _i64, _P]),
@@ -210,9 +222,16 @@ def lib():
             _LIB.sgx_debug_set_wgrad_group(*[int(v) for v in wgg.split(",")])
         # measurement switches of the weight-gradient loop: 32-pixel slabs (small tiles); ablation bits (honoured by -DSGX_WGRAD_LAB builds only);
         # one tile shape for every layer "bnk,bj"
-        if os.environ.get("SGX_WGRAD_SLAB") == "32" or os.environ.get("SGX_WGRAD_ABLATE") or os.environ.get("SGX_WGRAD_PF") or os.environ.get("SGX_WGRAD_MATH"):
-            _LIB.sgx_debug_set_wgrad_loop(int(os.environ.get("SGX_WGRAD_SLAB") == "32") + 2 * int(os.environ.get("SGX_WGRAD_PF") == "1")
-                                          + 8 * int(os.environ.get("SGX_WGRAD_MATH") == "bf16x3"), int(os.environ.get("SGX_WGRAD_ABLATE", "0")))
+        if os.environ.get("SGX_WGRAD_SLAB") == "32" or os.environ.get("SGX_WGRAD_ABLATE") or os.environ.get("SGX_WGRAD_PF"):
+            _LIB.sgx_debug_set_wgrad_loop(int(os.environ.get("SGX_WGRAD_SLAB") == "32") + 2 * int(os.environ.get("SGX_WGRAD_PF") == "1"),
+                                          int(os.environ.get("SGX_WGRAD_ABLATE", "0")))
+        wgm = os.environ.get("SGX_WGRAD_MATH")  # "fp32" | "bf16x3" (slab loop only) | "patch" (the default: bf16x3 + the patch kernel)
+        if wgm:
+            if wgm not in WGRAD_MATH:
+                raise RuntimeError(f"SGX_WGRAD_MATH={wgm!r}: expected one of {sorted(WGRAD_MATH)}")
+            _LIB.sgx_conv_set_wgrad_math(WGRAD_MATH[wgm])
+        if os.environ.get("SGX_WGRAD_PATCH"):  # measurement: "item_mflop,kb,min_fill_pct"
+            _LIB.sgx_debug_set_wgrad_patch(*[int(v) for v in os.environ["SGX_WGRAD_PATCH"].split(",")])
         if os.environ.get("SGX_WGRAD_TILE"):
             _LIB.sgx_debug_set_tiles(0, 0, *[int(v) for v in os.environ["SGX_WGRAD_TILE"].split(",")], 0)
         if os.environ.get("SGX_FUSED_FINALIZE") == "0":  # measurement switch: two-launch BatchNorm / column-sum finalize (default: one launch)
@@ -227,6 +246,7 @@ def lib():
     return _LIB
 
 
+WGRAD_MATH = {"fp32": 0, "bf16x3": 1, "patch": 2}
 DEFAULT_TUNING = os.path.join(_HERE, "csrc", "conv_tuning_gfx950.json")
 TUNE_FIELDS = ("kind", "N", "H", "W", "C", "K", "R", "stride", "pad", "bm", "bn", "variant")
 

@@ -187,7 +187,66 @@ struct IgemmParams {
     float* Y2;
     int Hin2, Win2, Th2, Tw2, dh02, dw02, dstep2;
     long a2_ld_pix, a2_ld_img, w2_ld_n, a2_bytes, w2_bytes;
+    // BatchNorm-backward REDUCE of the layer(s) whose output gradient this launch finalises (data gradients; sgx_bn_reduce_req): per request
+    // a channel range of Y, that layer's saved conv output t (its own strides) and its BatchNorm scale / shift / mean.  The epilogue forms
+    // g = v * act'(scale t + shift) from the value v it is about to store and leaves sum g, sum g (t - mean) per column in row block
+    // (req_row0 + tile row) of the request's partials - the rows sgx_bn_bwd_reduce would have produced with a pass over dy and t.
+    int nreq, req_row0;
+    struct {
+        const float* t;
+        const float* scale;
+        const float* shift;
+        const float* mean;
+        float* parts;
+        long t_ld_pix, t_ld_img;
+        int c_lo, c_hi, act, rows;
+    } req[SGX_MAX_BN_REQ];
 };
+// this lane's request for the four output columns col .. col + 3 (ranges are multiples of 4): index or -1, the per-channel constants
+struct BnReqLane {
+    int rq;
+    int act;
+    const float* tp;  // t + (col - c_lo)
+    float4 sc, sh, mu;
+};
+__device__ __forceinline__ BnReqLane sgx_bnreq_lane(const IgemmParams& p, int col) {
+    BnReqLane L;
+    L.rq = -1;
+    L.act = 0;
+    L.tp = nullptr;
+    L.sc = L.sh = L.mu = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < SGX_MAX_BN_REQ; ++r)
+        if (r < p.nreq && col >= p.req[r].c_lo && col < p.req[r].c_hi) {
+            const int c = col - p.req[r].c_lo;
+            L.rq = r;
+            L.act = p.req[r].act;
+            L.tp = p.req[r].t + c;
+            L.sc = sgx_ld4(p.req[r].scale + c);
+            L.sh = sgx_ld4(p.req[r].shift + c);
+            L.mu = sgx_ld4(p.req[r].mean + c);
+        }
+    return L;
+}
+__device__ __forceinline__ void sgx_bnreq_acc(const BnReqLane& L, const float4& v, const float4& t, float4& cs, float4& cq) {
+    const float gx = L.act == SGX_ACT_NONE ? v.x : v.x * sgx_act_grad(L.sc.x * t.x + L.sh.x, L.act);
+    const float gy = L.act == SGX_ACT_NONE ? v.y : v.y * sgx_act_grad(L.sc.y * t.y + L.sh.y, L.act);
+    const float gz = L.act == SGX_ACT_NONE ? v.z : v.z * sgx_act_grad(L.sc.z * t.z + L.sh.z, L.act);
+    const float gw = L.act == SGX_ACT_NONE ? v.w : v.w * sgx_act_grad(L.sc.w * t.w + L.sh.w, L.act);
+    cs.x += gx; cs.y += gy; cs.z += gz; cs.w += gw;
+    cq.x += gx * (t.x - L.mu.x); cq.y += gy * (t.y - L.mu.y); cq.z += gz * (t.z - L.mu.z); cq.w += gw * (t.w - L.mu.w);
+}
+// the finished column sums of a tile row -> the request's partial rows (one thread per tile column)
+__device__ __forceinline__ void sgx_bnreq_publish(const IgemmParams& p, int col, int mtile, float s, float q) {
+#pragma unroll
+    for (int r = 0; r < SGX_MAX_BN_REQ; ++r)
+        if (r < p.nreq && col >= p.req[r].c_lo && col < p.req[r].c_hi) {
+            const int C = p.req[r].c_hi - p.req[r].c_lo;
+            float* const o = p.req[r].parts + (long)(p.req_row0 + mtile) * C + (col - p.req[r].c_lo);
+            o[0] = s;
+            o[(long)p.req[r].rows * C] = q;
+        }
+}
 
 #define IG_BK 16
 #define IG_LD 20
@@ -199,108 +258,8 @@ struct IgemmParams {
 // 16 consecutive rows hit 16 distinct 4-bank groups (conflict-free) at 2/3 of the LDS a padded pitch would need.
 #define IG_LDP 8
 #define IG_SWZ(row, dw) ((dw) ^ ((((row) >> 3) & 1) << 2))
-__device__ __forceinline__ unsigned sgx_f2u(float f) {
-    unsigned u;
-    memcpy(&u, &f, 4);
-    return u;
-}
-__device__ __forceinline__ float sgx_u2f(unsigned u) {
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-// (bf16(b) << 16) | bf16(a), round-to-nearest-even (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ unsigned sgx_pack_bf16(float a, float b) {
-#ifdef SGX_EMU
-    const unsigned ua = sgx_f2u(a), ub = sgx_f2u(b);
-    const unsigned ra = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16, rb = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
-    return (ra & 0xffffu) | (rb << 16);
-#else
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    const f32x2_t v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-#endif
-}
-// x = hi + mid + lo with every piece rounded to nearest: |x - (hi + mid + lo)| <= 2^-27 |x|, the residuals are exact in fp32, and the
-// pieces carry mixed signs, so the cross terms the six-product scheme drops (mid*lo, lo*mid, lo*lo: <= 2^-26 of a product) are unbiased.
-// (A truncating split is one instruction cheaper per pair but leaves every dropped term with the sign of the product: measured as a
-// 2x larger end-to-end error than the fp32 matrix pipe on the YOLO-NAS-M golden fixture.)
-__device__ __forceinline__ void sgx_split3(const float4& v, uint2& h, uint2& m, uint2& l) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    unsigned hp[2], mp[2], lp[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float a = x[2 * i], b = x[2 * i + 1];
-        hp[i] = sgx_pack_bf16(a, b);
-        const float ra = a - sgx_u2f(hp[i] << 16), rb = b - sgx_u2f(hp[i] & 0xffff0000u);
-        mp[i] = sgx_pack_bf16(ra, rb);
-        const float sa = ra - sgx_u2f(mp[i] << 16), sb = rb - sgx_u2f(mp[i] & 0xffff0000u);
-        lp[i] = sgx_pack_bf16(sa, sb);
-    }
-    h = make_uint2(hp[0], hp[1]);
-    m = make_uint2(mp[0], mp[1]);
-    l = make_uint2(lp[0], lp[1]);
-}
-#ifdef SGX_EMU
-// host emulation of v_mfma_f32_32x32x16_bf16: lane l holds A[row l%32][k = 8*(l/32) .. +7] and B[k = 8*(l/32) .. +7][col l%32]
-static inline sgx_f32x16 sgx_mfma_bf16(const uint4& a, const uint4& b, sgx_f32x16 c) {
-    uint64_t u[4];
-    memcpy(&u[0], &a, 16);
-    memcpy(&u[2], &b, 16);
-    auto x = sgx_emu::xchg_put(u, 4);
-    const int l = sgx_emu::t_lane;
-    const int col = l & 31;
-    sgx_f32x16 d = c;
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        float acc = d[r];
-        for (int half = 0; half < 2; ++half) {
-            unsigned short av[8], bv[8];
-            memcpy(av, &x.w->xbuf[x.buf][row + 32 * half][0], 16);
-            memcpy(bv, &x.w->xbuf[x.buf][col + 32 * half][2], 16);
-            for (int k = 0; k < 8; ++k) acc = fmaf(sgx_u2f((unsigned)av[k] << 16), sgx_u2f((unsigned)bv[k] << 16), acc);
-        }
-        d[r] = acc;
-    }
-    return d;
-}
-#else
-typedef __bf16 sgx_bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ sgx_f32x16 sgx_mfma_bf16(const uint4& a, const uint4& b, sgx_f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sgx_bf16x8, a), __builtin_bit_cast(sgx_bf16x8, b), c, 0, 0, 0);
-}
-#endif
-
-// ds_read_b64_tr_b16 (gfx950's LDS transpose read): every lane reads the four 16-bit elements at its own 8-byte-aligned LDS address; inside
-// each group of 16 lanes the 16 x 4 matrix In[lane][e] comes back transposed in 4 x 4 blocks - lane i receives In[(i >> 2) + 4 j][i & 3],
-// j = 0..3 (measured on the chip: tools/probe_tr_read.hip, profiles/r3zi_probe_ds_read_tr_b16.txt).  If the 16 lanes address a
-// [4 rows][16 columns] block of a row-major bf16 image (lane q: row q >> 2, columns 4 (q & 3) .. + 3), lane i gets column i of the four
-// rows: an MFMA operand whose reduction index runs along the ROWS of the LDS image (pixels of a weight gradient) without a transposing
-// store.  All 64 lanes take part (the host emulation exchanges through the wave buffer).
-#ifdef SGX_EMU
-static inline uint2 sgx_lds_tr_read(const unsigned short* p) {
-    uint64_t u;
-    memcpy(&u, p, 8);
-    auto x = sgx_emu::xchg_put(&u, 1);
-    const int l = sgx_emu::t_lane, g = l & ~15, i = l & 15;
-    unsigned short o[4];
-    for (int j = 0; j < 4; ++j) {
-        unsigned short in[4];
-        memcpy(in, &x.w->xbuf[x.buf][g + (i >> 2) + 4 * j][0], 8);
-        o[j] = in[i & 3];
-    }
-    uint2 r;
-    memcpy(&r, o, 8);
-    return r;
-}
-#else
-typedef short sgx_i16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint2 sgx_lds_tr_read(const unsigned short* p) {
-    const sgx_i16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sgx_i16x4*)(p));
-    return __builtin_bit_cast(uint2, v);
-}
-#endif
+#include "conv_mma.h"
+#include "wgrad_patch.h"
 
 // KD = slab depth, NBUF = LDS buffers.  (16, 2): one barrier per slab (the round-1 loop).  KD = 32 (fp32 arithmetic, C % 32 == 0;
 // experiment switches sgx_debug_set_variant(5 | 6), see run_igemm): every global load instruction covers whole 128-byte lines (8 lanes
@@ -332,6 +291,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     float* const Bs = smem + NBUF * BM * ROWW;
     __shared__ long long rowoff[BM];
     __shared__ long long rowoff2[PH2 == 1 ? BM : 1];  // offsets into addend2 (two-source data gradient only)
+    __shared__ long long rowoffT[PH2 == 2 ? 1 : SGX_MAX_BN_REQ][PH2 == 2 ? 1 : BM];  // offsets into the requests' saved conv outputs
     __shared__ float red[(PH2 == 2 ? 5 : 2) * WM * BN];
 
     const int tid = threadIdx.x;
@@ -413,6 +373,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             const int b = rem - a * p.Wa;
             off = (long long)img * p.y_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.y_ld_pix;
             if (PH2 == 1 && p.addend2) rowoff2[tid] = (long long)img * p.a2d_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.a2d_ld_pix;
+            if (PH2 != 2) {
+#pragma unroll
+                for (int r = 0; r < SGX_MAX_BN_REQ; ++r)
+                    if (r < p.nreq) rowoffT[PH2 == 2 ? 0 : r][PH2 == 2 ? 0 : tid] = (long long)img * p.req[r].t_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.req[r].t_ld_pix;
+            }
         }
         rowoff[tid] = off;
     }
@@ -742,6 +707,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             }
         }
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
+        const bool bnr = p.nreq > 0;
+        BnReqLane rql;
+        rql.rq = -1;
+        if (bnr && colok) rql = sgx_bnreq_lane(p, col);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -769,8 +738,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                             float4 u = sgx_ld4(yp);
                             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
                         }
-                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                        cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+                        if (bnr) {
+                            if (rql.rq >= 0) sgx_bnreq_acc(rql, v, sgx_ld4(rql.tp + rowoffT[rql.rq][wm * TM * 32 + i * 32 + rowl]), cs, cq);
+                        } else {
+                            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                            cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+                        }
                         sgx_st4(yp, make_float4(sgx_act(v.x, p.act), sgx_act(v.y, p.act), sgx_act(v.z, p.act), sgx_act(v.w, p.act)));
                     } else {
                         float e[4] = {v.x, v.y, v.z, v.w};
@@ -792,7 +765,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             }
             __syncthreads();
         }
-        if (p.stat_partials) {
+        if (p.stat_partials || bnr) {
             // the 8 lanes with equal (lane & 7) hold the same 4 columns: fold them, lanes 0-7 publish
             float vals[8] = {cs.x, cs.y, cs.z, cs.w, cq.x, cq.y, cq.z, cq.w};
 #pragma unroll
@@ -810,7 +783,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             }
         }
     }
-    if (p.stat_partials) {
+    if (p.stat_partials || p.nreq > 0) {
         __syncthreads();
         if (tid < BN) {
             int col = n0 + tid;
@@ -821,8 +794,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                     s += red[(0 * WM + w) * BN + tid];
                     q += red[(1 * WM + w) * BN + tid];
                 }
-                p.stat_partials[(long)mtile * p.Nout + col] = s;
-                p.stat_partials[((long)p.stat_nblk + mtile) * p.Nout + col] = q;
+                if (p.nreq > 0) sgx_bnreq_publish(p, col, mtile, s, q);
+                else {
+                    p.stat_partials[(long)mtile * p.Nout + col] = s;
+                    p.stat_partials[((long)p.stat_nblk + mtile) * p.Nout + col] = q;
+                }
             }
         }
     }
@@ -881,6 +857,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
     float* const smem = reinterpret_cast<float*>(smem_raw);
     __shared__ long long rowoff[BM];
     __shared__ long long rowoff2[PH2 == 1 ? BM : 1];
+    __shared__ long long rowoffT[PH2 == 2 ? 1 : SGX_MAX_BN_REQ][PH2 == 2 ? 1 : BM];
     __shared__ float red[(PH2 == 2 ? 5 : 2) * WM * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -906,6 +883,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
         if (a < p.Ha && b < p.Wa) {
             off = (long long)img * p.y_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.y_ld_pix;
             if (PH2 == 1 && p.addend2) rowoff2[tid] = (long long)img * p.a2d_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.a2d_ld_pix;
+            if (PH2 != 2) {
+#pragma unroll
+                for (int r = 0; r < SGX_MAX_BN_REQ; ++r)
+                    if (r < p.nreq) rowoffT[PH2 == 2 ? 0 : r][PH2 == 2 ? 0 : tid] = (long long)img * p.req[r].t_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.req[r].t_ld_pix;
+            }
         }
         rowoff[tid] = off;
     }
@@ -1196,6 +1178,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias && colok) bv = sgx_ld4(p.bias + col);
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
+        const bool bnr = p.nreq > 0;
+        BnReqLane rql;
+        rql.rq = -1;
+        if (bnr && colok) rql = sgx_bnreq_lane(p, col);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1222,14 +1208,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
                         float4 u = sgx_ld4(yp);
                         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
                     }
-                    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                    cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+                    if (bnr) {
+                        if (rql.rq >= 0) sgx_bnreq_acc(rql, v, sgx_ld4(rql.tp + rowoffT[rql.rq][(wm * TM + i) * 32 + rowl]), cs, cq);
+                    } else {
+                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                        cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+                    }
                     sgx_st4(yp, make_float4(sgx_act(v.x, p.act), sgx_act(v.y, p.act), sgx_act(v.z, p.act), sgx_act(v.w, p.act)));
                 }
             }
             __syncthreads();
         }
-        if (p.stat_partials) {
+        if (p.stat_partials || bnr) {
             float vals[8] = {cs.x, cs.y, cs.z, cs.w, cq.x, cq.y, cq.z, cq.w};
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -1246,7 +1236,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
             }
         }
     }
-    if (p.stat_partials) {
+    if (p.stat_partials || p.nreq > 0) {
         __syncthreads();
         if (tid < BN) {
             int col = n0 + tid;
@@ -1257,8 +1247,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
                     s += red[(0 * WM + w) * BN + tid];
                     q += red[(1 * WM + w) * BN + tid];
                 }
-                p.stat_partials[(long)mtile * p.Nout + col] = s;
-                p.stat_partials[((long)p.stat_nblk + mtile) * p.Nout + col] = q;
+                if (p.nreq > 0) sgx_bnreq_publish(p, col, mtile, s, q);
+                else {
+                    p.stat_partials[(long)mtile * p.Nout + col] = s;
+                    p.stat_partials[((long)p.stat_nblk + mtile) * p.Nout + col] = q;
+                }
             }
         }
     }
@@ -1446,6 +1439,10 @@ static bool pconv_ok(const IgemmParams& p, int ph2) {
     for (int j = 0; j < p.Tw; ++j)
         if (p.dw0 + p.dstep * j < -1 || p.dw0 + p.dstep * j > 1) return false;
     if (p.C % 16 || p.C < 16 || !p.vec) return false;
+    // A forward launch that emits BatchNorm statistic rows must be a problem sgx_conv2d_fwd_stat_blocks sized those rows for (one row per
+    // patch tile): the 3x3 pad-1 shape of pconv_shape_ok and nothing wider - a 2x2 / 1x3 stride-1 filter would otherwise get patch-tile row
+    // counts written into a buffer allocated for cdiv(M, bm) rows
+    if (p.stat_partials && !(p.Th == 3 && p.Tw == 3 && p.dh0 == -1 && p.dw0 == -1 && p.dstep == 1 && p.so == 1 && p.Nout % 4 == 0)) return false;
     // Where it pays (r3g, replay of every conv problem of a YOLO-NAS-S step): the stride-1 problems on maps of 40 x 40 and larger (1.25-1.6x
     // over the fp32 pipe).  20 x 20 maps fill their 8 x 16 tiles to 52 %, and the parity classes of a stride-2 data gradient carry
     // 2x2 / 2x1 taps only - a quarter of the reuse the patch is staged for, and 0.65x on the 768-channel layer.  Variant 9 lifts both.
@@ -1498,6 +1495,7 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
              ((uintptr_t)p.bias % 16) == 0)
                 ? 1
                 : 0;
+    if (p.nreq && !p.vec) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: BatchNorm-reduce requests need 16-byte aligned outputs");
     // algorithmic work: every input element, weight and output element once (fp32); the second source adds its taps
     const double T2 = (ph2 && p.A2) ? (double)p.Th2 * p.Tw2 : 0.0;
     // (profiling class 0 = fp32-MFMA implicit GEMM, 2 = the bf16x3 patch kernel: same algorithmic FLOPs, priced separately by bench.py)
@@ -1688,7 +1686,8 @@ struct DgradSecond {  // the 1x1 branch of a QARepVGG block: dx += dgrad1x1(ds) 
     const float* a2_scale_dev;
 };
 static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const float* w, const float* bias, const float* addend,
-                                  float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream, int mode, const DgradSecond* sec = nullptr);
+                                  float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream, int mode, const DgradSecond* sec = nullptr,
+                                  const sgx_bn_reduce_req* reqs = nullptr, int nreq = 0, int* rows_out = nullptr);
 extern "C" int32_t sgx_conv2d_bwd_data(const sgx_conv_desc* d, const float* dy, const float* w, const float* addend,
                                        float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream) {
     return conv_bwd_data_impl(d, dy, w, nullptr, addend, dx, accumulate, ws, ws_bytes, stream, 0);
@@ -1773,14 +1772,44 @@ extern "C" int32_t sgx_conv2d_bwd_data_dual(const sgx_conv_desc* d, const float*
     DgradSecond sec{ds, (long)ds_ld_pix, (long)ds_ld_img, w1t, addend2, (long)a2_ld_pix, (long)a2_ld_img, a2_scale, a2_scale_dev};
     return conv_bwd_data_impl(d, dy, nullptr, nullptr, addend, dx, accumulate, const_cast<float*>(wt), sgx_conv2d_bwd_data_workspace(d), stream, 2, &sec);
 }
+extern "C" int32_t sgx_conv2d_bwd_data_dual_req(const sgx_conv_desc* d, const float* dy, const float* wt, const float* ds, int64_t ds_ld_pix,
+                                                int64_t ds_ld_img, const float* w1t, const float* addend, const float* addend2, int64_t a2_ld_pix,
+                                                int64_t a2_ld_img, float a2_scale, const float* a2_scale_dev, float* dx, int32_t accumulate,
+                                                const sgx_bn_reduce_req* reqs, int32_t nreq, void* stream) {
+    SGX_CHECK_ARG(ds && w1t && d && d->K >= IG_BK && ds_ld_pix % 4 == 0, "conv bwd_data_dual: bad args (needs K >= 16)");
+    SGX_CHECK_ARG(!addend2 || (d->stride == 1 && a2_ld_pix % 4 == 0 && a2_ld_img % 4 == 0 && ((uintptr_t)addend2 % 16) == 0),
+                  "conv bwd_data_dual: the scaled second addend needs stride 1 and 16-byte aligned rows");
+    DgradSecond sec{ds, (long)ds_ld_pix, (long)ds_ld_img, w1t, addend2, (long)a2_ld_pix, (long)a2_ld_img, a2_scale, a2_scale_dev};
+    return conv_bwd_data_impl(d, dy, nullptr, nullptr, addend, dx, accumulate, const_cast<float*>(wt), sgx_conv2d_bwd_data_workspace(d), stream, 2, &sec, reqs, nreq);
+}
+// mode 3: no launch - counts the statistic rows a launch with requests would write (*rows_out; 0 = cannot carry requests)
 static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const float* w, const float* bias, const float* addend,
-                                  float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream, int mode, const DgradSecond* sec) {
+                                  float* dx, int32_t accumulate, void* ws, int64_t ws_bytes, void* stream, int mode, const DgradSecond* sec,
+                                  const sgx_bn_reduce_req* reqs, int nreq, int* rows_out) {
     int32_t rc = check_desc(d);
     if (rc) return rc;
-    SGX_CHECK_ARG((mode == 1 || (dy && dx)) && (mode == 2 || w), "conv bwd_data: null pointer");
+    const bool dry = mode == 3;
+    SGX_CHECK_ARG(dry || ((mode == 1 || (dy && dx)) && (mode == 2 || w)), "conv bwd_data: null pointer");
     TuneScope tune(1, d);
     SGX_CHECK_ARG(d->K % 4 == 0 && d->y_ld_pix % 4 == 0, "conv bwd_data: K and dy pixel stride must be multiples of 4");
-    if (ws_bytes < sgx_conv2d_bwd_data_workspace(d) || !ws) SGX_FAIL(SGX_ERR_WORKSPACE, "conv bwd_data: workspace too small");
+    if (!dry && (ws_bytes < sgx_conv2d_bwd_data_workspace(d) || !ws)) SGX_FAIL(SGX_ERR_WORKSPACE, "conv bwd_data: workspace too small");
+    SGX_CHECK_ARG(nreq >= 0 && nreq <= SGX_MAX_BN_REQ && (nreq == 0 || (reqs && mode == 2)), "conv bwd_data: bad BatchNorm-reduce requests");
+    for (int r = 0; r < nreq; ++r)
+        SGX_CHECK_ARG(reqs[r].t && reqs[r].scale && reqs[r].shift && reqs[r].mean && reqs[r].partials && reqs[r].c_lo >= 0 && reqs[r].c_hi <= d->C &&
+                          reqs[r].c_lo < reqs[r].c_hi && reqs[r].c_lo % 4 == 0 && reqs[r].c_hi % 4 == 0 && reqs[r].t_ld_pix % 4 == 0 &&
+                          reqs[r].t_ld_img % 4 == 0 && ((uintptr_t)reqs[r].t % 16) == 0 && ((uintptr_t)reqs[r].scale % 16) == 0 &&
+                          ((uintptr_t)reqs[r].shift % 16) == 0 && ((uintptr_t)reqs[r].mean % 16) == 0,
+                      "conv bwd_data: BatchNorm-reduce request %d: null pointer, unaligned operand or a channel range outside [0, C)", r);
+    if (nreq) {  // the rows the launches below will write, before anything is launched
+        int rows = 0;
+        rc = conv_bwd_data_impl(d, nullptr, nullptr, nullptr, nullptr, sec ? reinterpret_cast<float*>(16) : nullptr, 0, nullptr, 0, nullptr, 3, nullptr, nullptr, 0, &rows);
+        if (rc) return rc;
+        if (rows <= 0) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv bwd_data: this problem cannot carry BatchNorm-reduce requests (sgx_conv2d_bwd_data_stat_blocks = 0)");
+        for (int r = 0; r < nreq; ++r)
+            SGX_CHECK_ARG(reqs[r].rows == rows, "conv bwd_data: request %d was allocated for %d rows, the launch writes %d (sgx_conv2d_bwd_data_stat_blocks)", r, reqs[r].rows, rows);
+    }
+    int rows_total = 0;
+    bool rows_ok = true;  // every parity class can carry requests
     const int s = d->stride;
     float* wt = (float*)ws;
     for (int ph = 0; ph < s; ++ph)
@@ -1816,6 +1845,11 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
             p.act = SGX_ACT_NONE; p.accumulate = accumulate;
             if (T == 0) {
                 if (mode == 1) continue;
+                if (dry || nreq) {  // a class no filter tap reaches still defines dx there (zeros / the addends): its g is not formed by any launch
+                    rows_ok = false;
+                    if (nreq) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv bwd_data: BatchNorm-reduce requests need a filter that reaches every output-parity class");
+                    continue;
+                }
                 // no filter tap reaches this parity class (e.g. 1x1 stride 2): nothing to add when accumulating
                 if (accumulate && !addend && !bias) continue;
                 long n = (long)p.M * (p.Nout / 4);
@@ -1823,6 +1857,34 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
                 SGX_LAUNCH(dgrad_fill_kernel, dim3(grid), dim3(256), 0, stream, p);
                 SGX_CHECK_LAUNCH("dgrad_fill");
                 continue;
+            }
+            if (dry || nreq) {
+                // the rows of this class: one per pixel tile of the launch, decided exactly as run_igemm decides below
+                IgemmParams q = p;
+                q.vec = (q.Nout % 4 == 0 && q.y_ld_pix % 4 == 0 && q.y_ld_img % 4 == 0) ? 1 : 0;
+                const int ph2 = (sec || (dry && dx != nullptr)) && ph == 0 && pw == 0 ? 1 : 0;  // (dry: dx != nullptr marks the two-source form)
+                if (ph2) {
+                    q.A2 = q.A ? q.A : reinterpret_cast<const float*>(16);
+                    q.Th2 = q.Tw2 = 1; q.dh02 = q.dw02 = 0; q.dstep2 = 1;
+                }
+                const bool flat = q.C < IG_BK && T > 1;
+                int mt;
+                if (!q.vec || flat || (ph2 && q.C < IG_BK)) rows_ok = false, mt = 0;
+                else if (pconv_ok(q, ph2)) mt = pconv_tiles(q.M / (q.Ha * q.Wa), q.Ha, q.Wa);
+                else if (ph2) mt = sgx_cdiv(q.M, pick_tile_heuristic(q.M, q.Nout).bm);
+                else mt = sgx_cdiv(q.M, pick_tile(q.M, q.Nout, conv_math_for(q.Th * q.Tw, q.C)).bm);
+                if (nreq) {
+                    if (!rows_ok) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv bwd_data: this problem cannot carry BatchNorm-reduce requests (sgx_conv2d_bwd_data_stat_blocks = 0)");
+                    p.nreq = nreq;
+                    p.req_row0 = rows_total;
+                    for (int r = 0; r < nreq; ++r) {
+                        p.req[r].t = reqs[r].t; p.req[r].scale = reqs[r].scale; p.req[r].shift = reqs[r].shift; p.req[r].mean = reqs[r].mean;
+                        p.req[r].parts = reqs[r].partials; p.req[r].t_ld_pix = reqs[r].t_ld_pix; p.req[r].t_ld_img = reqs[r].t_ld_img;
+                        p.req[r].c_lo = reqs[r].c_lo; p.req[r].c_hi = reqs[r].c_hi; p.req[r].act = reqs[r].act; p.req[r].rows = reqs[r].rows;
+                    }
+                }
+                rows_total += mt;
+                if (dry) continue;
             }
             if (mode == 1 && g_wt_rec) {
                 if (g_wt_rec->n < g_wt_rec->max) {
@@ -1855,9 +1917,21 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
                 rc = run_igemm(p, m.bm, t.bn, stream);
                 if (rc) return rc;
             }
+            if (nreq && p.req_row0 + p.mt != rows_total) SGX_FAIL(SGX_ERR_HIP, "conv bwd_data: internal - statistic rows %d + %d != %d", p.req_row0, p.mt, rows_total);
             wt += (long)d->C * T * d->K;
         }
+    if (rows_out) *rows_out = rows_ok ? rows_total : 0;
     return SGX_OK;
+}
+extern "C" int32_t sgx_conv2d_bwd_data_stat_blocks(const sgx_conv_desc* d, int32_t two_source) {
+    int rows = 0;
+    // (dry run: the non-null dx pointer only marks the two-source form, nothing is dereferenced)
+    if (conv_bwd_data_impl(d, nullptr, nullptr, nullptr, nullptr, two_source ? reinterpret_cast<float*>(16) : nullptr, 0, nullptr, 0, nullptr, 3, nullptr, nullptr, 0, &rows)) return 0;
+    return rows;
+}
+extern "C" int32_t sgx_conv2d_bwd_data_wt_req(const sgx_conv_desc* d, const float* dy, const float* wt, const float* addend, float* dx,
+                                              int32_t accumulate, const sgx_bn_reduce_req* reqs, int32_t nreq, void* stream) {
+    return conv_bwd_data_impl(d, dy, nullptr, nullptr, addend, dx, accumulate, const_cast<float*>(wt), sgx_conv2d_bwd_data_workspace(d), stream, 2, nullptr, reqs, nreq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2306,9 +2380,27 @@ extern "C" int32_t sgx_debug_set_wgrad_loop(int32_t deep_slab, int32_t ablate) {
     g_wg_lab = ablate;
     return SGX_OK;
 }
+// Arithmetic of the weight gradient (process-wide, product default 2).  0: the fp32 matrix pipe.  1: the bf16x3 slab loop (round 3: the whole
+// GPU parity suite green under it, r4a; 662 -> 686 images/s).  2: mode 1 + the PATCH kernel (wgrad_patch.hip) on the 3x3 pad-1 problems.
+static std::atomic<int> g_wg_math{2};
+static std::atomic<int> g_wp_item_mflop{48}, g_wp_kb{0}, g_wp_fill{60};
+extern "C" int32_t sgx_conv_set_wgrad_math(int32_t mode) {
+    SGX_CHECK_ARG(mode >= 0 && mode <= 2, "conv_set_wgrad_math: mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16x3 + patch kernel)");
+    g_wg_math = mode;
+    return SGX_OK;
+}
+extern "C" int32_t sgx_conv_get_wgrad_math(void) { return g_wg_math; }
+extern "C" int32_t sgx_debug_set_wgrad_patch(int32_t item_mflop, int32_t kb, int32_t min_fill_pct) {
+    SGX_CHECK_ARG(item_mflop >= 0 && kb >= 0 && kb <= 3 && min_fill_pct >= 0 && min_fill_pct <= 100, "debug_set_wgrad_patch: item_mflop >= 0, kb in 0..3, fill in 0..100");
+    g_wp_item_mflop = item_mflop ? item_mflop : 48;
+    g_wp_kb = kb;
+    g_wp_fill = min_fill_pct ? min_fill_pct : 60;
+    return SGX_OK;
+}
 struct WgPlan {
     int bnk, bj, waves, kt_tiles, jt_tiles, ksplit, mchunk;
     long part_off, ticket_off;  // floats, ints
+    WpPlan wp;                  // wp.cfg != 0: the patch kernel takes this job (the fields above are then unused)
 };
 // tile choice from the exhaustive search: 64x64 where the channel count allows, 96x128 for 96-wide layers; a tuning-table entry (kind 2)
 // or the measurement override replaces it
@@ -2333,12 +2425,21 @@ static void wgrad_tile(const sgx_conv_desc* d, WgPlan& pl) {
 #define WG_SLOTS 1536  // workgroups the chip holds at once (256 CUs x ~6): the unit a group's work is cut against
 static int32_t wgrad_group_plan(const sgx_wgrad_job* jobs, int n, std::vector<WgPlan>& plans, long* part_floats, long* ticket_ints) {
     plans.resize(n);
-    double work = 0.0;
+    double work = 0.0, pwork = 0.0;
+    // the patch kernel: product mode 2, no measurement override of the slab loop's tiles / loop in force
+    const bool patch_on = g_wg_math.load(std::memory_order_relaxed) == 2 && !g_ovr_wk.load(std::memory_order_relaxed) &&
+                          !g_ovr_wj.load(std::memory_order_relaxed) && !g_ovr_split.load(std::memory_order_relaxed) &&
+                          !(g_wg_deep.load(std::memory_order_relaxed) & 16) && !g_wg_lab.load(std::memory_order_relaxed);
     for (int i = 0; i < n; ++i) {
         const sgx_conv_desc* d = &jobs[i].d;
         int32_t rc = check_desc(d);
         if (rc) return rc;
         SGX_CHECK_ARG(d->K % 4 == 0 && d->y_ld_pix % 4 == 0, "conv bwd_weight: K and dy pixel stride must be multiples of 4");
+        plans[i].wp.cfg = 0;
+        if (patch_on && wpatch_plan_job(d, plans[i].wp, g_wp_kb.load(std::memory_order_relaxed), g_wp_fill.load(std::memory_order_relaxed))) {
+            pwork += 2.0 * 32.0 * plans[i].wp.ntiles * plans[i].wp.kt_tiles * 32.0 * plans[i].wp.kb * plans[i].wp.ct_tiles * 32.0 * 9.0;
+            continue;
+        }
         wgrad_tile(d, plans[i]);
         work += 2.0 * d->N * d->Ho * d->Wo * (double)plans[i].kt_tiles * plans[i].bnk * (double)plans[i].jt_tiles * plans[i].bj;
     }
@@ -2352,9 +2453,18 @@ static int32_t wgrad_group_plan(const sgx_wgrad_job* jobs, int n, std::vector<Wg
     if (item > 2.0 * lo) item = 2.0 * lo;
     const int osp = g_ovr_split.load(std::memory_order_relaxed);
     long poff = 0, toff = 0;
+    // patch jobs: ~5 rounds of the ~512 workgroups the chip holds, items of 16 .. g_wp_item_mflop MFLOP (a node of the fold tree is 37 - 110 KB:
+    // short items would spend their time handing partial tiles over)
+    double pitem = pwork / (512.0 * 5.0);
+    const double phi = 1e6 * g_wp_item_mflop.load(std::memory_order_relaxed);
+    if (pitem > phi) pitem = phi;
+    if (pitem < 16e6) pitem = fmin(16e6, phi);
+    for (int i = 0; i < n; ++i)
+        if (plans[i].wp.cfg) wpatch_plan_split(&jobs[i].d, plans[i].wp, pitem, &poff, &toff);
     for (int i = 0; i < n; ++i) {
         const sgx_conv_desc* d = &jobs[i].d;
         WgPlan& pl = plans[i];
+        if (pl.wp.cfg) continue;
         const long M = (long)d->N * d->Ho * d->Wo;
         const long tiles = (long)pl.kt_tiles * pl.jt_tiles;
         long mchunk = (long)(item / (2.0 * pl.bnk * pl.bj));
@@ -2411,9 +2521,10 @@ static void launch_wgrad(const WgGroupParams& g, int nblk, void* stream) {
             return;
         }
     }
-    // bit 3: the bf16x3 loop (r3zj: 13.50 -> 11.99 ms alone with four of the tile shapes; every shape since)
+    // the bf16x3 loop (r3zj: 13.50 -> 11.99 ms alone with four of the tile shapes; every shape since): product modes 1 and 2
+    // (sgx_conv_set_wgrad_math; r4a: the whole GPU suite green under it, 662 -> 686 images/s), or measurement bit 3; bit 5 forces the fp32 loop
     if constexpr (!(BNK == 64 && BJ == 64 && WK == 1)) {
-        if (loop & 8) {
+        if ((loop & 8) || (g_wg_math.load(std::memory_order_relaxed) >= 1 && !(loop & 32))) {
             SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP, 2, 1>), grid, block, 0, stream, g);
             return;
         }
@@ -2425,13 +2536,60 @@ static void launch_wgrad(const WgGroupParams& g, int nblk, void* stream) {
 extern "C" int32_t sgx_conv2d_bwd_weight_group(const sgx_wgrad_job* jobs, int32_t njobs, void* ws, int64_t ws_bytes, int32_t* tickets,
                                                int64_t ticket_ints, void* stream) {
     SGX_CHECK_ARG(jobs && njobs > 0, "conv bwd_weight_group: bad args");
+    // every job adds into its dw without atomics (one fold tree per job): two jobs of one group must not share a filter gradient
+    for (int i = 1; i < njobs; ++i)
+        for (int j = 0; j < i; ++j)
+            SGX_CHECK_ARG(jobs[i].dw != jobs[j].dw, "conv bwd_weight_group: jobs %d and %d write the same dw (shared weights: launch them in separate calls)", j, i);
     std::vector<WgPlan> plans;
     long pf = 0, ti = 0;
     int32_t rc = wgrad_group_plan(jobs, njobs, plans, &pf, &ti);
     if (rc) return rc;
     if (!ws || ws_bytes < pf * 4 + 256 || ((uintptr_t)ws % 16) != 0) SGX_FAIL(SGX_ERR_WORKSPACE, "conv bwd_weight_group: workspace too small / unaligned");
     if (!tickets || ticket_ints < ti + 1) SGX_FAIL(SGX_ERR_WORKSPACE, "conv bwd_weight_group: ticket buffer too small");
+    // The fold trees leave their tickets zero (the second arriver of a pair resets it), but that invariant would not survive an aborted
+    // launch or a plan that changed between two calls on one buffer: the used range is cleared on every call (a few KB, stream-ordered).
+    if (ti > 0) SGX_MEMSET_ASYNC(tickets, 0, ti * 4, stream);
     std::vector<char> done(njobs, 0);
+    // ---- the patch kernel's jobs: one launch per kernel form (stride, tile columns, filter blocks) and WP_MAX_JOBS jobs of it
+    for (int first = 0; first < njobs; ++first) {
+        if (done[first] || !plans[first].wp.cfg) continue;
+        WpGroupParams g;
+        memset(&g, 0, sizeof(g));
+        g.xcd_order = g_wg_xcd.load(std::memory_order_relaxed);
+        const WpPlan& form = plans[first].wp;
+        const int stride = jobs[first].d.stride;
+        int nblk = 0;
+        double flops = 0.0, bytes = 0.0;
+        for (int i = first; i < njobs && g.njobs < WP_MAX_JOBS; ++i) {
+            const WpPlan& w = plans[i].wp;
+            if (done[i] || !w.cfg || jobs[i].d.stride != stride || w.pc != form.pc || w.kb != form.kb) continue;
+            done[i] = 1;
+            const sgx_conv_desc* d = &jobs[i].d;
+            SGX_CHECK_ARG(jobs[i].x && jobs[i].dy && jobs[i].dw, "conv bwd_weight: null pointer");
+            WpJob& p = g.jobs[g.njobs++];
+            p.X = jobs[i].x; p.DY = jobs[i].dy; p.dw = jobs[i].dw;
+            p.part = (float*)ws + w.part_off; p.tickets = tickets + w.ticket_off;
+            p.x_ld_pix = d->x_ld_pix; p.x_ld_img = d->x_ld_img; p.y_ld_pix = d->y_ld_pix; p.y_ld_img = d->y_ld_img;
+            p.x_bytes = view_bytes(d->N, d->H, d->W, d->C, d->x_ld_pix, d->x_ld_img);
+            p.dy_bytes = view_bytes(d->N, d->Ho, d->Wo, d->K, d->y_ld_pix, d->y_ld_img);
+            p.H = d->H; p.W = d->W; p.C = d->C; p.K = d->K; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+            p.tiles_h = w.tiles_h; p.tiles_w = w.tiles_w; p.ntiles = (int)w.ntiles;
+            p.ksplit = w.ksplit; p.tchunk = w.tchunk; p.kt_tiles = w.kt_tiles; p.ct_tiles = w.ct_tiles;
+            p.blk0 = nblk;
+            g.blk0[g.njobs - 1] = nblk;
+            // range-major XCD order idles XCDs when the last round of eight ranges is short (r4b: 12 ranges x 144 tiles, +18 % against the
+            // plain order): only with a multiple of eight ranges or enough rounds for the remainder not to matter
+            p.xcd_ranges = (w.ksplit % 8 == 0 || w.ksplit >= 40) ? 1 : 0;
+            nblk += p.xcd_ranges ? 8 * sgx_cdiv(w.ksplit, 8) * w.kt_tiles * w.ct_tiles : 8 * sgx_cdiv((long)w.ksplit * w.kt_tiles * w.ct_tiles, 8);
+            flops += 2.0 * (double)d->N * d->Ho * d->Wo * (double)d->K * 9.0 * d->C;
+            bytes += 4.0 * ((double)d->N * d->H * d->W * d->C + (double)d->N * d->Ho * d->Wo * d->K + (double)d->K * 9.0 * d->C);
+        }
+        {
+            SGX_PROF(1, flops, bytes, stream);
+            rc = wpatch_launch(stride, form, g, nblk, stream);
+            if (rc) return rc;
+        }
+    }
     for (int first = 0; first < njobs; ++first) {
         if (done[first]) continue;
         // one launch per tile shape (and per WG_MAX_JOBS jobs of it)

@@ -203,14 +203,70 @@ def wtrans_batch(jobs_dev, njobs):
     check(lib().sgx_wtrans_batch(ptr(jobs_dev), int(njobs), stream()), "sgx_wtrans_batch")
 
 
-def conv2d_bwd_data_wt(dy, w, wt, x_shape, stride=1, pad=0, addend=None, out=None, accumulate=False):
-    """conv2d_bwd_data with weights already transposed into `wt` by conv2d_transpose_weights (same stride / pad)."""
+class BnReduceRequest:
+    """A BatchNorm layer's backward reduce, handed to the data gradient that finalises the layer's output gradient (sgx_bn_reduce_req):
+    the layer's saved conv output t and its scale / shift / mean, and the channel range [c_lo, c_hi) of that data gradient's dx which IS the
+    layer's dy.  After the launch `parts` holds the partial rows [2, rows, C] sgx_bn_bwd_reduce would have produced (None: the launch could
+    not carry the request - the layer then runs its own reduce sweep)."""
+
+    __slots__ = ("t", "scale", "shift", "mean", "act", "c_lo", "c_hi", "parts")
+
+    def __init__(self, t, scale, shift, mean, act, c_lo=0, c_hi=None):
+        self.t, self.scale, self.shift, self.mean, self.act = t, scale, shift, mean, act
+        self.c_lo, self.c_hi = c_lo, (t.shape[3] + c_lo) if c_hi is None else c_hi
+        self.parts = None
+
+    def at(self, c_lo):
+        """the same request, for a dx whose channel c_lo is this layer's channel 0 (a concat-slice gradient)"""
+        self.c_lo, self.c_hi = c_lo, c_lo + self.t.shape[3]
+        return self
+
+
+BN_REQ_STATS = {"taken": 0, "declined": 0}  # requests carried by a data gradient / left to the layer's own sweep (tests, tools)
+
+
+def _bn_reqs(reqs, d, two_source, out):
+    """-> (ctypes array, n) for the requests this launch can carry, partial rows allocated; (None, 0) when it cannot (requests keep parts = None)"""
+    reqs = [r for r in (reqs or ()) if r is not None]
+    if not reqs:
+        return None, 0
+    arr, n = _bn_reqs_build(reqs, d, two_source, out)
+    BN_REQ_STATS["taken" if n else "declined"] += len(reqs)
+    return arr, n
+
+
+def _bn_reqs_build(reqs, d, two_source, out):
+    if len(reqs) > 2:
+        return None, 0
+    n_, h_, w_, _ = out.shape
+    for r in reqs:
+        if tuple(r.t.shape[:3]) != (n_, h_, w_) or r.c_hi > out.shape[3] or r.c_lo % 4 or r.c_hi % 4:
+            return None, 0
+    rows = lib().sgx_conv2d_bwd_data_stat_blocks(d.ref, int(two_source))
+    if rows <= 0:
+        return None, 0
+    arr = (_lib.BnReduceReq * len(reqs))()
+    for a, r in zip(arr, reqs):
+        r.parts = torch.empty(2, rows, r.c_hi - r.c_lo, device=out.device, dtype=torch.float32)
+        tl, ti = nhwc_strides(r.t)
+        a.c_lo, a.c_hi, a.t, a.t_ld_pix, a.t_ld_img = r.c_lo, r.c_hi, ptr(r.t), tl, ti
+        a.scale, a.shift, a.mean, a.act, a.rows, a.partials = ptr(r.scale), ptr(r.shift), ptr(r.mean), ACT[r.act], rows, ptr(r.parts)
+    return arr, len(reqs)
+
+
+def conv2d_bwd_data_wt(dy, w, wt, x_shape, stride=1, pad=0, addend=None, out=None, accumulate=False, reqs=None):
+    """conv2d_bwd_data with weights already transposed into `wt` by conv2d_transpose_weights (same stride / pad).
+    reqs: BnReduceRequest objects of the layer(s) whose dy this launch finalises (<= 2 channel ranges of dx)."""
     K, C, R, S = w.shape
     if out is None:
         out = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
     d = conv_desc(out, K, R, S, stride, pad, dy)
     if addend is not None and nhwc_strides(addend) != nhwc_strides(out):
         raise _lib.SgxError("bwd_data addend must share dx's strides")
+    arr, n = _bn_reqs(reqs, d, False, out)
+    if n:
+        check(lib().sgx_conv2d_bwd_data_wt_req(d.ref, ptr(dy), ptr(wt), ptr(addend), ptr(out), int(accumulate), arr, n, stream()), "sgx_conv2d_bwd_data_wt_req")
+        return out
     check(lib().sgx_conv2d_bwd_data_wt(d.ref, ptr(dy), ptr(wt), ptr(addend), ptr(out), int(accumulate), stream()), "sgx_conv2d_bwd_data_wt")
     return out
 
@@ -230,7 +286,7 @@ def conv2d_fwd_dual(x, w, w1p, bias1, stride=1):
     return y, u, stat5
 
 
-def conv2d_bwd_data_dual(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, out=None, accumulate=False, addend2=None, addend2_scale=None):
+def conv2d_bwd_data_dual(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, out=None, accumulate=False, addend2=None, addend2_scale=None, reqs=None):
     """dx = convT RxS(dy) + convT 1x1(ds) [+ addend] [+ addend2_scale * addend2] [+ dx] in one launch per parity class; wt:
     conv2d_transpose_weights(w), w1pt: [C, K]; addend2 has its own strides, its scale is a float or a one-element device tensor."""
     K, C, R, S = w.shape
@@ -243,6 +299,11 @@ def conv2d_bwd_data_dual(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, ou
     a2l, a2i = nhwc_strides(addend2) if addend2 is not None else (0, 0)
     a2_dev = addend2_scale if torch.is_tensor(addend2_scale) else None
     a2s = 1.0 if addend2_scale is None or a2_dev is not None else float(addend2_scale)
+    arr, n = _bn_reqs(reqs, d, True, out)
+    if n:
+        check(lib().sgx_conv2d_bwd_data_dual_req(d.ref, ptr(dy), ptr(wt), ptr(ds), sl, si, ptr(w1pt), ptr(addend), ptr(addend2), a2l, a2i, a2s,
+                                                 ptr(a2_dev), ptr(out), int(accumulate), arr, n, stream()), "sgx_conv2d_bwd_data_dual_req")
+        return out
     check(lib().sgx_conv2d_bwd_data_dual(d.ref, ptr(dy), ptr(wt), ptr(ds), sl, si, ptr(w1pt), ptr(addend), ptr(addend2), a2l, a2i, a2s,
                                          ptr(a2_dev), ptr(out), int(accumulate), stream()), "sgx_conv2d_bwd_data_dual")
     return out

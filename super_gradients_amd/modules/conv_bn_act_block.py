@@ -64,6 +64,7 @@ class _ConvBN(SgxBlock):
             else:
                 y = K.dual_affine_act(t, scale, shift, post_add=post_add, act=self.act, out=out)
             self._ctx = (x, t, scale, shift, mean, invstd)
+            self._req = None
             return y
         if self._folded is not None and post_add is None:
             return K.conv2d_fwd(x, self._folded[0], bias=self._folded[1], out=out, act=self.act, stride=conv.stride, pad=conv.padding)
@@ -73,14 +74,28 @@ class _ConvBN(SgxBlock):
             return K.dual_affine_act(t, scale, shift, post_add=post_add, act=self.act, out=out if out is not None else t)
         return K.affine_act(t, scale, shift, act=self.act, out=out if out is not None else t)
 
-    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
+    def bn_reduce_request(self):
+        """This layer's BatchNorm-backward reduce as a request for the data-gradient launch that finalises its output gradient (the caller
+        hands it to that launch; bwd() then finds the partial sums ready and skips its own reduce sweep).  None when it cannot be handed over
+        (synchronised BatchNorm reduces across ranks on its own path)."""
+        conv, bn = self._parts()
+        if self._ctx is None or bn._synced() or not self._net.fuse_bn_reduce:
+            return None
+        _, t, scale, shift, mean, _ = self._ctx
+        self._req = K.BnReduceRequest(t, scale, shift, mean, self.act)
+        return self._req
+
+    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True, dx_req=None):
+        """dx_req: reduce requests of the layer(s) whose output gradient is this call's dx (ConvLayer.dgrad)"""
         conv, bn = self._parts()
         (x, t, scale, shift, mean, invstd), self._ctx = self._ctx, None
-        dt = bn.backward(dy, t, scale, shift, mean, invstd, self.act, dx_out=t)  # in place over the saved conv output
+        req, self._req = getattr(self, "_req", None), None
+        parts = req.parts if req is not None else None
+        dt = bn.backward(dy, t, scale, shift, mean, invstd, self.act, dx_out=t, parts=parts)  # in place over the saved conv output
         conv.wgrad(x, dt)
         if not need_dx:
             return None
-        return conv.dgrad(dt, tuple(x.shape), out=dx_out, accumulate=accumulate, addend=addend)
+        return conv.dgrad(dt, tuple(x.shape), out=dx_out, accumulate=accumulate, addend=addend, reqs=dx_req)
 
 
 class Conv(_ConvBN):

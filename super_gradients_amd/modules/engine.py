@@ -207,9 +207,14 @@ class SgxNetwork(nn.Module):
         # worth together (kernels.conv2d_bwd_weight_group: one launch per tile shape, splits sized for the group, partials folded inside
         # the launch) - whenever the queued work passes SGX_WGRAD_GROUP_GFLOP (default 160, ~2 ms of chip time; measured r3i/r3j on
         # YOLO-NAS-S: 40 -> 613, 160 -> 633, 400 -> 629 images/s - every launch ends in a fold chain that nothing of its own fills), at every
-        # gradient-bucket boundary and at the end of backward.  0: one call per layer.
+        # gradient-bucket boundary and at the end of backward.  0: one call per layer.  Memory: the queue keeps the (x, dy) of its entries
+        # alive until the flush - up to ~0.4 GB of operands per 160 GFLOP on YOLO-NAS-S (both would have been freed a few launches later).
         self.wg_group_flops = float(os.environ.get("SGX_WGRAD_GROUP_GFLOP", "160")) * 1e9
         self._wg_pending, self._wg_flops = [], 0.0
+        # BatchNorm-backward reduce of a plain conv -> BatchNorm -> activation layer inside the data-gradient launch that finalises the layer's
+        # output gradient (kernels.BnReduceRequest; round 4): the reduce sweep over (dy, saved conv output) disappears wherever a layer's
+        # gradient has a single last writer that is a convolution's data gradient.  SGX_FUSE_BN_REDUCE=0: every layer runs its own sweep.
+        self.fuse_bn_reduce = os.environ.get("SGX_FUSE_BN_REDUCE", "1") != "0"
         # The data-gradient weight transposes of ALL convolutions run as one launch at the start of every training forward (a job table
         # built once - the operands are arena views, their addresses never change) instead of one launch per convolution and parity class
         # inside backward (YOLO-NAS-S: 165 launches of ~10 us per step; SGX_WT_BATCH=0 restores the per-call form), and so do the
@@ -452,7 +457,12 @@ class NetFunction(torch.autograd.Function):
     def backward(ctx, *grads):
         net = ctx.net
         net.join_aux()
-        net._bwd(*grads)
+        try:
+            net._bwd(*grads)
+        except BaseException:
+            # the queue holds operands of THIS backward: a later one must not launch them into the gradient arena
+            net._wg_pending, net._wg_flops = [], 0.0
+            raise
         net.flush_wgrads()
         net._wt_valid = False
         net.join_side()

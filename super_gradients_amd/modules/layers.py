@@ -85,9 +85,12 @@ class ConvLayer(SgxBlock):
         net.fork_side(lambda: K.conv2d_bwd_weight(x, dy, self._gw, self.bias.grad if (self.bias is not None and bias_grad) else None,
                                                   stride=self.stride, pad=self.padding), x, dy)
 
-    def dgrad(self, dy, x_shape, out=None, accumulate=False, addend=None):
+    def dgrad(self, dy, x_shape, out=None, accumulate=False, addend=None, reqs=None):
+        """reqs: BatchNorm-backward reduce requests (kernels.BnReduceRequest) of the layer(s) whose output gradient this launch finalises -
+        carried by the launch's epilogue where it can (their .parts is set), left alone otherwise (the layer reduces on its own)."""
         if self._wt is not None and self._net._wt_valid:  # transposed under the forward pass (engine.prefetch_dgrad_weights)
-            return K.conv2d_bwd_data_wt(dy, self._w, self._wt, x_shape, stride=self.stride, pad=self.padding, addend=addend, out=out, accumulate=accumulate)
+            return K.conv2d_bwd_data_wt(dy, self._w, self._wt, x_shape, stride=self.stride, pad=self.padding, addend=addend, out=out, accumulate=accumulate,
+                                        reqs=reqs if self._net.fuse_bn_reduce else None)
         return K.conv2d_bwd_data(dy, self._w, x_shape, stride=self.stride, pad=self.padding, addend=addend, out=out, accumulate=accumulate)
 
 

@@ -189,9 +189,10 @@ class QARepVGGBlock(SgxBlock):
         else:
             self.partial_fusion()
 
-    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True, addend2=None, addend2_scale=None):
+    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True, addend2=None, addend2_scale=None, dx_req=None):
         """addend (dx's strides) and addend2_scale * addend2 (its own strides) are added to dx; on the two-branch path both ride in
-        the data-gradient launch's epilogue."""
+        the data-gradient launch's epilogue - and so do the BatchNorm-backward reduce requests (dx_req) of the layer(s) whose output
+        gradient dx is."""
         c3, bn3, c1, pbn = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1, self.post_bn
         if addend2 is not None and need_dx and not (self._ctx[0] == "dual" and self.stride == 1 and K.nhwc_strides(addend2)[0] % 4 == 0):
             a, a_dev = (1.0, addend2_scale) if torch.is_tensor(addend2_scale) else (1.0 if addend2_scale is None else float(addend2_scale), None)
@@ -205,7 +206,8 @@ class QARepVGGBlock(SgxBlock):
             if not need_dx:
                 return None
             return K.conv2d_bwd_data_dual(dy3, c3._w, c3._wt, ds, self._w1pt, tuple(x.shape), stride=self.stride, addend=addend, out=dx_out,
-                                          accumulate=accumulate, addend2=addend2, addend2_scale=addend2_scale)
+                                          accumulate=accumulate, addend2=addend2, addend2_scale=addend2_scale,
+                                          reqs=dx_req if self._net.fuse_bn_reduce else None)
         (x, t3, s, sc3, sh3, m3, i3, scp, shp, mp, ip, t1), self._ctx = self._ctx, None
         ds = pbn.backward(dy, s, scp, shp, mp, ip, self.act, dx_out=s)          # in place over s
         ds1 = ds                                                                # gradient of the 1x1 branch output: alpha * ds

@@ -47,11 +47,12 @@ class _PredConv(ConvLayer):
         self._x = x if self.training else None
         return self.conv(x, out=out)
 
-    def bwd(self, dy, need_dx=True, **kw):
+    def bwd(self, dy, need_dx=True, dx_req=None, **kw):
+        """dx_req: BatchNorm reduce requests of the layer whose output gradient this conv's dx is (ConvLayer.dgrad)"""
         x, self._x = self._x, None
         if self.out_channels % 4 == 0:
             self.wgrad(x, dy)
-            return self.dgrad(dy, tuple(x.shape), **kw) if need_dx else None
+            return self.dgrad(dy, tuple(x.shape), reqs=dx_req, **kw) if need_dx else None
         k, kp, r, dev = self.out_channels, (self.out_channels + 3) // 4 * 4, self.kernel_size, dy.device
         cp = self._w.shape[1]
         dyp = torch.zeros(*dy.shape[:3], kp, device=dev, dtype=torch.float32)
@@ -113,8 +114,14 @@ class YoloNASDFLHead(BaseDetectionModule):
         self.reg_pred.fwd(self.reg_convs.block.fwd(f), out=reg_out)
 
     def bwd(self, d_reg, d_cls):
-        df = self.cls_convs.block.bwd(self.cls_pred.bwd(d_cls))
-        self.reg_convs.block.bwd(self.reg_pred.bwd(d_reg), dx_out=df, accumulate=True)
+        # BatchNorm reduces riding in data gradients: the two 3x3 blocks' in their prediction convs', the stem's in the regression
+        # block's (the second, accumulating writer of the stem's output gradient)
+        def req(block):
+            r = block.bn_reduce_request()
+            return [r] if r is not None else None
+
+        df = self.cls_convs.block.bwd(self.cls_pred.bwd(d_cls, dx_req=req(self.cls_convs.block)))
+        self.reg_convs.block.bwd(self.reg_pred.bwd(d_reg, dx_req=req(self.reg_convs.block)), dx_out=df, accumulate=True, dx_req=req(self.stem))
         return self.stem.bwd(df)
 
 

@@ -58,22 +58,29 @@ class YoloNASBottleneck(SgxBlock):
         y = self.cv2.fwd(self.cv1.fwd(x))
         return K.affine_act(y, r1=x, a1=a, a1_dev=a_dev, out=out if out is not None else y)
 
-    def bwd(self, dz, dx_out=None, accumulate=False, addend=None, need_dx=True):
+    def _mid_req(self):
+        """cv1's BatchNorm reduce rides in cv2's data gradient (the only writer of cv1's output gradient) when cv1 is a plain conv block"""
+        r = self.cv1.bn_reduce_request() if hasattr(self.cv1, "bn_reduce_request") else None
+        return [r] if r is not None else None
+
+    def bwd(self, dz, dx_out=None, accumulate=False, addend=None, need_dx=True, dx_req=None):
+        """dx_req: reduce requests of the layer(s) whose output gradient this block's dx is - cv1's data gradient writes it last"""
         if not self.add:
-            return self.cv1.bwd(self.cv2.bwd(dz), dx_out=dx_out, accumulate=accumulate, addend=addend, need_dx=need_dx)
+            return self.cv1.bwd(self.cv2.bwd(dz, dx_req=self._mid_req()), dx_out=dx_out, accumulate=accumulate, addend=addend, need_dx=need_dx, dx_req=dx_req)
         x, self._x = self._x, None
         a, a_dev = self._alpha()
         if a_dev is not None:
             K.dot_sum(x, dz, self.alpha.grad, accumulate=True)
-        dmid = self.cv2.bwd(dz)
+        dmid = self.cv2.bwd(dz, dx_req=self._mid_req())
         if isinstance(self.cv1, QARepVGGBlock):  # d(alpha * x) = alpha * dz rides in cv1's data-gradient launch
-            return self.cv1.bwd(dmid, dx_out=dx_out, accumulate=accumulate, addend=addend, addend2=dz, addend2_scale=a_dev if a_dev is not None else a)
+            return self.cv1.bwd(dmid, dx_out=dx_out, accumulate=accumulate, addend=addend, addend2=dz, addend2_scale=a_dev if a_dev is not None else a,
+                                dx_req=dx_req)
         if dx_out is not None:
             K.axpy(dz, a=a, a_dev=a_dev, out=dx_out, accumulate=accumulate)
             pre = dx_out
         else:
             pre = K.axpy(dz, a=a, a_dev=a_dev)
-        return self.cv1.bwd(dmid, dx_out=pre, accumulate=True, addend=addend)
+        return self.cv1.bwd(dmid, dx_out=pre, accumulate=True, addend=addend, dx_req=dx_req)
 
 
 class _BottleneckList(nn.Module):
@@ -136,21 +143,29 @@ class YoloNASCSPLayer(SgxBlock):
         self.conv2.fwd(x, out=sl(self.n_cat - 1))
         return self.conv3.fwd(cat, out=out)
 
-    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
+    def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True, dx_req=None):
+        """dx_req: reduce requests of the layer(s) whose output gradient this layer's dx is - conv1's data gradient writes it last.
+        Inside: conv2's output gradient is a slice of conv3's data gradient (its only writer); conv1's is written last by the first
+        bottleneck's data gradient (or is a slice of conv3's when there are no bottlenecks)."""
         hid = self.hidden
-        dcat = self.conv3.bwd(dy)
+        blocks = list(self.bottlenecks)
+        r2, r1 = self.conv2.bn_reduce_request(), self.conv1.bn_reduce_request()
+        cat_req = [r2.at((self.n_cat - 1) * hid)] if r2 is not None else []
+        if not blocks and r1 is not None:
+            cat_req.append(r1.at(0))
+        dcat = self.conv3.bwd(dy, dx_req=cat_req or None)
         sl = lambda i: dcat[..., i * hid:(i + 1) * hid]  # noqa: E731
         dx = self.conv2.bwd(sl(self.n_cat - 1), dx_out=dx_out, accumulate=accumulate, addend=addend)
-        blocks = list(self.bottlenecks)
+        first_req = [r1] if (blocks and r1 is not None) else None
         if self.concat_intermediates:
             g = sl(len(blocks))
             for i in range(len(blocks) - 1, -1, -1):  # the block's input gradient accumulates onto the concat slice of the same tensor
-                g = blocks[i].bwd(g, dx_out=sl(i), accumulate=True)
+                g = blocks[i].bwd(g, dx_out=sl(i), accumulate=True, dx_req=first_req if i == 0 else None)
         else:
             g = sl(0)
             for i in range(len(blocks) - 1, -1, -1):
-                g = blocks[i].bwd(g)
-        return self.conv1.bwd(g, dx_out=dx, accumulate=True)
+                g = blocks[i].bwd(g, dx_req=first_req if i == 0 else None)
+        return self.conv1.bwd(g, dx_out=dx, accumulate=True, dx_req=dx_req)
 
 
 @register_detection_module()
@@ -247,13 +262,20 @@ class YoloNASUpStage(BaseDetectionModule):
         """d_inter: gradient arriving at x_inter from its other consumer (a down stage), or None.
         dx/ds1/ds2: (buffer, accumulate) destinations for the three input gradients."""
         oc = self._oc
-        dcat = self.reduce_after_concat.bwd(self.blocks.bwd(d_out))
+        # BatchNorm reduces that ride in data gradients: reduce_after_concat's in the CSP layer's last launch; reduce_skip1's and
+        # downsample's (two slices of the concat gradient) in reduce_after_concat's; reduce_skip2's in downsample's (stride 2)
+        r_rac = self.reduce_after_concat.bn_reduce_request()
+        g_rac = self.blocks.bwd(d_out, dx_req=[r_rac] if r_rac is not None else None)
+        r_s1, r_ds = self.reduce_skip1.bn_reduce_request(), self.downsample.bn_reduce_request()
+        cat_req = [r.at(c) for r, c in ((r_s1, oc), (r_ds, 2 * oc)) if r is not None]
+        dcat = self.reduce_after_concat.bwd(g_rac, dx_req=cat_req or None)
         g_inter = self.upsample.bwd(dcat[..., :oc])
         if d_inter is not None:
             K.axpy(d_inter, out=g_inter, accumulate=True)
         gx = self.conv.bwd(g_inter, dx_out=dx[0], accumulate=dx[1])
         g1 = self.reduce_skip1.bwd(dcat[..., oc:2 * oc], dx_out=ds1[0], accumulate=ds1[1])
-        g2 = self.reduce_skip2.bwd(self.downsample.bwd(dcat[..., 2 * oc:]), dx_out=ds2[0], accumulate=ds2[1])
+        r_s2 = self.reduce_skip2.bn_reduce_request()
+        g2 = self.reduce_skip2.bwd(self.downsample.bwd(dcat[..., 2 * oc:], dx_req=[r_s2] if r_s2 is not None else None), dx_out=ds2[0], accumulate=ds2[1])
         return gx, g1, g2
 
 
@@ -289,6 +311,7 @@ class YoloNASDownStage(BaseDetectionModule):
 
     def bwd(self, d_out, dx=None):
         """-> (gx, d_skip view); d_skip is a channel slice of the concat gradient (read in place by the up stage)."""
-        dcat = self.blocks.bwd(d_out)
+        r = self.conv.bn_reduce_request()  # its output gradient = the first half of the CSP layer's input gradient
+        dcat = self.blocks.bwd(d_out, dx_req=[r.at(0)] if r is not None else None)
         gx = self.conv.bwd(dcat[..., : self._half], dx_out=dx[0], accumulate=dx[1])
         return gx, dcat[..., self._half:]

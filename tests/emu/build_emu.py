@@ -9,13 +9,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "..", "super_gradients_amd", "csrc"))
 OUTDIR = os.path.join(HERE, "_build")
 OUT = os.path.join(OUTDIR, "libsgx_emu.so")
-SOURCES = ["conv.hip", "bn.hip", "pool.hip", "se.hip", "loss.hip", "nms.hip", "optim.hip", "image.hip", "api.cpp"]
+SOURCES = ["conv.hip", "wgrad_patch.hip", "bn.hip", "pool.hip", "se.hip", "loss.hip", "nms.hip", "optim.hip", "image.hip", "api.cpp"]
 CXX = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 
 def build(force=False, verbose=False):
     os.makedirs(OUTDIR, exist_ok=True)
-    deps = [os.path.join(HERE, "hip_emu.h"), os.path.join(HERE, "hip_emu.cpp"), os.path.join(CSRC, "sgx_common.h"),
+    deps = [os.path.join(HERE, "hip_emu.h"), os.path.join(HERE, "hip_emu.cpp"), os.path.join(CSRC, "sgx_common.h"), os.path.join(CSRC, "conv_mma.h"), os.path.join(CSRC, "wgrad_patch.h"),
             os.path.join(CSRC, "..", "..", "include", "sgx_hip.h")]
     objs, procs = [], []
     for src in SOURCES + ["hip_emu.cpp"]:

@@ -248,6 +248,60 @@ def test_csp_layer(backend, concat, two_branch):
     assert not two_branch or all(b.cv1._w1p is not None for b in blk.bottlenecks)
 
 
+@pytest.mark.parametrize("kind", ["csp_qarep", "csp_plain", "head"])
+def test_bn_reduce_rides_in_data_gradients(backend, kind):
+    """Round 4: a plain conv -> BatchNorm -> activation layer whose output gradient is finalised by a convolution's data gradient gets its
+    BatchNorm-backward reduce from that launch's epilogue (kernels.BnReduceRequest) instead of a sweep over (dy, saved conv output).
+    The same block, same weights, same batch with the hand-over on and off: identical forward, gradients equal to fp32 round-off (the
+    partial rows regroup with the launch's tiles; the fp64 finalize is the same) - and the requests are really taken."""
+    from super_gradients_amd import kernels as KK
+    from super_gradients_amd.modules import Conv, QARepVGGBlock
+    from super_gradients_amd.training.models.detection_models.yolo_nas.dfl_heads import YoloNASDFLHead
+    from super_gradients_amd.training.models.detection_models.yolo_nas.yolo_stages import YoloNASCSPLayer
+    from functools import partial
+
+    gpu = backend.type == "cuda"
+    n, c, h, w, hid = (2, 64, 24, 24, 32) if gpu else (1, 32, 5, 6, 16)
+    results = {}
+    for fuse in (True, False):
+        torch.manual_seed(3)
+        if kind == "csp_qarep":
+            blk = YoloNASCSPLayer(c, c, 2, QARepVGGBlock, "relu", True, hidden_channels=hid, concat_intermediates=False)
+        elif kind == "csp_plain":
+            blk = YoloNASCSPLayer(c, c, 2, partial(Conv, kernel=3, stride=1), "relu", True, hidden_channels=hid, concat_intermediates=True)
+        else:
+            blk = YoloNASDFLHead(c, hid, 1.0, 0, 8, 8, 16)
+        net = _wrap(blk, backend)
+        net.fuse_bn_reduce = fuse
+        net.train()
+        net.zero_grad()
+        net.prefetch_dgrad_weights()
+        KK.BN_REQ_STATS["taken"] = KK.BN_REQ_STATS["declined"] = 0
+        g = torch.Generator().manual_seed(9)
+        x = to_nhwc(torch.randn(n, c, h, w, generator=g) + 0.3, backend)
+        if kind == "head":
+            reg, cls = torch.empty(n, h, w, 68, device=backend), torch.empty(n, h, w, 8, device=backend)
+            blk.fwd(x, out=(reg, cls))
+            out = torch.cat([reg.flatten(), cls.flatten()]).cpu()
+            dx = blk.bwd(torch.randn(n, h, w, 68, generator=g).to(backend), torch.randn(n, h, w, 8, generator=g).to(backend))
+        else:
+            y = blk.fwd(x)
+            out = y.cpu().clone()
+            dx = blk.bwd(torch.randn(tuple(y.shape), generator=g).to(backend))
+        net.join_side()
+        results[fuse] = (out, dx.cpu().clone(), {k: p.grad.cpu().clone() for k, p in blk.named_parameters() if p.grad is not None}, dict(KK.BN_REQ_STATS))
+    on, off = results[True], results[False]
+    # conv2 + conv1 (+ the first conv of each plain bottleneck); the two 3x3 blocks + the stem of a head
+    expect = {"csp_qarep": 2, "csp_plain": 4, "head": 3}[kind]
+    assert on[3]["taken"] == expect and on[3]["declined"] == 0 and off[3]["taken"] == 0, f"requests taken: {on[3]} / {off[3]}"
+    assert torch.equal(on[0], off[0])
+    assert_close(on[1], off[1], 2e-5, "input gradient")
+    gmax = max(float(v.abs().max()) for v in off[2].values())
+    for k, v in off[2].items():
+        e = float((on[2][k].double() - v.double()).abs().max()) / max(float(v.abs().max()), 1e-2 * gmax)
+        assert e <= 5e-5, f"grad {k}: {e:.3e}"
+
+
 def test_spp(backend):
     from oracle.yolo_nas import SPP as OSPP
     from super_gradients_amd.modules.detection_modules import SPP

@@ -1195,8 +1195,8 @@ def test_conv_math_patch_auto(backend):
 
 
 def test_wgrad_bf16x3_loop(backend):
-    """The weight gradient's bf16x3 loop (sgx_debug_set_wgrad_loop bit 3: three bf16 planes per slab, MFMA operands through the LDS transpose
-    read) on tile shapes of every wave layout, against ATen's fp32 gradient: fp32-level agreement (the six-product scheme drops terms
+    """The weight gradient's bf16x3 slab loop (the default arithmetic since round 4 - sgx_conv_set_wgrad_math; sgx_debug_set_wgrad_loop bit 3
+    selects it, bit 5 the fp32 loop: three bf16 planes per slab, MFMA operands through the LDS transpose read) on tile shapes of every wave layout, against ATen's fp32 gradient: fp32-level agreement (the six-product scheme drops terms
     <= 2^-24 of a product), i.e. much tighter than the conv tolerance; pixel splits + several images + stride 2 + channel-slice operands."""
     from super_gradients_amd._lib import lib
 
@@ -1217,13 +1217,13 @@ def test_wgrad_bf16x3_loop(backend):
                 y.backward(dy)
                 ent = (to_nhwc(x, backend, ld_pix=c + 4, c_off=4), to_nhwc(dy, backend, ld_pix=k + 4, c_off=0), K.ohwi_empty(k, c, r, r, backend), s_, p_)
                 got = {}
-                for loop in (0, 8):
+                for loop in (32, 8):  # bit 5: the fp32 loop, bit 3: the bf16x3 loop (the tile override keeps the patch kernel out)
                     lib().sgx_debug_set_wgrad_loop(loop, 0)
                     ent[2].zero_()
                     K.conv2d_bwd_weight_group([ent])
                     got[loop] = ent[2].cpu().clone()
                 scale = float(wt.grad.abs().max())
-                e_fp32 = float((got[0] - wt.grad).abs().max()) / scale
+                e_fp32 = float((got[32] - wt.grad).abs().max()) / scale
                 e_bf = float((got[8] - wt.grad).abs().max()) / scale
                 assert e_bf <= max(2e-6, 4.0 * e_fp32), f"tile {bnk}x{bj} {shape}: bf16x3 {e_bf:.2e}, fp32 loop {e_fp32:.2e}"
                 wt.grad = None
@@ -1235,6 +1235,163 @@ def test_wgrad_bf16x3_loop(backend):
             from super_gradients_amd import _lib as _l
 
             _l._LIB = None
+
+
+def test_dgrad_carries_bn_reduce(backend):
+    """sgx_conv2d_bwd_data_wt_req / _dual_req: the data gradient that finalises a layer's output gradient also leaves that layer's
+    BatchNorm-backward reduce (sum g, sum g (t - mean) per channel; g = dx * act'(scale t + shift)) - per tile row, the rows
+    sgx_bn_bwd_reduce would have produced with its own pass.  Checked: the column totals of the rows against an fp64 evaluation of the
+    same sums on the launch's own dx (forms: 1x1 and 3x3 on the slab kernels, 3x3 on the patch kernel, stride 2 with its four parity-class
+    launches, accumulate, two channel ranges = two layers behind one concat gradient, the two-source QARepVGG launch), and the whole
+    BatchNorm backward fed with those rows against the same backward fed by the reduce sweep."""
+    from super_gradients_amd._lib import lib
+
+    gpu = backend.type == "cuda"
+    # (N, H, W, C, K, R, stride, pad, two_source, accumulate, ranges)
+    cases = [(2, 80, 80, 64, 64, 1, 1, 0, False, True, [(0, 64, "relu")]), (2, 48, 56, 64, 32, 3, 1, 1, False, False, [(16, 48, "relu")]),
+             (2, 40, 40, 96, 48, 3, 2, 1, False, False, [(0, 96, "silu")]), (2, 20, 20, 192, 96, 1, 1, 0, False, False, [(0, 64, "relu"), (128, 192, None)]),
+             (2, 80, 80, 32, 32, 3, 1, 1, True, True, [(0, 32, "relu")]), (2, 24, 24, 32, 32, 3, 1, 1, True, False, [(0, 32, "relu")])] if gpu else \
+            [(1, 9, 10, 8, 8, 1, 1, 0, False, True, [(0, 8, "relu")]), (2, 6, 7, 16, 16, 3, 1, 1, False, False, [(4, 12, "relu")]),
+             (1, 9, 11, 8, 16, 3, 2, 1, False, False, [(0, 8, "silu")]), (1, 5, 6, 24, 8, 1, 1, 0, False, False, [(0, 8, "relu"), (16, 24, None)]),
+             (1, 6, 6, 16, 16, 3, 1, 1, True, True, [(0, 16, "relu")])]
+    if not gpu:  # the patch kernel's epilogue too: variant 9 lifts its map-size condition (on the chip the 80 x 80 / 48 x 56 cases reach it)
+        cases += [(1, 8, 16, 8, 16, 3, 1, 1, False, True, [(0, 8, "relu")], 9), (1, 9, 17, 16, 16, 3, 1, 1, True, False, [(4, 16, "silu")], 9)]
+    for ci, case in enumerate(cases):
+        n, h, w, c, k, r, s, p, dual, acc, ranges = case[:11]
+        lib().sgx_debug_set_variant(case[11] if len(case) > 11 else 0)
+        g = torch.Generator().manual_seed(100 + ci)
+        ho, wo = (h + 2 * p - r) // s + 1, (w + 2 * p - r) // s + 1
+        dy = to_nhwc(torch.randn(n, k, ho, wo, generator=g), backend)
+        wt_l = K.to_ohwi((torch.randn(k, c, r, r, generator=g) / (c * r * r) ** 0.5).to(backend))
+        wbuf = K.conv2d_wt_buffer(wt_l, backend)
+        K.conv2d_transpose_weights(wt_l, wbuf, stride=s, pad=p)
+        dx0 = torch.randn(n, h, w, c + 8, generator=g).to(backend)[..., 4:4 + c]  # a channel slice of a wider buffer, pre-filled (accumulate)
+        reqs, layers = [], []
+        for (lo, hi, act) in ranges:
+            cr = hi - lo
+            t = torch.randn(n, h, w, cr, generator=g).to(backend)
+            scale, shift, mean = (torch.rand(cr, generator=g) + 0.5).to(backend), (torch.randn(cr, generator=g) * 0.3).to(backend), (torch.randn(cr, generator=g) * 0.2).to(backend)
+            reqs.append(K.BnReduceRequest(t, scale, shift, mean, act, lo, hi))
+            layers.append((lo, hi, act, t, scale, shift, mean))
+        dx_plain, dx_req = dx0.clone(), dx0.clone()
+        if dual:
+            ds = to_nhwc(torch.randn(n, k, ho, wo, generator=g), backend)
+            w1pt = (torch.randn(c, k, generator=g) / k ** 0.5).to(backend)
+            K.conv2d_bwd_data_dual(dy, wt_l, wbuf, ds, w1pt, (n, h, w, c), stride=s, out=dx_plain, accumulate=acc)
+            K.conv2d_bwd_data_dual(dy, wt_l, wbuf, ds, w1pt, (n, h, w, c), stride=s, out=dx_req, accumulate=acc, reqs=reqs)
+        else:
+            K.conv2d_bwd_data_wt(dy, wt_l, wbuf, (n, h, w, c), stride=s, pad=p, out=dx_plain, accumulate=acc)
+            K.conv2d_bwd_data_wt(dy, wt_l, wbuf, (n, h, w, c), stride=s, pad=p, out=dx_req, accumulate=acc, reqs=reqs)
+        assert torch.equal(dx_plain.cpu(), dx_req.cpu()), f"case {ci}: the requests must not change dx"
+        for rq, (lo, hi, act, t, scale, shift, mean) in zip(reqs, layers):
+            assert rq.parts is not None, f"case {ci}: the launch did not take the request"
+            gsl = dx_req[..., lo:hi].cpu().double()
+            td = t.cpu().double()
+            pre = scale.cpu().double() * td + shift.cpu().double()
+            if act == "relu":
+                gg = gsl * (pre > 0)
+            elif act == "silu":
+                sg = torch.sigmoid(pre)
+                gg = gsl * (sg * (1 + pre * (1 - sg)))
+            else:
+                gg = gsl
+            s0, s1 = gg.sum((0, 1, 2)), (gg * (td - mean.cpu().double())).sum((0, 1, 2))
+            got = rq.parts.cpu().double().sum(1)
+            den = (gg.abs().sum((0, 1, 2)) + 1e-30)
+            assert float(((got[0] - s0).abs() / den).max()) < 2e-6 and float(((got[1] - s1).abs() / (den * 3)).max()) < 2e-6, f"case {ci} range {lo}:{hi}"
+            # the whole BatchNorm backward on these rows == the one that sweeps (dy, t) itself
+            gamma, invstd = (torch.rand(hi - lo, generator=g) + 0.5).to(backend), (torch.rand(hi - lo, generator=g) + 0.5).to(backend)
+            outs = []
+            for parts in (None, rq.parts):
+                dg, db = torch.zeros(hi - lo, device=backend), torch.zeros(hi - lo, device=backend)
+                dxb = K.bn_bwd(dx_req[..., lo:hi], t, scale, shift, gamma, mean, invstd, dg, db, act=act, parts=parts)
+                outs.append((dxb.cpu(), dg.cpu(), db.cpu()))
+            for a, b, what in zip(outs[0], outs[1], ("dx", "dgamma", "dbeta")):
+                assert_close(b, a, 2e-5, f"case {ci} range {lo}:{hi}: BatchNorm backward {what} from the data gradient's rows")
+    lib().sgx_debug_set_variant(0)
+
+
+def test_wgrad_patch_kernel(backend, monkeypatch):
+    """The weight gradient's PATCH kernel (wgrad_patch.hip; sgx_conv_set_wgrad_math mode 2, the default) against ATen's fp32 gradient AND
+    against the fp32 slab loop: every kernel form - stride 1 / 2, tile columns 16 / 8 / 4 (by the map's width), one / two / three filter
+    blocks per workgroup (by K) - with border tiles on all four sides, ragged maps (tile rows / columns beyond the map), several images,
+    several pixel ranges (the fold tree: odd counts, several levels), filter / channel counts that do not fill their 32-wide blocks,
+    operands that are channel slices of wider buffers; dw accumulates; a second call on the same tickets is correct; the result does
+    not depend on the order in which the workgroups arrive."""
+    from super_gradients_amd._lib import lib
+
+    gpu = backend.type == "cuda"
+    # (N, H, W, C, K, R, stride, pad)
+    cases = [(4, 80, 80, 64, 64, 3, 1, 1), (2, 160, 160, 32, 32, 3, 1, 1), (3, 40, 40, 96, 96, 3, 1, 1), (5, 20, 20, 192, 192, 3, 1, 1),
+             (2, 160, 160, 48, 96, 3, 2, 1), (2, 80, 80, 96, 192, 3, 2, 1), (3, 40, 40, 192, 384, 3, 2, 1), (2, 23, 37, 40, 72, 3, 1, 1),
+             (2, 45, 31, 36, 100, 3, 2, 1)] if gpu else \
+            [(2, 12, 16, 8, 8, 3, 1, 1),    # 16 columns, one filter block, 2 x 6 tiles -> two pixel ranges
+             (1, 9, 20, 4, 40, 3, 1, 1),    # 20 wide -> 4-column tiles; two filter blocks, the second one partly empty; ragged tile rows
+             (3, 7, 8, 12, 72, 3, 1, 1),    # 8-column tiles; three filter blocks; several images inside one range
+             (3, 13, 34, 8, 16, 3, 2, 1),   # stride 2: 17 x 7 outputs, parity-split patch, ragged both ways, 15 tiles -> two ranges
+             (5, 16, 16, 36, 8, 3, 2, 1),   # stride 2, 8 x 8 outputs, two channel chunks (the second one 4 wide), two ranges
+             (4, 40, 8, 4, 8, 3, 2, 1)]     # stride 2, 4 x 20 outputs -> 4-column tiles, tall, two ranges
+    ents, refs = [], []
+    for i, shape in enumerate(cases):
+        n, h, w, c, k, r, s, p = shape
+        x, wt, _ = _conv_case(shape, seed=60 + i)
+        wt.requires_grad_(True)
+        y = F.conv2d(x, wt, None, stride=s, padding=p)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(70 + i))
+        y.backward(dy)
+        refs.append(wt.grad)
+        ents.append((to_nhwc(x, backend, ld_pix=c + 8, c_off=4), to_nhwc(dy, backend, ld_pix=k + 4, c_off=0), K.ohwi_empty(k, c, r, r, backend), s, p))
+    if not gpu:
+        monkeypatch.setenv("SGX_EMU_SHUFFLE", "11")
+    try:
+        assert lib().sgx_conv_get_wgrad_math() == 2
+        lib().sgx_debug_set_wgrad_patch(1, 0, 1)  # smallest items (8 tiles = 256 pixels), every 3x3 pad-1 job takes the kernel whatever its fill
+        got = {}
+        for mode, loop in (("patch", 0), ("fp32", 16 + 32)):
+            lib().sgx_debug_set_wgrad_loop(loop, 0)
+            for e in ents:
+                e[2].fill_(0.25)
+            K.conv2d_bwd_weight_group(ents)
+            got[mode] = [e[2].cpu().clone() for e in ents]
+        for shape, a, b, ref in zip(cases, got["patch"], got["fp32"], refs):
+            scale = float(ref.abs().max())
+            e_patch, e_fp32 = float((a - 0.25 - ref).abs().max()) / scale, float((b - 0.25 - ref).abs().max()) / scale
+            assert e_patch <= max(2e-6, 4.0 * e_fp32), f"patch wgrad {shape}: error {e_patch:.2e} (fp32 slab loop {e_fp32:.2e})"
+        # the other workgroup shapes (two / three filter blocks = six / nine waves; the default policy takes one block below 192 filters)
+        lib().sgx_debug_set_wgrad_loop(0, 0)
+        for kb in (2, 3):
+            lib().sgx_debug_set_wgrad_patch(1, kb, 1)
+            for e in ents:
+                e[2].fill_(0.25)
+            K.conv2d_bwd_weight_group(ents)
+            for shape, e, ref in zip(cases, ents, refs):
+                err = float((e[2].cpu() - 0.25 - ref).abs().max()) / float(ref.abs().max())
+                assert err <= 1e-5, f"patch wgrad, {kb} filter blocks {shape}: error {err:.2e}"
+        lib().sgx_debug_set_wgrad_patch(1, 0, 1)
+        # accumulates; tickets were left zero; another arrival order is bit-identical
+        lib().sgx_debug_set_wgrad_loop(0, 0)
+        if not gpu:
+            monkeypatch.setenv("SGX_EMU_SHUFFLE", "4321")
+        K.conv2d_bwd_weight_group(ents)
+        for shape, e, a, ref in zip(cases, ents, got["patch"], refs):
+            assert_close(e[2].cpu(), 2 * ref + 0.25, TOL, f"patch wgrad, second call {shape}")
+            e[2].fill_(0.25)
+        lib().sgx_debug_set_wgrad_group(0, 0, 0)  # plain workgroup order instead of the XCD-aware one
+        K.conv2d_bwd_weight_group(ents)
+        for shape, e, a in zip(cases, ents, got["patch"]):
+            assert torch.equal(e[2].cpu(), a), f"patch wgrad must not depend on the workgroup order {shape}"
+        # default policy (fill threshold, item size): whichever kernel takes a job, the gradient is the same to fp32 accuracy
+        lib().sgx_debug_set_wgrad_patch(0, 0, 0)
+        lib().sgx_debug_set_wgrad_group(0, 0, 1)
+        for e in ents:
+            e[2].zero_()
+        K.conv2d_bwd_weight_group(ents)
+        for shape, e, ref in zip(cases, ents, refs):
+            assert_close(e[2].cpu(), ref, TOL, f"wgrad, default policy {shape}")
+    finally:
+        lib().sgx_debug_set_wgrad_patch(0, 0, 0)
+        lib().sgx_debug_set_wgrad_group(0, 0, 1)
+        lib().sgx_debug_set_wgrad_loop(0, 0)
 
 
 # (N, H, W, C, K): 3x3 stride-1 pad-1 problems for the patch kernel - ragged 8 x 16 tiles in both directions, both chunk depths (C % 32),

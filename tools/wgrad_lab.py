@@ -3,8 +3,11 @@ the loop / the grouping - interleaved in ONE process (rounds x configs, median).
 
     python tools/wgrad_lab.py [--model s] [--batch 32] [--size 640] [--configs base,slab32,ab1,ab3,ab7,ab8,ab15] [--rounds 3] [--iters 5]
 
-A config is a '+'-joined list of:  base | slab32 | pf1 (one slab of loads in flight instead of two) | w2 (64x64 tile on two waves) | bf16 (the bf16x3 loop) | abN (ablation bits, needs a library built with -DSGX_WGRAD_LAB: 1 no global loads,
-2 no LDS stores, 4 no MFMAs, 8 no fold / dW) | gR.I.X (sgx_debug_set_wgrad_group rounds.item_mflop.xcd) | tBxJ (tile override).
+A config is a '+'-joined list of:  base (the product default: bf16x3 arithmetic, patch kernel on the 3x3 problems) | nopatch (bf16x3 slab loop
+everywhere) | fp32 (the fp32 slab loop everywhere) | slab32 | pf1 (one slab of loads in flight instead of two) | w2 (64x64 tile on two
+waves) | bf16 (force the bf16x3 slab loop) | abN (ablation bits, needs a library built with -DSGX_WGRAD_LAB: 1 no global loads,
+2 no LDS stores, 4 no MFMAs, 8 no fold / dW) | gR.I.X (sgx_debug_set_wgrad_group rounds.item_mflop.xcd) | tBxJ (tile override of the slab
+loop) | pI.K.F (sgx_debug_set_wgrad_patch: largest item MFLOP . filter blocks . least fill percent).
 Per group (= one K.conv2d_bwd_weight_group call of the step): jobs, GFLOP, then microseconds per config; last line: ms per step and
 algorithmic TFLOP/s.  Measurement tool: product library only.
 """
@@ -53,10 +56,15 @@ def record_groups(model, batch, size, dev):
 def apply_config(cfg, lib):
     lib.sgx_debug_set_wgrad_group(0, 0, 1)
     lib.sgx_debug_set_tiles(0, 0, 0, 0, 0)
+    lib.sgx_debug_set_wgrad_patch(0, 0, 0)
     deep = ab = 0
     for part in cfg.split("+"):
         if part == "base":
             pass
+        elif part == "nopatch":
+            deep |= 16
+        elif part == "fp32":
+            deep |= 16 + 32
         elif part == "slab32":
             deep |= 1
         elif part == "pf1":
@@ -70,6 +78,8 @@ def apply_config(cfg, lib):
         elif part.startswith("g"):
             r, i, xo = (int(v) for v in part[1:].split("."))
             lib.sgx_debug_set_wgrad_group(r, i, xo)
+        elif part.startswith("p"):
+            lib.sgx_debug_set_wgrad_patch(*[int(v) for v in part[1:].split(".")])
         elif part.startswith("t"):
             b, j = (int(v) for v in part[1:].split("x"))
             lib.sgx_debug_set_tiles(0, 0, b, j, 0)
