@@ -2425,7 +2425,7 @@ static void wgrad_tile(const sgx_conv_desc* d, WgPlan& pl) {
 #define WG_SLOTS 1536  // workgroups the chip holds at once (256 CUs x ~6): the unit a group's work is cut against
 static int32_t wgrad_group_plan(const sgx_wgrad_job* jobs, int n, std::vector<WgPlan>& plans, long* part_floats, long* ticket_ints) {
     plans.resize(n);
-    double work = 0.0, pwork = 0.0;
+    double work = 0.0;
     // the patch kernel: product mode 2, no measurement override of the slab loop's tiles / loop in force
     const bool patch_on = g_wg_math.load(std::memory_order_relaxed) == 2 && !g_ovr_wk.load(std::memory_order_relaxed) &&
                           !g_ovr_wj.load(std::memory_order_relaxed) && !g_ovr_split.load(std::memory_order_relaxed) &&
@@ -2437,7 +2437,6 @@ static int32_t wgrad_group_plan(const sgx_wgrad_job* jobs, int n, std::vector<Wg
         SGX_CHECK_ARG(d->K % 4 == 0 && d->y_ld_pix % 4 == 0, "conv bwd_weight: K and dy pixel stride must be multiples of 4");
         plans[i].wp.cfg = 0;
         if (patch_on && wpatch_plan_job(d, plans[i].wp, g_wp_kb.load(std::memory_order_relaxed), g_wp_fill.load(std::memory_order_relaxed))) {
-            pwork += 2.0 * 32.0 * plans[i].wp.ntiles * plans[i].wp.kt_tiles * 32.0 * plans[i].wp.kb * plans[i].wp.ct_tiles * 32.0 * 9.0;
             continue;
         }
         wgrad_tile(d, plans[i]);
@@ -2453,14 +2452,34 @@ static int32_t wgrad_group_plan(const sgx_wgrad_job* jobs, int n, std::vector<Wg
     if (item > 2.0 * lo) item = 2.0 * lo;
     const int osp = g_ovr_split.load(std::memory_order_relaxed);
     long poff = 0, toff = 0;
-    // patch jobs: ~5 rounds of the ~512 workgroups the chip holds, items of 16 .. g_wp_item_mflop MFLOP (a node of the fold tree is 37 - 110 KB:
-    // short items would spend their time handing partial tiles over)
-    double pitem = pwork / (512.0 * 5.0);
-    const double phi = 1e6 * g_wp_item_mflop.load(std::memory_order_relaxed);
-    if (pitem > phi) pitem = phi;
-    if (pitem < 16e6) pitem = fmin(16e6, phi);
-    for (int i = 0; i < n; ++i)
-        if (plans[i].wp.cfg) wpatch_plan_split(&jobs[i].d, plans[i].wp, pitem, &poff, &toff);
+    // patch jobs: the jobs of one kernel form (stride, tile columns, filter blocks) run as ONE launch, so the items are sized per form: ONE
+    // round of the ~1024 workgroups the chip holds (four per CU) - all of a launch resident together - never more than g_wp_item_mflop MFLOP
+    // and never fewer than 256 pixels (wpatch_plan_split).  r4g (lab, ms per step of all weight gradients alone): 1 round 11.22, 2 rounds
+    // 11.40, 3 rounds 11.61, 6 rounds 13.14, 12 rounds 16.72 - an item pays its prologue, its first tile's latency and a 37 KB hand-over
+    // of its partial tile, and short items pay them too often; the tail of a one-round launch is filled by the main stream's kernels.
+    {
+        const double phi = 1e6 * g_wp_item_mflop.load(std::memory_order_relaxed);
+        std::vector<char> sized(n, 0);
+        for (int first = 0; first < n; ++first) {
+            if (sized[first] || !plans[first].wp.cfg) continue;
+            const WpPlan& f = plans[first].wp;
+            double fw = 0.0;
+            for (int i = first; i < n; ++i) {
+                const WpPlan& w = plans[i].wp;
+                if (!sized[i] && w.cfg && jobs[i].d.stride == jobs[first].d.stride && w.pc == f.pc && w.kb == f.kb)
+                    fw += 2.0 * 16.0 * w.nks * w.ntiles * w.kt_tiles * 32.0 * w.kb * w.ct_tiles * 32.0 * 9.0;
+            }
+            double pitem = fw / 1024.0;
+            if (pitem > phi) pitem = phi;
+            for (int i = first; i < n; ++i) {
+                WpPlan& w = plans[i].wp;
+                if (!sized[i] && w.cfg && jobs[i].d.stride == jobs[first].d.stride && w.pc == f.pc && w.kb == f.kb) {
+                    sized[i] = 1;
+                    wpatch_plan_split(&jobs[i].d, w, pitem, &poff, &toff);
+                }
+            }
+        }
+    }
     for (int i = 0; i < n; ++i) {
         const sgx_conv_desc* d = &jobs[i].d;
         WgPlan& pl = plans[i];

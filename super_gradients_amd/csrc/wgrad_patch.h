@@ -28,6 +28,7 @@ struct WpGroupParams {
 struct WpPlan {
     int cfg;              // 0: not a patch problem
     int pc, kb, cb, wt;   // kernel form: tile columns, wave grid (filter blocks x channel blocks x tap groups)
+    int nks;              // K steps of 16 pixels per tile (by stride)
     int kt_tiles, ct_tiles, tiles_h, tiles_w;
     long ntiles;
     int ksplit, tchunk;

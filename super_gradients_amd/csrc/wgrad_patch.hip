@@ -8,9 +8,9 @@
 // its pixel / bounds arithmetic.  Read off the ISA (r4): wgrad_kernel<128,128,...,bf16x3> issues 7.2 VALU + 1 LDS instructions per MFMA,
 // the 64x64 tile 15 - on a pipe that hides about five; the split alone is 7.33 x (32 / BNK + 32 / BJ) VALU per MFMA, i.e. the narrow
 // layers of YOLO-NAS-S (K = 32 ... 96) are bound by the vector unit at a quarter of the matrix rate whatever the tile.
-// Here a workgroup owns a (filter tile BNK) x (channel chunk CT) x ALL NINE TAPS block of dW and walks a range of pixel TILES of 32 output
-// pixels (PR rows x PC columns, PC in {16, 8, 4} so that 160/80-, 40- and 20-wide maps all tile exactly).  Per tile it stages
-//   * the dY tile   [32 pixels][BNK]                                    and
+// Here a workgroup owns a (filter tile BNK) x (channel chunk CT) x ALL NINE TAPS block of dW and walks a range of pixel TILES of 64 (stride 2: 32)
+// output pixels (PR rows x PC columns, PC in {16, 8, 4} so that 160/80-, 40- and 20-wide maps all tile exactly).  Per tile it stages
+//   * the dY tile   [64 | 32 pixels][BNK]                               and
 //   * the X patch   [(PR-1) S + 3 rows][(PC-1) S + 3 columns][CT]       ONCE (split once per element: 1.3 - 3 VALU per MFMA),
 // and the nine taps read their MFMA operands straight out of the patch: the GEMM-K axis is the pixel axis, so an operand is eight
 // consecutive PIXELS of one channel per lane - ds_read_b64_tr_b16 (the LDS transpose read) delivers exactly that from the pixel-major
@@ -29,24 +29,27 @@
 #define WP_TAPS 9
 constexpr int wp_pitch(int n) { return n + (n % 64 == 0 ? 32 : 0); }  // bf16 elements per LDS pixel row: 16 or 48 banks mod 64
 
-// S: stride; PC: tile columns (tile = 32 / PC rows x PC columns); KB: 32-row filter blocks of the workgroup's dW tile (its channel chunk is
+// S: stride; PC: tile columns (tile = 16 NKS / PC rows x PC columns); KB: 32-row filter blocks of the workgroup's dW tile (its channel chunk is
 // 32 wide).  A wave owns ONE filter block and ONE tap row (three 32x32 accumulators, 48 registers): 3 KB waves per workgroup, ~110
 // registers per lane, 20 - 51 KB of LDS - several workgroups per CU, three to four waves per SIMD.  (The first form of this kernel gave a
 // wave all nine taps of a block - 144 accumulator registers: every 256-thread variant sat on the 256-register line, three of them
 // spilling.)
-template <int S, int PC, int KB>
+// NKS: K steps (16 pixels each) per tile: a tile is 16 NKS / PC rows x PC columns (four at stride 1 - 64 pixels, half the barriers and 1.7
+// instead of 2.25 patch pixels staged per output pixel; two at stride 2, whose 9 x 33 patch of a 64-pixel tile would take 57 KB of LDS)
+template <int S, int PC, int KB, int NKS>
 __global__ __launch_bounds__(192 * KB, 3) void wpatch_kernel(WpGroupParams g) {
     constexpr int CB = 1, WT = 3;
     constexpr int NW = KB * CB * WT, NTH = 64 * NW;
-    constexpr int PR = 32 / PC, RW = 16 / PC;  // tile rows; tile rows per K step of 16 pixels
+    constexpr int PIX = 16 * NKS;
+    constexpr int PR = PIX / PC, RW = 16 / PC;  // tile rows; tile rows per K step of 16 pixels
     constexpr int PRin = (PR - 1) * S + 3, PCin = (PC - 1) * S + 3;
     constexpr int PCH = (PCin + 1) / 2, PSLOTS = S == 1 ? PCin : 2 * PCH;  // stride 2: even columns first, then the odd ones
     constexpr int BNK = 32 * KB, CT = 32 * CB;
     constexpr int CTP = wp_pitch(CT), DP = wp_pitch(BNK);
     constexpr int TAPW = WP_TAPS / WT;  // taps per wave
-    constexpr int XPL = PRin * PSLOTS * CTP, DPL = 32 * DP;  // elements per plane
+    constexpr int XPL = PRin * PSLOTS * CTP, DPL = PIX * DP;  // elements per plane
     constexpr int XG = CT / 4, DG = BNK / 4;                 // 16-byte groups per pixel
-    constexpr int NXE = PRin * PCin * XG, NDE = 32 * DG;     // staging items of a tile
+    constexpr int NXE = PRin * PCin * XG, NDE = PIX * DG;    // staging items of a tile
     constexpr int NXI = (NXE + NTH - 1) / NTH, NDI = (NDE + NTH - 1) / NTH;
     static_assert(PC == 16 || PC == 8 || PC == 4, "tile columns");
     __shared__ __attribute__((aligned(16))) unsigned short Xs[3 * XPL];
@@ -205,35 +208,30 @@ __global__ __launch_bounds__(192 * KB, 3) void wpatch_kernel(WpGroupParams g) {
     };
     auto mfma_tile = [&]() {
         static_assert(TAPW == 3, "the hand-placed order below is written for one tap row per wave");
-        uint4 a0[3], a1[3], b0[3], b1[3], b2[3];
+        // steps s = 0 .. 3 NKS - 1 = (K step s / 3, tap s % 3).  Operand sets: A of a K step in a[ks & 1] (requested during the first tap of
+        // the K step before), B of step s in b[s % 3] (requested during step s - 2, into the registers step s - 3 released).
+        uint4 a[2][3], b[3][3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a0[pl] = afrag(0, pl);
+        for (int pl = 0; pl < 3; ++pl) a[0][pl] = afrag(0, pl);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b0[pl] = bfrag(0, 0, 0, pl);
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b1[pl] = bfrag(0, 0, 1, pl);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b2[pl] = bfrag(0, 0, 2, pl);
+            for (int pl = 0; pl < 3; ++pl) b[t][pl] = bfrag(0, 0, t, pl);
         sgx_sched_fence();
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a1[pl] = afrag(1, pl);
-        six(acc[0], a0, b0);
-        sgx_sched_fence();
+        for (int st = 0; st < 3 * NKS; ++st) {
+            const int ks = st / 3, t = st % 3;
+            if (t == 0 && ks + 1 < NKS) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b0[pl] = bfrag(1, 0, 0, pl);
-        six(acc[1], a0, b1);
-        sgx_sched_fence();
+                for (int pl = 0; pl < 3; ++pl) a[(ks + 1) & 1][pl] = afrag(ks + 1, pl);
+            }
+            if (st >= 1 && st + 2 < 3 * NKS) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b1[pl] = bfrag(1, 0, 1, pl);
-        six(acc[2], a0, b2);
-        sgx_sched_fence();
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b2[pl] = bfrag(1, 0, 2, pl);
-        six(acc[0], a1, b0);
-        sgx_sched_fence();
-        six(acc[1], a1, b1);
-        six(acc[2], a1, b2);
-        sgx_sched_fence();
+                for (int pl = 0; pl < 3; ++pl) b[(st + 2) % 3][pl] = bfrag((st + 2) / 3, 0, (st + 2) % 3, pl);
+            }
+            six(acc[t], a[ks & 1], b[st % 3]);
+            sgx_sched_fence();
+        }
     };
 
     const int ntl = t1 - t0;
@@ -330,19 +328,21 @@ bool wpatch_plan_job(const sgx_conv_desc* d, WpPlan& pl, int kb_override, int mi
     pl.kt_tiles = sgx_cdiv(d->K, bnk);
     pl.ct_tiles = sgx_cdiv(d->C, ct);
     // tile columns: the exact fit with the widest rows
+    const int nks = d->stride == 1 ? 4 : 2, pix = 16 * nks;
     int best = 16;
     double bu = -1.0;
     const int cand[3] = {16, 8, 4};
     for (int i = 0; i < 3; ++i) {
-        const int pc = cand[i], pr = 32 / pc;
+        const int pc = cand[i], pr = pix / pc;
         const double u = ((double)d->Wo / (sgx_cdiv(d->Wo, pc) * pc)) * ((double)d->Ho / (sgx_cdiv(d->Ho, pr) * pr));
         if (u > bu + 1e-9) bu = u, best = pc;
     }
     const double fill = ((double)d->K / (pl.kt_tiles * bnk)) * ((double)d->C / (pl.ct_tiles * ct)) * bu;
     if (fill * 100.0 < (double)min_fill_pct) return false;  // padded matrix work the slab loop (flattened tap x channel axis) would not do
     pl.pc = best;
+    pl.nks = nks;
     pl.kb = kb; pl.cb = cb; pl.wt = wt;
-    pl.tiles_h = sgx_cdiv(d->Ho, 32 / best);
+    pl.tiles_h = sgx_cdiv(d->Ho, pix / best);
     pl.tiles_w = sgx_cdiv(d->Wo, best);
     pl.ntiles = (long)d->N * pl.tiles_h * pl.tiles_w;
     pl.cfg = 1;
@@ -352,9 +352,9 @@ bool wpatch_plan_job(const sgx_conv_desc* d, WpPlan& pl, int kb_override, int mi
 // pixel-tile ranges of the jobs of one group: items of ~item_flops (the caller sizes them for the whole group)
 void wpatch_plan_split(const sgx_conv_desc* d, WpPlan& pl, double item_flops, long* part_floats, long* ticket_ints) {
     const int bnk = 32 * pl.kb, ct = 32 * pl.cb, nw = pl.kb * pl.cb * pl.wt;
-    const double tile_flops = 2.0 * 32 * bnk * ct * WP_TAPS;
+    const double tile_flops = 2.0 * 16 * pl.nks * bnk * ct * WP_TAPS;
     long tchunk = (long)(item_flops / tile_flops);
-    if (tchunk < 8) tchunk = 8;  // at least 256 pixels per item
+    if (tchunk < 16 / pl.nks) tchunk = 16 / pl.nks;  // at least 256 pixels per item
     if (tchunk > pl.ntiles) tchunk = pl.ntiles;
     long ks = (pl.ntiles + tchunk - 1) / tchunk;
     if (ks > WP_MAX_SPLIT) ks = WP_MAX_SPLIT;
@@ -378,7 +378,7 @@ void wpatch_plan_split(const sgx_conv_desc* d, WpPlan& pl, double item_flops, lo
 
 template <int S, int PC, int KB>
 static void wpatch_launch_t(const WpGroupParams& g, int nblk, void* stream) {
-    SGX_LAUNCH((wpatch_kernel<S, PC, KB>), dim3((unsigned)nblk), dim3(192 * KB), 0, stream, g);
+    SGX_LAUNCH((wpatch_kernel<S, PC, KB, S == 1 ? 4 : 2>), dim3((unsigned)nblk), dim3(192 * KB), 0, stream, g);
 }
 template <int S, int KB>
 static void wpatch_launch_pc(int pc, const WpGroupParams& g, int nblk, void* stream) {

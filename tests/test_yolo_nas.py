@@ -175,6 +175,14 @@ def _train_step_parity(variant, B, size, device, tol, static=False):
         acc_c += float((ref_params[n].grad.double() - t).pow(2).sum())
         acc_d += float(t.pow(2).sum())
     a_h, a_c = (acc_h / acc_d) ** 0.5, (acc_c / acc_d) ** 0.5
+    if os.environ.get("SGX_TEST_DUMP"):
+        with open(os.environ["SGX_TEST_DUMP"], "a") as f:
+            f.write(f"backward A {variant} B={B} {size} static={static}: hip {a_h:.3e} cpu fp32 {a_c:.3e}\n")
+            contrib = sorted(((float((net_params[n].grad.cpu().double() - ref64_params[n].grad).pow(2).sum()) / acc_d,
+                               float((ref_params[n].grad.double() - ref64_params[n].grad).pow(2).sum()) / acc_d, n)
+                              for n in live if ref64_params[n].grad.numel() > 1), reverse=True)[:8]
+            for eh, ec, n in contrib:
+                f.write(f"    share of the squared error: hip {eh:.3e} cpu {ec:.3e}  {n}\n")
     # (2e-2: the ReLU-flip noise floor of this aggregate at these sizes - measured 1.4-1.6e-2 for the HIP path AND for the CPU fp32 path
     # against fp64, r2g; a CPU run that happens to flip fewer elements must not fail the HIP path.  The flip-free, strict form of this
     # check is test_yolo_nas_s_backward_exact_without_relu_flips below.)
