@@ -131,12 +131,15 @@ def _train_step_parity(variant, B, size, device, tol, static=False):
     if os.environ.get("SGX_TEST_DUMP"):
         with open(os.environ["SGX_TEST_DUMP"], "a") as f:
             f.write(f"backward B {variant} B={B} {size}: hip {l2_h:.3e} cpu fp32 {l2_c:.3e} ratio {l2_h / max(l2_c, 1e-30):.2f}\n")
-    # measured (profiles/r3zb_backward_b_ratios.txt): S 0.61, M 0.97, L 2.96 with fp32 conv arithmetic and 3.03 with the default bf16x3 patch
-    # kernel - the same figure under every weight-gradient grouping / prefetch setting (the arithmetic is deterministic).  L at 1 x 256^2 ends
-    # in 8 x 8 maps: BatchNorm statistics over 64 values, the worst-conditioned case of the family; ATen's CPU kernels form those sums in
-    # double, a pure-fp32 device path cannot be expected closer than a small multiple of it.  4x holds all three with margin for an arithmetic
-    # mode; backward A below is the strict per-parameter check.
-    assert l2_h <= max(10 * tol, 4.0 * l2_c), f"loss-gradient L2 error vs fp64: hip {l2_h:.2e}, cpu fp32 {l2_c:.2e}"
+    # measured: S 0.61, M 0.80 - 0.97, L 2.96 (fp32 conv arithmetic, r3) / 2.97 - 3.04 (bf16x3 patch kernels, r3 / r4) - the same figure
+    # under every weight-gradient grouping / prefetch setting (the arithmetic is deterministic).  This aggregate is the ILL-conditioned one
+    # (round-off amplified 1e3 - 1e4x on both fp32 paths, see the docstring): on the well-conditioned upstream of backward A the same L
+    # network is at 0.96x the CPU path's distance (r4i: 3.07e-2 vs 3.20e-2) and EVERY L gradient passes the element-wise 1e-4 check of
+    # test_yolo_nas_l_backward_exact_without_relu_flips.  L at 1 x 256^2 ends in 8 x 8 maps (64 values per BatchNorm channel); forming
+    # those statistics in double like ATen was tried and changes nothing (r4i: 3.04 with, 2.97 without -
+    # profiles/r4i_parity_exact_small_map_statistics.txt), so the factor is the two paths' different summation orders under that
+    # amplification, not a statistic.  The bar is the measured 3.0 plus margin, for every arithmetic mode: 3.5x.
+    assert l2_h <= max(10 * tol, 3.5 * l2_c), f"loss-gradient L2 error vs fp64: hip {l2_h:.2e}, cpu fp32 {l2_c:.2e}"
     for n in [k for k, _ in net.named_parameters() if ".rbr_reparam." in k]:
         assert ref_params[n].grad is None
 
@@ -329,6 +332,13 @@ def test_yolo_nas_m_backward_exact_without_relu_flips(gpu_device):
 
 
 @pytest.mark.gpu
+def test_yolo_nas_l_backward_exact_without_relu_flips(gpu_device):
+    """YOLO-NAS-L: the widest stages and the deepest CSP layers get the element-wise backward check too (round 4: the three-way aggregate of
+    test_yolo_nas_l_train_step_parity can only bound L's gradient error from above - here every parameter is held to 1e-4)."""
+    _backward_exact_without_relu_flips("l", 1, 256, gpu_device)
+
+
+@pytest.mark.gpu
 def test_yolo_nas_s_headline_config_backward_exact(gpu_device):
     """BASELINE.json configs[2] at FULL size (YOLO-NAS-S, 32 x 640^2): the conv problems, pixel splits and tuning-table entries the
     benchmark runs - element-wise gradient check of every parameter against the CPU fp32 oracle (flip-free form, see the helper, with the
@@ -339,7 +349,11 @@ def test_yolo_nas_s_headline_config_backward_exact(gpu_device):
 
 @pytest.mark.gpu
 def test_yolo_nas_s_train_step_parity_atss(gpu_device):
-    _train_step_parity("s", 2, 256, gpu_device, 1e-4, static=True)
+    """(at 320 x 320 like the task-aligned variant above: a 2 x 256^2 batch ends in 8 x 8 maps - 128 values per BatchNorm channel - where ONE
+    ReLU pre-activation that changes sign between two fp32 builds moves a tensor's gradient by 10-20 %: r4d measured exactly that between
+    two builds whose forward outputs differ by 4e-5 and which both pass the element-wise flip-free checks below; the assigner, which is
+    all this variant changes, does not enter the random-upstream backward at all)"""
+    _train_step_parity("s", 2, 320, gpu_device, 1e-4, static=True)
 
 
 @pytest.mark.gpu

@@ -79,7 +79,9 @@ def pmc(d):
     print(f"{'TOTAL':<92} {sum(len(s) for s in calls.values()):>7} {sum(dur.values()) / 1e6:>9.3f} " + " ".join(f"{tot[c]:>22.1f}" for c in names))
 
 
-def timeline(d, top=12):
+def timeline(d, top=12, steps=0):
+    """steps > 0: only the last `steps` whole train steps of the trace (from the end of one adamw_kernel launch to the end of the last one) -
+    the process start (library load, first-touch allocation, the oracle check) otherwise dominates every figure"""
     ev = []
     for f in find(d, "*kernel_trace.csv"):
         for r in csv.DictReader(open(f, newline="")):
@@ -89,6 +91,12 @@ def timeline(d, top=12):
         print("# no *kernel_trace.csv under", d)
         return
     ev.sort()
+    if steps > 0:
+        marks = [e for s_, e, _, n in ev if n.startswith("adamw_kernel")]
+        if len(marks) > steps:
+            lo, hi = marks[-steps - 1], marks[-1]
+            ev = [e for e in ev if e[0] >= lo and e[1] <= hi]
+            print(f"# window: the last {steps} train steps ({(hi - lo) / 1e6 / steps:.3f} ms per step)")
     t0, t1 = ev[0][0], max(e[1] for e in ev)
     wall = t1 - t0
     # sweep line over start/end points: time with 0 / 1 / >= 2 kernels resident
@@ -139,4 +147,7 @@ def timeline(d, top=12):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "timeline": timeline}[sys.argv[1]](sys.argv[2])
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2], steps=int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+    else:
+        {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
