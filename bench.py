@@ -130,6 +130,9 @@ def oracle_loss_check(net, crit, x, targets, model, family):
     return rec
 
 
+NMS_SCORE_PASSES = 3  # selection passes of the current kernels over the score tensor (csrc/nms.hip, stage 1)
+
+
 def nms_leg(device, iters=100, warmup=10):
     """BASELINE.json's second metric: NMS boxes/s.  SURVEY 8(d) config-5 style input: B=32 images, L=8400 anchors, 80 classes, scores
     ~ Beta(0.5,0.5)^4 and boxes clustered around 30 centres so that every image has >= 1000 candidates above the recipe's
@@ -177,16 +180,18 @@ def nms_leg(device, iters=100, warmup=10):
         onms.nms(bx[i][top], conf[top], 0.7)
         n_cpu += 1000
     cpu_s = time.perf_counter() - t0
-    # HBM roofline of the call: stage 1 streams the B*L*C scores three times (two histogram passes + the gather pass); everything after
-    # that works on <= 8192 keys per image in LDS
-    stream_bytes = 3.0 * B * L * C * 4
+    # HBM roofline of the call: the ALGORITHMIC traffic of post-prediction is one read of the B*L*C scores plus the selected
+    # candidates' boxes and the output rows (K * 20 B per image) - whatever the implementation re-reads on top of that (its selection passes
+    # over the scores) is reported as `traffic` / `passes_over_scores`, not credited
+    algo_bytes = 1.0 * B * L * C * 4 + B * 1000 * 20.0
     return {"value": round(ncand / (ms * 1e-3), 1), "unit": "boxes/s", "ms_per_batch": round(ms, 4), "candidates": ncand, "kept": kept, "batch": B,
-            "roofline": {"bound": "hbm", "achieved": round(stream_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(stream_bytes / (ms * 1e-3) / 8e12, 4), "traffic": measured_nms_traffic().get("nms_bytes_per_call"),
-                         "traffic_unit": "bytes/call (HBM, PMC: FETCH_SIZE x2 + WRITE_SIZE over the kernels of one post-prediction call)",
-                         "algorithmic_bytes_per_call": round(stream_bytes),
-                         "note": "algorithmic bytes = 3 passes over the fp32 scores (258 MB per batch) / time of the WHOLE post-prediction call "
-                                 "(selection + per-image sort + suppression scan, which are latency-bound and move no HBM bytes)"},
+            "roofline": {"bound": "hbm", "achieved": round(algo_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(algo_bytes / (ms * 1e-3) / 8e12, 4), "traffic": measured_nms_traffic().get("nms_bytes_per_call"),
+                         "traffic_unit": "bytes/call (HBM, PMC: FETCH_SIZE x2 + WRITE_SIZE over the kernels of one post-prediction call; from the "
+                                         "committed profiles/nms_traffic.json of the round's profiling visit, not re-measured in this run)",
+                         "algorithmic_bytes_per_call": round(algo_bytes), "passes_over_scores": NMS_SCORE_PASSES,
+                         "note": "algorithmic bytes = ONE read of the fp32 scores (86 MB per batch) + 20 B per selected candidate / time of the WHOLE "
+                                 "post-prediction call (selection + per-image sort + suppression scan; the last two are latency-bound and move no HBM bytes)"},
             "config": "B=32 L=8400 C=80 multi-label, score>0.01, top-k 1000, IoU 0.7, max 300, class-agnostic",
             "cpu_baseline": {"value": round(n_cpu / cpu_s, 1), "unit": "boxes/s", "cores": 1, "kind": "port",
                              "sample": "4 images x 1000 candidates: threshold + top-k (ATen) + oracle/nms.c"}}
@@ -266,14 +271,40 @@ def resnet50_main(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     value = 64 * args.steps / dt
+    # kernel-level roofline: the same steps once more with a HIP event pair around every conv launch on its launch stream (as the
+    # detection workloads do): class 0 = fp32-MFMA forward / data gradient, 2 = the bf16x3 patch kernel, 1 = weight gradients
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd._lib import lib
+
+    K.prof_enable(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    pc_ms, pc_fl, pc_n = K.prof_summary(2)
+    ig_ms, ig_fl, ig_n = (a + b for a, b in zip(K.prof_summary(0), (pc_ms, pc_fl, pc_n)))
+    wg_ms, wg_fl, wg_n = K.prof_summary(1)
+    ig_bytes = K.prof_bytes(0) + K.prof_bytes(2)
+    ig_bound_ms = K.prof_bound_ms(0, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12) + K.prof_bound_ms(2, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
+    K.prof_enable(False)
+    ig_tf = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
+    wg_tf = wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
     print(json.dumps({"metric": "images/sec ResNet-50 224x224 fwd+bwd", "value": round(value, 2), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                       "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
                       "config": {"workload": "ResNet-50 synthetic ImageNet-shape 224x224, bs=64, forward+backward only, random-init weights",
-                                 "final_loss": round(float(loss), 5)},
-                      "roofline": {"bound": "mfma", "achieved": round(value * 24.54 / 1e3, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(value * 24.54 / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                                   "note": "whole-step figure: images/s x 24.54 GFLOP (SURVEY 8d) / peak"}}), flush=True)
+                                 "final_loss": round(float(loss), 5), "conv_math": K.get_conv_math()},
+                      "roofline": {"bound": "mfma", "kernel": "igemm_kernel / pconv_kernel (conv forward + data gradient)", "achieved": round(ig_tf, 2),
+                                   "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                                   "timed_over": f"{args.steps} further steps with a HIP event pair around every launch of the kernel on its launch stream",
+                                   "launches_per_step": ig_n // max(args.steps, 1), "kernel_ms_per_step": round(ig_ms / args.steps, 3),
+                                   "algorithmic_bytes_per_launch": round(ig_bytes / max(ig_n, 1)),
+                                   "per_launch_bound": {"frac": round(ig_bound_ms / ig_ms, 4) if ig_ms > 0 else None,
+                                                        "note": f"sum over launches of max(FLOPs / {PEAK_FP32_MFMA_TFLOPS} TFLOP/s, algorithmic bytes / {HBM_ACHIEVABLE_TBS} TB/s) / measured kernel time"},
+                                   "wgrad": {"achieved": round(wg_tf, 2), "frac": round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4), "launches_per_step": wg_n // max(args.steps, 1),
+                                             "kernel_ms_per_step": round(wg_ms / args.steps, 3),
+                                             "math": {0: "fp32", 1: "bf16x3", 2: "bf16x3+patch"}[int(lib().sgx_conv_get_wgrad_math())]},
+                                   "step_mfma_frac": round(value * 24.54 / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   "note": "step_mfma_frac: images/s x 24.54 GFLOP (SURVEY 8d) / peak"}}), flush=True)
 
 
 def main():
@@ -435,6 +466,7 @@ def main():
                        # conv_math "fp32" = fp32 matrix pipe (default; SGX_CONV_MATH=auto|bf16x3 opts into the split arithmetic); conv_variant /
                        # conv_tuning_entries: experiment switch and per-problem (tile, variant) table (tools/conv_tune.py --emit-table), 0 = heuristics
                        "conv_math": K.get_conv_math(), "conv_variant": int(os.environ.get("SGX_CONV_VARIANT") or 0),
+                       "bn_reduce_in_data_gradients": bool(getattr(net, "fuse_bn_reduce", False)),
                        "conv_tuning_entries": int(lib().sgx_conv_tuning_size()),
                        "allreduce_from_side_stream": bool(reducer.from_side) if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data gradient, "
@@ -443,7 +475,16 @@ def main():
                                                        else "v_mfma_f32_32x32x16_bf16 x6 / v_mfma_f32_32x32x2_f32 per problem)"),
                          "achieved": round(ig_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                          "timed_over": f"{args.steps} further steps of the same loop with a HIP event pair around every launch of the kernel on its launch stream",
-                         "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_src, "traffic_measured_in_this_run": False,
+                         # the two matrix pipes apart (round 4): launches on the fp32 pipe against the fp32 peak, launches of the bf16x3 patch kernel
+                         # by the bf16 MFMA work they EXECUTE (six products per algorithmic one) against the dense bf16 peak; `achieved` above is
+                         # the combined fp32-equivalent figure
+                         "fp32_pipe": {"achieved": round((ig_fl - pc_fl) / ((ig_ms - pc_ms) * 1e-3) / 1e12, 2) if ig_ms > pc_ms else None, "peak": PEAK_FP32_MFMA_TFLOPS,
+                                       "frac": round((ig_fl - pc_fl) / ((ig_ms - pc_ms) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ig_ms > pc_ms else None,
+                                       "launches_per_step": (ig_n - pc_n) // max(args.steps, 1), "kernel_ms_per_step": round((ig_ms - pc_ms) / args.steps, 3)},
+                         "bf16_pipe": None if pc_n == 0 else {"achieved": round(6.0 * pc_fl / (pc_ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                                                              "frac": round(6.0 * pc_fl / (pc_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                                              "launches_per_step": pc_n // max(args.steps, 1), "kernel_ms_per_step": round(pc_ms / args.steps, 3)},
                          "algorithmic_bytes_per_launch": round(ig_bytes / max(ig_n, 1)), "launches_per_step": ig_n // max(args.steps, 1), "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
                          "gflop_per_launch": round(ig_fl / max(ig_n, 1) / 1e9, 3), "kernel_ms_per_step": round(ig_ms / args.steps, 3),
                          # the launch mix against the bound that applies to EACH launch's shape (shallow 1x1 layers are nearer the HBM bound than the MFMA one)
@@ -458,6 +499,11 @@ def main():
                                                "3 extra untimed steps after the timed region"},
                          "wgrad": {"achieved": round(wg_tf, 2), "frac": round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4), "launches_per_step": wg_n // max(args.steps, 1),
                                    "kernel_ms_per_step": round(wg_ms / args.steps, 3),
+                                   # arithmetic of the weight gradient (sgx_conv_get_wgrad_math: 0 fp32 pipe, 1 bf16x3 slab loop, 2 + patch kernel): in
+                                   # modes 1 / 2 the algorithmic FLOPs run as six bf16 MFMA products each - priced against the dense bf16 peak too
+                                   "math": {0: "fp32", 1: "bf16x3", 2: "bf16x3+patch"}[int(lib().sgx_conv_get_wgrad_math())],
+                                   "executed_bf16_tflops": round(6.0 * wg_tf, 1) if lib().sgx_conv_get_wgrad_math() else None,
+                                   "frac_of_bf16_mfma_peak": round(6.0 * wg_tf / PEAK_BF16_MFMA_TFLOPS, 4) if lib().sgx_conv_get_wgrad_math() else None,
                                    "traffic": pmc.get("wgrad_bytes_per_launch"), "traffic_unit": "bytes/launch (HBM, PMC; a launch = one group of weight gradients)",
                                    "algorithmic_bytes_per_launch": round(wg_bytes / max(wg_n, 1)), "gflop_per_launch": round(wg_fl / max(wg_n, 1) / 1e9, 3)},
                          # the patch kernel alone, priced against BOTH pipes: algorithmic (fp32-equivalent) FLOPs against the fp32 matrix peak, and the
