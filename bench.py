@@ -280,11 +280,11 @@ def resnet50_main(args):
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    pc_ms, pc_fl, pc_n = K.prof_summary(2)
+    pc_ms, pc_fl, pc_n = (a + b for a, b in zip(K.prof_summary(2), K.prof_summary(3)))  # launches on the bf16 pipe: patch kernel + bf16x3 GEMM
     ig_ms, ig_fl, ig_n = (a + b for a, b in zip(K.prof_summary(0), (pc_ms, pc_fl, pc_n)))
     wg_ms, wg_fl, wg_n = K.prof_summary(1)
-    ig_bytes = K.prof_bytes(0) + K.prof_bytes(2)
-    ig_bound_ms = K.prof_bound_ms(0, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12) + K.prof_bound_ms(2, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
+    ig_bytes = K.prof_bytes(0) + K.prof_bytes(2) + K.prof_bytes(3)
+    ig_bound_ms = sum(K.prof_bound_ms(c, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12) for c in (0, 2, 3))
     K.prof_enable(False)
     ig_tf = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
     wg_tf = wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
@@ -298,6 +298,14 @@ def resnet50_main(args):
                                    "timed_over": f"{args.steps} further steps with a HIP event pair around every launch of the kernel on its launch stream",
                                    "launches_per_step": ig_n // max(args.steps, 1), "kernel_ms_per_step": round(ig_ms / args.steps, 3),
                                    "algorithmic_bytes_per_launch": round(ig_bytes / max(ig_n, 1)),
+                                   "fp32_pipe": {"achieved": round((ig_fl - pc_fl) / ((ig_ms - pc_ms) * 1e-3) / 1e12, 2) if ig_ms > pc_ms else None,
+                                                 "peak": PEAK_FP32_MFMA_TFLOPS, "launches_per_step": (ig_n - pc_n) // max(args.steps, 1),
+                                                 "kernel_ms_per_step": round((ig_ms - pc_ms) / args.steps, 3)},
+                                   "bf16_pipe": None if pc_n == 0 else {"achieved": round(6.0 * pc_fl / (pc_ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                                                                        "frac": round(6.0 * pc_fl / (pc_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                                                        "launches_per_step": pc_n // max(args.steps, 1),
+                                                                        "kernel_ms_per_step": round(pc_ms / args.steps, 3),
+                                                                        "note": "executed bf16 MFMA FLOPs = 6 x algorithmic"},
                                    "per_launch_bound": {"frac": round(ig_bound_ms / ig_ms, 4) if ig_ms > 0 else None,
                                                         "note": f"sum over launches of max(FLOPs / {PEAK_FP32_MFMA_TFLOPS} TFLOP/s, algorithmic bytes / {HBM_ACHIEVABLE_TBS} TB/s) / measured kernel time"},
                                    "wgrad": {"achieved": round(wg_tf, 2), "frac": round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4), "launches_per_step": wg_n // max(args.steps, 1),
@@ -409,13 +417,16 @@ def main():
     for _ in range(args.steps):
         step()
     fence()
-    # class 0 = fp32-MFMA implicit GEMM, class 2 = the bf16x3 patch kernel (conv math "patch"): forward / data gradient together
+    # class 0 = fp32-MFMA implicit GEMM, class 2 = the bf16x3 patch kernel, class 3 = the implicit GEMM in bf16x3 arithmetic (conv math
+    # "patch_bf3": the deep problems the patch kernel does not take): forward / data gradient together
     pc_ms, pc_fl, pc_n = K.prof_summary(2)
-    ig_bytes, wg_bytes = K.prof_bytes(0) + K.prof_bytes(2), K.prof_bytes(1)
-    ig_ms, ig_fl, ig_n = (a + b for a, b in zip(K.prof_summary(0), (pc_ms, pc_fl, pc_n)))
+    g3_ms, g3_fl, g3_n = K.prof_summary(3)
+    bf_ms, bf_fl, bf_n = pc_ms + g3_ms, pc_fl + g3_fl, pc_n + g3_n  # everything on the bf16 matrix pipe
+    ig_bytes, wg_bytes = K.prof_bytes(0) + K.prof_bytes(2) + K.prof_bytes(3), K.prof_bytes(1)
+    ig_ms, ig_fl, ig_n = (a + b for a, b in zip(K.prof_summary(0), (bf_ms, bf_fl, bf_n)))
     wg_ms, wg_fl, wg_n = K.prof_summary(1)
     # per-launch roofline time: max(FLOPs / MFMA peak, algorithmic bytes / achievable HBM rate) summed over the same launches
-    ig_bound_ms = K.prof_bound_ms(0, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12) + K.prof_bound_ms(2, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
+    ig_bound_ms = sum(K.prof_bound_ms(c, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12) for c in (0, 2, 3))
     wg_bound_ms = K.prof_bound_ms(1, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
     K.prof_enable(False)
     # The per-launch figures above are taken while the weight-gradient kernels run concurrently on the side HIP stream (they share the
@@ -428,9 +439,10 @@ def main():
         step()
     fence()
     expc_ms, expc_fl, expc_n = K.prof_summary(2)
-    ex_ms, ex_fl, ex_n = (a + b for a, b in zip(K.prof_summary(0), (expc_ms, expc_fl, expc_n)))
+    exg3_ms, exg3_fl, exg3_n = K.prof_summary(3)
+    ex_ms, ex_fl, ex_n = (a + b + c for a, b, c in zip(K.prof_summary(0), (expc_ms, expc_fl, expc_n), (exg3_ms, exg3_fl, exg3_n)))
     exw_ms, exw_fl, exw_n = K.prof_summary(1)
-    ex_bound_ms = K.prof_bound_ms(0, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12) + K.prof_bound_ms(2, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
+    ex_bound_ms = sum(K.prof_bound_ms(c, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12) for c in (0, 2, 3))
     K.prof_enable(False)
     net.side_stream = side
     # host side of one step: enqueue time of a step with the device idle at the start (no sync inside)
@@ -463,7 +475,7 @@ def main():
             "config": {"workload": f"{family}-{args.model.upper()} synthetic COCO {args.size}x{args.size}, bs={args.batch}/GPU, PPYoloELoss(TAL)+AdamW"
                                    + ("" if args.no_ema else "+EMA") + ", random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
-                       # conv_math "fp32" = fp32 matrix pipe (default; SGX_CONV_MATH=auto|bf16x3 opts into the split arithmetic); conv_variant /
+                       # conv_math: "patch_bf3" (default) = bf16x3 patch kernel + per-problem bf16x3 / fp32 implicit GEMM; SGX_CONV_MATH=fp32|patch|... ; conv_variant /
                        # conv_tuning_entries: experiment switch and per-problem (tile, variant) table (tools/conv_tune.py --emit-table), 0 = heuristics
                        "conv_math": K.get_conv_math(), "conv_variant": int(os.environ.get("SGX_CONV_VARIANT") or 0),
                        "bn_reduce_in_data_gradients": bool(getattr(net, "fuse_bn_reduce", False)),
@@ -472,6 +484,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data gradient, "
                                                     + ("v_mfma_f32_32x32x2_f32)" if K.get_conv_math() == "fp32" else
                                                        "v_mfma_f32_32x32x2_f32) + pconv_kernel (3x3 problems from an LDS patch, v_mfma_f32_32x32x16_bf16 x6)" if K.get_conv_math() == "patch"
+                                                       else "v_mfma_f32_32x32x16_bf16 x6 where taps x channels >= 192, v_mfma_f32_32x32x2_f32 below) + pconv_kernel (3x3 stride-1 "
+                                                            "problems from an LDS patch, v_mfma_f32_32x32x16_bf16 x6)" if K.get_conv_math() == "patch_bf3"
                                                        else "v_mfma_f32_32x32x16_bf16 x6 / v_mfma_f32_32x32x2_f32 per problem)"),
                          "achieved": round(ig_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                          "timed_over": f"{args.steps} further steps of the same loop with a HIP event pair around every launch of the kernel on its launch stream",
@@ -479,12 +493,19 @@ def main():
                          # the two matrix pipes apart (round 4): launches on the fp32 pipe against the fp32 peak, launches of the bf16x3 patch kernel
                          # by the bf16 MFMA work they EXECUTE (six products per algorithmic one) against the dense bf16 peak; `achieved` above is
                          # the combined fp32-equivalent figure
-                         "fp32_pipe": {"achieved": round((ig_fl - pc_fl) / ((ig_ms - pc_ms) * 1e-3) / 1e12, 2) if ig_ms > pc_ms else None, "peak": PEAK_FP32_MFMA_TFLOPS,
-                                       "frac": round((ig_fl - pc_fl) / ((ig_ms - pc_ms) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ig_ms > pc_ms else None,
-                                       "launches_per_step": (ig_n - pc_n) // max(args.steps, 1), "kernel_ms_per_step": round((ig_ms - pc_ms) / args.steps, 3)},
-                         "bf16_pipe": None if pc_n == 0 else {"achieved": round(6.0 * pc_fl / (pc_ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
-                                                              "frac": round(6.0 * pc_fl / (pc_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
-                                                              "launches_per_step": pc_n // max(args.steps, 1), "kernel_ms_per_step": round(pc_ms / args.steps, 3)},
+                         "fp32_pipe": {"achieved": round((ig_fl - bf_fl) / ((ig_ms - bf_ms) * 1e-3) / 1e12, 2) if ig_ms > bf_ms else None, "peak": PEAK_FP32_MFMA_TFLOPS,
+                                       "frac": round((ig_fl - bf_fl) / ((ig_ms - bf_ms) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ig_ms > bf_ms else None,
+                                       "launches_per_step": (ig_n - bf_n) // max(args.steps, 1), "kernel_ms_per_step": round((ig_ms - bf_ms) / args.steps, 3)},
+                         "bf16_pipe": None if bf_n == 0 else {"achieved": round(6.0 * bf_fl / (bf_ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                                                              "frac": round(6.0 * bf_fl / (bf_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                                              "launches_per_step": bf_n // max(args.steps, 1), "kernel_ms_per_step": round(bf_ms / args.steps, 3),
+                                                              "note": "patch kernel + implicit-GEMM launches in bf16x3 arithmetic; executed bf16 MFMA FLOPs = 6 x algorithmic"},
+                         # the implicit GEMM's launches that run in bf16x3 arithmetic (conv math "patch_bf3": stride-2 3x3, deep 1x1, QARepVGG two-branch forms)
+                         "gemm_bf16x3": None if g3_n == 0 else {
+                             "launches_per_step": g3_n // max(args.steps, 1), "kernel_ms_per_step": round(g3_ms / args.steps, 3),
+                             "algorithmic_tflops": round(g3_fl / (g3_ms * 1e-3) / 1e12, 2), "executed_bf16_tflops": round(6.0 * g3_fl / (g3_ms * 1e-3) / 1e12, 1),
+                             "frac_of_bf16_mfma_peak": round(6.0 * g3_fl / (g3_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                             "exclusive_algorithmic_tflops": round(exg3_fl / (exg3_ms * 1e-3) / 1e12, 2) if exg3_ms > 0 else None},
                          "algorithmic_bytes_per_launch": round(ig_bytes / max(ig_n, 1)), "launches_per_step": ig_n // max(args.steps, 1), "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
                          "gflop_per_launch": round(ig_fl / max(ig_n, 1) / 1e9, 3), "kernel_ms_per_step": round(ig_ms / args.steps, 3),
                          # the launch mix against the bound that applies to EACH launch's shape (shallow 1x1 layers are nearer the HBM bound than the MFMA one)

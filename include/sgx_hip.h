@@ -44,7 +44,8 @@ const char* sgx_last_error(void);
 /* Measurement aid (bench.py roofline leg).  While enabled, every launch of the two MFMA kernel classes is bracketed by
  * HIP events on its own launch stream and its algorithmic FLOPs (2*M*N*K of the real, unpadded problem) are tallied.
  * cls 0 = implicit-GEMM kernel (conv forward and data gradient, fp32 matrix pipe), cls 1 = weight-gradient kernel (one record per
- * grouped launch), cls 2 = the patch kernel (conv forward and data gradient of 3x3 problems on the bf16 matrix pipe, conv math mode 3).
+ * grouped launch), cls 2 = the patch kernel (conv forward and data gradient of 3x3 problems on the bf16 matrix pipe, conv math modes 3+),
+ * cls 3 = implicit-GEMM launches in bf16x3 arithmetic (bf16 matrix pipe; conv math modes 1, 2, 4, 5).
  * sgx_prof_summary synchronises on the recorded events and returns the sums since the last sgx_prof_enable().      */
 int32_t sgx_prof_enable(int32_t on);
 int32_t sgx_prof_summary(int32_t cls, double* ms, double* flops, int64_t* launches);
@@ -222,6 +223,12 @@ int32_t sgx_conv_get_wgrad_math(void);
 /* Measurement aid for the patch kernel: largest work item (MFLOP, 0 = default 48), filter blocks per workgroup (1..3, 0 = by padding), least
  * share of useful matrix work (filters x channels x pixels over their padded tiles, percent, 0 = default 60) for a job to take the kernel. */
 int32_t sgx_debug_set_wgrad_patch(int32_t item_mflop, int32_t kb, int32_t min_fill_pct);
+/* A HIP stream whose kernels are dispatched to `percent` (10..100) of the device's CUs only, evenly spread over the chip
+ * (hipExtStreamCreateWithCUMask).  For the weight gradients' side stream: their long-lived workgroups otherwise take every CU and the short
+ * dependent kernels of the main stream - the step's critical path - queue between them.  *stream is a hipStream_t; release it with
+ * sgx_stream_destroy.  SGX_ERR_UNSUPPORTED on the host emulation.                                                          */
+int32_t sgx_stream_create_partial(int32_t percent, void** stream);
+int32_t sgx_stream_destroy(void* stream);
 
 /* ConvTranspose2d kernel 2, stride 2 (+bias): modules/sampling.py:72-73 via yolo_stages.py:292-294.
  * x [N,H,W,C] -> y [N,2H,2W,K].  It is the adjoint of a 2x2 stride-2 convolution, so it runs on the same

@@ -119,6 +119,8 @@ PROTOTYPES = {
     "sgx_conv_set_wgrad_math": (_i32, [_i32]),
     "sgx_conv_get_wgrad_math": (_i32, []),
     "sgx_debug_set_wgrad_patch": (_i32, [_i32] * 3),
+    "sgx_stream_create_partial": (_i32, [_i32, ctypes.POINTER(ctypes.c_void_p)]),
+    "sgx_stream_destroy": (_i32, [ctypes.c_void_p]),
     "sgx_debug_set_nms_split": (_i32, [_i32]),
     "sgx_convT2x2_workspace": (_i64, [_i32] * 5),
     "sgx_convT2x2_fwd": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _P, _i64, _i64, _P, _i64, _P]),
@@ -211,9 +213,10 @@ def lib():
         _check_single_runtime()
         mode = os.environ.get("SGX_CONV_MATH")   # "fp32" | "bf16x3" | "auto" (kernels.set_conv_math); unset = the library default
         if mode:
-            if mode not in ("fp32", "bf16x3", "auto", "patch", "patch_auto"):
-                raise RuntimeError(f"SGX_CONV_MATH={mode!r}: expected 'fp32', 'bf16x3', 'auto', 'patch' or 'patch_auto'")
-            _LIB.sgx_conv_set_math({"fp32": 0, "bf16x3": 1, "auto": 2, "patch": 3, "patch_auto": 4}[mode])
+            modes = {"fp32": 0, "bf16x3": 1, "auto": 2, "patch": 3, "patch_auto": 4, "patch_bf3": 5}
+            if mode not in modes:
+                raise RuntimeError(f"SGX_CONV_MATH={mode!r}: expected one of {sorted(modes)}")
+            _LIB.sgx_conv_set_math(modes[mode])
         var = os.environ.get("SGX_CONV_VARIANT")  # measurement switch of the conv kernels (sgx_debug_set_variant; 7 = the 16-deep loop)
         if var:
             _LIB.sgx_debug_set_variant(int(var))

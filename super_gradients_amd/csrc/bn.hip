@@ -146,10 +146,13 @@ struct ColSrc {  // what a finalize kernel sums over: either the fp32 partials o
 // These kernels are a handful of workgroups on an otherwise idle chip (they sit between a convolution and the sweep that needs its
 // statistics), so their time is load LATENCY x dependent rounds, not bytes: all planes of FOUR rows are loaded before the first add
 // (r3: the per-plane form measured 27 us for the five-moment finalize of an 80 x 80 map - 500 loads per lane, eight in flight).
-#ifndef CO_CH
-#define CO_CH 16
-#endif
-#define CO_RL (1024 / CO_CH)
+// Workgroup shape (round 4): 256 threads = 4 channels x 64 row lanes, LDS 32 doubles per plane.  The first form was 1024 threads (16
+// channels x 64 row lanes, 8 KB of LDS per plane): during the backward pass the weight-gradient kernels of the side stream fill every CU's
+// LDS and wave slots, and a 1024-thread workgroup then waits until ONE CU has sixteen wave slots and its LDS free at the same moment -
+// r4t: 250-450 us for a 7 us kernel, 1.35 ms per step on the critical path (profiles/r4t_*).  Four waves with half a KB fit anywhere.
+#define CO_CH 4
+#define CO_RL 64
+#define CO_WAVES (CO_CH * CO_RL / 64)
 #define CR_COOP_MAX 4096
 static std::atomic<int> g_fused_finalize{1};
 extern "C" int32_t sgx_bn_set_fused_finalize(int32_t on) {
@@ -205,7 +208,7 @@ __device__ __forceinline__ void col_totals(const ColSrc& s, int C, int c, bool c
         for (int q = 0; q < P; ++q) out[q] = cok ? colsrc_sum(s, q, C, c) : 0.0;
         return;
     }
-    __shared__ double red[P][CO_RL][CO_CH + 1];
+    __shared__ double red[P][CO_WAVES][CO_CH];
     const int cl = threadIdx.x % CO_CH, rl = threadIdx.x / CO_CH;
     double acc[P];
 #pragma unroll
@@ -214,32 +217,24 @@ __device__ __forceinline__ void col_totals(const ColSrc& s, int C, int c, bool c
         if (s.d) col_lane_sums<P>(s.d + c, (long)s.n * C, s.n, C, rl, acc);
         else col_lane_sums<P>(s.f + c, (long)s.n * C, s.n, C, rl, acc);
     }
+    // lane sums -> totals in a fixed order: the sixteen row lanes of a wave meet by exchange (lane = row lane x CO_CH + channel), the
+    // waves' sums through LDS, added in wave order by the writer lanes
 #pragma unroll
-    for (int q = 0; q < P; ++q) red[q][rl][cl] = acc[q];
-    __syncthreads();
-    // lane sums -> totals in two fixed steps: row lanes 0..7 each add eight consecutive lane sums, the writer lane adds those eight.
-    // (All 1024 threads adding all CO_RL sums, as this was first written, is 2.6 MB of LDS reads for five planes: ~8 us on its own.)
-    constexpr int F1 = 8, F2 = CO_RL / F1;
-    if (rl < F1) {
+    for (int q = 0; q < P; ++q) {
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            double t = 0.0;
-#pragma unroll
-            for (int k = 0; k < F2; ++k) t += red[q][rl * F2 + k][cl];
-            acc[q] = t;
-        }
+        for (int m = CO_CH; m < 64; m <<= 1) acc[q] += __shfl_xor(acc[q], m);
     }
-    __syncthreads();
-    if (rl < F1)
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < CO_CH)
 #pragma unroll
-        for (int q = 0; q < P; ++q) red[q][rl][cl] = acc[q];
+        for (int q = 0; q < P; ++q) red[q][wave][cl] = acc[q];
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < P; ++q) {
         double t = 0.0;
         if (rl == 0)
 #pragma unroll
-            for (int k = 0; k < F1; ++k) t += red[q][k][cl];
+            for (int k = 0; k < CO_WAVES; ++k) t += red[q][k][cl];
         out[q] = t;  // valid in the writer lanes (row lane 0) only
     }
 }

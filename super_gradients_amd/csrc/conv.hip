@@ -271,7 +271,15 @@ __device__ __forceinline__ void sgx_bnreq_publish(const IgemmParams& p, int col,
 template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && NBUF == 1), "32-deep slabs: channel-chunked K axis, one LDS buffer");
-    static_assert(PH2 == 0 || (MATH == 0 && !FLAT), "second K-axis source: fp32 arithmetic, channel-chunked K axis");
+    static_assert(PH2 == 0 || !FLAT, "second K-axis source: channel-chunked K axis");
+    static_assert(MATH == 0 || MATH == 1, "arithmetic: 0 = fp32 matrix pipe, 1 = bf16x3");
+    // (Round 4 tried MATH = 2: the five correction products of the bf16x3 scheme added into the SAME accumulator as the leading one - it
+    // frees 16 registers per block and ran the step 4 % faster, but the bf16 MFMA's accumulate floors what it shifts out: small terms added
+    // to a large accumulator leave a NEGATIVE bias of 1e-8 .. 8e-8 of the output's rms per convolution (tools/conv_error_probe.py,
+    // profiles/r4m_*: two accumulators 1e-10, fp32 pipe 1e-10), which adds up coherently through a hundred layers - YOLO-NAS-L's
+    // element-wise gradient check came out at 5e-4.  The corrections therefore keep their own accumulator, also in the two-source /
+    // two-output forms: three accumulators per block there.)
+    constexpr bool BF3 = MATH == 1;
     constexpr int NTH = WM * WN * 64;   // threads per workgroup
     constexpr int CPR = KD / 4;         // threads per slab row (16 B each)
     constexpr int RPP = NTH / CPR;      // slab rows staged per pass
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "bad tile");
     static_assert(NTH >= BM && NTH >= BN, "epilogue helpers need one thread per tile row/col");
     constexpr int LDPW = KD / 2;        // bf16x3: dwords per slab row and plane (KD bf16), unpadded
-    constexpr int ROWW = MATH == 1 ? 3 * LDPW : LD;                            // dwords of LDS per slab row (all planes)
+    constexpr int ROWW = BF3 ? 3 * LDPW : LD;                                  // dwords of LDS per slab row (all planes)
     // bf16x3 plane swizzle: 16-byte chunks of a row are permuted by row bits so that the fragment reads of 16 consecutive rows hit 16
     // distinct 4-bank groups - 32-byte rows: halves swapped on rows with bit 3 set; 64-byte rows: chunk ^= row bits 2-3
     auto swz = [](int row, int dw) { return KD == 16 ? IG_SWZ(row, dw) : (dw ^ (((row >> 2) & 3) << 2)); };
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     };
     auto load_tile = [&]() { load_tile_to(ra, rb); };
     auto store_tile_from = [&](int buf, const float4* ra, const float4* rb) {
-        if (MATH == 1) {  // planes [buf][hi|mid|lo][row][IG_LDP dwords]; this lane's 4 k-values are 2 dwords of a row
+        if (BF3) {  // planes [buf][hi|mid|lo][row][IG_LDP dwords]; this lane's 4 k-values are 2 dwords of a row
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 const int row = lrow + RPP * j;
@@ -475,16 +483,19 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
     // at 2^-8 of the result's magnitude; the leading hi*hi products are exact and add into `acc` once per 16-deep slab - fewer
     // roundings at full magnitude than the fp32 matrix pipe's eight per slab.  The two are summed once, before the epilogue.
     // PH2 = 2 (fp32 arithmetic only) reuses the name for the accumulator of the second output.
-    constexpr bool ACC2 = MATH == 1 || PH2 == 2;
+    // acc2: the second output of the PH2 = 2 form; accc: the bf16x3 correction products of the source being accumulated
+    constexpr bool ACC2 = PH2 == 2;
     sgx_f32x16 acc2[ACC2 ? TM : 1][ACC2 ? TN : 1];
-    if (ACC2) {
+    sgx_f32x16 accc[BF3 ? TM : 1][BF3 ? TN : 1];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[ACC2 ? i : 0][ACC2 ? j : 0][r] = 0.f;
-    }
+            for (int r = 0; r < 16; ++r) {
+                if (ACC2) acc2[ACC2 ? i : 0][ACC2 ? j : 0][r] = 0.f;
+                if (BF3) accc[BF3 ? i : 0][BF3 ? j : 0][r] = 0.f;
+            }
 
     const int frow = lane & 31, fk = (lane >> 5) * 8;
     // bf16x3 fragment reads + the six cross-product MFMAs of one slab (smallest terms first)
@@ -505,26 +516,27 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             bl[j] = *reinterpret_cast<const uint4*>(s + 2 * BN * LDPW);
         }
         // smallest terms first; the six products of one (i, j) are interleaved across the tile's accumulators
+        auto corr = [&](int i, int j) -> sgx_f32x16& { return accc[BF3 ? i : 0][BF3 ? j : 0]; };
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc2[i][j] = sgx_mfma_bf16(al[i], bh[j], acc2[i][j]);
+            for (int j = 0; j < TN; ++j) corr(i, j) = sgx_mfma_bf16(al[i], bh[j], corr(i, j));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc2[i][j] = sgx_mfma_bf16(ah[i], bl[j], acc2[i][j]);
+            for (int j = 0; j < TN; ++j) corr(i, j) = sgx_mfma_bf16(ah[i], bl[j], corr(i, j));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc2[i][j] = sgx_mfma_bf16(am[i], bm[j], acc2[i][j]);
+            for (int j = 0; j < TN; ++j) corr(i, j) = sgx_mfma_bf16(am[i], bm[j], corr(i, j));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc2[i][j] = sgx_mfma_bf16(am[i], bh[j], acc2[i][j]);
+            for (int j = 0; j < TN; ++j) corr(i, j) = sgx_mfma_bf16(am[i], bh[j], corr(i, j));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc2[i][j] = sgx_mfma_bf16(ah[i], bm[j], acc2[i][j]);
+            for (int j = 0; j < TN; ++j) corr(i, j) = sgx_mfma_bf16(ah[i], bm[j], corr(i, j));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -571,8 +583,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            acc2[ACC2 ? i : 0][ACC2 ? j : 0][r] = acc[i][j][r];
+                            acc2[ACC2 ? i : 0][ACC2 ? j : 0][r] = acc[i][j][r] + (BF3 ? accc[BF3 ? i : 0][BF3 ? j : 0][r] : 0.f);
                             acc[i][j][r] = 0.f;
+                            if (BF3) accc[BF3 ? i : 0][BF3 ? j : 0][r] = 0.f;
                         }
             }
         }
@@ -585,7 +598,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             if (KD == 32) {
                 // one LDS buffer: the next slab travels in registers under 16 x TM x TN MFMAs and is written after every wave has read this one
                 if (kt + 1 < nkt) load_tile();
-                if (MATH == 1) {
+                if (BF3) {
                     compute_bf3(0, 0);
                     compute_bf3(0, 1);
                 } else {
@@ -602,20 +615,20 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
             const int buf = kt & 1;
             if (kt + 1 < nkt) load_tile();  // global loads in flight under the MFMA block
             // (bf16x3: a second register stage - slabs fetched two iterations ahead, counted vmcnt - was measured: no gain, r1z/r1z2)
-            if (MATH == 1) compute_bf3(buf, 0);
+            if (BF3) compute_bf3(buf, 0);
             else compute_f32(buf, 0);
             if (kt + 1 < nkt) store_tile(buf ^ 1);
             __syncthreads();
         }
     }
 
-    if (MATH == 1) {
+    if (BF3) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[ACC2 ? i : 0][ACC2 ? j : 0][r];
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += accc[BF3 ? i : 0][BF3 ? j : 0][r];
     }
     if constexpr (PH2 == 2) {
         // ---- two-output epilogue (QARepVGG forward): y = acc2 -> Y, u = acc + bias2 -> Y2 (same strides), and the five per-channel sums both
@@ -1268,11 +1281,14 @@ struct TileCfg {
 // the library stays re-entrant, as include/sgx_hip.h promises)
 static std::atomic<int> g_ovr_bm{0}, g_ovr_bn{0}, g_ovr_wk{0}, g_ovr_wj{0}, g_ovr_split{0}, g_ovr_var{0};
 // arithmetic of the forward / data-gradient GEMMs: 0 = fp32 MFMA (exact fp32 FMA chains), 1 = bf16x3 split (see IG_LDP above)
-// default 3: fp32 matrix pipe everywhere except the 3x3 stride-1 problems on maps of 40 x 40 and larger, which run pconv_kernel (bf16x3 from
-// an LDS-resident patch): 1.25-1.6x on those launches, every GPU parity test green in that mode (r3g)
-static std::atomic<int> g_conv_math{3};
+// mode 3 (the default of round 3): fp32 matrix pipe everywhere except the 3x3 stride-1 problems on maps of 40 x 40 and larger, which run
+// pconv_kernel (bf16x3 from an LDS-resident patch): 1.25-1.6x on those launches, every GPU parity test green in that mode (r3g)
+// default 5 (round 4): mode 3, and every other problem whose reduction is deep enough (taps x channels >= 192: the stride-2 3x3 layers, the
+// deep 1x1 layers, the QARepVGG two-branch forward / two-source data gradient) on the bf16 pipe as well - +3.9 % of the step (r4n: 737
+// against 709 img/s), single convolutions 3-4x CLOSER to fp64 than the fp32 pipe (profiles/r4n_conv_arithmetic_error_probe.txt)
+static std::atomic<int> g_conv_math{5};
 extern "C" int32_t sgx_conv_set_math(int32_t mode) {
-    SGX_CHECK_ARG(mode >= 0 && mode <= 4, "conv math mode %d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = per problem, 3 = patch kernel for 3x3 stride-1, 4 = 3 + 2)", mode);
+    SGX_CHECK_ARG(mode >= 0 && mode <= 5, "conv math mode %d (0 = fp32 MFMA, 1 = bf16x3 split, 2 = per problem, 3 = patch kernel for 3x3 stride-1, 4 = 3 + 2, 5 = 4 + the two-source / two-output launches)", mode);
     g_conv_math = mode;
     return SGX_OK;
 }
@@ -1284,8 +1300,9 @@ extern "C" int32_t sgx_conv_get_math(void) { return g_conv_math; }
 static int conv_math_for(int taps, int C) {
     const int m = g_conv_math.load(std::memory_order_relaxed);
     if (m == 3) return 0;  // the patch kernel takes the 3x3 stride-1 problems (pconv_ok), everything else stays on the fp32 pipe
-    // mode 4 (measurement, not yet measured): the patch kernel on its problems AND the per-problem rule of mode 2 for the rest
-    return (m == 2 || m == 4) ? ((long)taps * C >= SGX_BF3_MIN_DEPTH ? 1 : 0) : m;
+    // mode 4 (measurement; r4a: +0.5 %): the patch kernel on its problems AND the per-problem rule of mode 2 for the rest
+    // mode 5 (round 4): mode 4, and the two-source / two-output (QARepVGG) launches follow the same rule
+    return (m == 2 || m == 4 || m == 5) ? ((long)taps * C >= SGX_BF3_MIN_DEPTH ? 1 : 0) : m;
 }
 // Mode 3: 3x3, stride 1, pad 1, channel counts in 16s -> pconv_kernel (bf16x3 from an LDS-resident patch).  Decidable from the descriptor,
 // so that the forward statistics rows (one per 8 x 16 pixel tile and image) are known before the launch.
@@ -1410,12 +1427,12 @@ static bool igemm_deep_slabs(const IgemmParams& p) { return conv_variant() != 7 
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no tile %dx%d (math %d, %d-deep slabs)", bm, bn, MATH_, KD_);   \
     } while (0)
 // the two-source kernels exist for the tiles the heuristic picks (pick_tile_heuristic): overrides / table entries do not apply to them
-#define SGX_IGEMM_TILES_PH2(KD_, NBUF_, PH2_)                                                                     \
+#define SGX_IGEMM_TILES_PH2(MATH_, KD_, NBUF_, PH2_)                                                              \
     do {                                                                                                          \
-        if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, 0, KD_, NBUF_, PH2_>(p, stream);            \
-        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 0, KD_, NBUF_, PH2_>(p, stream);       \
-        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, KD_, NBUF_, PH2_>(p, stream);         \
-        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, 0, KD_, NBUF_, PH2_>(p, stream);         \
+        if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);        \
+        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);   \
+        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, MATH_, KD_, NBUF_, PH2_>(p, stream);     \
+        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);     \
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (two sources): no tile %dx%d", bm, bn);                          \
     } while (0)
 template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0>
@@ -1498,8 +1515,10 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
     if (p.nreq && !p.vec) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: BatchNorm-reduce requests need 16-byte aligned outputs");
     // algorithmic work: every input element, weight and output element once (fp32); the second source adds its taps
     const double T2 = (ph2 && p.A2) ? (double)p.Th2 * p.Tw2 : 0.0;
-    // (profiling class 0 = fp32-MFMA implicit GEMM, 2 = the bf16x3 patch kernel: same algorithmic FLOPs, priced separately by bench.py)
-    SGX_PROF(pconv_ok(p, ph2) ? 2 : 0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * ((double)T + T2),
+    // (profiling class 0 = fp32-MFMA implicit GEMM, 2 = the bf16x3 patch kernel, 3 = the implicit GEMM in bf16x3 arithmetic: same algorithmic
+    // FLOPs, priced separately by bench.py)
+    const bool gemm_bf3 = conv_math_for(T, p.C) == 1 && (!ph2 || g_conv_math.load(std::memory_order_relaxed) == 5);
+    SGX_PROF(pconv_ok(p, ph2) ? 2 : gemm_bf3 ? 3 : 0, 2.0 * (double)p.M * (double)p.Nout * (double)p.C * ((double)T + T2),
              4.0 * ((double)p.M / ((double)p.Ha * p.Wa) * p.Hin * p.Win * p.C * (ph2 == 1 && p.A2 ? 2.0 : 1.0) + (double)p.Nout * p.C * (T + T2) +
                     (double)p.M * p.Nout * (ph2 == 2 ? 2.0 : 1.0)), stream);
     const bool flat = p.C < IG_BK && T > 1;
@@ -1513,14 +1532,21 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
     }
     if (ph2) {
         if (flat || !p.vec) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (two sources): needs C >= 16 and 16-byte aligned outputs");
+        const bool bf3 = gemm_bf3;  // (mode 5: the primary source's depth decides for the launch)
         if (p.C % 32 == 0) {
-            if (ph2 == 1) SGX_IGEMM_TILES_PH2(32, 1, 1);
-            else SGX_IGEMM_TILES_PH2(32, 1, 2);
+            if (bf3) {
+                if (ph2 == 1) SGX_IGEMM_TILES_PH2(1, 32, 1, 1);
+                else SGX_IGEMM_TILES_PH2(1, 32, 1, 2);
+            } else if (ph2 == 1) SGX_IGEMM_TILES_PH2(0, 32, 1, 1);
+            else SGX_IGEMM_TILES_PH2(0, 32, 1, 2);
         } else {
-            if (ph2 == 1) SGX_IGEMM_TILES_PH2(16, 2, 1);
-            else SGX_IGEMM_TILES_PH2(16, 2, 2);
+            if (bf3) {
+                if (ph2 == 1) SGX_IGEMM_TILES_PH2(1, 16, 2, 1);
+                else SGX_IGEMM_TILES_PH2(1, 16, 2, 2);
+            } else if (ph2 == 1) SGX_IGEMM_TILES_PH2(0, 16, 2, 1);
+            else SGX_IGEMM_TILES_PH2(0, 16, 2, 2);
         }
-    } else if (conv_math_for(T, p.C) == 1) {
+    } else if (gemm_bf3) {
         if (flat && bn > 64) bn = 64;
         if (flat && bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, true, 1>(p, stream);
         else if (flat && bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, true, 1>(p, stream);
@@ -2750,5 +2776,42 @@ extern "C" int32_t sgx_convT2x2_bwd_weight(int32_t N, int32_t H, int32_t W, int3
         if (ws_bytes < sgx_colsum_workspace(M, K)) SGX_FAIL(SGX_ERR_WORKSPACE, "convT bwd_weight: workspace too small");
         return sgx_colsum(dy, dy_ld_pix, M, K, 4L * H * W, dy_ld_img, dbias, 1, (float*)ws, stream);
     }
+    return SGX_OK;
+}
+
+// ---- a HIP stream confined to part of the chip ---------------------------------------------------------------------------------------
+// The weight gradients run on a side stream underneath the backward pass.  Their workgroups live for hundreds of microseconds and take every
+// CU; the short, dependent kernels of the main stream (the critical path of the step) then wait for slots between them - r4t: the
+// BatchNorm-backward sweeps run 7x longer while a weight-gradient kernel is resident, 6.8 ms per step over all main-stream kernels
+// (profiles/r4t_*).  A stream created here dispatches to `cus` of the device's CUs only (spread evenly: every `keep`-th ... CU index is
+// left out), so the rest of the chip always has room for the main stream.
+extern "C" int32_t sgx_stream_create_partial(int32_t percent, void** stream) {
+    SGX_CHECK_ARG(stream && percent >= 10 && percent <= 100, "stream_create_partial: percent of the CUs in 10..100");
+#ifdef SGX_EMU
+    SGX_FAIL(SGX_ERR_UNSUPPORTED, "stream_create_partial: no CU masks on the host emulation");
+#else
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+        SGX_FAIL(SGX_ERR_HIP, "stream_create_partial: cannot query the device");
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    // bit i set <=> floor((i + 1) * percent / 100) > floor(i * percent / 100): `percent` of every run of 100 consecutive CU indices, evenly
+    // spaced - whatever the driver's mapping of mask bits to XCDs is (round-robin or blocked), every XCD keeps the same share
+    int on = 0;
+    for (int i = 0; i < ncu; ++i)
+        if ((long)(i + 1) * percent / 100 > (long)i * percent / 100) {
+            mask[i / 32] |= 1u << (i % 32);
+            ++on;
+        }
+    hipStream_t st = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data());
+    if (e != hipSuccess) SGX_FAIL(SGX_ERR_HIP, "hipExtStreamCreateWithCUMask(%d of %d CUs): %s", on, ncu, hipGetErrorString(e));
+    *stream = (void*)st;
+    return SGX_OK;
+#endif
+}
+extern "C" int32_t sgx_stream_destroy(void* stream) {
+#ifndef SGX_EMU
+    if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) SGX_FAIL(SGX_ERR_HIP, "hipStreamDestroy failed");
+#endif
     return SGX_OK;
 }

@@ -946,7 +946,7 @@ def ema_update(ema, p, decay):
 
 
 # --------------------------------------------------------------------------------------------- conv arithmetic
-CONV_MATH = {"fp32": 0, "bf16x3": 1, "auto": 2, "patch": 3, "patch_auto": 4}
+CONV_MATH = {"fp32": 0, "bf16x3": 1, "auto": 2, "patch": 3, "patch_auto": 4, "patch_bf3": 5}
 DEFAULT_CONV_MATH = "patch"  # what the library starts with (csrc/conv.hip g_conv_math): fp32 matrix pipe + the patch kernel on its problems
 
 

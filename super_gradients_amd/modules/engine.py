@@ -197,7 +197,7 @@ class SgxNetwork(nn.Module):
         # Weight gradients are independent of the data-gradient chain: they are forked onto a side HIP stream so that they fill
         # the CUs the (dependent) main-stream kernels leave idle in their tails (most YOLO-NAS layers are 1-2 waves of
         # workgroups).  SGX_SIDE_STREAM=0 disables the fork.
-        self.side_stream = torch.cuda.Stream(device=device) if (device.type == "cuda" and os.environ.get("SGX_SIDE_STREAM", "1") != "0") else None
+        self.side_stream = _make_side_stream(device) if (device.type == "cuda" and os.environ.get("SGX_SIDE_STREAM", "1") != "0") else None
         # Optional (SGX_AUX_STREAM=1): transpose all data-gradient weights on a third stream underneath the forward pass instead of
         # per call.  Measured neutral-to-negative on YOLO-NAS-S (r1p: 528.7 vs 533.3 images/s): the per-call transposes already hide
         # under the side-stream weight gradients, so it stays off by default.
@@ -442,6 +442,28 @@ class SgxNetwork(nn.Module):
         if a is None:
             a = self._anchor = torch.zeros(1, device=self._device, requires_grad=True)
         return a
+
+
+# Share of the chip's CUs the weight gradients' side stream may use (SGX_SIDE_CUS, percent; 100 = an ordinary stream).
+SIDE_STREAM_CU_PERCENT = 100
+
+
+def _make_side_stream(device):
+    """The side HIP stream of the weight gradients.  Below 100 % it is created with a CU mask (sgx_stream_create_partial): the
+    weight-gradient workgroups live for hundreds of microseconds and otherwise occupy every CU, and the short dependent kernels of the main
+    stream - the critical path of the step - then wait between them (r4t: 6.8 ms per step)."""
+    import ctypes
+    import os
+
+    pct = int(os.environ.get("SGX_SIDE_CUS") or SIDE_STREAM_CU_PERCENT)
+    if pct >= 100:
+        return torch.cuda.Stream(device=device)
+    from .._lib import check, lib
+
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        check(lib().sgx_stream_create_partial(pct, ctypes.byref(handle)), "sgx_stream_create_partial")
+    return torch.cuda.ExternalStream(handle.value, device=device)  # (lives as long as the process: a network's streams are never recycled)
 
 
 class NetFunction(torch.autograd.Function):

@@ -1160,22 +1160,25 @@ def test_wgrad_group(backend, monkeypatch):
             _l._LIB = None
 
 
-def test_conv_math_patch_auto(backend):
-    """Conv math mode 4 ("patch_auto", a measurement mode): the patch kernel on the 3x3 stride-1 problems, the per-problem bf16x3 / fp32 rule
-    on the rest - forward (with the statistics rows, whose count follows the dispatch) and data gradient against ATen on a problem of each
-    kind.  Emulation only this round: the dispatch combination has not met the chip yet (its two kernels have)."""
+@pytest.mark.parametrize("mode", ["patch_auto", "patch_bf3"])
+def test_conv_math_patch_auto(backend, mode):
+    """Conv math modes 4 / 5: the patch kernel on the 3x3 stride-1 problems, the per-problem bf16x3 / fp32 rule on the rest - mode 5
+    ("patch_bf3", the default since round 4) extends the rule to the QARepVGG two-branch forward and two-source data gradient (three
+    accumulators per block there: leading products, corrections, second output).  Forward (with the statistics rows, whose count follows the
+    dispatch), data gradient, and for mode 5 the two-output / two-source launches (stride 2: the forms the patch kernel does not take)
+    against ATen on a problem of each kind; the bf16x3 results must be at least as close to fp64 as a small multiple of the fp32 pipe's."""
     from super_gradients_amd._lib import lib
 
-    if backend.type == "cuda":
-        pytest.skip("mode 4 has only met the emulation so far")
-    cases = [(1, 9, 20, 16, 32, 3, 1, 1),    # 3x3 stride 1 -> patch kernel (variant 9 lifts the 40 x 40 floor for the small map)
+    gpu = backend.type == "cuda"
+    cases = [(2, 40, 40, 32, 64, 3, 1, 1), (2, 20, 20, 192, 64, 1, 1, 0), (2, 24, 24, 8, 16, 1, 1, 0), (2, 40, 40, 64, 128, 3, 2, 1)] if gpu else \
+            [(1, 9, 20, 16, 32, 3, 1, 1),    # 3x3 stride 1 -> patch kernel (variant 9 lifts the 40 x 40 floor for the small map)
              (1, 6, 6, 192, 16, 1, 1, 0),    # depth 192 -> bf16x3 GEMM
              (1, 8, 8, 8, 16, 1, 1, 0),      # shallow -> fp32 pipe
              (1, 10, 10, 32, 16, 3, 2, 1)]   # 3x3 stride 2, depth 288 -> bf16x3 GEMM
-    K.set_conv_math("patch_auto")
-    lib().sgx_debug_set_variant(9)
+    K.set_conv_math(mode)
+    lib().sgx_debug_set_variant(0 if gpu else 9)
     try:
-        assert K.get_conv_math() == "patch_auto"
+        assert K.get_conv_math() == mode
         for i, shape in enumerate(cases):
             n, h, w, c, k, r, s_, p_ = shape
             x, wt, b = _conv_case(shape, seed=60 + i)
@@ -1185,10 +1188,33 @@ def test_conv_math_patch_auto(backend):
             y.backward(dy)
             xd, wd = to_nhwc(x.detach(), backend), K.to_ohwi(wt.to(backend))
             yd, parts = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s_, pad=p_, stat_partials=True)
-            assert_close(to_nchw_cpu(yd), y.detach(), TOL, f"patch_auto fwd {shape}")
-            assert_close(parts[0].sum(0).cpu() / (y.numel() // k), y.detach().mean((0, 2, 3)), 1e-4, f"patch_auto stats {shape}")
+            assert_close(to_nchw_cpu(yd), y.detach(), TOL, f"{mode} fwd {shape}")
+            assert_close(parts[0].sum(0).cpu() / (y.numel() // k), y.detach().mean((0, 2, 3)), 1e-4, f"{mode} stats {shape}")
             dx = K.conv2d_bwd_data(to_nhwc(dy, backend), wd, (n, h, w, c), stride=s_, pad=p_)
-            assert_close(to_nchw_cpu(dx), x.grad, TOL, f"patch_auto dgrad {shape}")
+            assert_close(to_nchw_cpu(dx), x.grad, TOL, f"{mode} dgrad {shape}")
+            if mode == "patch_bf3" and r == 3 and c >= 16 and k >= 16:
+                # the QARepVGG forms on the bf16 pipe: y3 / u / five moments, and dx = dgrad3x3(dy) + dgrad1x1(ds)
+                g = torch.Generator().manual_seed(80 + i)
+                w1 = torch.randn(k, c, 1, 1, generator=g) / c ** 0.5
+                w1d = K.to_ohwi(w1.to(backend))
+                y3, ud, st5 = K.conv2d_fwd_dual(xd, wd, w1d, b.to(backend), stride=s_)
+                y3r, ur = F.conv2d(x.detach(), wt, None, stride=s_, padding=1), F.conv2d(x.detach(), w1, b, stride=s_)
+                assert_close(to_nchw_cpu(y3), y3r, TOL, f"{mode} dual y {shape}")
+                assert_close(to_nchw_cpu(ud), ur, TOL, f"{mode} dual u {shape}")
+                M = y3r.numel() // k
+                u0 = ur - b.view(1, -1, 1, 1)
+                for q, ref in enumerate((y3r, y3r * y3r, u0, u0 * u0, y3r * u0)):
+                    assert_close(st5[q].sum(0).cpu() / M, ref.mean((0, 2, 3)), 1e-4, f"{mode} dual moment {q} {shape}")
+                ds = torch.randn(y.shape, generator=g)
+                xs = x.detach().clone().requires_grad_(True)
+                (F.conv2d(xs, wt, None, stride=s_, padding=1) * dy).sum().backward()
+                gx3 = xs.grad.clone()
+                xs.grad = None
+                (F.conv2d(xs, w1, None, stride=s_) * ds).sum().backward()
+                wtb = K.conv2d_wt_buffer(wd, backend)
+                K.conv2d_transpose_weights(wd, wtb, stride=s_, pad=1)
+                dxd = K.conv2d_bwd_data_dual(to_nhwc(dy, backend), wd, wtb, to_nhwc(ds, backend), w1d.reshape(k, c).t().contiguous(), (n, h, w, c), stride=s_)
+                assert_close(to_nchw_cpu(dxd), gx3 + xs.grad, TOL, f"{mode} dual dgrad {shape}")
     finally:
         lib().sgx_debug_set_variant(0)
         K.set_conv_math(K.DEFAULT_CONV_MATH)
@@ -1532,3 +1558,32 @@ def test_pconv_stride2_data_gradient(backend, case):
     finally:
         lib().sgx_debug_set_variant(0)
         K.set_conv_math(K.DEFAULT_CONV_MATH)
+
+
+@pytest.mark.gpu
+def test_partial_chip_stream(gpu_device):
+    """sgx_stream_create_partial: a HIP stream confined to part of the CUs (the weight gradients' side stream).  Kernels launched on it
+    give the results of the ordinary stream; the mask it was created with has the requested share of bits, evenly spread; bad shares are
+    refused."""
+    import ctypes
+
+    from super_gradients_amd._lib import check, lib
+
+    shape = (2, 40, 40, 32, 64, 3, 1, 1)
+    x, wt, b = _conv_case(shape, seed=3)
+    xd, wd = to_nhwc(x, gpu_device), K.to_ohwi(wt.to(gpu_device))
+    ref = K.conv2d_fwd(xd, wd, bias=b.to(gpu_device), stride=1, pad=1)
+    torch.cuda.synchronize()
+    for pct in (25, 75):
+        h = ctypes.c_void_p()
+        check(lib().sgx_stream_create_partial(pct, ctypes.byref(h)), "sgx_stream_create_partial")
+        assert h.value
+        st = torch.cuda.ExternalStream(h.value, device=gpu_device)
+        with torch.cuda.stream(st):
+            y = K.conv2d_fwd(xd, wd, bias=b.to(gpu_device), stride=1, pad=1)
+        st.synchronize()
+        assert torch.equal(y, ref)
+        del st
+        check(lib().sgx_stream_destroy(h), "sgx_stream_destroy")
+    h = ctypes.c_void_p()
+    assert lib().sgx_stream_create_partial(5, ctypes.byref(h)) == -1 and lib().sgx_stream_create_partial(101, ctypes.byref(h)) == -1

@@ -202,6 +202,35 @@ def test_yolo_nas_s_train_step_parity(gpu_device):
     assert abs(l - lr) <= 2e-4 * abs(lr)
 
 
+def _spp_smallest_top2_gap(ref, x):
+    """Smallest gap between the largest and second-largest value of any max-pool window of the reference forward, relative to the pooled map's
+    largest magnitude (the oracle's SPP calls F.max_pool2d: wrapped for the duration of one forward)."""
+    import oracle.yolo_nas as oracle_yolo_nas
+    import torch.nn.functional as F
+
+    real, gaps = F.max_pool2d, []
+
+    def probe(t, k, stride=None, padding=0, *a, **kw):
+        win = F.unfold(F.pad(t, (k // 2,) * 4, value=float("-inf")), k).view(t.shape[0], t.shape[1], k * k, -1)
+        top = win.topk(2, dim=2).values
+        gaps.append(float((top[:, :, 0] - top[:, :, 1]).min()) / float(t.abs().max()))
+        return real(t, k, stride, padding, *a, **kw)
+
+    class _Shim:
+        def __getattr__(self, name):
+            return probe if name == "max_pool2d" else getattr(F, name)
+
+    saved = oracle_yolo_nas.F
+    oracle_yolo_nas.F = _Shim()
+    try:
+        with torch.no_grad():
+            ref.train()(x)
+    finally:
+        oracle_yolo_nas.F = saved
+    assert gaps, "the reference forward made no max-pool call"
+    return min(gaps)
+
+
 def _backward_exact_without_relu_flips(variant, B, size, gpu_device, lazy_fp64=False, threads=None, certify=False):
     """The strict form of the whole-model backward check.  At random init a handful of ReLU pre-activations change sign between any two
     fp32 implementations, and every flip is an O(1) local gradient error - which is why the three-way checks can only bound the aggregate.
@@ -224,7 +253,18 @@ def _backward_exact_without_relu_flips(variant, B, size, gpu_device, lazy_fp64=F
     if threads:
         torch.set_num_threads(threads)
     ref.train()
-    x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(8))
+    # The other selection in the network is the SPP's max pooling (5 / 9 / 13 windows on the last map): where a window's two largest values
+    # are a few ulp apart, two fp32 builds route that gradient to DIFFERENT pixels - the same O(1) local error as a ReLU flip.  r4n met it:
+    # YOLO-NAS-L with input seed 8 has a 5x5 window whose top two differ by 3.0e-7 of the map's scale (5 ulp); the bf16x3 convolution modes
+    # pick the other pixel, and context_module.cv1.weight is then 2.7e-2 off, everything upstream of it 5e-4 - 1e-2, everything downstream
+    # 1e-5 (profiles/r4n_*).  So this premise is certified too: the input seed is the first from 8 on whose windows all keep their top two
+    # more than 2e-6 of the map's scale apart on the reference forward (S and M: seed 8, smallest gap 4.1e-6 / 4.2e-6; L: seed 9, 1.1e-5).
+    for in_seed in range(8, 24):
+        x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(in_seed))
+        if certify or _spp_smallest_top2_gap(copy.deepcopy(ref), x) >= 2e-6:
+            break
+    else:
+        raise AssertionError("no input seed keeps the SPP's max-pool selections apart")
     if certify:
         # "+4" is not flip-free at 32 x 640^2: BatchNorm outputs are heavy-tailed and with ~1e8 elements per layer the minima reach -5 (r3f:
         # backbone.stage1 ... post_bn -4.98; the HIP and CPU paths then clip DIFFERENT elements and a whole sub-network's gradients differ by
