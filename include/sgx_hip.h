@@ -223,6 +223,12 @@ int32_t sgx_conv_get_wgrad_math(void);
 /* Measurement aid for the patch kernel: largest work item (MFLOP, 0 = default 48), filter blocks per workgroup (1..3, 0 = by padding), least
  * share of useful matrix work (filters x channels x pixels over their padded tiles, percent, 0 = default 60) for a job to take the kernel. */
 int32_t sgx_debug_set_wgrad_patch(int32_t item_mflop, int32_t kb, int32_t min_fill_pct);
+/* LDS (KB per CU, 0..120; 0 = off) the weight-gradient kernels leave free for kernels of other streams: their launches then request
+ * dynamic LDS on top of their static allocation so that fewer of their workgroups fit a CU.  The weight gradients run on a side stream
+ * under the backward pass; four of their workgroups hold 150 of a CU's 160 KB, and a data-gradient workgroup of the main stream (the
+ * step's critical path) cannot start before one of them ends.                                                                */
+int32_t sgx_conv_set_wgrad_lds_reserve(int32_t kb);
+int32_t sgx_conv_get_wgrad_lds_reserve(void);
 /* A HIP stream whose kernels are dispatched to `percent` (10..100) of the device's CUs only, evenly spread over the chip
  * (hipExtStreamCreateWithCUMask).  For the weight gradients' side stream: their long-lived workgroups otherwise take every CU and the short
  * dependent kernels of the main stream - the step's critical path - queue between them.  *stream is a hipStream_t; release it with

@@ -2562,7 +2562,7 @@ static void launch_wgrad(const WgGroupParams& g, int nblk, void* stream) {
     }
     if constexpr (BNK + BJ <= 128) {  // 32-pixel slabs (half the barriers, twice the bytes in flight per lane) where two of them fit 32 KB
         if (loop & 1) {
-            SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP_DEEP, 1>), grid, block, 0, stream, g);
+            SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP_DEEP, 1>), grid, block, wg_lds_pad(wgrad_kernel<BNK, BJ, WK, WC, WG_BKP_DEEP, 1>), stream, g);
             return;
         }
     }
@@ -2570,13 +2570,13 @@ static void launch_wgrad(const WgGroupParams& g, int nblk, void* stream) {
     // (sgx_conv_set_wgrad_math; r4a: the whole GPU suite green under it, 662 -> 686 images/s), or measurement bit 3; bit 5 forces the fp32 loop
     if constexpr (!(BNK == 64 && BJ == 64 && WK == 1)) {
         if ((loop & 8) || (g_wg_math.load(std::memory_order_relaxed) >= 1 && !(loop & 32))) {
-            SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP, 2, 1>), grid, block, 0, stream, g);
+            SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP, 2, 1>), grid, block, wg_lds_pad(wgrad_kernel<BNK, BJ, WK, WC, WG_BKP, 2, 1>), stream, g);
             return;
         }
     }
     // two register sets of loads in flight: measured r3n on YOLO-NAS-S, 14.29 -> 13.92 ms of weight-gradient time alone, +0.6 % on the step
-    if (loop & 2) SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP, 1>), grid, block, 0, stream, g);
-    else SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP, 2>), grid, block, 0, stream, g);
+    if (loop & 2) SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP, 1>), grid, block, wg_lds_pad(wgrad_kernel<BNK, BJ, WK, WC, WG_BKP, 1>), stream, g);
+    else SGX_LAUNCH((wgrad_kernel<BNK, BJ, WK, WC, WG_BKP, 2>), grid, block, wg_lds_pad(wgrad_kernel<BNK, BJ, WK, WC, WG_BKP, 2>), stream, g);
 }
 extern "C" int32_t sgx_conv2d_bwd_weight_group(const sgx_wgrad_job* jobs, int32_t njobs, void* ws, int64_t ws_bytes, int32_t* tickets,
                                                int64_t ticket_ints, void* stream) {
@@ -2785,6 +2785,12 @@ extern "C" int32_t sgx_convT2x2_bwd_weight(int32_t N, int32_t H, int32_t W, int3
 // BatchNorm-backward sweeps run 7x longer while a weight-gradient kernel is resident, 6.8 ms per step over all main-stream kernels
 // (profiles/r4t_*).  A stream created here dispatches to `cus` of the device's CUs only (spread evenly: every `keep`-th ... CU index is
 // left out), so the rest of the chip always has room for the main stream.
+extern "C" int32_t sgx_conv_set_wgrad_lds_reserve(int32_t kb) {
+    SGX_CHECK_ARG(kb >= 0 && kb <= 120, "wgrad LDS reserve: 0..120 KB");
+    g_wg_lds_reserve = kb * 1024;
+    return SGX_OK;
+}
+extern "C" int32_t sgx_conv_get_wgrad_lds_reserve(void) { return g_wg_lds_reserve.load() / 1024; }
 extern "C" int32_t sgx_stream_create_partial(int32_t percent, void** stream) {
     SGX_CHECK_ARG(stream && percent >= 10 && percent <= 100, "stream_create_partial: percent of the CUs in 10..100");
 #ifdef SGX_EMU

@@ -37,3 +37,38 @@ struct WpPlan {
 bool wpatch_plan_job(const sgx_conv_desc* d, WpPlan& pl, int kb_override, int min_fill_pct);
 void wpatch_plan_split(const sgx_conv_desc* d, WpPlan& pl, double item_flops, long* part_floats, long* ticket_ints);
 int32_t wpatch_launch(int stride, const WpPlan& form, const WpGroupParams& g, int nblk, void* stream);
+
+// ---- LDS the weight-gradient kernels leave to the other streams ------------------------------------------------------------------------
+// The weight gradients run on a side stream underneath the dependent kernels of the backward pass.  Their workgroups live for hundreds of
+// microseconds and, four to a CU, hold 150 of its 160 KB of LDS: a data-gradient workgroup of the main stream (21 - 78 KB) then waits for
+// one of them to END before it can start at all (r4t: 77 us kernels taking 500 - 700 us; 6.8 ms per step over the main stream).  With a
+// reserve set (sgx_conv_set_wgrad_lds_reserve), the weight-gradient launches ask for enough dynamic LDS on top of their static
+// allocation that one workgroup fewer fits a CU and at least the reserve stays free.
+#include <atomic>
+inline std::atomic<int> g_wg_lds_reserve{0};  // bytes
+template <typename KernelFn>
+static unsigned wg_lds_pad(KernelFn kernel) {
+#ifdef SGX_EMU
+    (void)kernel;
+    return 0;
+#else
+    const long reserve = g_wg_lds_reserve.load(std::memory_order_relaxed);
+    if (reserve <= 0) return 0;
+    static std::atomic<long> static_lds{-1};  // per kernel instantiation
+    long s = static_lds.load(std::memory_order_relaxed);
+    if (s < 0) {
+        hipFuncAttributes a;
+        s = hipFuncGetAttributes(&a, (const void*)kernel) == hipSuccess ? (long)a.sharedSizeBytes : 0;
+        static_lds.store(s, std::memory_order_relaxed);
+    }
+    if (s <= 0) return 0;
+    const long cu = 160 * 1024;
+    const long now = cu / s;
+    long want = (cu - reserve) / s;
+    if (want < 1) want = 1;
+    if (want >= now) return 0;
+    long per = cu / (want + 1) + 2048;  // one more workgroup than `want` must not fit
+    if (per * want > cu) per = cu / want;
+    return per > s ? (unsigned)(per - s) : 0u;
+#endif
+}

@@ -378,7 +378,7 @@ void wpatch_plan_split(const sgx_conv_desc* d, WpPlan& pl, double item_flops, lo
 
 template <int S, int PC, int KB>
 static void wpatch_launch_t(const WpGroupParams& g, int nblk, void* stream) {
-    SGX_LAUNCH((wpatch_kernel<S, PC, KB, S == 1 ? 4 : 2>), dim3((unsigned)nblk), dim3(192 * KB), 0, stream, g);
+    SGX_LAUNCH((wpatch_kernel<S, PC, KB, S == 1 ? 4 : 2>), dim3((unsigned)nblk), dim3(192 * KB), wg_lds_pad(wpatch_kernel<S, PC, KB, S == 1 ? 4 : 2>), stream, g);
 }
 template <int S, int KB>
 static void wpatch_launch_pc(int pc, const WpGroupParams& g, int nblk, void* stream) {

@@ -131,15 +131,15 @@ def _train_step_parity(variant, B, size, device, tol, static=False):
     if os.environ.get("SGX_TEST_DUMP"):
         with open(os.environ["SGX_TEST_DUMP"], "a") as f:
             f.write(f"backward B {variant} B={B} {size}: hip {l2_h:.3e} cpu fp32 {l2_c:.3e} ratio {l2_h / max(l2_c, 1e-30):.2f}\n")
-    # measured: S 0.61, M 0.80 - 0.97, L 2.96 (fp32 conv arithmetic, r3) / 2.97 - 3.04 (bf16x3 patch kernels, r3 / r4) - the same figure
-    # under every weight-gradient grouping / prefetch setting (the arithmetic is deterministic).  This aggregate is the ILL-conditioned one
-    # (round-off amplified 1e3 - 1e4x on both fp32 paths, see the docstring): on the well-conditioned upstream of backward A the same L
-    # network is at 0.96x the CPU path's distance (r4i: 3.07e-2 vs 3.20e-2) and EVERY L gradient passes the element-wise 1e-4 check of
-    # test_yolo_nas_l_backward_exact_without_relu_flips.  L at 1 x 256^2 ends in 8 x 8 maps (64 values per BatchNorm channel); forming
-    # those statistics in double like ATen was tried and changes nothing (r4i: 3.04 with, 2.97 without -
-    # profiles/r4i_parity_exact_small_map_statistics.txt), so the factor is the two paths' different summation orders under that
-    # amplification, not a statistic.  The bar is the measured 3.0 plus margin, for every arithmetic mode: 3.5x.
-    assert l2_h <= max(10 * tol, 3.5 * l2_c), f"loss-gradient L2 error vs fp64: hip {l2_h:.2e}, cpu fp32 {l2_c:.2e}"
+    # measured under the default conv arithmetic of round 4 (bf16x3 per problem, "patch_bf3"; r4o): S 0.51 - 0.57, M 0.74, L 0.20 - the HIP
+    # path is CLOSER to fp64 than ATen's CPU fp32 path on every model (single convolutions: 3-4x, profiles/r4n_conv_arithmetic_error_probe.txt),
+    # and the bar is the 2x of every other three-way check.  Under the fp32-pipe modes ("fp32", "patch": sequential fp32 MFMA chains) the
+    # same aggregate measured S 0.61, M 0.80 - 0.97, L 2.96 - 3.04 (r3 / r4i; this aggregate is the ILL-conditioned one, round-off amplified
+    # 1e3 - 1e4x on both fp32 paths - see the docstring): those measurement modes keep the 3.5x of round 3.
+    from super_gradients_amd import kernels as K_
+
+    ratio_bar = 3.5 if K_.get_conv_math() in ("fp32", "patch") else 2.0
+    assert l2_h <= max(10 * tol, ratio_bar * l2_c), f"loss-gradient L2 error vs fp64: hip {l2_h:.2e}, cpu fp32 {l2_c:.2e}"
     for n in [k for k, _ in net.named_parameters() if ".rbr_reparam." in k]:
         assert ref_params[n].grad is None
 

@@ -27,7 +27,16 @@ def record_problems(model, batch, size, dev):
     from util import synthetic_targets
 
     torch.manual_seed(0)
-    net = models.get(f"yolo_nas_{model}", num_classes=80).materialize(dev).train()
+    # (weight gradients one call per layer for the recording: the grouped launches of the product go through conv2d_bwd_weight_group)
+    group_env = os.environ.get("SGX_WGRAD_GROUP_GFLOP")
+    os.environ["SGX_WGRAD_GROUP_GFLOP"] = "0"
+    try:
+        net = models.get(f"yolo_nas_{model}", num_classes=80).materialize(dev).train()
+    finally:
+        if group_env is None:
+            del os.environ["SGX_WGRAD_GROUP_GFLOP"]
+        else:
+            os.environ["SGX_WGRAD_GROUP_GFLOP"] = group_env
     x = torch.rand(batch, 3, size, size, device=dev)
     t = synthetic_targets(batch, seed=0, kmax=20, size=size).to(dev)
     crit = PPYoloELoss(80, use_static_assigner=False)
@@ -61,14 +70,15 @@ def record_problems(model, batch, size, dev):
         rec[k] = rec.get(k, 0) + 1
         return r
 
-    def dgrad2(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, out=None, accumulate=False, addend2=None, addend2_scale=None):
-        o = orig[4](dy, w, wt, ds, w1pt, x_shape, stride=stride, addend=addend, out=out, accumulate=accumulate, addend2=addend2, addend2_scale=addend2_scale)
+    def dgrad2(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, out=None, accumulate=False, addend2=None, addend2_scale=None, reqs=None):
+        o = orig[4](dy, w, wt, ds, w1pt, x_shape, stride=stride, addend=addend, out=out, accumulate=accumulate, addend2=addend2, addend2_scale=addend2_scale,
+                    reqs=reqs)
         k = key_of("dgrad2", x_shape, w.shape[0], w.shape[2], stride, w.shape[2] // 2, o.stride(2), dy.stride(2), (addend is not None, bool(accumulate)))
         rec[k] = rec.get(k, 0) + 1
         return o
 
-    def dgrad_wt(dy, w, wt, x_shape, stride=1, pad=0, addend=None, out=None, accumulate=False):
-        o = orig[5](dy, w, wt, x_shape, stride=stride, pad=pad, addend=addend, out=out, accumulate=accumulate)
+    def dgrad_wt(dy, w, wt, x_shape, stride=1, pad=0, addend=None, out=None, accumulate=False, reqs=None):
+        o = orig[5](dy, w, wt, x_shape, stride=stride, pad=pad, addend=addend, out=out, accumulate=accumulate, reqs=reqs)
         k = key_of("dgrad", x_shape, w.shape[0], w.shape[2], stride, pad, o.stride(2), dy.stride(2), (addend is not None, bool(accumulate)))
         rec[k] = rec.get(k, 0) + 1
         return o

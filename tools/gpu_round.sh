@@ -69,7 +69,7 @@ if has nms; then
   find "$OUT" -name "*.csv" -size +8M -delete
 fi
 if has tests; then
-  timeout 600 python -m pytest tests -m gpu -x -q --durations=15 > "$OUT/pytest_gpu.log" 2>&1
+  SGX_TEST_DUMP="$OUT/test_dump.txt" timeout 900 python -m pytest tests -m gpu -q --durations=15 > "$OUT/pytest_gpu.log" 2>&1
   echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
   tail -5 "$OUT/pytest_gpu.log"
 fi

@@ -8,8 +8,9 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-nms --no-predict ${BENCH_ARGS:-}"
 for rep in 1 2; do
 for cfg in "$@"; do
-  timeout 120 env $cfg $B > "$OUT/bench_${cfg// /_}_$rep.json" 2> "$OUT/bench_${cfg// /_}_$rep.err"
-  python - "$OUT/bench_${cfg// /_}_$rep.json" "$cfg" <<'PY'
+  name=$(echo "$cfg" | tr ' /' '__' | tail -c 60)
+  timeout 120 env $cfg $B > "$OUT/bench_${name}_$rep.json" 2> "$OUT/bench_${name}_$rep.err"
+  python - "$OUT/bench_${name}_$rep.json" "$cfg" <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d["roofline"]
