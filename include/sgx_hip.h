@@ -223,6 +223,9 @@ int32_t sgx_conv_get_wgrad_math(void);
 /* Measurement aid for the patch kernel: largest work item (MFLOP, 0 = default 48), filter blocks per workgroup (1..3, 0 = by padding), least
  * share of useful matrix work (filters x channels x pixels over their padded tiles, percent, 0 = default 60) for a job to take the kernel. */
 int32_t sgx_debug_set_wgrad_patch(int32_t item_mflop, int32_t kb, int32_t min_fill_pct);
+/* Measurement aid: the reduction depth (taps x channels) from which conv math modes 2 / 4 / 5 run a problem in bf16x3 arithmetic
+ * (0 = the default, 192).                                                                                                      */
+int32_t sgx_debug_set_bf3_min_depth(int32_t depth);
 /* LDS (KB per CU, 0..120; 0 = off) the weight-gradient kernels leave free for kernels of other streams: their launches then request
  * dynamic LDS on top of their static allocation so that fewer of their workgroups fit a CU.  The weight gradients run on a side stream
  * under the backward pass; four of their workgroups hold 150 of a CU's 160 KB, and a data-gradient workgroup of the main stream (the

@@ -1297,12 +1297,18 @@ extern "C" int32_t sgx_conv_get_math(void) { return g_conv_math; }
 // is deep enough to be matrix-pipe bound.  Measured on all YOLO-NAS-S problems (profiles/r1y_conv_bench_bf16x3.txt vs r1n): bf16x3
 // wins from a depth (taps x channels) of ~192 (1.2-1.3x on the 3x3 layers), loses 5-30 % on shallow 1x1 layers.
 #define SGX_BF3_MIN_DEPTH 192
+static std::atomic<int> g_bf3_min_depth{SGX_BF3_MIN_DEPTH};
+extern "C" int32_t sgx_debug_set_bf3_min_depth(int32_t depth) {  // measurement: 0 = the default
+    SGX_CHECK_ARG(depth >= 0, "bf3_min_depth: negative");
+    g_bf3_min_depth = depth > 0 ? depth : SGX_BF3_MIN_DEPTH;
+    return SGX_OK;
+}
 static int conv_math_for(int taps, int C) {
     const int m = g_conv_math.load(std::memory_order_relaxed);
     if (m == 3) return 0;  // the patch kernel takes the 3x3 stride-1 problems (pconv_ok), everything else stays on the fp32 pipe
     // mode 4 (measurement; r4a: +0.5 %): the patch kernel on its problems AND the per-problem rule of mode 2 for the rest
     // mode 5 (round 4): mode 4, and the two-source / two-output (QARepVGG) launches follow the same rule
-    return (m == 2 || m == 4 || m == 5) ? ((long)taps * C >= SGX_BF3_MIN_DEPTH ? 1 : 0) : m;
+    return (m == 2 || m == 4 || m == 5) ? ((long)taps * C >= g_bf3_min_depth.load(std::memory_order_relaxed) ? 1 : 0) : m;
 }
 // Mode 3: 3x3, stride 1, pad 1, channel counts in 16s -> pconv_kernel (bf16x3 from an LDS-resident patch).  Decidable from the descriptor,
 // so that the forward statistics rows (one per 8 x 16 pixel tile and image) are known before the launch.

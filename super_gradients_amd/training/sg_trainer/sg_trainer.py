@@ -24,7 +24,7 @@ from ...common.registry import LOSSES, LR_SCHEDULERS_CLS_DICT, LR_WARMUP_CLS_DIC
 from ...modules.engine import SgxNetwork
 from ..utils import distributed_training_utils as dtu
 from ..utils.callbacks import Callback, CallbackHandler, LRCallbackBase, PhaseContext
-from ..utils.checkpoint_utils import read_checkpoint
+from ..utils.checkpoint_utils import plain_number, read_checkpoint
 from ..utils.ema import ModelEMA
 from ..utils.optimizers import build_optimizer
 from ..utils.utils import HpmStruct
@@ -497,11 +497,11 @@ class Trainer:
             for name in ("exp_avg", "exp_avg_sq", "momentum_buffer"):
                 if name in st and hasattr(self.optimizer, name):
                     getattr(self.optimizer, name).copy_(st[name])
-            self.optimizer._steps = st.get("steps", 0)
+            self.optimizer._steps = plain_number(st, "steps", int, 0)
             for g, s in zip(self.optimizer.param_groups, st["param_groups"]):
                 g.update({k: v for k, v in s.items() if k in ("lr",)})
-        self.best_metric = ckpt.get("acc")
-        return int(ckpt["epoch"]) + 1
+        self.best_metric = plain_number(ckpt, "acc", float)
+        return plain_number(ckpt, "epoch", int, -1) + 1
 
     # ------------------------------------------------------------------------------------------------ recipe entry
     @classmethod

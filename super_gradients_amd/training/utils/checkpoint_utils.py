@@ -30,17 +30,19 @@ _ALLOWED = {
     ("collections", "OrderedDict"), ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"),
     ("torch", "Size"), ("torch", "device"), ("torch._tensor", "_rebuild_from_type_v2"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
 }
-_ALLOWED_PREFIX = (("torch", "Storage"), ("torch", "dtype"))
+# torch's typed storage classes and dtypes by NAME (protocol 4 resolves a dotted name by attribute traversal - "nn.Module.load_state_dict"
+# under "torch" would be reachable through any suffix rule - so: exact names only, and a '.' in a name is never admitted)
+_TORCH_STORAGES = {n for n in ("UntypedStorage", "TypedStorage", "DoubleStorage", "FloatStorage", "HalfStorage", "BFloat16Storage", "LongStorage",
+                               "IntStorage", "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "ComplexFloatStorage", "ComplexDoubleStorage")
+                   if hasattr(torch, n)}
+_TORCH_DTYPES = {n for n in dir(torch) if isinstance(getattr(torch, n), torch.dtype)}
 
 
 class _InertUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        if (module, name) in _ALLOWED or (module == "torch" and (name.endswith("Storage") or name in _TORCH_DTYPES)):
+        if "." not in name and ((module, name) in _ALLOWED or (module == "torch" and (name in _TORCH_STORAGES or name in _TORCH_DTYPES))):
             return super().find_class(module, name)
-        return type(name, (OpaqueObject,), {"pickled_name": f"{module}.{name}"})
-
-
-_TORCH_DTYPES = {n for n in dir(torch) if isinstance(getattr(torch, n), torch.dtype)}
+        return type(name.rsplit(".", 1)[-1], (OpaqueObject,), {"pickled_name": f"{module}.{name}"})
 
 
 class _InertPickle:
@@ -61,6 +63,20 @@ def contains_opaque(obj, _depth=0) -> bool:
     if isinstance(obj, (list, tuple)):
         return any(contains_opaque(v, _depth + 1) for v in obj)
     return False
+
+
+def plain_number(ckpt, key, kind=float, default=None):
+    """ckpt[key] as a Python number.  A field the reading above turned into a placeholder (a numpy scalar pickled by the reference's Trainer,
+    say) is refused HERE, by name - not as a TypeError somewhere inside int() later."""
+    if key not in ckpt or ckpt[key] is None:
+        return default
+    v = ckpt[key]
+    if contains_opaque(v):
+        raise ValueError(f"checkpoint field {key!r} is a pickled object ({v!r}), not a number: this package does not construct objects from "
+                         "checkpoint files - re-save the field as a plain int / float")
+    if isinstance(v, torch.Tensor):
+        v = v.item()
+    return kind(v)
 
 
 def read_checkpoint(path):

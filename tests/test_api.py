@@ -292,3 +292,41 @@ def test_checkpoint_with_pickled_objects_loads_weights_without_constructing_them
         warnings.simplefilter("always")
         read_checkpoint(path)
     assert not w
+
+
+def test_inert_unpickler_admits_exact_names_only(tmp_path):
+    """the second reading of a checkpoint admitted any ("torch", name) ending in "Storage", and protocol 4 resolves dotted names by
+    attribute traversal.  Exact storage / dtype names only, never a dotted name; and a scalar field that arrives as a placeholder (the
+    reference's Trainer may pickle numpy scalars for epoch / metrics) is refused by name, not as a TypeError inside int()."""
+    import io
+    import pickle
+
+    import numpy as np
+    import pytest as _pytest
+    import torch
+
+    from super_gradients_amd.training.utils.checkpoint_utils import OpaqueObject, _InertUnpickler, plain_number, read_checkpoint
+
+    def resolve(module, name):
+        return _InertUnpickler(io.BytesIO(b"")).find_class(module, name)
+
+    assert resolve("torch", "FloatStorage") is torch.FloatStorage and resolve("torch", "float32") is torch.float32
+    for module, name in (("torch", "nn.Module.load_state_dict"), ("torch", "serialization.load.EvilStorage"), ("torch", "MadeUpStorage"),
+                         ("os", "system"), ("torch", "hub.load")):
+        cls = resolve(module, name)
+        assert isinstance(cls, type) and issubclass(cls, OpaqueObject) and cls.pickled_name == f"{module}.{name}"
+    # a numpy scalar where a number is expected: weights_only refuses the file, the inert reading makes it a placeholder, the field is refused by name
+    path = str(tmp_path / "np_scalar.pth")
+    torch.save({"net": {}, "epoch": np.int64(7), "acc": 0.5}, path, pickle_protocol=pickle.DEFAULT_PROTOCOL)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ckpt = read_checkpoint(path)
+    if isinstance(ckpt["epoch"], OpaqueObject) or not isinstance(ckpt["epoch"], (int, np.integer)):
+        with _pytest.raises(ValueError, match="epoch"):
+            plain_number(ckpt, "epoch", int)
+    else:  # (a torch that admits numpy scalars under weights_only=True)
+        assert plain_number(ckpt, "epoch", int) == 7
+    assert plain_number(ckpt, "acc", float) == 0.5 and plain_number(ckpt, "missing", int, -1) == -1
+    assert plain_number({"steps": torch.tensor(4)}, "steps", int) == 4
