@@ -2,6 +2,7 @@
 // global average pool.  One thread owns a float4 channel group of one output pixel.
 // Reference call sites: include/sgx_hip.h (Pooling section).
 #include "sgx_common.h"
+#include <atomic>
 
 __global__ void maxpool_fwd_kernel(int N, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, const float* x, long x_ld_pix,
                                    long x_ld_img, float* y, long y_ld_pix, long y_ld_img, int* argmax) {
@@ -60,33 +61,45 @@ __global__ __launch_bounds__(256) void maxpool_fwd_tile_kernel(int H, int W, int
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < H * Wo * MP_CG; i += blockDim.x) {
-        const int c = i % MP_CG, t = i / MP_CG, wo = t % Wo, hi = t / Wo;
-        float m = -INFINITY;
-        int q = -1;
+    // (a lane owns FOUR channels: 16-byte LDS reads and 16-byte stores - as one channel per lane the kernel took 52 / 67 / 82 us for k = 5 / 9 /
+    // 13 on the 32 x 20 x 20 x 384 map, r4w, bound by its instruction count and its 4-byte stores)
+    for (int i = threadIdx.x; i < H * Wo * (MP_CG / 4); i += blockDim.x) {
+        const int c4 = (i % (MP_CG / 4)) * 4, t = i / (MP_CG / 4), wo = t % Wo, hi = t / Wo;
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int q[4] = {-1, -1, -1, -1};
         for (int j = 0; j < k; ++j) {
             const int wi = wo - pad + j;
             if (wi < 0 || wi >= W) continue;
-            const float v = s_x[(hi * W + wi) * MP_CG + c];
-            if (v > m || q < 0) { m = v; q = wi; }
+            const float4 v4 = sgx_ld4(s_x + (hi * W + wi) * MP_CG + c4);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int z = 0; z < 4; ++z)
+                if (v[z] > m[z] || q[z] < 0) { m[z] = v[z]; q[z] = wi; }
         }
-        s_v[i] = m;
-        s_q[i] = (unsigned short)q;
+        sgx_st4(s_v + t * MP_CG + c4, make_float4(m[0], m[1], m[2], m[3]));
+        unsigned short* sq = s_q + t * MP_CG + c4;
+        sq[0] = (unsigned short)q[0]; sq[1] = (unsigned short)q[1]; sq[2] = (unsigned short)q[2]; sq[3] = (unsigned short)q[3];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < Ho * Wo * MP_CG; i += blockDim.x) {
-        const int c = i % MP_CG, o = i / MP_CG, wo = o % Wo, ho = o / Wo;
-        float m = -INFINITY;
-        int idx = -1;
+    for (int i = threadIdx.x; i < Ho * Wo * (MP_CG / 4); i += blockDim.x) {
+        const int c4 = (i % (MP_CG / 4)) * 4, o = i / (MP_CG / 4), wo = o % Wo, ho = o / Wo;
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int idx[4] = {-1, -1, -1, -1};
         for (int r = 0; r < k; ++r) {
             const int hi = ho - pad + r;
             if (hi < 0 || hi >= H) continue;
-            const int e = (hi * Wo + wo) * MP_CG + c;
-            const float v = s_v[e];
-            if (v > m || idx < 0) { m = v; idx = hi * W + (int)s_q[e]; }
+            const int e = (hi * Wo + wo) * MP_CG + c4;
+            const float4 v4 = sgx_ld4(s_v + e);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int z = 0; z < 4; ++z)
+                if (v[z] > m[z] || idx[z] < 0) { m[z] = v[z]; idx[z] = hi * W + (int)s_q[e + z]; }
         }
-        y[(long)img * y_ld_img + (long)o * y_ld_pix + c0 + c] = m;
-        if (argmax) argmax[((long)img * Ho * Wo + o) * C + c0 + c] = idx;
+        sgx_st4(y + (long)img * y_ld_img + (long)o * y_ld_pix + c0 + c4, make_float4(m[0], m[1], m[2], m[3]));
+        if (argmax) {
+            int* am = argmax + ((long)img * Ho * Wo + o) * C + c0 + c4;
+            am[0] = idx[0]; am[1] = idx[1]; am[2] = idx[2]; am[3] = idx[3];
+        }
     }
 }
 
@@ -188,11 +201,73 @@ __global__ __launch_bounds__(256) void maxpool_bwd_tile_kernel(int H, int W, int
     }
 }
 
+// The gather forms above cost k x k window tests per input element whatever they read from (r4z: the LDS form 198 us per call against the
+// direct kernel's 226 - 1.35 G tests per step for the SPP's 5 / 9 / 13 pools, bound by their ~5 vector instructions each).  The scatter form
+// costs ONE add per OUTPUT element: a wave owns 64 channels of one image, lane = channel, keeps that (image, channels) slice of dx in LDS
+// (H x W x 64 floats: 100 KB for the 20 x 20 map) and walks the outputs in ascending order - every lane adds its gradient at its arg-max
+// pixel.  Lanes never share an address (different channels) and a lane's additions happen in output order: the sums are deterministic and in
+// the order of ATen's CPU kernel.  Eight outputs of loads in flight per lane; no atomics.
+#define MP_SCATTER_CH 64
+#define MP_SCATTER_THREADS 256
+#define MP_SCATTER_MAX_LDS (152 * 1024)
+__global__ __launch_bounds__(MP_SCATTER_THREADS) void maxpool_bwd_scatter_kernel(int HW, int C, int HoWo, const int* argmax, const float* dy, long dy_ld_pix,
+                                                                                 long dy_ld_img, float* dx, long dx_ld_pix, long dx_ld_img, int accumulate) {
+    SGX_DYN_SMEM(float, tile);  // [HW][MP_SCATTER_CH]
+    const int groups = C / MP_SCATTER_CH, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int img = blockIdx.x / groups, c = (blockIdx.x % groups) * MP_SCATTER_CH + lane;
+    float* const gx = dx + (long)img * dx_ld_img + c;
+    // the slice's starting value: all four waves, eight pixels of loads in flight per lane (a lane's scatter below is a chain of ~1 us memory
+    // round trips as it is: r4v measured 372 us per call with one wave doing everything, eight outputs at a time)
+    for (int p0 = wave * 8; p0 < HW; p0 += 8 * (MP_SCATTER_THREADS / 64)) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (accumulate && p0 + u < HW) ? gx[(long)(p0 + u) * dx_ld_pix] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (p0 + u < HW) tile[(p0 + u) * MP_SCATTER_CH + lane] = v[u];
+    }
+    __syncthreads();
+    if (wave == 0) {  // ONE wave adds, in output order
+        const int* const a = argmax + (long)img * HoWo * C + c;
+        const float* const g = dy + (long)img * dy_ld_img + c;
+        int o = 0;
+        for (; o + 32 <= HoWo; o += 32) {
+            int ix[32];
+            float d[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                ix[u] = a[(long)(o + u) * C];
+                d[u] = g[(long)(o + u) * dy_ld_pix];
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) tile[ix[u] * MP_SCATTER_CH + lane] += d[u];
+        }
+        for (; o < HoWo; ++o) tile[a[(long)o * C] * MP_SCATTER_CH + lane] += g[(long)o * dy_ld_pix];
+    }
+    __syncthreads();
+    for (int p = wave; p < HW; p += MP_SCATTER_THREADS / 64) gx[(long)p * dx_ld_pix] = tile[p * MP_SCATTER_CH + lane];
+}
+
 extern "C" int32_t sgx_maxpool_bwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad, const int32_t* argmax,
                                    const float* dy, int64_t dy_ld_pix, int64_t dy_ld_img, float* dx, int64_t dx_ld_pix, int64_t dx_ld_img,
                                    int32_t accumulate, void* stream) {
     SGX_CHECK_ARG(argmax && dy && dx && C % 4 == 0, "maxpool_bwd: bad args");
     int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    if (C % MP_SCATTER_CH == 0 && Ho > 0 && Wo > 0 && (long)H * W * MP_SCATTER_CH * 4 <= MP_SCATTER_MAX_LDS) {
+        const unsigned lds = (unsigned)((long)H * W * MP_SCATTER_CH * 4);
+#ifndef SGX_EMU
+        static std::atomic<bool> raised{false};  // dynamic LDS beyond 64 KB is opt-in per function
+        if (!raised.load(std::memory_order_acquire)) {
+            if (hipFuncSetAttribute((const void*)maxpool_bwd_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MP_SCATTER_MAX_LDS) != hipSuccess)
+                SGX_FAIL(SGX_ERR_HIP, "maxpool_bwd: cannot raise the scatter kernel's dynamic LDS limit");
+            raised.store(true, std::memory_order_release);
+        }
+#endif
+        SGX_LAUNCH(maxpool_bwd_scatter_kernel, dim3((unsigned)(N * (C / MP_SCATTER_CH))), dim3(MP_SCATTER_THREADS), lds, stream, H * W, C, Ho * Wo, argmax, dy,
+                   (long)dy_ld_pix, (long)dy_ld_img, dx, (long)dx_ld_pix, (long)dx_ld_img, accumulate);
+        SGX_CHECK_LAUNCH("maxpool_bwd (scatter)");
+        return SGX_OK;
+    }
     if (stride == 1 && C % MP_CG == 0 && Ho > 0 && Wo > 0 && (long)H * W < 65536 && (long)Ho * Wo * MP_CG * 6 <= MP_TILE_MAX_LDS && k > 2) {
         SGX_LAUNCH(maxpool_bwd_tile_kernel, dim3((unsigned)(N * (C / MP_CG))), dim3(256), (unsigned)((long)Ho * Wo * MP_CG * 6), stream, H, W, C, k, pad, Ho, Wo,
                    argmax, dy, (long)dy_ld_pix, (long)dy_ld_img, dx, (long)dx_ld_pix, (long)dx_ld_img, accumulate);

@@ -273,17 +273,25 @@ def test_affine_residuals_and_sweeps(backend):
 
 @pytest.mark.parametrize("k,stride,pad", [(5, 1, 2), (9, 1, 4), (13, 1, 6), (3, 2, 1)])
 def test_maxpool(backend, k, stride, pad):
-    n, h, w, c = _sizes(backend, (2, 20, 20, 384), (1, 7, 6, 8))
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(n, c, h, w, generator=g).round(decimals=1).requires_grad_(True)  # ties on purpose
-    y = F.max_pool2d(x, k, stride, pad)
-    dy = torch.randn(y.shape, generator=g)
-    y.backward(dy)
-    xd = to_nhwc(x.detach(), backend)
-    yd, am = K.maxpool_fwd(xd, k, stride, pad)
-    assert torch.equal(to_nchw_cpu(yd), y.detach())
-    dx = K.maxpool_bwd(to_nhwc(dy, backend), am, tuple(xd.shape), k, stride, pad)
-    assert_close(to_nchw_cpu(dx), x.grad, TOL, "maxpool bwd")
+    """Forward values and arg-max routing against ATen (ties on purpose: the first maximum in row-major window order wins), through every
+    kernel form: the direct kernels (C = 8 at stride 2; large maps), the LDS-tile forms (stride 1, 8-channel groups) and the scatter-form
+    backward (64-channel groups of a map whose gradient slice fits LDS), plain and accumulating."""
+    shapes = [(2, 20, 20, 384), (2, 56, 56, 64)] if backend.type == "cuda" else [(1, 7, 6, 8), (1, 6, 5, 64)]
+    for n, h, w, c in shapes:
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(n, c, h, w, generator=g).round(decimals=1).requires_grad_(True)  # ties on purpose
+        y = F.max_pool2d(x, k, stride, pad)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        xd = to_nhwc(x.detach(), backend)
+        yd, am = K.maxpool_fwd(xd, k, stride, pad)
+        assert torch.equal(to_nchw_cpu(yd), y.detach())
+        dx = K.maxpool_bwd(to_nhwc(dy, backend), am, tuple(xd.shape), k, stride, pad)
+        assert_close(to_nchw_cpu(dx), x.grad, TOL, f"maxpool bwd {(n, h, w, c)}")
+        base = torch.randn(n, c, h, w, generator=g)
+        acc = to_nhwc(base, backend)
+        K.maxpool_bwd(to_nhwc(dy, backend), am, tuple(xd.shape), k, stride, pad, out=acc, accumulate=True)
+        assert_close(to_nchw_cpu(acc), base + x.grad, TOL, f"maxpool bwd accumulate {(n, h, w, c)}")
 
 
 def test_avgpool(backend):
