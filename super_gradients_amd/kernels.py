@@ -947,7 +947,8 @@ def ema_update(ema, p, decay):
 
 # --------------------------------------------------------------------------------------------- conv arithmetic
 CONV_MATH = {"fp32": 0, "bf16x3": 1, "auto": 2, "patch": 3, "patch_auto": 4, "patch_bf3": 5}
-DEFAULT_CONV_MATH = "patch"  # what the library starts with (csrc/conv.hip g_conv_math): fp32 matrix pipe + the patch kernel on its problems
+DEFAULT_CONV_MATH = "patch_bf3"  # what the library starts with (csrc/conv.hip g_conv_math): the patch kernel on its problems + bf16x3 per problem elsewhere
+DEFAULT_WGRAD_MATH = "patch"  # (csrc/conv.hip g_wg_math): bf16x3 slab loop + the weight-gradient patch kernel
 
 
 def set_conv_math(mode: str):

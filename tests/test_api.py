@@ -25,6 +25,28 @@ def test_header_symbols_are_exported_and_bound():
     assert cdll.sgx_version() >= 1
 
 
+def test_default_arithmetic_constants_match_the_library():
+    """kernels.DEFAULT_CONV_MATH / DEFAULT_WGRAD_MATH are what the tests restore after switching arithmetic: they must be the modes the
+    library STARTS in (round 4: a stale constant left every whole-model test of a full-suite run in the previous round's mode after the first
+    kernel test had "restored" it).  Read from a fresh process: no test of this session can have switched anything there."""
+    import subprocess
+    import sys
+
+    from super_gradients_amd import _lib
+    from super_gradients_amd import kernels as K
+
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libsgx_hip.so not built")
+    code = ("import ctypes, sys; l = ctypes.CDLL(sys.argv[1]); l.sgx_conv_get_math.restype = ctypes.c_int32; l.sgx_conv_get_wgrad_math.restype = ctypes.c_int32; "
+            "print(l.sgx_conv_get_math(), l.sgx_conv_get_wgrad_math())")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SGX_")}
+    out = subprocess.run([sys.executable, "-c", code, _lib.LIB_PATH], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    conv, wgrad = (int(v) for v in out.stdout.split())
+    assert K.CONV_MATH[K.DEFAULT_CONV_MATH] == conv, f"library starts in conv math {conv}, kernels.DEFAULT_CONV_MATH = {K.DEFAULT_CONV_MATH!r}"
+    assert _lib.WGRAD_MATH[K.DEFAULT_WGRAD_MATH] == wgrad, f"library starts in weight-gradient math {wgrad}, kernels.DEFAULT_WGRAD_MATH = {K.DEFAULT_WGRAD_MATH!r}"
+
+
 def test_no_cpu_fallback():
     from super_gradients_amd import _lib
     from super_gradients_amd import kernels as K
