@@ -77,6 +77,20 @@ def pmc(d):
         for c in names:
             tot[c] += v.get(c, 0.0)
     print(f"{'TOTAL':<92} {sum(len(s) for s in calls.values()):>7} {sum(dur.values()) / 1e6:>9.3f} " + " ".join(f"{tot[c]:>22.1f}" for c in names))
+    if "GRBM_GUI_ACTIVE" in names and "SQ_VALU_MFMA_BUSY_CYCLES" in names:
+        # ratios per kernel: GRBM_GUI_ACTIVE is summed over the 8 XCDs -> cycles of kernel time = GUI / 8; the SQ counters are summed over the
+        # chip: 256 CUs (SQ_BUSY_CU_CYCLES, SQ_LDS_IDX_ACTIVE) x 4 SIMDs (SQ_VALU_MFMA_BUSY_CYCLES)
+        print()
+        print("# per-kernel ratios (the kernels of this pass, 10 largest by time): matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs); "
+              "LDS busy = SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs); CU busy = SQ_BUSY_CU_CYCLES / (cycles x 256); cycles = GRBM_GUI_ACTIVE / 8")
+        print(f"{'kernel':<92} {'calls':>7} {'dur_ms':>9} {'clock_GHz':>10} {'mfma_busy':>10} {'lds_busy':>9} {'cu_busy':>8} {'lds_conflict':>13}")
+        for n, v in sorted(acc.items(), key=lambda kv: -dur[kv[0]])[:14]:
+            cyc = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            if cyc <= 0 or dur[n] <= 0:
+                continue
+            print(f"{n:<92} {len(calls[n]):>7} {dur[n] / 1e6:>9.3f} {cyc / dur[n]:>10.3f} {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (cyc * 1024):>10.3f} "
+                  f"{v.get('SQ_LDS_IDX_ACTIVE', 0.0) / (cyc * 256):>9.3f} {v.get('SQ_BUSY_CU_CYCLES', 0.0) / (cyc * 256):>8.3f} "
+                  f"{v.get('SQ_LDS_BANK_CONFLICT', 0.0) / max(v.get('SQ_LDS_IDX_ACTIVE', 0.0), 1.0):>13.4f}")
 
 
 def timeline(d, top=12, steps=0):
