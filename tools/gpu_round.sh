@@ -52,6 +52,7 @@ if has pmc; then
   done
   python tools/pmc_traffic.py "$OUT/pmc1" "$OUT/pmc2" "$OUT/igemm_traffic.json" "$OUT/pmc3" > "$OUT/pmc_traffic.log" 2>&1
   cat "$OUT/pmc_traffic.log" | head -5
+  python tools/prof_summary.py hbm "$OUT/pmc1" "$OUT/pmc2" > "$OUT/hbm_rate_per_kernel.txt" 2>&1
   for i in 1 2 3; do find "$OUT/pmc$i" -name "*.csv" -size +8M -delete; done
 fi
 if has pmcx; then
@@ -68,6 +69,7 @@ if has pmcx; then
     python tools/prof_summary.py pmc "$OUT/pmcx$i" > "$OUT/pmcx${i}_summary.txt" 2>&1
     head -8 "$OUT/pmcx${i}_summary.txt"
   done
+  python tools/prof_summary.py hbm "$OUT/pmcx1" "$OUT/pmcx2" > "$OUT/hbm_rate_per_kernel_exclusive.txt" 2>&1
   for i in 1 2 3; do find "$OUT/pmcx$i" -name "*.csv" -size +8M -delete; done
 fi
 if has nms; then
@@ -83,6 +85,11 @@ if has nms; then
   done
   python tools/pmc_traffic.py "$OUT/nms_pmc1" "$OUT/nms_pmc2" "$OUT/nms_traffic.json" - 20 > "$OUT/nms_traffic.log" 2>&1; head -4 "$OUT/nms_traffic.json"
   find "$OUT" -name "*.csv" -size +8M -delete
+fi
+if has subset; then  # a short parity pass on this build: kernels, blocks, the S model's whole-step checks
+  timeout 400 python -m pytest tests/test_kernels.py tests/test_blocks.py -m gpu -q > "$OUT/pytest_gpu_subset.log" 2>&1
+  timeout 300 python -m pytest tests/test_yolo_nas.py -m gpu -q -k "s_train_step_parity or s_backward_exact or l_backward_exact" >> "$OUT/pytest_gpu_subset.log" 2>&1
+  grep -E "passed|failed" "$OUT/pytest_gpu_subset.log"
 fi
 if has tests; then
   SGX_TEST_DUMP="$OUT/test_dump.txt" timeout 900 python -m pytest tests -m gpu -q --durations=15 > "$OUT/pytest_gpu.log" 2>&1
