@@ -33,12 +33,14 @@ if has stats; then
   cd "$REPO"
   python tools/prof_summary.py stats "$OUT/stats" > "$OUT/kernel_stats_summary.txt" 2>&1
   head -40 "$OUT/kernel_stats_summary.txt"
-  python tools/prof_summary.py timeline "$OUT/stats" > "$OUT/kernel_timeline_summary.txt" 2>&1   # idle / overlap / per-queue gaps
+  python tools/prof_summary.py timeline "$OUT/stats" 4 > "$OUT/kernel_timeline_summary.txt" 2>&1   # idle / overlap / per-queue gaps over the last 4 train steps
   head -12 "$OUT/kernel_timeline_summary.txt"
   # the raw per-dispatch trace is large; keep the stats csv only
   find "$OUT/stats" -name "*kernel_trace.csv" -size +8M -delete
 fi
 if has pmc; then
+  # (rocprofv3 --pmc serialises the dispatches: every kernel of these passes has the chip to itself - the per-kernel figures are EXCLUSIVE ones,
+  # whatever stream the kernel was launched on; r4zz: a pass with the side stream off measured the same durations)
   PMC_CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-nms --no-predict --no-exclusive"
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
@@ -54,23 +56,6 @@ if has pmc; then
   cat "$OUT/pmc_traffic.log" | head -5
   python tools/prof_summary.py hbm "$OUT/pmc1" "$OUT/pmc2" > "$OUT/hbm_rate_per_kernel.txt" 2>&1
   for i in 1 2 3; do find "$OUT/pmc$i" -name "*.csv" -size +8M -delete; done
-fi
-if has pmcx; then
-  # the same three counter passes with the side stream OFF (SGX_SIDE_STREAM=0): every kernel has the chip to itself - per-kernel matrix-pipe /
-  # LDS / HBM figures without the other stream's kernels in the same counters
-  PMC_CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-nms --no-predict --no-exclusive"
-  i=0
-  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
-    i=$((i+1))
-    cd /tmp
-    SGX_SIDE_STREAM=0 timeout -k 10 420 rocprofv3 --pmc $set --kernel-trace -f csv -d "$OUT/pmcx$i" -o bench -- bash -c "cd $REPO && $PMC_CMD" > "$OUT/pmcx$i.log" 2>&1
-    echo "pmcx$i ($set) rc=$?" >> "$OUT/pmcx$i.log"
-    cd "$REPO"
-    python tools/prof_summary.py pmc "$OUT/pmcx$i" > "$OUT/pmcx${i}_summary.txt" 2>&1
-    head -8 "$OUT/pmcx${i}_summary.txt"
-  done
-  python tools/prof_summary.py hbm "$OUT/pmcx1" "$OUT/pmcx2" > "$OUT/hbm_rate_per_kernel_exclusive.txt" 2>&1
-  for i in 1 2 3; do find "$OUT/pmcx$i" -name "*.csv" -size +8M -delete; done
 fi
 if has nms; then
   # the post-prediction kernels alone: kernel stats + FETCH_SIZE / WRITE_SIZE passes of 20 calls -> profiles/nms_traffic.json
