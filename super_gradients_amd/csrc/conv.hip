@@ -268,8 +268,21 @@ __device__ __forceinline__ void sgx_bnreq_publish(const IgemmParams& p, int col,
 // cycles) ahead instead of 8.  (32, 1): ONE LDS buffer (18 KB for 64x64: occupancy stays VGPR-bound, 7 workgroups per CU) with a
 // write-after-barrier hand-over - two barriers per slab, i.e. as many per FLOP as (16, 2).  (32, 2): two buffers (37 KB for 64x64:
 // 4 workgroups per CU), one barrier per slab - half the barriers per FLOP at lower occupancy.
+// Waves per SIMD the register allocation aims for.  The bf16x3 32-deep loop with one 32x32 block per wave (64x64, 128x32, 64x32 tiles) needs
+// 70 + 32 registers as the compiler allocates it unprompted - 4 waves per SIMD where its 27 KB of LDS would admit 5 workgroups per CU; the
+// loop lives on occupancy (r4y: a variant that cost one wave of it lost 8 %), so those forms ask for 5 (<= 96 registers).
+#ifndef IG_BF3_MIN_WAVES
+#define IG_BF3_MIN_WAVES 5
+#endif
+#ifndef IG_BF3_MIN_WAVES_PH2
+#define IG_BF3_MIN_WAVES_PH2 1  // (the two-source form as well: 93 registers; the two-output form would spill - three accumulators)
+#endif
+template <int BM, int BN, int WM, int WN, int MATH, int KD, int PH2>
+constexpr int igemm_min_waves() {
+    return (MATH == 1 && KD == 32 && PH2 <= IG_BF3_MIN_WAVES_PH2 && BM / (WM * 32) == 1 && BN / (WN * 32) == 1) ? IG_BF3_MIN_WAVES : 1;
+}
 template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0>
-__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2>())) void igemm_kernel(IgemmParams p) {
     static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && NBUF == 1), "32-deep slabs: channel-chunked K axis, one LDS buffer");
     static_assert(PH2 == 0 || !FLAT, "second K-axis source: channel-chunked K axis");
     static_assert(MATH == 0 || MATH == 1, "arithmetic: 0 = fp32 matrix pipe, 1 = bf16x3");
