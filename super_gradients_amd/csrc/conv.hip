@@ -2029,8 +2029,8 @@ struct WgGroupParams {
 // waves per SIMD the register budget is held to: accumulators (16 per 32x32 block of the wave's sub-tile) + 48 for the loop
 // (one-block sub-tiles fit 64 registers unprompted: no request)
 constexpr int wg_min_waves(int acc_regs, int pf) { return acc_regs <= 16 ? 1 : 512 / (acc_regs + (pf == 2 ? 64 : 48)); }
-// MATH = 1 (measurement switch, NOT yet measured on the chip - written against the host emulation in round 3 after the transpose read's
-// lane mapping had been probed): the bf16x3 arithmetic of the patch kernel for the weight gradient.  A slab is staged as three bf16 planes
+// MATH = 1 (the default since round 4 - r3zj / r4a: alone 13.5 -> 12.0 -> with the patch kernel 11.0 ms per step of weight gradients; written
+// against the host emulation in round 3 after the transpose read's lane mapping had been probed): the bf16x3 arithmetic of the patch kernel for the weight gradient.  A slab is staged as three bf16 planes
 // [plane][pixel][channel] (the split happens once per element, at the LDS store); the MFMA operands - eight consecutive PIXELS of one channel
 // per lane - come out of that pixel-major image through ds_read_b64_tr_b16, two reads per plane and 32-row block; six v_mfma_f32_32x32x16_bf16
 // per block pair and 16 pixels (hi*hi into the accumulator, the five cross terms into a second one that is added at the end).  Pixel rows are
