@@ -276,7 +276,7 @@ def test_maxpool(backend, k, stride, pad):
     """Forward values and arg-max routing against ATen (ties on purpose: the first maximum in row-major window order wins), through every
     kernel form: the direct kernels (C = 8 at stride 2; large maps), the LDS-tile forms (stride 1, 8-channel groups) and the scatter-form
     backward (64-channel groups of a map whose gradient slice fits LDS), plain and accumulating."""
-    shapes = [(2, 20, 20, 384), (2, 56, 56, 64)] if backend.type == "cuda" else [(1, 7, 6, 8), (1, 6, 5, 64)]
+    shapes = [(2, 20, 20, 384), (2, 56, 56, 64), (2, 20, 20, 72)] if backend.type == "cuda" else [(1, 7, 6, 8), (1, 6, 5, 64)]
     for n, h, w, c in shapes:
         g = torch.Generator().manual_seed(0)
         x = torch.randn(n, c, h, w, generator=g).round(decimals=1).requires_grad_(True)  # ties on purpose
