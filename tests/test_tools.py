@@ -74,3 +74,38 @@ def test_host_overhead_null_library_covers_the_abi(tmp_path):
     assert all(hasattr(lib, name) for name in _lib.PROTOTYPES)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_overhead.py"), "--steps", "2"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "host time per step without kernels" in out.stdout, out.stderr[-2000:]
+
+
+def test_prof_counter_ratios_and_hbm_rate_on_synthetic_passes(tmp_path, capsys):
+    """tools/prof_summary.py `pmc` (per-kernel busy ratios) and `hbm` (rate per kernel from the FETCH_SIZE and WRITE_SIZE passes) on
+    hand-made counter files: one kernel, two dispatches of 1 ms; 8 XCDs x 2.0e6 cycles; the matrix pipe busy on a quarter of the
+    SIMD-cycles, the LDS on half of the CU-cycles; 1 GiB fetched (reported as 0.5 GiB: the gfx950 correction doubles it), 0.5 GiB written."""
+    import prof_summary
+
+    def write(d, counters):
+        os.makedirs(d)
+        with open(os.path.join(d, "x_counter_collection.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=["Dispatch_Id", "Process_Id", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"])
+            w.writeheader()
+            for disp in (1, 2):
+                for name, v in counters.items():
+                    w.writerow(dict(Dispatch_Id=disp, Process_Id=7, Kernel_Name="void igemm_kernel<64, 64>(IgemmParams)", Counter_Name=name, Counter_Value=v,
+                                    Start_Timestamp=disp * 10_000_000, End_Timestamp=disp * 10_000_000 + 1_000_000))
+
+    cyc = 2.0e6
+    write(str(tmp_path / "sq"), {"GRBM_GUI_ACTIVE": 8 * cyc, "SQ_VALU_MFMA_BUSY_CYCLES": 0.25 * cyc * 1024, "SQ_LDS_IDX_ACTIVE": 0.5 * cyc * 256,
+                                 "SQ_BUSY_CU_CYCLES": 0.75 * cyc * 256, "SQ_LDS_BANK_CONFLICT": 0.0, "SQ_WAVE_CYCLES": 1.0})
+    prof_summary.pmc(str(tmp_path / "sq"))
+    out = capsys.readouterr().out
+    row = [l for l in out.splitlines() if l.startswith("igemm_kernel<64, 64>") and "0.250" in l]
+    assert row, out
+    cols = row[0].split()
+    assert cols[-4:] == ["0.250", "0.500", "0.750", "0.0000"] and cols[-5] == "2.000"  # busy ratios; cycles per ns of kernel time
+    gib = 1 << 30
+    write(str(tmp_path / "rd"), {"FETCH_SIZE": 0.25 * gib / 1024})   # KiB per dispatch, as rocprofv3 reports it (half of the bytes moved)
+    write(str(tmp_path / "wr"), {"WRITE_SIZE": 0.25 * gib / 1024})
+    prof_summary.hbm(str(tmp_path / "rd"), str(tmp_path / "wr"))
+    out = capsys.readouterr().out
+    row = [l for l in out.splitlines() if l.startswith("igemm_kernel<64, 64>")][0].split()
+    # 2 dispatches: read 2 x 0.25 GiB x 2 = 1.074 GB, written 0.537 GB, over 2 ms -> 0.81 TB/s
+    assert row[-3:] == ["1.07", "0.54", "0.81"], row
