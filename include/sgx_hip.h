@@ -68,12 +68,15 @@ int32_t sgx_debug_set_tiles(int32_t bm, int32_t bn, int32_t wgrad_bnk, int32_t w
 /* Arithmetic of the forward / data-gradient GEMMs.  0: fp32 matrix pipe, exact fp32 FMA chains.  1: "bf16x3" - every fp32
  * operand is split into three bf16 pieces (24 mantissa bits) and the six significant cross products run on the bf16 matrix pipe with
  * fp32 accumulation: fp32-accurate results (dropped terms <= 2^-24 of a product) at 2.7x fewer matrix-pipe cycles.  2: per problem -
- * bf16x3 where the reduction depth (taps x channels) is >= 192, fp32 MFMA for shallow ones.  3 (DEFAULT): the 3x3 stride-1 pad-1
+ * bf16x3 where the reduction depth (taps x channels) is >= 192, fp32 MFMA for shallow ones.  3 (the default of round 3): the 3x3 stride-1 pad-1
  * problems with C % 16 == 0 on output maps of 40 x 40 and larger (forward, the QARepVGG two-branch forward, data gradient, two-source
  * data gradient) run the PATCH kernel: a workgroup owns 8 x 16 output pixels of one image, stages their 10 x 18 input patch and the
  * filter slabs of all nine taps in LDS once per 16-channel chunk (split into three bf16 planes) and reads the taps from there - bf16x3
  * arithmetic as in mode 1; statistics rows are then one per tile (sgx_conv2d_fwd_stat_blocks follows); every other problem stays on the
- * fp32 pipe.  4 (measurement): mode 3's patch kernel on its problems, mode 2's per-problem rule for the rest.  Process-wide.            */
+ * fp32 pipe.  4: mode 3's patch kernel on its problems, mode 2's per-problem rule for the rest.  5 (DEFAULT since round 4): mode 4, and the
+ * two-branch / two-source (QARepVGG) launches follow the per-problem rule too - the five correction products of the bf16x3 scheme keep their
+ * own accumulator in every form (three accumulators per block in the two-output launch): a single shared accumulator leaves a same-signed
+ * offset of 1e-8 .. 8e-8 of the output's rms per convolution (the bf16 MFMA's accumulate floors what it shifts out).  Process-wide.           */
 int32_t sgx_conv_set_math(int32_t mode);
 int32_t sgx_conv_get_math(void);
 int32_t sgx_debug_set_variant(int32_t wave_layout_variant);
