@@ -1595,3 +1595,46 @@ def test_partial_chip_stream(gpu_device):
         check(lib().sgx_stream_destroy(h), "sgx_stream_destroy")
     h = ctypes.c_void_p()
     assert lib().sgx_stream_create_partial(5, ctypes.byref(h)) == -1 and lib().sgx_stream_create_partial(101, ctypes.byref(h)) == -1
+
+
+def test_round4_measurement_switches(backend):
+    """The measurement switches added in round 4 keep results correct and restore cleanly: the depth from which the per-problem rule runs a
+    problem in bf16x3 arithmetic (sgx_debug_set_bf3_min_depth; 0 = the default 192), and the LDS the weight-gradient launches leave to other
+    streams (sgx_conv_set_wgrad_lds_reserve: a launch-time dynamic-LDS request, no effect on results; 0..120 KB)."""
+    from super_gradients_amd._lib import lib
+
+    shape = _sizes(backend, (2, 24, 24, 64, 32, 1, 1, 0), (1, 6, 6, 64, 16, 1, 1, 0))  # depth 64: fp32 pipe under the default rule
+    n, h, w, c, k, r, s_, p_ = shape
+    x, wt, b = _conv_case(shape, seed=7)
+    ref = F.conv2d(x, wt, b, stride=s_, padding=p_)
+    xd, wd = to_nhwc(x, backend), K.to_ohwi(wt.to(backend))
+    try:
+        y_default = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s_, pad=p_).clone()
+        assert lib().sgx_debug_set_bf3_min_depth(64) == 0
+        K.clear_desc_cache()
+        y_bf3 = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s_, pad=p_).clone()
+        assert_close(to_nchw_cpu(y_default), ref, TOL, "depth-64 problem, default rule (fp32 pipe)")
+        assert_close(to_nchw_cpu(y_bf3), ref, TOL, "depth-64 problem in bf16x3 arithmetic")
+        assert not torch.equal(y_default, y_bf3), "the depth switch did not change the arithmetic of a depth-64 problem"
+        assert lib().sgx_debug_set_bf3_min_depth(-1) == -1
+    finally:
+        lib().sgx_debug_set_bf3_min_depth(0)
+        K.clear_desc_cache()
+    assert torch.equal(K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s_, pad=p_), y_default)
+    # LDS reserve: the same weight gradient with and without it
+    wshape = _sizes(backend, (2, 24, 24, 32, 32, 3, 1, 1), (1, 8, 8, 16, 16, 3, 1, 1))
+    n, h, w, c, k, r, s_, p_ = wshape
+    x, wt, _ = _conv_case(wshape, seed=8)
+    dy = torch.randn(n, k, h, w, generator=torch.Generator().manual_seed(9))
+    xd, dyd = to_nhwc(x, backend), to_nhwc(dy, backend)
+    outs = []
+    try:
+        for kb in (0, 48):
+            assert lib().sgx_conv_set_wgrad_lds_reserve(kb) == 0 and lib().sgx_conv_get_wgrad_lds_reserve() == kb
+            dw = K.to_ohwi(torch.zeros(k, c, r, r, device=backend))
+            K.conv2d_bwd_weight_group([(xd, dyd, dw, s_, p_)])
+            outs.append(dw.clone())
+        assert lib().sgx_conv_set_wgrad_lds_reserve(121) == -1 and lib().sgx_conv_set_wgrad_lds_reserve(-1) == -1
+    finally:
+        lib().sgx_conv_set_wgrad_lds_reserve(0)
+    assert torch.equal(outs[0], outs[1])
