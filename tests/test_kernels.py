@@ -1638,3 +1638,54 @@ def test_round4_measurement_switches(backend):
     finally:
         lib().sgx_conv_set_wgrad_lds_reserve(0)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("case", ["random", "crowded", "per_class", "boundary", "few_kept"])
+def test_nms_suppression_forms_agree(backend, case):
+    """The two forms of the suppression stage (sgx_debug_set_nms_split: 0 inside the per-image kernel, 1 = default: bit matrix built by a
+    chip-wide launch + one-wave walk) give the same rows bit for bit, and the oracle's: sparse boxes (the scan stops at max_predictions after
+    a few chunks), crowded boxes (almost everything suppressed: the scan visits every chunk), exact per-class mode, candidate counts around
+    the 64-candidate chunks, and max_predictions cutting a chunk in the middle.  (Round 4 built and measured a third form - one workgroup
+    per image, 64 candidates at a time against the kept list: the same rows, 102 us against 72 for the pair of launches it replaced,
+    profiles/r4_nms_chunked_form.txt; removed.)"""
+    from oracle import nms as onms
+    from super_gradients_amd._lib import lib
+
+    gpu = backend.type == "cuda"
+    g = np.random.RandomState({"random": 1, "crowded": 2, "per_class": 3, "boundary": 4, "few_kept": 5}[case])
+    B, L, C = (4, 2100, 8) if gpu else (2, 150, 3)
+    topk, maxp, class_mode, iou = (1000 if gpu else 130), (300 if gpu else 40), 0, 0.6
+    spread = 4.0
+    if case == "crowded":
+        spread, iou = 0.15, 0.3
+    elif case == "per_class":
+        class_mode = 2
+    elif case == "boundary":
+        topk = 129 if not gpu else 961
+        maxp = topk
+    elif case == "few_kept":
+        maxp = 37
+    c = g.uniform(100, 540, (B, L, 2)) * (1.0 if spread > 1 else 0.0) + (320 if spread < 1 else 0) + g.normal(0, 40 * spread, (B, L, 2))
+    wh = g.uniform(40, 160, (B, L, 2))
+    boxes = torch.from_numpy(np.concatenate([c - wh / 2, c + wh / 2], -1).astype(np.float32))
+    scores = torch.from_numpy(g.uniform(0.0, 1.0, (B, L, C)).astype(np.float32))
+    kw = dict(score_threshold=0.05, nms_threshold=iou, nms_top_k=topk, max_predictions=maxp, multi_label_per_box=True)
+    ref = onms.post_prediction(boxes, scores, class_agnostic_nms=class_mode == 0, force_vanilla=class_mode == 2, **kw) if class_mode else \
+        onms.post_prediction(boxes, scores, class_agnostic_nms=True, **kw)
+    outs = []
+    try:
+        for mode in (0, 1):
+            assert lib().sgx_debug_set_nms_split(mode) == 0
+            out, cnt, idx, ncand = K.nms(boxes.to(backend), scores.to(backend), 0.05, iou, topk, maxp, multi_label=True, class_mode=class_mode)
+            outs.append((out.cpu().clone(), cnt.cpu().clone(), idx.cpu().clone(), ncand.cpu().clone()))
+    finally:
+        lib().sgx_debug_set_nms_split(1)
+    for a, b_, what in zip(outs[0], outs[1], ("rows", "counts", "indices", "candidate counts")):
+        assert torch.equal(a, b_), f"{case}: {what} of the split form differ from the per-image kernel's"
+    out, cnt = outs[1][0], outs[1][1]
+    for b in range(B):
+        n = int(cnt[b])
+        assert n == ref[b].shape[0], f"{case} image {b}: kept {n} vs oracle {ref[b].shape[0]}"
+        assert torch.equal(out[b, :n], ref[b]), f"{case} image {b}: rows differ from the oracle"
+    if case == "crowded":
+        assert int(cnt.max()) < maxp  # the scan ran through every chunk
