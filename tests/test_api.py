@@ -141,11 +141,9 @@ def test_trainer_resume(backend, tmp_path):
 
     _, net_a = _tiny_models(backend)
     Trainer("a", ckpt_root_dir=str(tmp_path)).train(net_a, params(2), loader)
-    _, net_b = _tiny_models(backend)
-    Trainer("b", ckpt_root_dir=str(tmp_path)).train(net_b, params(1), loader)
     _, net_c = _tiny_models(backend)
-    tp = params(2, resume_path=os.path.join(str(tmp_path), "b", "ckpt_latest.pth"))
-    # the schedule must see max_epochs=2 from the start for both runs: re-train "b" with max_epochs=2 but stop after epoch 0 via a callback
+    # the schedule must see max_epochs=2 from the start for both runs: the interrupted run trains with max_epochs=2 and is stopped after
+    # epoch 0 by a callback
     from super_gradients_amd.training.utils.callbacks import Callback
 
     class StopAfterFirst(Callback):
@@ -154,7 +152,7 @@ def test_trainer_resume(backend, tmp_path):
 
     _, net_b = _tiny_models(backend)
     Trainer("b2", ckpt_root_dir=str(tmp_path)).train(net_b, params(2, phase_callbacks=[StopAfterFirst()]), loader)
-    tp["resume_path"] = os.path.join(str(tmp_path), "b2", "ckpt_latest.pth")
+    tp = params(2, resume_path=os.path.join(str(tmp_path), "b2", "ckpt_latest.pth"))
     tr = Trainer("c", ckpt_root_dir=str(tmp_path))
     tr.train(net_c, tp, loader)
     for (k, va), vc in zip(net_a.state_dict().items(), net_c.state_dict().values()):
