@@ -33,6 +33,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 TRAIN_GFLOP_PER_IMG = {"s": 101.634, "m": 282.556, "l": 386.959}  # 3 x forward conv FLOPs @640^2
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md; the headline figures with 2:1 sparsity are not used)
+# a launch in bf16x3 arithmetic executes six bf16 MFMA products per algorithmic fp32 product: its matrix-pipe ceiling in algorithmic FLOPs
+PEAK_BF16X3_EQUIV_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+
+
+def conv_bound_ms(K, classes=(0, 2, 3)):
+    """Per-launch roofline time of the recorded conv launches, every class priced on the pipe it EXECUTES on: class 0 = fp32
+    matrix pipe, classes 2 / 3 (patch kernel, bf16x3 implicit GEMM) = the bf16 pipe at six products per algorithmic one."""
+    return sum(K.prof_bound_ms(c, (PEAK_FP32_MFMA_TFLOPS if c == 0 else PEAK_BF16X3_EQUIV_TFLOPS) * 1e12, HBM_ACHIEVABLE_TBS * 1e12) for c in classes)
+
+
+def dtype_label(K):
+    """Storage and accumulation are fp32 everywhere; what differs is the pipe the products run on."""
+    return "fp32" if K.get_conv_math() == "fp32" else "fp32 (bf16x3 MFMA)"
 HBM_ACHIEVABLE_TBS = 6.3  # MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable
 
 
@@ -284,13 +297,13 @@ def resnet50_main(args):
     ig_ms, ig_fl, ig_n = (a + b for a, b in zip(K.prof_summary(0), (pc_ms, pc_fl, pc_n)))
     wg_ms, wg_fl, wg_n = K.prof_summary(1)
     ig_bytes = K.prof_bytes(0) + K.prof_bytes(2) + K.prof_bytes(3)
-    ig_bound_ms = sum(K.prof_bound_ms(c, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12) for c in (0, 2, 3))
+    ig_bound_ms = conv_bound_ms(K)
     K.prof_enable(False)
     ig_tf = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
     wg_tf = wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
     print(json.dumps({"metric": "images/sec ResNet-50 224x224 fwd+bwd", "value": round(value, 2), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                      "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+                      "vs_baseline": None, "dtype": dtype_label(K), "data": "synthetic",
                       "config": {"workload": "ResNet-50 synthetic ImageNet-shape 224x224, bs=64, forward+backward only, random-init weights",
                                  "final_loss": round(float(loss), 5), "conv_math": K.get_conv_math()},
                       "roofline": {"bound": "mfma", "kernel": "igemm_kernel / pconv_kernel (conv forward + data gradient)", "achieved": round(ig_tf, 2),
@@ -307,7 +320,7 @@ def resnet50_main(args):
                                                                         "kernel_ms_per_step": round(pc_ms / args.steps, 3),
                                                                         "note": "executed bf16 MFMA FLOPs = 6 x algorithmic"},
                                    "per_launch_bound": {"frac": round(ig_bound_ms / ig_ms, 4) if ig_ms > 0 else None,
-                                                        "note": f"sum over launches of max(FLOPs / {PEAK_FP32_MFMA_TFLOPS} TFLOP/s, algorithmic bytes / {HBM_ACHIEVABLE_TBS} TB/s) / measured kernel time"},
+                                                        "note": f"sum over launches of max(FLOPs / the peak of the pipe the launch executes on ({PEAK_FP32_MFMA_TFLOPS} TFLOP/s fp32 MFMA; {PEAK_BF16X3_EQUIV_TFLOPS:.1f} = {PEAK_BF16_MFMA_TFLOPS:.0f} / 6 for bf16x3 launches), algorithmic bytes / {HBM_ACHIEVABLE_TBS} TB/s) / measured kernel time"},
                                    "wgrad": {"achieved": round(wg_tf, 2), "frac": round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4), "launches_per_step": wg_n // max(args.steps, 1),
                                              "kernel_ms_per_step": round(wg_ms / args.steps, 3),
                                              "math": {0: "fp32", 1: "bf16x3", 2: "bf16x3+patch"}[int(lib().sgx_conv_get_wgrad_math())]},
@@ -426,8 +439,8 @@ def main():
     ig_ms, ig_fl, ig_n = (a + b for a, b in zip(K.prof_summary(0), (bf_ms, bf_fl, bf_n)))
     wg_ms, wg_fl, wg_n = K.prof_summary(1)
     # per-launch roofline time: max(FLOPs / MFMA peak, algorithmic bytes / achievable HBM rate) summed over the same launches
-    ig_bound_ms = sum(K.prof_bound_ms(c, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12) for c in (0, 2, 3))
-    wg_bound_ms = K.prof_bound_ms(1, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
+    ig_bound_ms = conv_bound_ms(K)
+    wg_bound_ms = K.prof_bound_ms(1, (PEAK_BF16X3_EQUIV_TFLOPS if lib().sgx_conv_get_wgrad_math() else PEAK_FP32_MFMA_TFLOPS) * 1e12, HBM_ACHIEVABLE_TBS * 1e12)
     K.prof_enable(False)
     # The per-launch figures above are taken while the weight-gradient kernels run concurrently on the side HIP stream (they share the
     # CUs, which is what makes the step faster but stretches every launch).  For the kernel's own efficiency: 3 extra, untimed steps
@@ -442,7 +455,7 @@ def main():
     exg3_ms, exg3_fl, exg3_n = K.prof_summary(3)
     ex_ms, ex_fl, ex_n = (a + b + c for a, b, c in zip(K.prof_summary(0), (expc_ms, expc_fl, expc_n), (exg3_ms, exg3_fl, exg3_n)))
     exw_ms, exw_fl, exw_n = K.prof_summary(1)
-    ex_bound_ms = sum(K.prof_bound_ms(c, PEAK_FP32_MFMA_TFLOPS * 1e12, HBM_ACHIEVABLE_TBS * 1e12) for c in (0, 2, 3))
+    ex_bound_ms = conv_bound_ms(K)
     K.prof_enable(False)
     net.side_stream = side
     # host side of one step: enqueue time of a step with the device idle at the start (no sync inside)
@@ -471,7 +484,7 @@ def main():
             "metric": f"images/sec/node {family}-{args.model.upper()} {args.size}x{args.size} train-step",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(host_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32", "data": "synthetic",
+            "dtype": dtype_label(K), "data": "synthetic",
             "config": {"workload": f"{family}-{args.model.upper()} synthetic COCO {args.size}x{args.size}, bs={args.batch}/GPU, PPYoloELoss(TAL)+AdamW"
                                    + ("" if args.no_ema else "+EMA") + ", random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
@@ -488,6 +501,10 @@ def main():
                                                             "problems from an LDS patch, v_mfma_f32_32x32x16_bf16 x6)" if K.get_conv_math() == "patch_bf3"
                                                        else "v_mfma_f32_32x32x16_bf16 x6 / v_mfma_f32_32x32x2_f32 per problem)"),
                          "achieved": round(ig_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                         # the same launches priced on the pipe most of them EXECUTE on: bf16 MFMA FLOPs issued (6 x algorithmic) / the dense bf16 peak
+                         "frac_of_executed_pipe": None if bf_n == 0 else round(6.0 * bf_fl / (bf_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                         "frac_note": "frac = algorithmic fp32 FLOPs / the fp32-MFMA peak BASELINE.md prices the target against; "
+                                      "frac_of_executed_pipe = the bf16x3 launches (most of the step) against the bf16 pipe they run on",
                          "timed_over": f"{args.steps} further steps of the same loop with a HIP event pair around every launch of the kernel on its launch stream",
                          "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_src, "traffic_measured_in_this_run": False,
                          # the two matrix pipes apart (round 4): launches on the fp32 pipe against the fp32 peak, launches of the bf16x3 patch kernel
@@ -512,7 +529,7 @@ def main():
                          "per_launch_bound": {"bound_ms_per_step": round(ig_bound_ms / args.steps, 3), "frac": round(ig_bound_ms / ig_ms, 4) if ig_ms > 0 else None,
                                               "exclusive_frac": round(ex_bound_ms / ex_ms, 4) if ex_ms > 0 else None,
                                               "wgrad_frac": round(wg_bound_ms / wg_ms, 4) if wg_ms > 0 else None,
-                                              "note": f"sum over launches of max(FLOPs / {PEAK_FP32_MFMA_TFLOPS} TFLOP/s, algorithmic bytes / {HBM_ACHIEVABLE_TBS} TB/s) / measured kernel time"},
+                                              "note": f"sum over launches of max(FLOPs / the peak of the pipe the launch executes on ({PEAK_FP32_MFMA_TFLOPS} TFLOP/s fp32 MFMA; {PEAK_BF16X3_EQUIV_TFLOPS:.1f} = {PEAK_BF16_MFMA_TFLOPS:.0f} / 6 for bf16x3 launches), algorithmic bytes / {HBM_ACHIEVABLE_TBS} TB/s) / measured kernel time"},
                          "exclusive": {"achieved": round(ex_fl / (ex_ms * 1e-3) / 1e12, 2) if ex_ms > 0 else None,
                                        "frac": round(ex_fl / (ex_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ex_ms > 0 else None,
                                        "wgrad_achieved": round(exw_fl / (exw_ms * 1e-3) / 1e12, 2) if exw_ms > 0 else None,

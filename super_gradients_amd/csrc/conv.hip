@@ -1906,6 +1906,9 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
                 // the rows of this class: one per pixel tile of the launch, decided exactly as run_igemm decides below
                 IgemmParams q = p;
                 q.vec = (q.Nout % 4 == 0 && q.y_ld_pix % 4 == 0 && q.y_ld_img % 4 == 0) ? 1 : 0;
+                // the launch itself (run_igemm) also looks at the operands' addresses: a real call decides with them BEFORE anything is
+                // launched, so a launch that cannot carry the requests is refused here and never writes partial rows
+                if (!dry && (((uintptr_t)p.Y % 16) || ((uintptr_t)p.addend % 16) || ((uintptr_t)p.bias % 16))) q.vec = 0;
                 const int ph2 = (sec || (dry && dx != nullptr)) && ph == 0 && pw == 0 ? 1 : 0;  // (dry: dx != nullptr marks the two-source form)
                 if (ph2) {
                     q.A2 = q.A ? q.A : reinterpret_cast<const float*>(16);

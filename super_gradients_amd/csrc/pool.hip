@@ -107,6 +107,7 @@ extern "C" int32_t sgx_maxpool_fwd(int32_t N, int32_t H, int32_t W, int32_t C, i
                                    int64_t x_ld_pix, int64_t x_ld_img, float* y, int64_t y_ld_pix, int64_t y_ld_img, int32_t* argmax,
                                    void* stream) {
     SGX_CHECK_ARG(x && y && C % 4 == 0 && k > 0 && stride > 0, "maxpool_fwd: bad args");
+    SGX_CHECK_ARG(pad >= 0 && 2 * pad <= k, "maxpool_fwd: pad %d must be at most half the window %d (F.max_pool2d's own rule)", pad, k);
     int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     if (stride == 1 && C % MP_CG == 0 && Ho > 0 && Wo > 0 && (long)H * W < 65536 && maxpool_fwd_tile_lds(H, W, Wo) <= MP_TILE_MAX_LDS && k > 2) {
         SGX_LAUNCH(maxpool_fwd_tile_kernel, dim3((unsigned)(N * (C / MP_CG))), dim3(256), (unsigned)maxpool_fwd_tile_lds(H, W, Wo), stream, H, W, C, k, pad,
@@ -240,9 +241,13 @@ __global__ __launch_bounds__(MP_SCATTER_THREADS) void maxpool_bwd_scatter_kernel
                 d[u] = g[(long)(o + u) * dy_ld_pix];
             }
 #pragma unroll
-            for (int u = 0; u < 32; ++u) tile[ix[u] * MP_SCATTER_CH + lane] += d[u];
+            for (int u = 0; u < 32; ++u)
+                if (ix[u] >= 0) tile[ix[u] * MP_SCATTER_CH + lane] += d[u];  // (-1: a window that lies in the padding only)
         }
-        for (; o < HoWo; ++o) tile[a[(long)o * C] * MP_SCATTER_CH + lane] += g[(long)o * dy_ld_pix];
+        for (; o < HoWo; ++o) {
+            const int ix = a[(long)o * C];
+            if (ix >= 0) tile[ix * MP_SCATTER_CH + lane] += g[(long)o * dy_ld_pix];
+        }
     }
     __syncthreads();
     for (int p = wave; p < HW; p += MP_SCATTER_THREADS / 64) gx[(long)p * dx_ld_pix] = tile[p * MP_SCATTER_CH + lane];
@@ -252,15 +257,20 @@ extern "C" int32_t sgx_maxpool_bwd(int32_t N, int32_t H, int32_t W, int32_t C, i
                                    const float* dy, int64_t dy_ld_pix, int64_t dy_ld_img, float* dx, int64_t dx_ld_pix, int64_t dx_ld_img,
                                    int32_t accumulate, void* stream) {
     SGX_CHECK_ARG(argmax && dy && dx && C % 4 == 0, "maxpool_bwd: bad args");
+    SGX_CHECK_ARG(pad >= 0 && 2 * pad <= k, "maxpool_bwd: pad %d must be at most half the window %d", pad, k);
     int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     if (C % MP_SCATTER_CH == 0 && Ho > 0 && Wo > 0 && (long)H * W * MP_SCATTER_CH * 4 <= MP_SCATTER_MAX_LDS) {
         const unsigned lds = (unsigned)((long)H * W * MP_SCATTER_CH * 4);
 #ifndef SGX_EMU
-        static std::atomic<bool> raised{false};  // dynamic LDS beyond 64 KB is opt-in per function
-        if (!raised.load(std::memory_order_acquire)) {
+        // dynamic LDS beyond 64 KB is opt-in per function AND per device: one flag bit per device ordinal
+        static std::atomic<unsigned long long> raised{0ull};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(raised.load(std::memory_order_acquire) & bit)) {
             if (hipFuncSetAttribute((const void*)maxpool_bwd_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MP_SCATTER_MAX_LDS) != hipSuccess)
                 SGX_FAIL(SGX_ERR_HIP, "maxpool_bwd: cannot raise the scatter kernel's dynamic LDS limit");
-            raised.store(true, std::memory_order_release);
+            raised.fetch_or(bit, std::memory_order_release);
         }
 #endif
         SGX_LAUNCH(maxpool_bwd_scatter_kernel, dim3((unsigned)(N * (C / MP_SCATTER_CH))), dim3(MP_SCATTER_THREADS), lds, stream, H * W, C, Ho * Wo, argmax, dy,

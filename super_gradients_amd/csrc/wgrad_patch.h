@@ -45,6 +45,8 @@ int32_t wpatch_launch(int stride, const WpPlan& form, const WpGroupParams& g, in
 // reserve set (sgx_conv_set_wgrad_lds_reserve), the weight-gradient launches ask for enough dynamic LDS on top of their static
 // allocation that one workgroup fewer fits a CU and at least the reserve stays free.
 #include <atomic>
+#include <map>
+#include <mutex>
 inline std::atomic<int> g_wg_lds_reserve{0};  // bytes
 template <typename KernelFn>
 static unsigned wg_lds_pad(KernelFn kernel) {
@@ -54,12 +56,19 @@ static unsigned wg_lds_pad(KernelFn kernel) {
 #else
     const long reserve = g_wg_lds_reserve.load(std::memory_order_relaxed);
     if (reserve <= 0) return 0;
-    static std::atomic<long> static_lds{-1};  // per kernel instantiation
-    long s = static_lds.load(std::memory_order_relaxed);
-    if (s < 0) {
-        hipFuncAttributes a;
-        s = hipFuncGetAttributes(&a, (const void*)kernel) == hipSuccess ? (long)a.sharedSizeBytes : 0;
-        static_lds.store(s, std::memory_order_relaxed);
+    // keyed by the kernel's ADDRESS: every wgrad_kernel<...> instantiation has the same function-pointer type, so a function-local static
+    // of this template would be shared by all tile shapes
+    static std::mutex mu;
+    static std::map<const void*, long> sizes;
+    long s;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = sizes.find((const void*)kernel);
+        if (it == sizes.end()) {
+            hipFuncAttributes a;
+            it = sizes.emplace((const void*)kernel, hipFuncGetAttributes(&a, (const void*)kernel) == hipSuccess ? (long)a.sharedSizeBytes : 0L).first;
+        }
+        s = it->second;
     }
     if (s <= 0) return 0;
     const long cu = 160 * 1024;

@@ -225,10 +225,14 @@ class BnReduceRequest:
 BN_REQ_STATS = {"taken": 0, "declined": 0}  # requests carried by a data gradient / left to the layer's own sweep (tests, tools)
 
 
-def _bn_reqs(reqs, d, two_source, out):
+def _bn_reqs(reqs, d, two_source, out, addend=None):
     """-> (ctypes array, n) for the requests this launch can carry, partial rows allocated; (None, 0) when it cannot (requests keep parts = None)"""
     reqs = [r for r in (reqs or ()) if r is not None]
     if not reqs:
+        return None, 0
+    # the epilogue that carries requests is the 16-byte one: operands it cannot address that way decline here, before any launch
+    if out.data_ptr() % 16 or (addend is not None and addend.data_ptr() % 16) or any(r.t.data_ptr() % 16 for r in reqs):
+        BN_REQ_STATS["declined"] += len(reqs)
         return None, 0
     arr, n = _bn_reqs_build(reqs, d, two_source, out)
     BN_REQ_STATS["taken" if n else "declined"] += len(reqs)
@@ -263,7 +267,7 @@ def conv2d_bwd_data_wt(dy, w, wt, x_shape, stride=1, pad=0, addend=None, out=Non
     d = conv_desc(out, K, R, S, stride, pad, dy)
     if addend is not None and nhwc_strides(addend) != nhwc_strides(out):
         raise _lib.SgxError("bwd_data addend must share dx's strides")
-    arr, n = _bn_reqs(reqs, d, False, out)
+    arr, n = _bn_reqs(reqs, d, False, out, addend)
     if n:
         check(lib().sgx_conv2d_bwd_data_wt_req(d.ref, ptr(dy), ptr(wt), ptr(addend), ptr(out), int(accumulate), arr, n, stream()), "sgx_conv2d_bwd_data_wt_req")
         return out
@@ -299,7 +303,7 @@ def conv2d_bwd_data_dual(dy, w, wt, ds, w1pt, x_shape, stride=1, addend=None, ou
     a2l, a2i = nhwc_strides(addend2) if addend2 is not None else (0, 0)
     a2_dev = addend2_scale if torch.is_tensor(addend2_scale) else None
     a2s = 1.0 if addend2_scale is None or a2_dev is not None else float(addend2_scale)
-    arr, n = _bn_reqs(reqs, d, True, out)
+    arr, n = _bn_reqs(reqs, d, True, out, addend)
     if n:
         check(lib().sgx_conv2d_bwd_data_dual_req(d.ref, ptr(dy), ptr(wt), ptr(ds), sl, si, ptr(w1pt), ptr(addend), ptr(addend2), a2l, a2i, a2s,
                                                  ptr(a2_dev), ptr(out), int(accumulate), arr, n, stream()), "sgx_conv2d_bwd_data_dual_req")

@@ -482,8 +482,14 @@ class NetFunction(torch.autograd.Function):
         try:
             net._bwd(*grads)
         except BaseException:
-            # the queue holds operands of THIS backward: a later one must not launch them into the gradient arena
+            # the queue holds operands of THIS backward: a later one must not launch them into the gradient arena; weight
+            # gradients already forked onto the side stream are joined, and the per-step transposes count as stale
             net._wg_pending, net._wg_flops = [], 0.0
+            net._wt_valid = False
+            try:
+                net.join_side()
+            except Exception:  # (the original error is the one to report)
+                pass
             raise
         net.flush_wgrads()
         net._wt_valid = False
