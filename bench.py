@@ -213,7 +213,8 @@ def nms_leg(device, iters=100, warmup=10):
 def predict_leg(device, model="s", batch=32, batches=10):
     """Inference side of the same model, reported next to the headline number: `model.predict()` end to end on `batch`
     synthetic 480x640 uint8 images resident in HBM with the reference's default YOLO-NAS COCO processing (longest side -> 636, centre pad to
-    640x640, /255): one device pre-processing launch, the fused eval forward (fp32), the NMS kernels, one device-to-host copy of the kept
+    640x640, /255): one device pre-processing launch, the fused eval forward (bf16 kernels for predict's default fp16=True; the fp32 path
+    is timed beside it), the NMS kernels, one device-to-host copy of the kept
     rows, the reference's box maps and result objects.  A failure is reported in the object, it does not take the bench line down."""
     import torch
 
@@ -225,16 +226,22 @@ def predict_leg(device, model="s", batch=32, batches=10):
         net.set_dataset_processing_params(**default_yolo_nas_coco_processing_params())
         g = torch.Generator().manual_seed(0)
         images = [torch.randint(0, 256, (480, 640, 3), generator=g, dtype=torch.uint8).to(device) for _ in range(batch)]
-        pipe = net._get_pipeline(conf=0.01)
-        pipe(images, batch_size=batch)  # warm-up; takes the fused copy
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(batches):
-            res = pipe(images, batch_size=batch)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / batches
-        return {"value": round(batch / dt, 1), "unit": "images/s", "ms_per_batch": round(1e3 * dt, 3), "batch": batch, "dtype": "fp32",
-                "detections_first_image": len(res[0].prediction),
+        def run(fp16):
+            pipe = net._get_pipeline(conf=0.01, fp16=fp16)
+            pipe(images, batch_size=batch)  # warm-up; takes the fused copy
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(batches):
+                res = pipe(images, batch_size=batch)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / batches, len(res[0].prediction), pipe.half
+
+        dt, ndet, half = run(True)        # the reference's default: predict(fp16=True) -> the bf16 kernels (csrc/half.hip)
+        dt32, ndet32, _ = run(False)      # the fp32 path, for the price of the precision
+        return {"value": round(batch / dt, 1), "unit": "images/s", "ms_per_batch": round(1e3 * dt, 3), "batch": batch,
+                "dtype": "bf16 (bf16 activations / filters, fp32 accumulate, fp32 prediction outputs)" if half else "fp32",
+                "detections_first_image": ndet,
+                "fp32_path": {"value": round(batch / dt32, 1), "ms_per_batch": round(1e3 * dt32, 3), "detections_first_image": ndet32},
                 "config": f"YOLO-NAS-{model.upper()} predict(): 480x640 uint8 -> 640x640, conf 0.01, iou 0.7, fused copy, random-init weights"}
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}

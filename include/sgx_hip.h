@@ -535,6 +535,33 @@ int32_t sgx_detection_match(const sgx_match_desc* d, const float* preds, const i
                             const int32_t* crowd_index, const float* thresholds, uint8_t* matched, uint8_t* ignore, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Half-precision INFERENCE (csrc/half.hip): what `predict(fp16=True)` runs on the fused deployment form of the model
+ * (training/pipelines/pipelines.py:76,223,375 wraps the reference's forward in torch.autocast; the fused form is
+ * modules/qarepvgg_block.py:255-321 + conv/BatchNorm folding).  Activations are NHWC **bf16** (void* = bf16 elements; strides in
+ * elements; channel counts, strides and addresses multiples of 8 elements = 16 bytes), filters OHWI bf16, bias fp32, accumulation
+ * fp32 on v_mfma_f32_32x32x16_bf16.  Training never calls these.
+ * ------------------------------------------------------------------------------------------- */
+/* y = act(conv(x, w) + bias) [+ post_scale * (*post_scale_dev) * post_add, AFTER the activation]; y is bf16, or fp32 when y_is_f32 (the
+ * prediction convs, whose outputs feed the fp32 decode / NMS kernels); post_add: bf16, y's logical shape, its own strides (the YOLO-NAS
+ * bottleneck's shortcut, yolo_stages.py:61-63); bias / post_add / post_scale_dev may be NULL.  d: the fp32 path's descriptor, strides in
+ * the operands' own elements.                                                                                                      */
+int32_t sgx_hconv2d_fwd(const sgx_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int32_t y_is_f32, int32_t act,
+                        const void* post_add, int64_t post_ld_pix, int64_t post_ld_img, float post_scale, const float* post_scale_dev,
+                        void* stream);
+/* ConvTranspose2d(kernel 2, stride 2) + bias on bf16 (modules/sampling.py:72-73): w4 = [2][2][K][C] bf16, parity-major          */
+int32_t sgx_hconvT2x2_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const void* x, int64_t x_ld_pix, int64_t x_ld_img,
+                          const void* w4, const float* bias, void* y, int64_t y_ld_pix, int64_t y_ld_img, void* stream);
+/* F.max_pool2d on bf16 (the SPP of csp_darknet53.py:136-157; no arg-max: inference only)                                        */
+int32_t sgx_hmaxpool_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad, const void* x, int64_t x_ld_pix,
+                         int64_t x_ld_img, void* y, int64_t y_ld_pix, int64_t y_ld_img, void* stream);
+/* M rows of C bf16 elements from one row-strided view into another (a skip tensor into its concat slice)                        */
+int32_t sgx_hcopy(const void* x, int64_t x_ld, int64_t M, int32_t C, void* y, int64_t y_ld, void* stream);
+/* fp32 rows [M][Cs] -> bf16 rows [M][Cd], Cd >= Cs, extra channels zero, round-to-nearest-even (the image batch at the entrance)  */
+int32_t sgx_cast_f32_bf16(const float* x, int64_t x_ld, int64_t M, int32_t Cs, void* y, int64_t y_ld, int32_t Cd, void* stream);
+/* Measurement aid: force the tile / slab depth of sgx_hconv2d_fwd (0 = heuristic)                                               */
+int32_t sgx_hconv_debug_set_tile(int32_t bm, int32_t bn, int32_t kd);
+
+/* ---------------------------------------------------------------------------------------------
  * Classification loss (training/losses/label_smoothing_cross_entropy_loss.py:32-111).
  * ------------------------------------------------------------------------------------------- */
 /* F.cross_entropy semantics (per-class weight, ignore_index, "mean" = sum w[y] * nll / sum w[y] over the rows that are not ignored) and,

@@ -110,6 +110,12 @@ PROTOTYPES = {
     "sgx_qarep_bwd_reduce": (_i32, [_P, _i64, _P, _i64, _P, _i64, _P, _P, _i64, _i32, _i32, _P, _P]),
     "sgx_qarep_bwd_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
     "sgx_qarep_bwd_apply": (_i32, [_P, _i64, _P, _i64, _P, _i64, _P, _P, _P, _P, _i64, _P, _i64, _i64, _i32, _i32, _P]),
+    "sgx_hconv2d_fwd": (_i32, [_CD, _P, _P, _P, _P, _i32, _i32, _P, _i64, _i64, _f, _P, _P]),
+    "sgx_hconvT2x2_fwd": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _P, _i64, _i64, _P]),
+    "sgx_hmaxpool_fwd": (_i32, [_i32] * 7 + [_P, _i64, _i64, _P, _i64, _i64, _P]),
+    "sgx_hcopy": (_i32, [_P, _i64, _i64, _i32, _P, _i64, _P]),
+    "sgx_cast_f32_bf16": (_i32, [_P, _i64, _i64, _i32, _P, _i64, _i32, _P]),
+    "sgx_hconv_debug_set_tile": (_i32, [_i32] * 3),
     "sgx_conv2d_bwd_weight_workspace": (_i64, [_CD]),
     "sgx_conv2d_bwd_weight": (_i32, [_CD, _P, _P, _P, _P, _P, _i64, _P]),
     "sgx_conv2d_bwd_weight_group_sizes": (_i32, [POINTER(WgradJob), _i32, POINTER(c_int64), POINTER(c_int64)]),
@@ -292,7 +298,7 @@ def check(rc, what=""):
         raise SgxError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
 
 
-_PTR_DTYPES = frozenset((torch.float32, torch.float64, torch.int32, torch.int64, torch.uint8))
+_PTR_DTYPES = frozenset((torch.float32, torch.float64, torch.int32, torch.int64, torch.uint8, torch.bfloat16))  # bf16: the half-precision inference path
 
 
 def ptr(t):

@@ -88,6 +88,11 @@ static inline float4 sgx_buf_ld4(const sgx_buf& b, unsigned off) {
     if (off < b.bytes && off + 16u <= b.bytes) memcpy(&v, b.base + off, 16);
     return v;
 }
+static inline uint4 sgx_buf_ld4u(const sgx_buf& b, unsigned off) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (off < b.bytes && off + 16u <= b.bytes) memcpy(&v, b.base + off, 16);
+    return v;
+}
 #else
 typedef __amdgpu_buffer_rsrc_t sgx_buf;
 __device__ __forceinline__ sgx_buf sgx_make_buf(const void* p, long bytes) {
@@ -100,6 +105,12 @@ __device__ __forceinline__ float4 sgx_buf_ld4(sgx_buf b, unsigned off) {
     // bit-cast the WHOLE vector: hipcc (ROCm 7.2) narrows the load to one dword when the lanes are bit-cast one by one
     sgx_f32x4 f = __builtin_bit_cast(sgx_f32x4, v);
     return make_float4(f.x, f.y, f.z, f.w);
+}
+// the same 16-byte load as raw dwords (bf16 operands: eight elements per lane)
+__device__ __forceinline__ uint4 sgx_buf_ld4u(sgx_buf b, unsigned off) {
+    typedef unsigned int sgx_u32x4 __attribute__((ext_vector_type(4)));
+    const sgx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 #endif
 

@@ -138,7 +138,14 @@ def to_ohwi(w: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------- convolution
-def conv2d_fwd(x, w, bias=None, addend=None, out=None, act=None, stride=1, pad=0, stat_partials=False):
+def conv2d_fwd(x, w, bias=None, addend=None, out=None, act=None, stride=1, pad=0, stat_partials=False, post_add=None, post_scale=None):
+    """post_add / post_scale: out = act(...) + post_scale * post_add - half-precision inference only (the bf16 conv epilogue carries it)."""
+    if x.dtype == torch.bfloat16:
+        if addend is not None or stat_partials:
+            raise _lib.SgxError("half-precision convolution: inference form only (no pre-activation addend, no BatchNorm statistics)")
+        return hconv2d_fwd(x, w, bias=bias, out=out, act=act, stride=stride, pad=pad, post_add=post_add, post_scale=post_scale)
+    if post_add is not None:
+        raise _lib.SgxError("conv2d_fwd: post_add rides in the half-precision convolution's epilogue only")
     K, C, R, S = w.shape
     _chk_w(w, K, R, S, x.shape[3])
     if out is None:
@@ -272,6 +279,76 @@ def conv2d_bwd_data_wt(dy, w, wt, x_shape, stride=1, pad=0, addend=None, out=Non
         check(lib().sgx_conv2d_bwd_data_wt_req(d.ref, ptr(dy), ptr(wt), ptr(addend), ptr(out), int(accumulate), arr, n, stream()), "sgx_conv2d_bwd_data_wt_req")
         return out
     check(lib().sgx_conv2d_bwd_data_wt(d.ref, ptr(dy), ptr(wt), ptr(addend), ptr(out), int(accumulate), stream()), "sgx_conv2d_bwd_data_wt")
+    return out
+
+
+# ---- half-precision inference (csrc/half.hip): bf16 activations, one bf16 MFMA product, fp32 accumulation ---------------------------------
+HALF = torch.bfloat16
+_HALF_W = {}
+
+
+def _half_cached(src, tag, build):
+    """A bf16 operand derived from the fp32 tensor `src` (a folded filter, a transposed-conv weight): built once per tensor object and
+    in-place version - the deployment form's filters never change, and a refreshed fold is a new tensor."""
+    key = (id(src), tag)
+    hit = _HALF_W.get(key)
+    if hit is not None and hit[0]() is src and hit[1] == src._version:
+        return hit[2]
+    if len(_HALF_W) > 4096:  # dead entries of models that are gone
+        for k in [k for k, v in _HALF_W.items() if v[0]() is None]:
+            del _HALF_W[k]
+    import weakref
+
+    h = build()
+    _HALF_W[key] = (weakref.ref(src), src._version, h)
+    return h
+
+
+def half_filter(w, cin):
+    """logical [K,C,R,S] fp32 (any strides) -> contiguous [K,R,S,cin] bf16 (OHWI; channels zero-padded to cin, round-to-nearest-even)."""
+    def build():
+        K, C, R, S = w.shape
+        o = torch.zeros(K, R, S, cin, device=w.device, dtype=HALF)
+        o[..., :C] = w.detach().permute(0, 2, 3, 1)
+        return o
+    return _half_cached(w, ("f", cin), build)
+
+
+def hconv2d_fwd(x, w, bias=None, out=None, act=None, stride=1, pad=0, post_add=None, post_scale=None):
+    """bf16 NHWC x; w: the fp32 filter of the fp32 path (converted once, cached) -> out bf16 (default) or the fp32 `out` given."""
+    K, C, R, S = w.shape
+    cin = x.shape[3]
+    if C > cin:
+        raise _lib.SgxError(f"hconv2d_fwd: the filter has {C} input channels, the activation {cin}")
+    wh = half_filter(w, cin)
+    if out is None:
+        out = torch.empty(conv_out_shape(x, K, R, S, stride, pad), device=x.device, dtype=HALF)
+    elif out.dtype not in (HALF, torch.float32):
+        raise _lib.SgxError(f"hconv2d_fwd: output dtype {out.dtype}")
+    d = conv_desc(x, K, R, S, stride, pad, out)
+    pl, pi = nhwc_strides(post_add) if post_add is not None else (0, 0)
+    if post_add is not None and (post_add.dtype != HALF or tuple(post_add.shape) != tuple(out.shape)):
+        raise _lib.SgxError("hconv2d_fwd: post_add must be a bf16 tensor of the output's shape")
+    ps_dev = post_scale if torch.is_tensor(post_scale) else None
+    ps = 1.0 if post_scale is None or ps_dev is not None else float(post_scale)
+    check(lib().sgx_hconv2d_fwd(d.ref, ptr(x), ptr(wh), ptr(bias), ptr(out), int(out.dtype == torch.float32), ACT[act], ptr(post_add), pl, pi, ps,
+                                ptr(ps_dev), stream()), "sgx_hconv2d_fwd")
+    return out
+
+
+def cast_bf16(x, cpad=None):
+    """fp32 NHWC [N,H,W,C] (uniform rows) -> bf16 [N,H,W,cpad] (default: C rounded up to 8), extra channels zero."""
+    n, h, w, c = x.shape
+    cpad = cpad or ((c + 7) // 8) * 8
+    M, ld = rows(x)
+    y = torch.empty(n, h, w, cpad, device=x.device, dtype=HALF)
+    check(lib().sgx_cast_f32_bf16(ptr(x), ld, M, c, ptr(y), cpad, cpad, stream()), "sgx_cast_f32_bf16")
+    return y
+
+
+def hcopy(x, out):
+    M, ld = rows(x)
+    check(lib().sgx_hcopy(ptr(x), ld, M, x.shape[3], ptr(out), rows(out)[1], stream()), "sgx_hcopy")
     return out
 
 
@@ -414,6 +491,14 @@ def convT2x2_fwd(x, wt, bias=None, out=None):
     n, h, w, c = x.shape
     K = wt.shape[1]
     _chk_wt(wt, c, K)
+    if x.dtype == HALF:  # half-precision inference: four 1x1 launches, one per output parity; w4 = [2][2][K][C] bf16, built once
+        w4 = _half_cached(wt, "T", lambda: wt.detach().permute(2, 3, 1, 0).contiguous().to(HALF))
+        if out is None:
+            out = torch.empty(n, 2 * h, 2 * w, K, device=x.device, dtype=HALF)
+        xl, xi = nhwc_strides(x)
+        yl, yi = nhwc_strides(out)
+        check(lib().sgx_hconvT2x2_fwd(n, h, w, c, K, ptr(x), xl, xi, ptr(w4), ptr(bias), ptr(out), yl, yi, stream()), "sgx_hconvT2x2_fwd")
+        return out
     if out is None:
         out = torch.empty(n, 2 * h, 2 * w, K, device=x.device, dtype=torch.float32)
     xl, xi = nhwc_strides(x)
@@ -649,6 +734,10 @@ def dot_sum(a, b, out, accumulate=True, scale=1.0):
 
 
 def axpy(x, a=1.0, a_dev=None, out=None, accumulate=False):
+    if x.dtype == HALF:
+        if a != 1.0 or a_dev is not None or accumulate or out is None:
+            raise _lib.SgxError("axpy on bf16: the half-precision inference path only copies a view into a concat slice")
+        return hcopy(x, out)
     M, ld = rows(x)
     if out is None:
         out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
@@ -755,6 +844,15 @@ def fill(t, v=0.0):
 def maxpool_fwd(x, k, stride, pad, out=None, want_argmax=True):
     n, h, w, c = x.shape
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    if x.dtype == HALF:
+        if want_argmax:
+            raise _lib.SgxError("maxpool_fwd on bf16: inference only (no arg-max)")
+        if out is None:
+            out = torch.empty(n, ho, wo, c, device=x.device, dtype=HALF)
+        xl, xi = nhwc_strides(x)
+        yl, yi = nhwc_strides(out)
+        check(lib().sgx_hmaxpool_fwd(n, h, w, c, k, stride, pad, ptr(x), xl, xi, ptr(out), yl, yi, stream()), "sgx_hmaxpool_fwd")
+        return out, None
     if out is None:
         out = torch.empty(n, ho, wo, c, device=x.device, dtype=torch.float32)
     am = torch.empty(n, ho, wo, c, device=x.device, dtype=torch.int32) if want_argmax else None

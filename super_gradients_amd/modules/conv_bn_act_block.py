@@ -50,10 +50,17 @@ class _ConvBN(SgxBlock):
             self._folded = None  # the weights are about to change
         return super().train(mode)
 
-    def fwd(self, x, out=None, post_add=None):
+    def fwd(self, x, out=None, post_add=None, post_scale=None):
         """post_add: tensor added AFTER the activation (pp_yolo_head.py:205 `stem_cls(feat, avg_feat) + feat`); its gradient is the
-        caller's (dy reaches it unchanged)."""
+        caller's (dy reaches it unchanged).  post_scale (half-precision inference only): a multiplier of post_add."""
         conv, bn = self._parts()
+        if x.dtype == K.HALF:  # half-precision inference: the folded deployment form, everything in ONE bf16 launch
+            if self.training or self._folded is None:
+                raise RuntimeError("half-precision inference runs the folded deployment form: call prep_model_for_conversion() in eval mode first")
+            return K.conv2d_fwd(x, self._folded[0], bias=self._folded[1], out=out, act=self.act, stride=conv.stride, pad=conv.padding,
+                                post_add=post_add, post_scale=post_scale)
+        if post_scale is not None:
+            raise RuntimeError("post_scale: half-precision inference only")
         if self.training:
             self._folded = None  # a training step follows: a folded eval filter would be stale afterwards
             t, parts = conv.conv(x, stats=True)

@@ -380,6 +380,20 @@ class SgxNetwork(nn.Module):
                 m.prep_model_for_conversion(input_size, **kwargs)
         return self
 
+    _half_inference = False
+
+    def half_inference(self, enabled: bool = True):
+        """Run eval-mode forwards on the half-precision path (csrc/half.hip: bf16 activations and filters, fp32 accumulation) - what the
+        reference's predict() does with torch.autocast (pipelines.py:76).  The model must be in its folded deployment form
+        (prep_model_for_conversion(full_fusion=True)); blocks that are not raise at the first forward.  Training is unaffected."""
+        if enabled and not self.supports_half_inference():
+            raise NotImplementedError(f"{type(self).__name__}: no half-precision inference path for this architecture")
+        self._half_inference = bool(enabled)
+        return self
+
+    def supports_half_inference(self) -> bool:
+        return False
+
     def weights_changed(self):
         """Anything that rewrites parameters or BatchNorm statistics outside a training step (load_state_dict, an EMA swap, a broadcast)
         calls this: eval-mode caches derived from the weights - the folded conv+BN filters of prep_model_for_conversion - are dropped and

@@ -81,6 +81,12 @@ class QARepVGGBlock(SgxBlock):
     def fwd(self, x, out=None, post_add=None, post_scale=None):
         """post_add / post_scale: out = block(x) + post_scale * post_add (the YOLO-NAS bottleneck's shortcut, yolo_stages.py:61-63),
         written by the block's last sweep on the two-branch path."""
+        if x.dtype == K.HALF:  # half-precision inference: the fully fused deployment form, shortcut included, as ONE bf16 launch
+            if self.training or not self.fully_fused:
+                raise RuntimeError("half-precision inference runs the fully fused deployment form: call prep_model_for_conversion(full_fusion=True) "
+                                   "in eval mode first")
+            return K.conv2d_fwd(x, self._fused_w, bias=self._fused_b, out=out, act=self.act, stride=self.stride, pad=1, post_add=post_add,
+                                post_scale=post_scale)
         if post_add is not None and not (self.training and self._two_branch_launch()):
             y = self.fwd(x)
             a, a_dev = (1.0, post_scale) if torch.is_tensor(post_scale) else (1.0 if post_scale is None else float(post_scale), None)

@@ -79,6 +79,8 @@ class CustomizableDetector(DetectionPredictMixin, SgxNetwork):
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise ValueError(f"expected an NCHW batch with {self.in_channels} channels, got {tuple(x.shape)}")
         xh = K.input_to_nhwc(x)
+        if self._half_inference and not self.training:
+            xh = K.cast_bf16(xh, cpad=8)  # the bf16 batch the first convolution reads (3 -> 8 channels: one 16-byte lane load per pixel)
         feats = self.backbone.fwd(xh)
         p = self.neck.fwd(feats)
         boxes, scores, logits, distri, anchors, pts, counts, strides = self.heads.fwd(p)

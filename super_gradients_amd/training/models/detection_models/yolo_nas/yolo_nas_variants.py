@@ -46,6 +46,10 @@ class YoloNAS(CustomizableDetector):
         return PPYoloEPostPredictionCallback(score_threshold=conf, nms_threshold=iou, nms_top_k=nms_top_k, max_predictions=max_predictions,
                                              multi_label_per_box=multi_label_per_box, class_agnostic_nms=class_agnostic_nms)
 
+    def supports_half_inference(self) -> bool:
+        """predict(fp16=True) runs the fused model on the bf16 kernels of csrc/half.hip (every op of the deployment form has one)."""
+        return True
+
     def get_decoding_module(self, num_pre_nms_predictions: int, **kwargs) -> YoloNASDecodingModule:
         return YoloNASDecodingModule(num_pre_nms_predictions)
 

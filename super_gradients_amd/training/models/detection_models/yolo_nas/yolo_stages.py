@@ -24,7 +24,7 @@ from .....modules.qarepvgg_block import QARepVGGBlock
 
 
 def _empty(n, h, w, c, like):
-    return torch.empty(n, h, w, c, device=like.device, dtype=torch.float32)
+    return torch.empty(n, h, w, c, device=like.device, dtype=like.dtype)  # (bf16 on the half-precision inference path, fp32 otherwise)
 
 
 class YoloNASBottleneck(SgxBlock):
@@ -53,6 +53,8 @@ class YoloNASBottleneck(SgxBlock):
             return self.cv2.fwd(self.cv1.fwd(x), out=out)
         a, a_dev = self._alpha()
         self._x = x if self.training else None
+        if x.dtype == K.HALF:  # half-precision inference: the shortcut rides in the epilogue of cv2's (fused) convolution
+            return self.cv2.fwd(self.cv1.fwd(x), out=out, post_add=x, post_scale=a_dev if a_dev is not None else a)
         if isinstance(self.cv2, QARepVGGBlock):  # the shortcut rides in cv2's last sweep
             return self.cv2.fwd(self.cv1.fwd(x), out=out, post_add=x, post_scale=a_dev if a_dev is not None else a)
         y = self.cv2.fwd(self.cv1.fwd(x))

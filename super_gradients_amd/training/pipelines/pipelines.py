@@ -8,8 +8,10 @@ protocol (`pipeline(images, batch_size)`) and result containers; what differs is
   np.array(list) -> torch.from_numpy -> .to(device)        raw uint8 images are uploaded, the fp32 batch is born in HBM
   deepcopy + prep_model_for_conversion on first batch      same, full fusion (QARepVGG / RepVGG blocks and every conv+BN pair become ONE conv launch
                                                            with bias + activation in its epilogue)
-  autocast(fp16) forward                                   fp32 forward on the MFMA fp32 path (fp16 is accepted and ignored: the build has no
-                                                           reduced-precision convolution; results are at least as precise as the reference's)
+  autocast(fp16) forward                                   fp16=True (the reference's default): the fused copy runs on the half-precision kernels
+                                                           (csrc/half.hip: bf16 activations / filters, fp32 accumulation on the bf16 matrix
+                                                           pipe, fp32 prediction outputs) for the architectures that have them (YOLO-NAS);
+                                                           fp16=False, or an architecture without them: the fp32 path
   post_prediction_callback (python loop + torchvision)     the batched NMS kernels (csrc/nms.hip)
   postprocess_predictions per image (numpy)                same arithmetic, on the <= max_predictions boxes of each image
 Video / webcam sources are cv2 I/O and outside the path.
@@ -63,16 +65,17 @@ def load_images(images) -> List[Union[np.ndarray, torch.Tensor]]:
 _FP16_NOTED = False
 
 
-def _note_fp16_once():
-    """fp16=True is the reference's default (pipelines.py:76: torch.autocast around the forward).  This build has no half-precision
-    kernels: the forward runs in fp32 - results are at least as precise, throughput is the fp32 path's.  Said once per process."""
+def _note_fp16_once(model):
+    """fp16=True is the reference's default (pipelines.py:76: torch.autocast around the forward).  Architectures without half-precision
+    kernels here (everything but YOLO-NAS) run the forward in fp32 - results are at least as precise, throughput is the fp32 path's.
+    Said once per process."""
     global _FP16_NOTED
     if not _FP16_NOTED:
         _FP16_NOTED = True
         import logging
 
-        logging.getLogger(__name__).warning("predict(fp16=True): no half-precision kernels on this build - the forward runs in fp32 "
-                                            "(pass fp16=False to silence this note)")
+        logging.getLogger(__name__).warning(f"predict(fp16=True): {type(model).__name__} has no half-precision kernels on this build - "
+                                            "the forward runs in fp32 (pass fp16=False to silence this note)")
 
 
 class Pipeline(ABC):
@@ -96,8 +99,11 @@ class Pipeline(ABC):
         self.image_processor = image_processor
         self.fuse_model = fuse_model  # fused on the first batch, like the reference (pipelines.py:91,95-100)
         self.fp16 = fp16
-        if fp16:
-            _note_fp16_once()
+        # the forward's compute type: bf16 on the fused copy of an architecture that has the kernels, fp32 otherwise (an unfused model has
+        # BatchNorm / two-branch blocks the half path does not carry)
+        self.half = bool(fp16 and fuse_model and getattr(model, "supports_half_inference", lambda: False)())
+        if fp16 and not self.half:
+            _note_fp16_once(model)
 
     def _fuse_model(self, input_size):
         cache, self.model._pipeline_cache = getattr(self.model, "_pipeline_cache", None), None  # (it holds this pipeline: not part of the copy)
@@ -110,6 +116,8 @@ class Pipeline(ABC):
         # the copy is private to this pipeline and inference-only, so it takes the deepest form every block offers (the reference's call
         # leaves QARepVGG blocks partially fused - post-BN as a separate op - because its copy stays trainable): same function, fewer passes
         self.model.prep_model_for_conversion(input_size=input_size, full_fusion=True)
+        if self.half:
+            self.model.half_inference(True)  # the private fused copy only: the caller's model keeps training in fp32
         self.fuse_model = False
 
     def __call__(self, inputs, batch_size: Optional[int] = 32):

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "..", "super_gradients_amd", "csrc"))
 OUTDIR = os.path.join(HERE, "_build")
 OUT = os.path.join(OUTDIR, "libsgx_emu.so")
-SOURCES = ["conv.hip", "wgrad_patch.hip", "bn.hip", "pool.hip", "se.hip", "loss.hip", "nms.hip", "optim.hip", "image.hip", "api.cpp"]
+SOURCES = ["conv.hip", "wgrad_patch.hip", "bn.hip", "pool.hip", "se.hip", "loss.hip", "nms.hip", "optim.hip", "image.hip", "half.hip", "api.cpp"]
 CXX = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 

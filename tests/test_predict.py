@@ -314,7 +314,7 @@ def test_predict_eval_forward_matches_oracle(gpu_device):
         (bx_r, sc_r), _ = ref(x_ref)
     net.set_dataset_processing_params(class_names=["a", "b", "c"], image_processor=ComposeProcessing(
         [DetectionCenterPadding((64, 64), 114), StandardizeImage(255.0), ImagePermute()]), conf=0.0)
-    pipe = net._get_pipeline()
+    pipe = net._get_pipeline(fp16=False)  # the fp32 path: parity with the fp32 oracle (the half path: tests/test_half.py)
     batch, _ = pipe.image_processor.preprocess_batch(images, device=backend)
     assert np.array_equal(batch.cpu().numpy(), x_ref.numpy())
     pipe.pass_images_through_model(batch)  # fuses on the first batch
