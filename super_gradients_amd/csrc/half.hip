@@ -284,7 +284,7 @@ __global__ __launch_bounds__(WM * WN * 64) void hconv_kernel(HconvParams p) {
 #include <atomic>
 static std::atomic<int> g_h_bm{0}, g_h_bn{0}, g_h_kd{0};
 extern "C" int32_t sgx_hconv_debug_set_tile(int32_t bm, int32_t bn, int32_t kd) {  // measurement aid (tools/predict_bench.py): 0 = heuristic
-    SGX_CHECK_ARG((bm == 0 || bm == 64 || bm == 128) && (bn == 0 || bn == 32 || bn == 64 || bn == 128) && (kd == 0 || kd == 32 || kd == 64),
+    SGX_CHECK_ARG((bm == 0 || bm == 64 || bm == 128) && (bn == 0 || bn == 32 || bn == 64 || bn == 96 || bn == 128) && (kd == 0 || kd == 32 || kd == 64),
                   "hconv_debug_set_tile: tile %dx%d, slab depth %d", bm, bn, kd);
     g_h_bm = bm; g_h_bn = bn; g_h_kd = kd;
     return SGX_OK;
@@ -303,6 +303,8 @@ static int32_t launch_hconv_tile(HconvParams& p, int bm, int bn, void* stream) {
     else if (bm == 128 && bn == 64) launch_hconv<128, 64, 2, 2, KD, false>(p, stream);
     else if (bm == 64 && bn == 128) launch_hconv<64, 128, 2, 2, KD, false>(p, stream);
     else if (bm == 64 && bn == 64) launch_hconv<64, 64, 2, 2, KD, false>(p, stream);
+    else if (bm == 128 && bn == 96) launch_hconv<128, 96, 4, 1, KD, false>(p, stream);
+    else if (bm == 64 && bn == 96) launch_hconv<64, 96, 2, 1, KD, false>(p, stream);
     else if (bm == 128 && bn == 32) launch_hconv<128, 32, 4, 1, KD, false>(p, stream);
     else if (bm == 64 && bn == 32) launch_hconv<64, 32, 2, 1, KD, false>(p, stream);
     else SGX_FAIL(SGX_ERR_UNSUPPORTED, "hconv: no tile %dx%d", bm, bn);
@@ -328,17 +330,18 @@ static int32_t run_hconv(HconvParams& p, void* stream) {
              (!p.post || (p.p_ld_pix % 4 == 0 && p.p_ld_img % 4 == 0 && ((uintptr_t)p.post % 8) == 0)))
                 ? 1
                 : 0;
-    // tile: the filter tile that pads the filter count least (ties: the wider one), the tallest pixel tile that still gives the chip four
-    // rounds of workgroups
-    int bn = 128;
-    {
-        long best = -1;
-        for (int cand : {128, 64, 32}) {
-            const long padded = (long)sgx_cdiv(p.Nout, cand) * cand;
-            if (best < 0 || padded < best) best = padded, bn = cand;
-        }
-    }
-    int bm = ((long)sgx_cdiv(p.M, 128) * sgx_cdiv(p.Nout, bn) >= 1024) ? 128 : 64;
+    // Tile and slab depth, fitted to the replay of every convolution of the fused YOLO-NAS-S / M forward under every instantiation
+    // (tools/hconv_lab.py, profiles/r5b_hconv_lab.txt): the loop moves bytes, not FLOPs (one MFMA per 16-deep step and block), so what a
+    // tile buys is fewer re-reads of the other operand - worth it only while enough workgroups remain to fill 256 CUs.
+    const long depth = (long)T * p.C;
+    const long mt128 = sgx_cdiv(p.M, 128);
+    int bm = 64, bn = 64;
+    if (p.Nout <= 32) bm = 128, bn = 32;
+    else if (p.Nout % 64 != 0 && p.Nout % 96 == 0) {  // 96, 288: three 32-wide blocks per wave, nothing padded
+        if (p.M >= 100000) bm = 128, bn = 96;
+        else if (T > 1) bm = 64, bn = 96;
+    } else if (p.Nout % 128 == 0 && depth >= 1024 && mt128 * (p.Nout / 128) >= 256) bm = 128, bn = 128;  // deep reductions: operand reuse pays
+    else if (mt128 * sgx_cdiv(p.Nout, 64) >= 2048 || (depth >= 512 && mt128 * sgx_cdiv(p.Nout, 64) >= 512)) bm = 128, bn = 64;
     if (const int o = g_h_bm.load(std::memory_order_relaxed)) bm = o;
     if (const int o = g_h_bn.load(std::memory_order_relaxed)) bn = o;
     {
@@ -347,7 +350,8 @@ static int32_t run_hconv(HconvParams& p, void* stream) {
         if (imgs * p.a_ld_img * 2 > SGX_BUF_MAX) SGX_FAIL(SGX_ERR_UNSUPPORTED, "hconv: one pixel tile spans more than 2 GiB of input");
     }
     const bool flat = p.C == 8 && T > 1;
-    int kd = (!flat && p.C % 64 == 0) ? 64 : 32;
+    // 64-deep slabs (whole 128-byte lines per row) pay on the small maps with many channels only; elsewhere their LDS costs occupancy
+    int kd = (!flat && p.C % 64 == 0 && p.C >= 192 && p.M <= 51200 && !(bm == 128 && bn == 128)) ? 64 : 32;
     if (const int o = g_h_kd.load(std::memory_order_relaxed)) kd = flat ? 32 : o;
     int32_t rc;
     if (flat) rc = launch_hconv_flat(p, bm, bn > 64 ? 64 : bn, stream);
