@@ -277,13 +277,17 @@ __device__ __forceinline__ void sgx_bnreq_publish(const IgemmParams& p, int col,
 #ifndef IG_BF3_MIN_WAVES_PH2
 #define IG_BF3_MIN_WAVES_PH2 1  // (the two-source form as well: 93 registers; the two-output form would spill - three accumulators)
 #endif
-template <int BM, int BN, int WM, int WN, int MATH, int KD, int PH2>
+template <int BM, int BN, int WM, int WN, int MATH, int KD, int PH2, int NBUF>
 constexpr int igemm_min_waves() {
+    // (the pipelined two-buffer loop: three workgroups' LDS per CU; a bound >= 2 also keeps the accumulators in ordinary registers -
+    // with 512 registers on offer hipcc parks them in AGPRs and copies 32 registers in and out per slab)
+    if (NBUF == 2 && KD == 32) return (BM + BN) * 192 * 2 > 52 * 1024 ? 2 : 3;
     return (MATH == 1 && KD == 32 && PH2 <= IG_BF3_MIN_WAVES_PH2 && BM / (WM * 32) == 1 && BN / (WN * 32) == 1) ? IG_BF3_MIN_WAVES : 1;
 }
 template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0>
-__global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2>())) void igemm_kernel(IgemmParams p) {
-    static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && NBUF == 1), "32-deep slabs: channel-chunked K axis, one LDS buffer");
+__global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2, NBUF>())) void igemm_kernel(IgemmParams p) {
+    static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && NBUF == 1) || (KD == 32 && !FLAT && NBUF == 2 && MATH == 1),
+                  "32-deep slabs: channel-chunked K axis; one LDS buffer, or (bf16x3) the two-buffer pipelined loop");
     static_assert(PH2 == 0 || !FLAT, "second K-axis source: channel-chunked K axis");
     static_assert(MATH == 0 || MATH == 1, "arithmetic: 0 = fp32 matrix pipe, 1 = bf16x3");
     // (Round 4 tried MATH = 2: the five correction products of the bf16x3 scheme added into the SAME accumulator as the leading one - it
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
     }
 
     float4 ra[AJ], rb[BJ];
-    auto load_tile_to = [&](float4* ra, float4* rb) {
+    auto load_tile_to = [&](float4* ra, float4* rb, bool live = true) {  // live = false: every lane out of bounds (a branch-free "no slab left")
         if (FLAT) {
             const int kk = s_kt * IG_BK + chunk4;  // flattened (tap, c) index of this lane's chunk
             const int t = kk / p.C;
@@ -424,21 +428,20 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
             const int tbit = s_ti * Tw_ + s_tj;
             const int tapoff = s_ti * rowstep + s_tj * pixstep + s_ck * (KD * 4);
             const int woff = (tbit * p.C + s_ck * KD) * 4;
-            const bool cok = s_ck * KD + chunk4 < p.C;
+            const bool cok = live && s_ck * KD + chunk4 < p.C;
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
-                const bool ok = cok && ((amask[j] >> tbit) & 1ull);
+                const bool ok = cok && ((amask[j] >> (tbit & 63)) & 1ull);
                 ra[j] = sgx_buf_ld4(bufA, ok ? (unsigned)(aoff[j] + tapoff) : SGX_BUF_OOB);
             }
 #pragma unroll
             for (int j = 0; j < BJ; ++j) rb[j] = sgx_buf_ld4(bufB, (cok && bok[j]) ? (unsigned)(boff[j] + woff) : SGX_BUF_OOB);
-            if (++s_ck == cpt) {
-                s_ck = 0;
-                if (++s_tj == Tw_) {
-                    s_tj = 0;
-                    ++s_ti;
-                }
-            }
+            const bool wck = ++s_ck == cpt;  // (selects, not branches: the pipelined loop wants its body in one basic block)
+            s_ck = wck ? 0 : s_ck;
+            s_tj += wck ? 1 : 0;
+            const bool wtj = s_tj == Tw_;
+            s_tj = wtj ? 0 : s_tj;
+            s_ti += wtj ? 1 : 0;
         }
         ++s_kt;
     };
@@ -601,6 +604,91 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                             if (BF3) accc[BF3 ? i : 0][BF3 ? j : 0][r] = 0.f;
                         }
             }
+        }
+        if constexpr (KD == 32 && NBUF == 2) {
+            // ---- round 5: the pipelined bf16x3 loop (variant 6).  Two LDS buffers and two register stages: while the matrix pipe works on
+            // slab k out of buffer k & 1, THE SAME WAVE splits slab k + 1 (in registers since the previous iteration) and writes its planes
+            // into the other buffer, and the global loads of slab k + 2 are in flight - one barrier per slab, and the split's vector
+            // instructions / LDS stores are placed between the MFMAs (an MFMA occupies the matrix pipe for 32 cycles; the wave issues
+            // ~8 two-cycle vector instructions in its shadow) instead of in a phase of their own behind a barrier.  The store is
+            // unconditional (branch-free block): behind the last slab it writes stale registers into the buffer nobody reads again.
+            // Same products in the same order as the one-buffer loop: bit-identical results.
+            float4 ra2[AJ], rb2[BJ];
+            load_tile_to(ra, rb, nkt > 0);
+            load_tile_to(ra2, rb2, nkt > 1);
+            store_tile_from(0, ra, rb);
+            __syncthreads();
+            // One slab = 12 x TM x TN MFMA steps (two 16-deep halves x six products, the order of compute_bf3); the split of the next slab is
+            // cut into pieces of one item half (two elements: 11 vector instructions) that follow the MFMA steps one by one, an item's
+            // three 8-byte LDS stores after its second half; scheduling fences keep the pieces where they are put.
+            constexpr int NMF = 12 * TM * TN;
+            constexpr int NPC = 2 * (AJ + BJ);  // split pieces
+            auto slab = [&](int cbuf, const float4* sa, const float4* sb) {
+                uint4 fa[2][3][TM], fb[2][3][TN];  // fragments [half][hi | mid | lo]
+                auto read_frags = [&](int half) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const unsigned* q = reinterpret_cast<const unsigned*>(As) + (cbuf * 3 * BM + wm * TM * 32 + i * 32 + frow) * LDPW + swz(frow, half * 8 + (lane >> 5) * 4);
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) fa[half][pl][i] = *reinterpret_cast<const uint4*>(q + pl * BM * LDPW);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const unsigned* q = reinterpret_cast<const unsigned*>(Bs) + (cbuf * 3 * BN + wn * TN * 32 + j * 32 + frow) * LDPW + swz(frow, half * 8 + (lane >> 5) * 4);
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) fb[half][pl][j] = *reinterpret_cast<const uint4*>(q + pl * BN * LDPW);
+                    }
+                };
+                unsigned hp[AJ + BJ][2], mp[AJ + BJ][2], lp[AJ + BJ][2];
+                auto split_piece = [&](int pc) {
+                    const int it = pc >> 1, hf = pc & 1;
+                    const float4& v = it < AJ ? sa[it < AJ ? it : 0] : sb[it < AJ ? 0 : it - AJ];
+                    const float a = hf ? v.z : v.x, b = hf ? v.w : v.y;
+                    hp[it][hf] = sgx_pack_bf16(a, b);
+                    const float r0 = a - sgx_u2f(hp[it][hf] << 16), r1 = b - sgx_u2f(hp[it][hf] & 0xffff0000u);
+                    mp[it][hf] = sgx_pack_bf16(r0, r1);
+                    const float s0 = r0 - sgx_u2f(mp[it][hf] << 16), s1 = r1 - sgx_u2f(mp[it][hf] & 0xffff0000u);
+                    lp[it][hf] = sgx_pack_bf16(s0, s1);
+                    if (hf) {
+                        const bool isa = it < AJ;
+                        const int row = lrow + RPP * (isa ? it : it - AJ);
+                        const int rows = isa ? BM : BN;
+                        if ((isa ? BM % RPP == 0 : BN % RPP == 0) || row < rows) {
+                            unsigned* d = reinterpret_cast<unsigned*>(isa ? As : Bs) + ((cbuf ^ 1) * 3 * rows + row) * LDPW + swz(row, chunk4 >> 1);
+                            *reinterpret_cast<uint2*>(d) = make_uint2(hp[it][0], hp[it][1]);
+                            *reinterpret_cast<uint2*>(d + rows * LDPW) = make_uint2(mp[it][0], mp[it][1]);
+                            *reinterpret_cast<uint2*>(d + 2 * rows * LDPW) = make_uint2(lp[it][0], lp[it][1]);
+                        }
+                    }
+                };
+                read_frags(0);
+                read_frags(1);
+                sgx_sched_fence();
+                int pc = 0;
+#pragma unroll
+                for (int st = 0; st < NMF; ++st) {
+                    const int half = st / (6 * TM * TN), pr = (st / (TM * TN)) % 6, i = (st / TN) % TM, j = st % TN;
+                    // products in compute_bf3's order: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid -> corrections; hi*hi -> leading
+                    const int pa = pr == 0 ? 2 : (pr == 2 || pr == 3) ? 1 : 0, pb = pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
+                    if (pr == 5) acc[i][j] = sgx_mfma_bf16(fa[half][0][i], fb[half][0][j], acc[i][j]);
+                    else accc[BF3 ? i : 0][BF3 ? j : 0] = sgx_mfma_bf16(fa[half][pa][i], fb[half][pb][j], accc[BF3 ? i : 0][BF3 ? j : 0]);
+#pragma unroll
+                    for (; pc < ((st + 1) * NPC + NMF - 1) / NMF && pc < NPC; ++pc) split_piece(pc);
+                    sgx_sched_fence();
+                }
+            };
+            // (Straight-line body, two slabs per trip: the loads are issued unconditionally - out of bounds, i.e. zeros, behind the last slab -
+            // and an odd slab count is rounded up with one all-zero slab (x + 0: the results stay bit-identical), so that the loop is ONE
+            // basic block and the compiler's vmcnt waits are exact: each split waits for the OLDER register set only.)
+            for (int kt = 0; kt < nkt; kt += 2) {
+                load_tile_to(ra, rb, kt + 2 < nkt);
+                slab(0, ra2, rb2);
+                __syncthreads();
+                load_tile_to(ra2, rb2, kt + 3 < nkt);
+                slab(1, ra, rb);
+                __syncthreads();
+            }
+            continue;
         }
         if (nkt > 0) {
             load_tile();
@@ -1388,7 +1476,7 @@ extern "C" int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n) {
                               (e[9] == 0) == (e[10] == 0),  // all 16 tiles of {32, 64, 96, 128}^2 are instantiated
                           "conv_tuning_load: entry %d: no weight-gradient kernel (tile %dx%d, split target %d)", i, e[9], e[10], e[11]);
         else
-            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && (e[11] == 0 || e[11] == 7),
+            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && (e[11] == 0 || e[11] == 6 || e[11] == 7),
                           "conv_tuning_load: entry %d: no kernel (tile %dx%d, variant %d)", i, e[9], e[10], e[11]);
         m[std::array<int, 9>{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8]}] = TuneVal{e[9], e[10], e[11]};
     }
@@ -1572,7 +1660,12 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
         else if (flat && bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, true, 1>(p, stream);
         else if (flat && bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true, 1>(p, stream);
         else if (flat) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (bf16x3): no flat tile %dx%d", bm, bn);
-        else if (igemm_deep_slabs(p)) SGX_IGEMM_TILES(1, 32, 1, 0);
+        else if (igemm_deep_slabs(p) && conv_variant() == 6 && bm * bn <= 128 * 32) {
+            // the pipelined loop (two LDS buffers: tiles whose two slabs fit 64 KB)
+            if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 1, 32, 2, 0>(p, stream);
+            else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 1, 32, 2, 0>(p, stream);
+            else launch_igemm<64, 32, 2, 1, false, 1, 32, 2, 0>(p, stream);
+        } else if (igemm_deep_slabs(p)) SGX_IGEMM_TILES(1, 32, 1, 0);
         else SGX_IGEMM_TILES(1, 16, 2, 0);
     } else if (flat) {
         if (bn > 64) bn = 64;  // the flat variants exist for the narrow tiles only (stem layers have few output channels)

@@ -128,7 +128,11 @@ static inline void sgx_st4_dev(float* p, float4 v) { *reinterpret_cast<float4*>(
 static inline float4 sgx_ld4_dev(const float* p) { return *reinterpret_cast<const float4*>(p); }
 #define sgx_wait_stores() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define sgx_sched_fence() ((void)0)
+#define SGX_SCHED_GROUP(mask, n) ((void)0)
 #else
+// "the next `n` instructions of class `mask` (0x8 MFMA, 0x2 vector ALU, 0x100 / 0x200 LDS read / write, 0x20 vector-memory read) come here":
+// a sequence of these lays out the instruction mix of a basic block - how the pipelined GEMM loop gets its split between its MFMAs
+#define SGX_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 // no instruction moves across this point in the scheduler: bounds how many independent loads an unrolled loop keeps in flight (and with
 // them the registers a kernel's tail claims for the WHOLE kernel: the allocation of a kernel is its hungriest region's)
 #define sgx_sched_fence() __builtin_amdgcn_sched_barrier(0)

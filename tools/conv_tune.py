@@ -104,6 +104,16 @@ def main():
                     note(key, calls, (bm, bn, 7), t)
                     if t < best:
                         best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + " variant=7"
+            # the pipelined bf16x3 loop (variant 6, round 5: two LDS buffers, two register stages, the split of slab k + 1 between the MFMAs of
+            # slab k) exists for the 64x64 / 128x32 / 64x32 tiles; on a problem that does not run the bf16x3 32-deep loop it is the default kernel
+            lib().sgx_debug_set_variant(6)
+            for bm, bn in ((0, 0), (64, 64), (128, 32), (64, 32)):
+                lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                K.clear_desc_cache()
+                t = timeit(fn)
+                note(key, calls, (bm, bn, 6), t)
+                if t < best:
+                    best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + " variant=6"
             lib().sgx_debug_set_variant(0)
         elif args.wgrad:
             note(key, calls, (0, 0, 0), base)
