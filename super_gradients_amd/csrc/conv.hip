@@ -664,18 +664,35 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                 read_frags(0);
                 read_frags(1);
                 sgx_sched_fence();
+                // MFMA order = compute_bf3's (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid -> corrections; hi*hi -> leading).  The five correction
+                // products of a half chain into one accumulator and must stay back to back: two MFMAs on the same accumulator run on a
+                // forwarding path, and ONE vector instruction between them costs ~43 cycles (MI355X_MICROARCH.md; r5c: the first form of
+                // this loop - a split piece after every MFMA - was 7 % slower than the one-buffer loop on the deep problems).  So the split
+                // pieces come in two groups, each AHEAD of a half's six MFMAs: they issue while the previous half's chain is still in the
+                // matrix pipe, their LDS stores have long landed when the barrier comes, and the wave reaches the barrier with its last
+                // MFMAs still executing.  SGX_PIN2 ties a register of each side into an empty volatile asm - the only ordering the
+                // optimiser honours for pure instructions (scheduling fences alone do not hold IR-level code motion).
                 int pc = 0;
 #pragma unroll
-                for (int st = 0; st < NMF; ++st) {
-                    const int half = st / (6 * TM * TN), pr = (st / (TM * TN)) % 6, i = (st / TN) % TM, j = st % TN;
-                    // products in compute_bf3's order: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid -> corrections; hi*hi -> leading
-                    const int pa = pr == 0 ? 2 : (pr == 2 || pr == 3) ? 1 : 0, pb = pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
-                    if (pr == 5) acc[i][j] = sgx_mfma_bf16(fa[half][0][i], fb[half][0][j], acc[i][j]);
-                    else accc[BF3 ? i : 0][BF3 ? j : 0] = sgx_mfma_bf16(fa[half][pa][i], fb[half][pb][j], accc[BF3 ? i : 0][BF3 ? j : 0]);
+                for (int half = 0; half < 2; ++half) {
+                    static_assert(TM == 1 && TN == 1, "the pipelined loop is laid out for one 32x32 block per wave");
+                    sgx_f32x16& cc = accc[0][0];
+                    SGX_PIN2(acc[0][0], cc);
+                    sgx_sched_fence();
 #pragma unroll
-                    for (; pc < ((st + 1) * NPC + NMF - 1) / NMF && pc < NPC; ++pc) split_piece(pc);
+                    for (; pc < (half + 1) * NPC / 2; ++pc) split_piece(pc);
+                    sgx_sched_fence();
+                    SGX_PIN2(acc[0][0], cc);
+                    cc = sgx_mfma_bf16(fa[half][2][0], fb[half][0][0], cc);
+                    cc = sgx_mfma_bf16(fa[half][0][0], fb[half][2][0], cc);
+                    cc = sgx_mfma_bf16(fa[half][1][0], fb[half][1][0], cc);
+                    cc = sgx_mfma_bf16(fa[half][1][0], fb[half][0][0], cc);
+                    cc = sgx_mfma_bf16(fa[half][0][0], fb[half][1][0], cc);
+                    acc[0][0] = sgx_mfma_bf16(fa[half][0][0], fb[half][0][0], acc[0][0]);
+                    SGX_PIN2(acc[0][0], cc);
                     sgx_sched_fence();
                 }
+                SGX_PIN2(acc[0][0], accc[0][0]);  // (the second chain stays ahead of the barrier and of the next trip's address arithmetic)
             };
             // (Straight-line body, two slabs per trip: the loads are issued unconditionally - out of bounds, i.e. zeros, behind the last slab -
             // and an odd slab count is rounded up with one all-zero slab (x + 0: the results stay bit-identical), so that the loop is ONE

@@ -129,7 +129,11 @@ static inline float4 sgx_ld4_dev(const float* p) { return *reinterpret_cast<cons
 #define sgx_wait_stores() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define sgx_sched_fence() ((void)0)
 #define SGX_SCHED_GROUP(mask, n) ((void)0)
+#define SGX_PIN2(a, b) ((void)0)
 #else
+// an ordering point for two register values: what produces them stays above, what consumes them below (an empty volatile asm statement;
+// volatile asm statements and scheduling fences keep their mutual order)
+#define SGX_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 // "the next `n` instructions of class `mask` (0x8 MFMA, 0x2 vector ALU, 0x100 / 0x200 LDS read / write, 0x20 vector-memory read) come here":
 // a sequence of these lays out the instruction mix of a basic block - how the pipelined GEMM loop gets its split between its MFMAs
 #define SGX_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
