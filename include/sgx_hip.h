@@ -229,6 +229,8 @@ int32_t sgx_debug_set_wgrad_patch(int32_t item_mflop, int32_t kb, int32_t min_fi
 /* Measurement aid: the reduction depth (taps x channels) from which conv math modes 2 / 4 / 5 run a problem in bf16x3 arithmetic
  * (0 = the default, 192).                                                                                                      */
 int32_t sgx_debug_set_bf3_min_depth(int32_t depth);
+/* measurement switch (round 5): the patch conv kernel's 32-filter tiles request the next tap's fragments ahead of this tap's MFMAs (1, default) or not (0) */
+int32_t sgx_debug_set_pconv_pipe(int32_t on);
 /* LDS (KB per CU, 0..120; 0 = off) the weight-gradient kernels leave free for kernels of other streams: their launches then request
  * dynamic LDS on top of their static allocation so that fewer of their workgroups fit a CU.  The weight gradients run on a side stream
  * under the backward pass; four of their workgroups hold 150 of a CU's 160 KB, and a data-gradient workgroup of the main stream (the

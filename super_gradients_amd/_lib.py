@@ -126,6 +126,7 @@ PROTOTYPES = {
     "sgx_conv_get_wgrad_math": (_i32, []),
     "sgx_debug_set_wgrad_patch": (_i32, [_i32] * 3),
     "sgx_debug_set_bf3_min_depth": (_i32, [_i32]),
+    "sgx_debug_set_pconv_pipe": (_i32, [_i32]),
     "sgx_conv_set_wgrad_lds_reserve": (_i32, [_i32]),
     "sgx_conv_get_wgrad_lds_reserve": (_i32, []),
     "sgx_stream_create_partial": (_i32, [_i32, ctypes.POINTER(ctypes.c_void_p)]),
@@ -244,6 +245,8 @@ def lib():
             _LIB.sgx_conv_set_wgrad_math(WGRAD_MATH[wgm])
         if os.environ.get("SGX_BF3_MIN_DEPTH"):  # measurement: depth (taps x channels) from which a problem runs in bf16x3 arithmetic
             _LIB.sgx_debug_set_bf3_min_depth(int(os.environ["SGX_BF3_MIN_DEPTH"]))
+        if os.environ.get("SGX_PCONV_PIPE"):  # measurement: second fragment set for the patch kernel's 32-filter tiles
+            _LIB.sgx_debug_set_pconv_pipe(int(os.environ["SGX_PCONV_PIPE"]))
         if os.environ.get("SGX_WGRAD_LDS_RESERVE"):  # KB of every CU's LDS the weight-gradient kernels leave to the main stream
             _LIB.sgx_conv_set_wgrad_lds_reserve(int(os.environ["SGX_WGRAD_LDS_RESERVE"]))
         if os.environ.get("SGX_WGRAD_PATCH"):  # measurement: "item_mflop,kb,min_fill_pct"

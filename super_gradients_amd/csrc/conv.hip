@@ -388,7 +388,10 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
         s_ti = s_tj = s_ck = s_kt = 0;
     };
     setup_src(p.A, p.Wt, p.Hin, p.Win, p.Th, p.Tw, p.dh0, p.dw0, p.dstep, p.a_ld_pix, p.a_ld_img, p.w_ld_n, p.a_bytes, p.w_bytes);
-    if (tid < BM) {
+    // output-row offsets: needed by the epilogue only - computed AFTER the first slab's loads are in flight (64-bit divisions and
+    // multiplies that used to sit between the kernel's start and its first global load); the K loop's barriers publish them
+    auto compute_rowoff = [&]() {
+      if (tid < BM) {
         const int m = m0 + tid;
         long long off = -1;
         if (m < p.M) {
@@ -405,7 +408,8 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
             }
         }
         rowoff[tid] = off;
-    }
+      }
+    };
 
     float4 ra[AJ], rb[BJ];
     auto load_tile_to = [&](float4* ra, float4* rb, bool live = true) {  // live = false: every lane out of bounds (a branch-free "no slab left")
@@ -616,6 +620,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
             float4 ra2[AJ], rb2[BJ];
             load_tile_to(ra, rb, nkt > 0);
             load_tile_to(ra2, rb2, nkt > 1);
+            if (src == 0) compute_rowoff();
             store_tile_from(0, ra, rb);
             __syncthreads();
             // One slab = 12 x TM x TN MFMA steps (two 16-deep halves x six products, the order of compute_bf3); the split of the next slab is
@@ -707,10 +712,9 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
             }
             continue;
         }
-        if (nkt > 0) {
-            load_tile();
-            store_tile(0);
-        }
+        if (nkt > 0) load_tile();
+        if (src == 0) compute_rowoff();
+        if (nkt > 0) store_tile(0);
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
             if (KD == 32) {
@@ -782,7 +786,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = o == 0 ? acc2[ACC2 ? i : 0][ACC2 ? j : 0][r] : acc[i][j][r];
-                    __syncthreads();
+                    sgx_wave_lds_sync();  // the staging patch is private to the wave
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int rowl = q * 8 + sr;
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                             sgx_st4((o == 0 ? p.Y : p.Y2) + off + col, v);
                         }
                     }
-                    __syncthreads();
+                    sgx_wave_lds_sync();  // the staging patch is private to the wave
                 }
             }
         }
@@ -846,7 +850,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][r];
-            __syncthreads();
+            sgx_wave_lds_sync();  // the staging patch is private to the wave
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int rowl = q * 8 + sr;
@@ -894,7 +898,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                     }
                 }
             }
-            __syncthreads();
+            sgx_wave_lds_sync();  // the staging patch is private to the wave
         }
         if (p.stat_partials || bnr) {
             // the 8 lanes with equal (lane & 7) hold the same 4 columns: fold them, lanes 0-7 publish
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
 #define PC_NPIX ((PC_TH + 2) * PC_PW)  // 180 patch pixels
 #define PC_KC 16                       // channels per chunk
 template <int BN, int WM, int WN, int PH2, bool FPIPE = true>
-__global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(IgemmParams p) {
     static_assert(4 % WM == 0, "WM divides the four 32-row sub-tiles");
     constexpr int NTH = WM * WN * 64;
     constexpr int BM = PC_TH * PC_TW;           // 128 output pixels = 4 sub-tiles of 32 MFMA rows
@@ -1006,7 +1010,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
     auto swz = [](int q, int row) { return q ^ ((row >> 3) & 1); };  // which 16-byte half of a 32-byte row holds k-half q
 
     // output rows: MFMA row r of sub-tile s <-> pixel (oy0 + ty, ox0 + tx), ty = 2 s + (r >> 4), tx = (r - 2 ty) & 15
-    if (tid < BM) {
+    // (epilogue data: computed once the first chunk's loads are in flight, published by the chunk loop's barriers)
+    auto compute_rowoff = [&]() {
+      if (tid < BM) {
         const int s = tid >> 5, r = tid & 31;
         const int ty = 2 * s + (r >> 4), tx = (r - 2 * ty) & 15;
         const int a = oy0 + ty, b = ox0 + tx;
@@ -1021,7 +1027,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
             }
         }
         rowoff[tid] = off;
-    }
+      }
+    };
 
     // ---- source state ------------------------------------------------------------------------------------------------------------
     sgx_buf bufA, bufB, bufB2;
@@ -1170,7 +1177,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
     };
     // patch offset of tap t: input pixel (a + dh0 + dstep * ti, b + dw0 + dstep * tj), patch origin (oy0 - 1, ox0 - 1)
     auto tap_off = [&](int t) {
-        const int ti = t / taps_w, tj = t - ti * taps_w;
+        // (t / taps_w without the scalar unit's 25-instruction division sequence per tap: taps_w is 1, 2 or 3 and t < 9)
+        const int ti = taps_w == 3 ? (t * 11) >> 5 : taps_w == 2 ? t >> 1 : t, tj = t - ti * taps_w;
         return (dh0_ + dstep_ * ti + 1) * PC_PW + dw0_ + dstep_ * tj + 1;
     };
 
@@ -1182,6 +1190,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
             setup_src(p.A2, p.Wt2, p.Hin2, p.Win2, p.Th2, p.Tw2, p.dh02, p.dw02, p.dstep2, p.a2_ld_pix, p.a2_ld_img, p.w2_ld_n, p.a2_bytes, p.w2_bytes);
         }
         load_chunk(0);
+        if (src == 0) compute_rowoff();
         for (int chunk = 0; chunk < cpt; ++chunk) {
             // every wave is past its last fragment read of the previous chunk (barrier below); this chunk has been travelling in registers
             store_chunk();
@@ -1269,7 +1278,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = o == 0 ? acc[i][j][r] : accu[DUAL ? i : 0][DUAL ? j : 0][r];
-                    __syncthreads();
+                    sgx_wave_lds_sync();  // the staging patch is private to the wave
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int rowl = q * 8 + sr;
@@ -1282,7 +1291,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
                             sgx_st4((o == 0 ? p.Y : p.Y2) + off + col, v);
                         }
                     }
-                    __syncthreads();
+                    sgx_wave_lds_sync();  // the staging patch is private to the wave
                 }
             }
         }
@@ -1317,7 +1326,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][r];
-            __syncthreads();
+            sgx_wave_lds_sync();  // the staging patch is private to the wave
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int rowl = q * 8 + sr;
@@ -1348,7 +1357,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(IgemmParams p) {
                     sgx_st4(yp, make_float4(sgx_act(v.x, p.act), sgx_act(v.y, p.act), sgx_act(v.z, p.act), sgx_act(v.w, p.act)));
                 }
             }
-            __syncthreads();
+            sgx_wave_lds_sync();  // the staging patch is private to the wave
         }
         if (p.stat_partials || bnr) {
             float vals[8] = {cs.x, cs.y, cs.z, cs.w, cq.x, cq.y, cq.z, cq.w};
@@ -1593,12 +1602,19 @@ static bool pconv_ok(const IgemmParams& p, int ph2) {
     if ((long)p.Hin * p.Win * p.a_ld_pix * 4 > SGX_BUF_MAX) return false;
     return true;
 }
+static std::atomic<int> g_pconv_pipe32{1};  // r5f: 716.0 -> 718.8 images/s (twice each, same box)
+extern "C" int32_t sgx_debug_set_pconv_pipe(int32_t on) {  // measurement switch, see launch_pconv
+    g_pconv_pipe32 = on ? 1 : 0;
+    return SGX_OK;
+}
 template <int BN, int WM, int WN, int PH2>
 static void launch_pconv(IgemmParams& p, void* stream) {
     // two fragment sets where they do not cost a wave of occupancy (r3f lab: the 64-filter tile gains 4-6 %, the 32-filter tiles - three
     // workgroups per CU with one set, two with two - lose 5-15 %); measurement: variant 8 = never, 9 = always
+    // (round 5: the 32-filter tiles of the one- / two-source forms take the second fragment set as well - under their launch bound of three
+    // waves per SIMD they fit it without spilling, 137 / 165 registers; the two-output form does not.  sgx_debug_set_pconv_pipe(0): off)
     const int var = conv_variant();
-    const bool fpipe = var == 9 || (var != 8 && BN == 64);
+    const bool fpipe = var == 9 || (var != 8 && (BN == 64 || (PH2 != 2 && g_pconv_pipe32.load(std::memory_order_relaxed))));
     p.mt = pconv_tiles(p.M / (p.Ha * p.Wa), p.Ha, p.Wa);
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;

@@ -130,7 +130,17 @@ static inline float4 sgx_ld4_dev(const float* p) { return *reinterpret_cast<cons
 #define sgx_sched_fence() ((void)0)
 #define SGX_SCHED_GROUP(mask, n) ((void)0)
 #define SGX_PIN2(a, b) ((void)0)
+#define sgx_wave_lds_sync() __syncthreads()  // (the emulation's lanes are OS threads: a workgroup barrier, reached by every thread alike)
 #else
+// LDS hand-over between the lanes of ONE wave (a patch only this wave touches): a wave's LDS instructions execute in order, so the
+// stores of all its lanes precede its later loads - only the compiler must keep them in program order and wait for the store counter.
+// No workgroup barrier: in the conv epilogues every 32x32 block used to cost the whole workgroup two of them.
+#define sgx_wave_lds_sync()                                \
+    do {                                                   \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                   \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
 // an ordering point for two register values: what produces them stays above, what consumes them below (an empty volatile asm statement;
 // volatile asm statements and scheduling fences keep their mutual order)
 #define SGX_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))

@@ -49,6 +49,14 @@ __global__ __launch_bounds__(192 * KB, 3) void wpatch_kernel(WpGroupParams g) {
     constexpr int TAPW = WP_TAPS / WT;  // taps per wave
     constexpr int XPL = PRin * PSLOTS * CTP, DPL = PIX * DP;  // elements per plane
     constexpr int XG = CT / 4, DG = BNK / 4;                 // 16-byte groups per pixel
+    // Staging enumeration of the patch.  One 16-lane store group covers two consecutive staging pixels; their de-interleaved stride-2 slots
+    // must lie on disjoint halves of the 32 store banks: an (even, odd) column pair does (slots PCH - odd - pixel rows of 16 banks apart), an
+    // (odd, even) pair does not (slots ONE row apart: the same 16 banks).  The patch is an odd number of columns wide, so a plain row-major
+    // enumeration pairs (odd, even) columns in every second patch row - a two-way conflict on half of the patch stores (r4final counters:
+    // 15.8 % of the stride-2 forms' LDS cycles).  Odd patch rows are therefore enumerated rotated by one column (one (even, even) pair
+    // per two rows is left).  (Padding the rows to an even width instead cost the 16-column form an eighth staging item per lane: its
+    // launches 0.50 -> 0.66 ms, r5e.)
+    static_assert(S == 1 || (PCH & 1) == 1, "stride 2: an odd half-width keeps (even, odd) column pairs on disjoint bank halves");
     constexpr int NXE = PRin * PCin * XG, NDE = PIX * DG;    // staging items of a tile
     constexpr int NXI = (NXE + NTH - 1) / NTH, NDI = (NDE + NTH - 1) / NTH;
     static_assert(PC == 16 || PC == 8 || PC == 4, "tile columns");
@@ -93,7 +101,8 @@ __global__ __launch_bounds__(192 * KB, 3) void wpatch_kernel(WpGroupParams g) {
     for (int i = 0; i < NXI; ++i) {
         const int e = tid + i * NTH;
         const int pix = e / XG, cg = e - pix * XG;
-        const int pr = pix / PCin, pc = pix - pr * PCin;
+        const int pr = pix / PCin, pj = pix - pr * PCin;
+        const int pc = S == 2 ? (pj + (pr & 1)) % PCin : pj;
         const bool ok = e < NXE && c0 + 4 * cg < C;
         xdelta[i] = (int)((((long)pr * W + pc) * p.x_ld_pix + 4 * cg) * 4);
         const int slot = S == 1 ? pc : (pc & 1) * PCH + (pc >> 1);
