@@ -169,6 +169,10 @@ struct IgemmParams {
     int act, accumulate;
     int vec;                  // 1: Nout, output strides and pointers allow 16-byte epilogue accesses
     int mt, nt, nblk, chunk;  // tile counts and XCD chunk
+    // divisions by launch constants as multiply-high + shift (sgx_fastdiv, filled by the launch helpers): nt, Ha * Wa, Wa, and the patch
+    // kernel's tiles per image / per tile row - a 32-bit division is a ~40-instruction sequence, and the prologue ahead of a workgroup's
+    // first global load held ten of them
+    sgx_fastdiv fd_nt, fd_hw, fd_wa, fd_txy, fd_tx;
     int stat_nblk;
     // second addend with its own strides and a scale (host value x optional device scalar): the residual branch of a YOLO-NAS bottleneck,
     // dx += alpha * dz, folded into the data gradient of its first block instead of an axpy pass + an accumulate pass over dx
@@ -328,13 +332,13 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
     const int bid = blockIdx.x;
     const int lin = (bid & 7) * p.chunk + (bid >> 3);
     if (lin >= p.nblk) return;  // whole workgroup leaves together (before any barrier)
-    const int mtile = lin / p.nt, ntile = lin - mtile * p.nt;
+    const int mtile = sgx_fdiv(lin, p.fd_nt), ntile = lin - mtile * p.nt;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int hw = p.Ha * p.Wa;
     const int T = p.Th * p.Tw;
 
     // ---- K-axis source state: (re)initialised by setup_src() for the primary source and, with PH2, for the second one -----------
-    const int img0 = m0 / hw;
+    const int img0 = sgx_fdiv(m0, p.fd_hw);
     const int lrow = tid / CPR, chunk4 = (tid % CPR) * 4;
     sgx_buf bufA, bufB;
     int aoff[AJ], boff[BJ];
@@ -356,9 +360,9 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
             aoff[j] = 0;
             amask[j] = 0ull;
             if (row < BM && m < p.M) {
-                const int img = m / hw;
+                const int img = sgx_fdiv(m, p.fd_hw);
                 const int rem = m - img * hw;
-                const int a = rem / p.Wa;
+                const int a = sgx_fdiv(rem, p.fd_wa);
                 const int b = rem - a * p.Wa;
                 const int hi0 = a * p.si + dh0, wi0 = b * p.si + dw0;
                 aoff[j] = (int)(((long)(img - img0) * a_ld_img + ((long)hi0 * Win + wi0) * a_ld_pix + (FLAT ? 0 : chunk4)) * 4);
@@ -395,9 +399,9 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
         const int m = m0 + tid;
         long long off = -1;
         if (m < p.M) {
-            const int img = m / hw;
+            const int img = sgx_fdiv(m, p.fd_hw);
             const int rem = m - img * hw;
-            const int a = rem / p.Wa;
+            const int a = sgx_fdiv(rem, p.fd_wa);
             const int b = rem - a * p.Wa;
             off = (long long)img * p.y_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.y_ld_pix;
             if (PH2 == 1 && p.addend2) rowoff2[tid] = (long long)img * p.a2d_ld_img + ((long long)(a * p.so + p.ph) * p.Wout + (b * p.so + p.pw)) * p.a2d_ld_pix;
@@ -1000,12 +1004,13 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
     const int bid = blockIdx.x;
     const int lin = (bid & 7) * p.chunk + (bid >> 3);
     if (lin >= p.nblk) return;
-    const int mtile = lin / p.nt, ntile = lin - mtile * p.nt;
+    const int mtile = sgx_fdiv(lin, p.fd_nt), ntile = lin - mtile * p.nt;
     const int n0 = ntile * BN;
     const int tiles_x = (p.Wa + PC_TW - 1) / PC_TW, tiles_y = (p.Ha + PC_TH - 1) / PC_TH;
-    const int img = mtile / (tiles_x * tiles_y);
+    const int img = sgx_fdiv(mtile, p.fd_txy);
     const int trem = mtile - img * (tiles_x * tiles_y);
-    const int oy0 = (trem / tiles_x) * PC_TH, ox0 = (trem % tiles_x) * PC_TW;
+    const int trow = sgx_fdiv(trem, p.fd_tx);
+    const int oy0 = trow * PC_TH, ox0 = (trem - trow * tiles_x) * PC_TW;
     const int cpt = p.C / KC;
     auto swz = [](int q, int row) { return q ^ ((row >> 3) & 1); };  // which 16-byte half of a 32-byte row holds k-half q
 
@@ -1574,6 +1579,9 @@ static void launch_igemm(IgemmParams& p, void* stream) {
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
     p.chunk = sgx_cdiv(p.nblk, 8);
+    p.fd_nt = sgx_make_fastdiv(p.nt);
+    p.fd_hw = sgx_make_fastdiv(p.Ha * p.Wa);
+    p.fd_wa = sgx_make_fastdiv(p.Wa);
     int grid = p.chunk * 8;
     SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF, PH2>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
 }
@@ -1619,6 +1627,9 @@ static void launch_pconv(IgemmParams& p, void* stream) {
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
     p.chunk = sgx_cdiv(p.nblk, 8);
+    p.fd_nt = sgx_make_fastdiv(p.nt);
+    p.fd_txy = sgx_make_fastdiv(sgx_cdiv(p.Wa, PC_TW) * sgx_cdiv(p.Ha, PC_TH));
+    p.fd_tx = sgx_make_fastdiv(sgx_cdiv(p.Wa, PC_TW));
     p.stat_nblk = p.mt;
     if (fpipe) SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, true>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
     else SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, false>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);

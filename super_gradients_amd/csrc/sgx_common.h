@@ -49,6 +49,28 @@ void sgx_set_error(const char* fmt, ...);
 
 static inline int sgx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// n / d for 0 <= n < 2^31 and a launch-constant d >= 1 as one multiply-high, one shift and one masked add - branch-free:
+// p = 31 + ceil(log2 d), mul = ceil(2^p / d) < 2^32, n / d = (n * mul) >> p; d = 1 (p would be 31): mul = 0 and the mask passes n through.
+// Host side fills the triple, device side applies it.
+struct sgx_fastdiv {
+    unsigned mul, shr, one;
+};
+static inline sgx_fastdiv sgx_make_fastdiv(int d) {
+    sgx_fastdiv f = {0u, 0u, 0xffffffffu};
+    if (d > 1) {
+        int lg = 0;
+        while ((1L << lg) < d) ++lg;  // ceil(log2 d)
+        const unsigned p = 31u + (unsigned)lg;
+        f.mul = (unsigned)((((unsigned long long)1 << p) + (unsigned)d - 1u) / (unsigned)d);
+        f.shr = p - 32u;
+        f.one = 0u;
+    }
+    return f;
+}
+__device__ __forceinline__ int sgx_fdiv(int n, const sgx_fastdiv& f) {
+    return (int)(((unsigned)(((unsigned long long)(unsigned)n * f.mul) >> 32) >> f.shr) + ((unsigned)n & f.one));
+}
+
 // activation codes shared by host and device
 #define SGX_ACT_NONE 0
 #define SGX_ACT_RELU 1
