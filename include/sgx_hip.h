@@ -518,6 +518,9 @@ typedef struct sgx_nms_desc {
 /* Measurement aid: 0 keeps the suppression stage inside the per-image kernel (the round-2 form); default 1 = the bit matrix is built by
  * a chip-wide launch and walked by one wave per image (top-k <= 1024, with a workspace).  Same rows either way.                       */
 int32_t sgx_debug_set_nms_split(int32_t on);
+/* Candidate selection of the multi-label path: 1 (default) = one pass over the scores behind a threshold estimated from a 1/32 sample (exact:
+ * stage 2 falls back to streaming an image whose list came out short or overflowed), 0 = the exact three-pass histogram selection. */
+int32_t sgx_debug_set_nms_selection(int32_t sampled);
 int64_t sgx_nms_workspace(const sgx_nms_desc* d);
 int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const float* scores, float* out, int32_t* out_count,
                 int32_t* out_index, int32_t* num_candidates, void* ws, int64_t ws_bytes, void* stream);

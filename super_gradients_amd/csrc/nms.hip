@@ -26,6 +26,10 @@
 #define NMS_HBINS 2048
 #define NMS_LIST_CAP 8192    // per-image candidate list of stage 1 (top k <= 4096 + boundary-bin slack)
 #define NMS_S1_THREADS 256
+// per-image counters of stage 1 (word 0: keys appended to the list, word 1: candidates above the score threshold), ONE 128-byte line per
+// image: every workgroup of a selection pass ends with an atomic on them, and atomics on 32 counters packed into one line serialise
+// through one L2 channel (r5k: 2 x 1344 of them cost the one-pass kernel 15 of its 30 us)
+#define NMS_CTR_INTS 32
 
 typedef unsigned long long u64;
 #include <atomic>
@@ -42,7 +46,7 @@ extern "C" int32_t sgx_debug_set_nms_split(int32_t on) {
 #define NMS_CAND_BYTES (NMS_SPLIT_K * (8 + 16 + 16 + 4 + 4) + 64)
 #define NMS_MASK_WORDS_1024 8704
 #define NMS_SPLIT_BYTES (NMS_CAND_BYTES + NMS_MASK_WORDS_1024 * 8)
-static int64_t nms_ws_head(const sgx_nms_desc* d) { return (((int64_t)d->B * (2 * NMS_HBINS + 2) * 4 + 255) & ~255L) + (int64_t)d->B * NMS_LIST_CAP * 8; }
+static int64_t nms_ws_head(const sgx_nms_desc* d) { return (((int64_t)d->B * (2 * NMS_HBINS + NMS_CTR_INTS) * 4 + 255) & ~255L) + (int64_t)d->B * NMS_LIST_CAP * 8; }
 extern "C" int64_t sgx_nms_workspace(const sgx_nms_desc* d) {
     if (!d || !d->multi_label) return 256;
     return nms_ws_head(d) + 256 + (int64_t)d->B * NMS_SPLIT_BYTES;
@@ -128,9 +132,9 @@ __global__ __launch_bounds__(NMS_S1_THREADS) void nms_select_kernel(sgx_nms_desc
     const float* sc = scores + (long)b * E;
     int* hist1 = ws + (long)b * NMS_HBINS;
     int* hist2 = ws + ((long)d.B + b) * NMS_HBINS;
-    int* list_count = ws + 2L * d.B * NMS_HBINS + b;
-    int* total = ws + 2L * d.B * NMS_HBINS + d.B + b;
-    u64* list = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + (((long)d.B * (2 * NMS_HBINS + 2) * 4 + 255) & ~255L)) + (long)b * NMS_LIST_CAP;
+    int* list_count = ws + 2L * d.B * NMS_HBINS + (long)b * NMS_CTR_INTS;
+    int* total = ws + 2L * d.B * NMS_HBINS + (long)b * NMS_CTR_INTS + 1;
+    u64* list = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + (((long)d.B * (2 * NMS_HBINS + NMS_CTR_INTS) * 4 + 255) & ~255L)) + (long)b * NMS_LIST_CAP;
     const int K = d.nms_top_k;
     int b1 = 0, above1 = 0, b2 = 0, above2 = 0, tot1 = 0, tot2 = 0;
     if (PASS >= 1) nms_kth_from_top<NMS_S1_THREADS>(hist1, NMS_HBINS, K, part, b1, above1, tot1);
@@ -187,6 +191,158 @@ __global__ __launch_bounds__(NMS_S1_THREADS) void nms_select_kernel(sgx_nms_desc
     }
 }
 
+// ---- stage 1, round 5: ONE pass over the scores behind a sampled threshold --------------------------------------------------------------
+// The three passes above read the 86 MB of scores three times to find the k-th largest key EXACTLY before a single key is selected.
+// Stage 2 does not need that: any superset of the top k that fits its list is as good (it selects / sorts exactly).  So a threshold is
+// first ESTIMATED from a sample: one 128-byte line out of every NMS_SAMPLE_STEP (1/32 of the scores, whole lines: 2.7 MB per batch), per
+// image the r-th largest sampled key, r = k / 10 - the threshold's true rank is then about 32 r = 3.2 k with a spread of 32 sqrt(r)
+// (k = 1000: 3200 +- 320), i.e. at least k and at most the list's 8192 entries by a wide margin; its two histogram levels resolve the top
+// 22 bits of the key, like the exact selection's.  Then ONE pass appends every key at or above the threshold and counts the candidates.
+// Exactness does not rest on the estimate: stage 2 takes the list only if it holds at least min(k, candidates) keys and did not
+// overflow - otherwise (adversarial inputs: the sample missing the top of the distribution) it streams the image's raw scores itself,
+// the path a caller without a workspace always gets.  Same rows bit for bit either way (tests: every test_nms* under both selections).
+#define NMS_SAMPLE_STEP 32
+static std::atomic<int> g_nms_sampled{1};
+extern "C" int32_t sgx_debug_set_nms_selection(int32_t sampled) {  // measurement / tests: 0 = the exact three-pass selection
+    g_nms_sampled = sampled ? 1 : 0;
+    return SGX_OK;
+}
+__global__ __launch_bounds__(NMS_THREADS) void nms_sample_kernel(sgx_nms_desc d, const float* scores, int* ws) {
+    __shared__ int hist[NMS_HBINS];
+    __shared__ int sh[NMS_THREADS / 64 + 3];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long E = (long)d.L * d.C;
+    const float* sc = scores + (long)b * E;
+    int* const thr_words = ws + (long)b * NMS_HBINS;  // (the first histogram's slot of this image: two words hold the threshold key)
+    int* list_count = ws + 2L * d.B * NMS_HBINS + (long)b * NMS_CTR_INTS;
+    int* total = ws + 2L * d.B * NMS_HBINS + (long)b * NMS_CTR_INTS + 1;
+    const long lines = E / 32, slines = (lines + NMS_SAMPLE_STEP - 1) / NMS_SAMPLE_STEP;  // sampled lines: 0, STEP, 2 STEP, ...
+    const long ns4 = slines * 8;
+    const int r = d.nms_top_k / 10 > 8 ? d.nms_top_k / 10 : 8;
+    int b1 = 0, above1 = 0, tot1 = 0, b2 = 0, above2 = 0, tot2 = 0;
+#pragma unroll 1
+    for (int level = 0; level < 2; ++level) {
+        for (int q = tid; q < NMS_HBINS; q += NMS_THREADS) hist[q] = 0;
+        __syncthreads();
+        // (four independent 16-byte loads per trip: one workgroup per image has nothing else to hide their latency behind)
+        for (long s0 = tid; s0 < ns4; s0 += 4L * NMS_THREADS) {
+            float4 v[4];
+            long e4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long s4 = s0 + (long)u * NMS_THREADS;
+                e4[u] = (s4 >> 3) * (32L * NMS_SAMPLE_STEP) + (s4 & 7) * 4;
+                const bool ok = s4 < ns4 && e4[u] + 3 < E;
+                v[u] = ok ? sgx_ld4(sc + e4[u]) : make_float4(0.f, 0.f, 0.f, 0.f);  // (0 is never above the non-negative score threshold)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!(vv[i] > d.score_threshold)) continue;
+                    const u64 k = nms_key(vv[i], e4[u] + i);
+                    const int h1 = (int)(k >> 42), h2 = (int)((k >> 31) & (NMS_HBINS - 1));
+                    if (level == 0) atomicAdd(&hist[h1], 1);
+                    else if (h1 == b1) atomicAdd(&hist[h2], 1);
+                }
+            }
+        }
+        __syncthreads();
+        if (level == 0) nms_kth_from_top<NMS_THREADS>(hist, NMS_HBINS, r, sh, b1, above1, tot1);
+        else nms_kth_from_top<NMS_THREADS>(hist, NMS_HBINS, r - above1, sh, b2, above2, tot2);
+    }
+    if (tid == 0) {
+        // fewer than r sampled candidates: everything above the score threshold is selected (key 0 sorts below every real key)
+        const u64 thr = tot1 < r ? 0ull : (((u64)b1 << 42) | ((u64)b2 << 31));
+        thr_words[0] = (int)(unsigned)(thr & 0xffffffffu);
+        thr_words[1] = (int)(unsigned)(thr >> 32);
+        list_count[0] = 0;
+        total[0] = 0;
+    }
+}
+// the one pass: keys >= the image's sampled threshold -> its list (LDS first, one global atomic per workgroup), candidates counted
+__global__ __launch_bounds__(NMS_S1_THREADS) void nms_append_kernel(sgx_nms_desc d, const float* scores, int* ws, int slab) {
+    __shared__ u64 lbuf[NMS_HBINS / 2];
+    __shared__ int lcount, lbase, lcand;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const long E = (long)d.L * d.C;
+    const float* sc = scores + (long)b * E;
+    const int* thr_words = ws + (long)b * NMS_HBINS;
+    int* list_count = ws + 2L * d.B * NMS_HBINS + (long)b * NMS_CTR_INTS;
+    int* total = ws + 2L * d.B * NMS_HBINS + (long)b * NMS_CTR_INTS + 1;
+    u64* list = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + (((long)d.B * (2 * NMS_HBINS + NMS_CTR_INTS) * 4 + 255) & ~255L)) + (long)b * NMS_LIST_CAP;
+    const u64 thr = ((u64)(unsigned)thr_words[1] << 32) | (u64)(unsigned)thr_words[0];
+    if (tid == 0) lcount = 0, lcand = 0;
+    __syncthreads();
+    const long e0 = (long)blockIdx.x * slab, e1 = e0 + slab < E ? e0 + slab : E;
+    const bool vec = ((((uintptr_t)sc) & 15) == 0) && (e0 % 4 == 0);
+    // Selected keys wait in four registers per lane and reach LDS after the streaming loop with ONE counter update per lane: at the
+    // ~0.5 % of the scores the sampled threshold lets through, 7 of 10 wave-trips of the loop hold a selected key, and a returning LDS
+    // atomic inside the loop parked every one of them (r5i: this pass 30 us where the histogram pass of the same bytes takes 15).  A
+    // lane with more than four (clustered scores) appends the excess at once, as before.
+    int cand = 0, nm = 0;
+    u64 m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    auto put = [&](u64 k) {
+        const int slot = atomicAdd(&lcount, 1);
+        if (slot < NMS_HBINS / 2) lbuf[slot] = k;
+        else {
+            const int g = atomicAdd(list_count, 1);
+            if (g < NMS_LIST_CAP) list[g] = k;
+        }
+    };
+    auto visit = [&](float s, long e) {
+        if (!(s > d.score_threshold)) return;
+        ++cand;
+        const u64 k = nms_key(s, e);
+        if (k >= thr) {
+            if (nm < 4) {
+                m3 = m2; m2 = m1; m1 = m0; m0 = k;
+                ++nm;
+            } else put(k);
+        }
+    };
+    long e = e0 + (vec ? 4L * tid : tid);
+    if (vec) {
+        // eight independent 16-byte loads per trip, THEN the visits: the visits' stores and atomics (which may alias the scores as far as
+        // the compiler knows) otherwise pin every load behind the previous trip - sixteen memory latencies in a row per lane (r5j: this
+        // pass 30 us against 15 for the histogram pass over the same bytes)
+        constexpr int U = 8;
+        for (; e + 3 + 4L * NMS_S1_THREADS * (U - 1) < e1; e += 4L * NMS_S1_THREADS * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = sgx_ld4(sc + e + 4L * NMS_S1_THREADS * u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long eu = e + 4L * NMS_S1_THREADS * u;
+                visit(v[u].x, eu); visit(v[u].y, eu + 1); visit(v[u].z, eu + 2); visit(v[u].w, eu + 3);
+            }
+        }
+        for (; e + 3 < e1; e += 4L * NMS_S1_THREADS) {
+            const float4 v = sgx_ld4(sc + e);
+            visit(v.x, e); visit(v.y, e + 1); visit(v.z, e + 2); visit(v.w, e + 3);
+        }
+        for (long q = e; q < e1 && q < e + 4; ++q) visit(sc[q], q);
+    } else {
+        for (; e < e1; e += NMS_S1_THREADS) visit(sc[e], e);
+    }
+    if (nm > 0) put(m0);
+    if (nm > 1) put(m1);
+    if (nm > 2) put(m2);
+    if (nm > 3) put(m3);
+    for (int off = 32; off > 0; off >>= 1) cand += __shfl_down(cand, off);
+    if ((tid & 63) == 0 && cand) atomicAdd(&lcand, cand);
+    __syncthreads();
+    const int cnt = lcount < NMS_HBINS / 2 ? lcount : NMS_HBINS / 2;
+    if (tid == 0 && (cnt || lcand)) {  // both counters in one 64-bit atomic (low word: list count - its old value is this workgroup's base)
+        const u64 old = atomicAdd(reinterpret_cast<unsigned long long*>(list_count), ((u64)(unsigned)lcand << 32) | (u64)(unsigned)cnt);
+        lbase = (int)(unsigned)(old & 0xffffffffu);
+    }
+    __syncthreads();
+    for (int q = tid; q < cnt; q += NMS_S1_THREADS)
+        if (lbase + q < NMS_LIST_CAP) list[lbase + q] = lbuf[q];
+}
+
 // ---- stage 2: one workgroup per image --------------------------------------------------------------------------------------------
 // Triangular suppression bit matrix for NMS_MAXK = 1024: row i keeps the 64-bit words w >= i / 64 (bit j of word w: "i suppresses 64*w + j").
 // Rows are grouped in blocks of 64 (g = i / 64, 16 - g words per row): 8 704 words = 68 KB of LDS.
@@ -221,9 +377,12 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
     const long E = d.multi_label ? (long)d.L * d.C : (long)d.L;
     const int K = d.nms_top_k < NMS_MAXK ? d.nms_top_k : NMS_MAXK;
     // stage 1's list (multi-label with a workspace): every candidate at or above the 22-bit boundary prefix - a superset of the top K
-    const int m_list = ws ? ws[2L * d.B * NMS_HBINS + b] : 0;
-    const bool use_list = ws != nullptr && m_list <= NMS_LIST_CAP;
-    const u64* list = ws ? reinterpret_cast<const u64*>(reinterpret_cast<const char*>(ws) + (((long)d.B * (2 * NMS_HBINS + 2) * 4 + 255) & ~255L)) + (long)b * NMS_LIST_CAP
+    const int m_list = ws ? ws[2L * d.B * NMS_HBINS + (long)b * NMS_CTR_INTS] : 0;
+    // (sampled selection: the list must also hold at least min(K, candidates) keys - a threshold estimated too high is the one way it
+    // could miss part of the top K; the exact selection's list always does)
+    const int m_cand = ws ? ws[2L * d.B * NMS_HBINS + (long)b * NMS_CTR_INTS + 1] : 0;
+    const bool use_list = ws != nullptr && m_list <= NMS_LIST_CAP && m_list >= (m_cand < K ? m_cand : K);
+    const u64* list = ws ? reinterpret_cast<const u64*>(reinterpret_cast<const char*>(ws) + (((long)d.B * (2 * NMS_HBINS + NMS_CTR_INTS) * 4 + 255) & ~255L)) + (long)b * NMS_LIST_CAP
                          : nullptr;
     // visits every candidate's composite key: the list, or (single-label / overflowing list) the raw scores of the image
     auto for_each_key = [&](auto fn) {
@@ -242,7 +401,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
     if (tid == 0) s_count = 0;
     __syncthreads();
     if (use_list) {
-        if (tid == 0) s_count = ws[2L * d.B * NMS_HBINS + d.B + b];
+        if (tid == 0) s_count = ws[2L * d.B * NMS_HBINS + (long)b * NMS_CTR_INTS + 1];
     } else {
         int local = 0;
         for_each_key([&](u64) { ++local; });
@@ -706,16 +865,23 @@ extern "C" int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const floa
         // stage 1 on the whole chip (a caller without a workspace gets the streaming stage 2: same rows, one workgroup per image)
         if (ws && ws_bytes >= sgx_nms_workspace(d)) {
             wsi = (const int*)ws;
-            SGX_MEMSET_ASYNC(ws, 0, (size_t)d->B * (2 * NMS_HBINS + 2) * 4, stream);
             const long E = (long)d->L * d->C;
+            const bool sampled = g_nms_sampled.load(std::memory_order_relaxed) && d->nms_top_k <= 2048 && E % 4 == 0 && ((uintptr_t)scores % 16) == 0 &&
+                                 E >= 32L * NMS_SAMPLE_STEP * 8;  // (a sample of at least 8 lines; 3.2 k expected keys must fit the list)
+            if (!sampled) SGX_MEMSET_ASYNC(ws, 0, (size_t)d->B * (2 * NMS_HBINS + NMS_CTR_INTS) * 4, stream);
             int S = (int)((E + 16383) / 16384);  // >= 16 k scores per workgroup, at most ~2048 workgroups in flight
             if (S * d->B > 2048) S = (2048 + d->B - 1) / d->B;
             if (S < 1) S = 1;
             const int slab = (int)((((E + S - 1) / S) + 3) / 4 * 4);
             const dim3 grid((unsigned)((E + slab - 1) / slab), (unsigned)d->B);
-            SGX_LAUNCH(nms_select_kernel<0>, grid, dim3(NMS_S1_THREADS), 0, stream, *d, scores, (int*)ws, slab);
-            SGX_LAUNCH(nms_select_kernel<1>, grid, dim3(NMS_S1_THREADS), 0, stream, *d, scores, (int*)ws, slab);
-            SGX_LAUNCH(nms_select_kernel<2>, grid, dim3(NMS_S1_THREADS), 0, stream, *d, scores, (int*)ws, slab);
+            if (sampled) {
+                SGX_LAUNCH(nms_sample_kernel, dim3((unsigned)d->B), dim3(NMS_THREADS), 0, stream, *d, scores, (int*)ws);
+                SGX_LAUNCH(nms_append_kernel, grid, dim3(NMS_S1_THREADS), 0, stream, *d, scores, (int*)ws, slab);
+            } else {
+                SGX_LAUNCH(nms_select_kernel<0>, grid, dim3(NMS_S1_THREADS), 0, stream, *d, scores, (int*)ws, slab);
+                SGX_LAUNCH(nms_select_kernel<1>, grid, dim3(NMS_S1_THREADS), 0, stream, *d, scores, (int*)ws, slab);
+                SGX_LAUNCH(nms_select_kernel<2>, grid, dim3(NMS_S1_THREADS), 0, stream, *d, scores, (int*)ws, slab);
+            }
             SGX_CHECK_LAUNCH("nms_select");
         }
     }

@@ -588,6 +588,46 @@ def test_nms(backend, multi_label, class_mode):
         assert torch.equal(out[b, :n], ref[b]), f"image {b}: rows differ"  # bit-exact boxes/scores/classes
 
 
+@pytest.mark.parametrize("case", ["random", "sample_overestimates", "sample_underestimates", "few_candidates"])
+def test_nms_sampled_selection(backend, case):
+    """Round 5: stage 1 selects behind a threshold estimated from a 1/32 line sample of the scores (one pass instead of three); stage 2 stays
+    exact - it takes the list only if it holds at least min(k, candidates) keys and did not overflow, else it streams the image.  The rows
+    must equal the oracle's AND the exact three-pass selection's bit for bit: on a random case; when every large score sits in a SAMPLED
+    line (threshold estimated too high, list shorter than k: fallback); when none does (threshold too low: a long list or an overflow);
+    and with fewer candidates than the sample rank asks for (threshold 0: everything selected)."""
+    from oracle import nms as onms
+    from super_gradients_amd._lib import lib
+
+    B, L, C, topk, maxp = _sizes(backend, (3, 4200, 80, 1000, 300), (1, 128, 80, 64, 20))
+    boxes, scores = _nms_case(B, L, C, seed=21)
+    E = L * C
+    flat = scores.reshape(B, E)
+    line = torch.arange(E) // 32
+    if case == "sample_overestimates":      # large scores only in the sampled lines (0, 32, 64, ...), a sea of medium ones elsewhere
+        flat[:] = torch.where((line % 32 == 0)[None], 0.6 + 0.39 * flat, 0.3 * flat)
+    elif case == "sample_underestimates":   # the sampled lines hold nothing above the score threshold's neighbourhood
+        flat[:] = torch.where((line % 32 == 0)[None], 0.06 + 0.001 * flat, flat)
+    elif case == "few_candidates":
+        flat[:] = torch.where(flat > 0.97, flat, torch.zeros_like(flat))
+    scores = flat.reshape(B, L, C)
+    kw = dict(score_threshold=0.05, nms_threshold=0.6, nms_top_k=topk, max_predictions=maxp, multi_label_per_box=True)
+    ref = onms.post_prediction(boxes, scores, class_agnostic_nms=True, **kw)
+    res = {}
+    try:
+        for sampled in (1, 0):
+            assert lib().sgx_debug_set_nms_selection(sampled) == 0
+            out, cnt, idx, ncand = K.nms(boxes.to(backend), scores.to(backend), 0.05, 0.6, topk, maxp, multi_label=True, class_mode=0)
+            res[sampled] = (out.cpu(), cnt.cpu(), idx.cpu(), ncand.cpu())
+    finally:
+        lib().sgx_debug_set_nms_selection(1)
+    for b in range(B):
+        n = int(res[1][1][b])
+        assert n == ref[b].shape[0], f"{case} image {b}: kept {n} vs oracle {ref[b].shape[0]}"
+        assert torch.equal(res[1][0][b, :n], ref[b]), f"{case} image {b}: rows differ from the oracle"
+    for a, c_ in zip(res[1], res[0]):
+        assert torch.equal(a, c_), f"{case}: sampled and exact selection disagree"
+
+
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 128, 129, 200])
 def test_nms_candidate_count_boundaries(backend, n):
     """Candidate counts around the 64-candidate flag words of the suppression matrix (empty list, one candidate, a full word, one past it,
