@@ -41,9 +41,13 @@ static SweepGeom sweep_geom(long M, int C) {
     return g;
 }
 
-// F: struct with  In load(long r, int c)  (all global loads of row r, channels c..c+3) and
-// void apply(long r, int c, const In&, float4& q0, float4& q1)  (the arithmetic, the stores and up to two per-channel
-// accumulations).  The split lets the sweep issue the loads of FOUR rows before the first store: with one row in flight
+// F: struct with  In load(long r, int c)  (all global loads of row r, channels c..c+3),  Cst consts(int c)  (the per-channel
+// constants of the lane's four channels - scale / shift / coefficient rows - loaded ONCE, ahead of the row loop) and
+// void apply(long r, int c, const In&, const Cst&, float4& q0, float4& q1)  (the arithmetic, the stores and up to two per-channel
+// accumulations).  (Round 5: the constants used to be re-read inside apply for every row - the compiler cannot hoist them past the
+// row's stores, which may alias them for all it knows: 7 of the 9 load instructions per row of the BatchNorm-backward apply, 14 of 17
+// of the QARepVGG one, all L1 hits but each a trip through the texture path, which at 64 B/clk/CU was busier with them than with the
+// data.)  The split lets the sweep issue the loads of FOUR rows before the first store: with one row in flight
 // per lane these streaming kernels sat at ~40 % of the HBM rate (r1b profile) - latency-bound, not bandwidth-bound.
 // In-place use (output aliasing an input) stays correct: a row is completely read before it is written, rows are disjoint.
 template <typename F, int NQ>
@@ -61,16 +65,17 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_kernel(F f, SweepGeom g, flo
         if (r1 > g.M) r1 = g.M;
         long r = r0 + rl;
         const long st = g.RL;
+        const typename F::Cst k = f.consts(c);
         for (; r + 3 * st < r1; r += 4 * st) {
             typename F::In i0 = f.load(r, c), i1 = f.load(r + st, c), i2 = f.load(r + 2 * st, c), i3 = f.load(r + 3 * st, c);
-            f.apply(r, c, i0, q0, q1);
-            f.apply(r + st, c, i1, q0, q1);
-            f.apply(r + 2 * st, c, i2, q0, q1);
-            f.apply(r + 3 * st, c, i3, q0, q1);
+            f.apply(r, c, i0, k, q0, q1);
+            f.apply(r + st, c, i1, k, q0, q1);
+            f.apply(r + 2 * st, c, i2, k, q0, q1);
+            f.apply(r + 3 * st, c, i3, k, q0, q1);
         }
         for (; r < r1; r += st) {
             typename F::In i0 = f.load(r, c);
-            f.apply(r, c, i0, q0, q1);
+            f.apply(r, c, i0, k, q0, q1);
         }
     }
     if (NQ > 0 && partials) {
@@ -110,7 +115,9 @@ struct StatsF {
     long ld;
     struct In { float4 v; };
     __device__ In load(long r, int c) const { return In{sgx_ld4(x + r * ld + c)}; }
-    __device__ void apply(long, int, const In& in, float4& q0, float4& q1) const {
+    struct Cst {};
+    __device__ Cst consts(int) const { return Cst{}; }
+    __device__ void apply(long, int, const In& in, const Cst&, float4& q0, float4& q1) const {
         const float4 v = in.v;
         q0.x += v.x; q0.y += v.y; q0.z += v.z; q0.w += v.w;
         q1.x += v.x * v.x; q1.y += v.y * v.y; q1.z += v.z * v.z; q1.w += v.w * v.w;
@@ -390,14 +397,19 @@ struct AffineActF {
         in.u2 = r2 ? sgx_ld4(r2 + r * r2_ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         return in;
     }
-    __device__ void apply(long r, int c, const In& in, float4& q0, float4& q1) const {
+    struct Cst { float4 s, t; float a; };
+    __device__ Cst consts(int c) const {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        return Cst{scale ? sgx_ld4(scale + c) : z, scale ? sgx_ld4(shift + c) : z, (r1 && a1_dev) ? a1_dev[0] : a1};
+    }
+    __device__ void apply(long r, int c, const In& in, const Cst& k, float4& q0, float4& q1) const {
         float4 v = in.v;
         if (scale) {
-            float4 s = sgx_ld4(scale + c), t = sgx_ld4(shift + c);
+            const float4 s = k.s, t = k.t;
             v.x = s.x * v.x + t.x; v.y = s.y * v.y + t.y; v.z = s.z * v.z + t.z; v.w = s.w * v.w + t.w;
         }
         if (r1) {
-            float a = a1_dev ? a1_dev[0] : a1;
+            const float a = k.a;
             const float4 u = in.u1;
             v.x += a * u.x; v.y += a * u.y; v.z += a * u.z; v.w += a * u.w;
         }
@@ -428,9 +440,11 @@ struct BnBwdReduceF {
     const float* dy; long dy_ld; const float* x; long x_ld; const float* scale; const float* shift; const float* mean; int act;
     struct In { float4 d, v; };
     __device__ In load(long r, int c) const { return In{sgx_ld4(dy + r * dy_ld + c), sgx_ld4(x + r * x_ld + c)}; }
-    __device__ void apply(long, int c, const In& in, float4& q0, float4& q1) const {
+    struct Cst { float4 s, t, mu; };
+    __device__ Cst consts(int c) const { return Cst{sgx_ld4(scale + c), sgx_ld4(shift + c), sgx_ld4(mean + c)}; }
+    __device__ void apply(long, int, const In& in, const Cst& k, float4& q0, float4& q1) const {
         const float4 d = in.d, v = in.v;
-        float4 s = sgx_ld4(scale + c), t = sgx_ld4(shift + c), mu = sgx_ld4(mean + c);
+        const float4 s = k.s, t = k.t, mu = k.mu;
         float gx = bn_masked(d.x, v.x, s.x, t.x, act), gy = bn_masked(d.y, v.y, s.y, t.y, act);
         float gz = bn_masked(d.z, v.z, s.z, t.z, act), gw = bn_masked(d.w, v.w, s.w, t.w, act);
         q0.x += gx; q0.y += gy; q0.z += gz; q0.w += gw;
@@ -501,11 +515,16 @@ struct BnBwdApplyF {
     float* dx; long dx_ld; float* g_out; long g_ld; int act;
     struct In { float4 d, v; };
     __device__ In load(long r, int c) const { return In{sgx_ld4(dy + r * dy_ld + c), sgx_ld4(x + r * x_ld + c)}; }
-    __device__ void apply(long r, int c, const In& in, float4& q0, float4& q1) const {
+    struct Cst { float4 s, t, c1, mg, k, mu, ml; };
+    __device__ Cst consts(int c) const {
+        return Cst{sgx_ld4(scale + c), sgx_ld4(shift + c), sgx_ld4(coef + c), sgx_ld4(coef + C + c), sgx_ld4(coef + 2 * C + c), sgx_ld4(coef + 3 * C + c),
+                   sgx_ld4(coef + 4 * C + c)};
+    }
+    __device__ void apply(long r, int c, const In& in, const Cst& kc, float4& q0, float4& q1) const {
         (void)q0; (void)q1;
         const float4 d = in.d, v = in.v;
-        float4 s = sgx_ld4(scale + c), t = sgx_ld4(shift + c);
-        float4 c1 = sgx_ld4(coef + c), mg = sgx_ld4(coef + C + c), k = sgx_ld4(coef + 2 * C + c), mu = sgx_ld4(coef + 3 * C + c), ml = sgx_ld4(coef + 4 * C + c);
+        const float4 s = kc.s, t = kc.t;
+        const float4 c1 = kc.c1, mg = kc.mg, k = kc.k, mu = kc.mu, ml = kc.ml;
         float4 g = make_float4(bn_masked(d.x, v.x, s.x, t.x, act), bn_masked(d.y, v.y, s.y, t.y, act),
                                bn_masked(d.z, v.z, s.z, t.z, act), bn_masked(d.w, v.w, s.w, t.w, act));
         float4 o = make_float4(c1.x * (((g.x - mg.x) - ml.x) - (v.x - mu.x) * k.x), c1.y * (((g.y - mg.y) - ml.y) - (v.y - mu.y) * k.y),
@@ -602,9 +621,11 @@ struct AxpyF {
     __device__ In load(long r, int c) const {
         return In{sgx_ld4(x + r * x_ld + c), accumulate ? sgx_ld4(y + r * y_ld + c) : make_float4(0.f, 0.f, 0.f, 0.f)};
     }
-    __device__ void apply(long r, int c, const In& in, float4& q0, float4& q1) const {
+    struct Cst { float s; };
+    __device__ Cst consts(int) const { return Cst{a_dev ? a_dev[0] : a}; }
+    __device__ void apply(long r, int c, const In& in, const Cst& k, float4& q0, float4& q1) const {
         (void)q0; (void)q1;
-        float s = a_dev ? a_dev[0] : a;
+        const float s = k.s;
         const float4 v = in.v;
         float4 o = make_float4(s * v.x, s * v.y, s * v.z, s * v.w);
         if (accumulate) {
@@ -627,7 +648,9 @@ struct ReluBwdF {
     const float* dy; long dy_ld; const float* y; long y_ld; float* g; long g_ld;
     struct In { float4 d, v; };
     __device__ In load(long r, int c) const { return In{sgx_ld4(dy + r * dy_ld + c), sgx_ld4(y + r * y_ld + c)}; }
-    __device__ void apply(long r, int c, const In& in, float4& q0, float4& q1) const {
+    struct Cst {};
+    __device__ Cst consts(int) const { return Cst{}; }
+    __device__ void apply(long r, int c, const In& in, const Cst&, float4& q0, float4& q1) const {
         (void)q0; (void)q1;
         const float4 d = in.d, v = in.v;
         sgx_st4(g + r * g_ld + c, make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f));
@@ -655,21 +678,26 @@ struct DualAffineF {
         in.u = r ? sgx_ld4(r + row * r_ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         return in;
     }
-    __device__ float4 pre(int c, const float4& a, const float4& b) const {
-        float4 s = sgx_ld4(s1 + c), t = sgx_ld4(t1 + c);
+    struct Cst { float4 s, t, p, q; float sc; };
+    __device__ Cst consts(int c) const {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        return Cst{sgx_ld4(s1 + c), sgx_ld4(t1 + c), x2 ? sgx_ld4(s2 + c) : z, x2 ? sgx_ld4(t2 + c) : z, r_scale * ((r && r_scale_dev) ? r_scale_dev[0] : 1.f)};
+    }
+    __device__ float4 pre(const Cst& k, const float4& a, const float4& b) const {
+        const float4 s = k.s, t = k.t;
         float4 v = make_float4(s.x * a.x + t.x, s.y * a.y + t.y, s.z * a.z + t.z, s.w * a.w + t.w);
         if (x2) {
-            float4 p = sgx_ld4(s2 + c), q = sgx_ld4(t2 + c);
+            const float4 p = k.p, q = k.q;
             v.x += p.x * b.x + q.x; v.y += p.y * b.y + q.y; v.z += p.z * b.z + q.z; v.w += p.w * b.w + q.w;
         }
         return v;
     }
-    __device__ void apply(long row, int c, const In& in, float4& q0, float4& q1) const {
+    __device__ void apply(long row, int c, const In& in, const Cst& k, float4& q0, float4& q1) const {
         (void)q0; (void)q1;
-        float4 v = pre(c, in.a, in.b);
+        float4 v = pre(k, in.a, in.b);
         float4 o = make_float4(sgx_act(v.x, act), sgx_act(v.y, act), sgx_act(v.z, act), sgx_act(v.w, act));
         if (r) {
-            const float sc = r_scale * (r_scale_dev ? r_scale_dev[0] : 1.f);
+            const float sc = k.sc;
             o.x += sc * in.u.x; o.y += sc * in.u.y; o.z += sc * in.u.z; o.w += sc * in.u.w;
         }
         sgx_st4(y + row * y_ld + c, o);
@@ -693,9 +721,11 @@ struct DualAffineBwdF {
         in.d = sgx_ld4(dy + row * dy_ld + c);
         return in;
     }
-    __device__ void apply(long row, int c, const In& in, float4& q0, float4& q1) const {
+    typedef DualAffineF::Cst Cst;
+    __device__ Cst consts(int c) const { return p.consts(c); }
+    __device__ void apply(long row, int c, const In& in, const Cst& k, float4& q0, float4& q1) const {
         (void)q0; (void)q1;
-        float4 v = p.pre(c, in.a, in.b);
+        float4 v = p.pre(k, in.a, in.b);
         sgx_st4(g + row * g_ld + c, make_float4(in.d.x * sgx_act_grad(v.x, p.act), in.d.y * sgx_act_grad(v.y, p.act),
                                                  in.d.z * sgx_act_grad(v.z, p.act), in.d.w * sgx_act_grad(v.w, p.act)));
     }
@@ -739,14 +769,15 @@ __global__ __launch_bounds__(SW_THREADS) void sweepq_kernel(F f, SweepGeom g, fl
         if (r1 > g.M) r1 = g.M;
         long r = r0 + rl;
         const long st = g.RL;
+        const typename F::Cst k = f.consts(c);
         for (; r + st < r1; r += 2 * st) {  // three tensors per row: two rows of loads in flight per lane
             typename F::In i0 = f.load(r, c), i1 = f.load(r + st, c);
-            f.apply(r, c, i0, q);
-            f.apply(r + st, c, i1, q);
+            f.apply(r, c, i0, k, q);
+            f.apply(r + st, c, i1, k, q);
         }
         for (; r < r1; r += st) {
             typename F::In i0 = f.load(r, c);
-            f.apply(r, c, i0, q);
+            f.apply(r, c, i0, k, q);
         }
     }
     if (!partials) return;  // no reduction (apply sweeps): uniform across the workgroup
@@ -826,12 +857,17 @@ struct QarepBwdBase {
     const float* dout; long d_ld; const float* y; long y_ld; const float* u; long u_ld; const float* cf; const float* sv; int C; int act;
     __device__ QarepBwdIn load(long r, int c) const { return QarepBwdIn{sgx_ld4(dout + r * d_ld + c), sgx_ld4(y + r * y_ld + c), sgx_ld4(u + r * u_ld + c)}; }
     // masked upstream gradient g and the centred s, y of one float4 (the pre-activation with the forward sweep's own roundings)
-    __device__ void terms(int c, const QarepBwdIn& in, float4& g, float4& sc, float4& yc) const {
-        const float4 a = sgx_ld4(cf + c), cc = sgx_ld4(cf + C + c), b = sgx_ld4(cf + 2 * C + c), t0 = sgx_ld4(cf + 3 * C + c);
+    struct Cst { float4 a, cc, b, t0, m3, s3, h3, ms; };
+    __device__ Cst consts(int c) const {
+        return Cst{sgx_ld4(cf + c), sgx_ld4(cf + C + c), sgx_ld4(cf + 2 * C + c), sgx_ld4(cf + 3 * C + c),
+                   sgx_ld4(sv + c), sgx_ld4(sv + 2 * C + c), sgx_ld4(sv + 3 * C + c), sgx_ld4(sv + 4 * C + c)};
+    }
+    __device__ void terms(const Cst& k, const QarepBwdIn& in, float4& g, float4& sc, float4& yc) const {
+        const float4 a = k.a, cc = k.cc, b = k.b, t0 = k.t0;
         float4 z = make_float4(a.x * in.y.x + cc.x, a.y * in.y.y + cc.y, a.z * in.y.z + cc.z, a.w * in.y.w + cc.w);
         z.x += b.x * in.u.x + t0.x; z.y += b.y * in.u.y + t0.y; z.z += b.z * in.u.z + t0.z; z.w += b.w * in.u.w + t0.w;
         g = make_float4(in.d.x * sgx_act_grad(z.x, act), in.d.y * sgx_act_grad(z.y, act), in.d.z * sgx_act_grad(z.z, act), in.d.w * sgx_act_grad(z.w, act));
-        const float4 m3 = sgx_ld4(sv + c), s3 = sgx_ld4(sv + 2 * C + c), h3 = sgx_ld4(sv + 3 * C + c), ms = sgx_ld4(sv + 4 * C + c);
+        const float4 m3 = k.m3, s3 = k.s3, h3 = k.h3, ms = k.ms;
         // s = bn3(y) + u as the reference forms it (qarepvgg_block.py:197-202), then centred
         sc = make_float4((s3.x * in.y.x + h3.x + in.u.x) - ms.x, (s3.y * in.y.y + h3.y + in.u.y) - ms.y, (s3.z * in.y.z + h3.z + in.u.z) - ms.z,
                          (s3.w * in.y.w + h3.w + in.u.w) - ms.w);
@@ -842,9 +878,11 @@ struct QarepBwdReduceF {
     QarepBwdBase b;
     typedef QarepBwdIn In;
     __device__ In load(long r, int c) const { return b.load(r, c); }
-    __device__ void apply(long, int c, const In& in, float4 (&q)[4]) const {
+    typedef QarepBwdBase::Cst Cst;
+    __device__ Cst consts(int c) const { return b.consts(c); }
+    __device__ void apply(long, int, const In& in, const Cst& k, float4 (&q)[4]) const {
         float4 g, sc, yc;
-        b.terms(c, in, g, sc, yc);
+        b.terms(k, in, g, sc, yc);
         q[0].x += g.x; q[0].y += g.y; q[0].z += g.z; q[0].w += g.w;
         q[1].x += g.x * sc.x; q[1].y += g.y * sc.y; q[1].z += g.z * sc.z; q[1].w += g.w * sc.w;
         q[2].x += g.x * yc.x; q[2].y += g.y * yc.y; q[2].z += g.z * yc.z; q[2].w += g.w * yc.w;
@@ -904,12 +942,15 @@ struct QarepBwdApplyF {
     const float* cb; float* ds; long ds_ld; float* dy; long dy_ld;
     typedef QarepBwdIn In;
     __device__ In load(long r, int c) const { return b.load(r, c); }
-    __device__ void apply(long r, int c, const In& in, float4 (&)[1]) const {
-        float4 g, sc, yc;
-        b.terms(c, in, g, sc, yc);
+    struct Cst { QarepBwdBase::Cst t; float4 cp, mg, kp, c3, k3, ml; };
+    __device__ Cst consts(int c) const {
         const int C = b.C;
-        const float4 cp = sgx_ld4(cb + c), mg = sgx_ld4(cb + C + c), kp = sgx_ld4(cb + 2 * C + c), c3 = sgx_ld4(cb + 3 * C + c), k3 = sgx_ld4(cb + 4 * C + c),
-                     ml = sgx_ld4(cb + 5 * C + c);
+        return Cst{b.consts(c), sgx_ld4(cb + c), sgx_ld4(cb + C + c), sgx_ld4(cb + 2 * C + c), sgx_ld4(cb + 3 * C + c), sgx_ld4(cb + 4 * C + c), sgx_ld4(cb + 5 * C + c)};
+    }
+    __device__ void apply(long r, int c, const In& in, const Cst& k, float4 (&)[1]) const {
+        float4 g, sc, yc;
+        b.terms(k.t, in, g, sc, yc);
+        const float4 cp = k.cp, mg = k.mg, kp = k.kp, c3 = k.c3, k3 = k.k3, ml = k.ml;
         // differences first, then the scale (the order ATen's CPU batch-norm backward uses)
         const float4 s = make_float4(cp.x * (((g.x - mg.x) - ml.x) - sc.x * kp.x), cp.y * (((g.y - mg.y) - ml.y) - sc.y * kp.y),
                                      cp.z * (((g.z - mg.z) - ml.z) - sc.z * kp.z), cp.w * (((g.w - mg.w) - ml.w) - sc.w * kp.w));
@@ -938,7 +979,9 @@ struct ColsumF {
         long img = r / rows_per_img;
         return In{sgx_ld4(x + img * ld_img + (r - img * rows_per_img) * ld + c)};
     }
-    __device__ void apply(long, int, const In& in, float4& q0, float4& q1) const {
+    struct Cst {};
+    __device__ Cst consts(int) const { return Cst{}; }
+    __device__ void apply(long, int, const In& in, const Cst&, float4& q0, float4& q1) const {
         (void)q1;
         const float4 v = in.v;
         q0.x += v.x; q0.y += v.y; q0.z += v.z; q0.w += v.w;
