@@ -82,20 +82,29 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x
 // ---------------------------------------------------------------------------------------------
 // 0. targets [T,6] -> per-image slot lists (order of appearance preserved, ppyolo_loss.py:747-769)
 // ---------------------------------------------------------------------------------------------
-__global__ void targets_index_kernel(const float* targets, int T, int B, int nmax, int* gt_count, int* gt_index, int* overflow) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    int n = 0, ovf = 0;
-    for (int t = 0; t < T; ++t) {
-        if ((int)targets[(long)t * 6] == b && targets[(long)t * 6] == (float)b) {
-            if (n < nmax) gt_index[(long)b * nmax + n] = t;
-            else ++ovf;
-            ++n;
+// One wave per image: the wave walks the target rows 64 at a time, a ballot marks the rows of this image, a row's slot is the image's
+// running count plus the matches in the lanes below it - order of appearance preserved.  (Rounds 1-4: one THREAD per image walked all T
+// rows, a chain of T dependent loads - 95 us at T = 640 on the critical path of every step.)
+__global__ __launch_bounds__(64) void targets_index_kernel(const float* targets, int T, int B, int nmax, int* gt_count, int* gt_index, int* overflow) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int n = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        float v = -1.f;
+        if (t < T) v = targets[(long)t * 6];
+        const bool hit = t < T && (int)v == b && v == (float)b;
+        const unsigned long long bits = __ballot(hit);
+        if (hit) {
+            const int slot = n + __popcll(bits & ((1ull << lane) - 1ull));
+            if (slot < nmax) gt_index[(long)b * nmax + slot] = t;
         }
+        n += __popcll(bits);
     }
-    gt_count[b] = n < nmax ? n : nmax;
-    for (int i = n; i < nmax; ++i) gt_index[(long)b * nmax + i] = -1;
-    if (ovf) atomicAdd(overflow, ovf);
+    if (lane == 0) {
+        gt_count[b] = n < nmax ? n : nmax;
+        if (n > nmax) atomicAdd(overflow, n - nmax);
+    }
+    for (int i = n + lane; i < nmax; i += 64) gt_index[(long)b * nmax + i] = -1;
 }
 extern "C" int32_t sgx_targets_index(const float* targets, int32_t T, int32_t B, int32_t nmax, int32_t* gt_count, int32_t* gt_index,
                                      int32_t* overflow, void* stream) {
@@ -103,7 +112,7 @@ extern "C" int32_t sgx_targets_index(const float* targets, int32_t T, int32_t B,
     SGX_CHECK_ARG(T == 0 || targets, "targets_index: null targets");
     SGX_CHECK_ARG(nmax == 0 || gt_index, "targets_index: null gt_index");
     SGX_MEMSET_ASYNC(overflow, 0, sizeof(int), stream);
-    SGX_LAUNCH(targets_index_kernel, dim3(sgx_cdiv(B, 64)), dim3(64), 0, stream, targets, T, B, nmax, gt_count, gt_index, overflow);
+    SGX_LAUNCH(targets_index_kernel, dim3(B), dim3(64), 0, stream, targets, T, B, nmax, gt_count, gt_index, overflow);
     SGX_CHECK_LAUNCH("targets_index");
     return SGX_OK;
 }
@@ -123,10 +132,41 @@ __device__ __forceinline__ void softmax_expect(const float* d, int R1, float& e)
     }
     e = acc / s;
 }
-// One thread per (anchor, side): a wave reads 64 consecutive (R+1)-float rows (contiguous memory) and writes 64 consecutive box
-// coordinates; the per-side arithmetic is unchanged.
+// One thread per (anchor, side).  A workgroup's 256 rows of (R+1) floats are one contiguous run of memory: it is staged through LDS with
+// coalesced 4-byte loads (thread t takes elements t, t + 256, ...) and every thread then reads ITS row out of LDS (row pitch R+1 - odd for
+// the networks' reg_max = 16: conflict-free) - the per-side arithmetic and its order are unchanged.  (Rounds 1-4: every thread read its
+// 68-byte row from global memory twice, element by element - 64 lanes x 68 B strides per instruction: 82 us for 73 MB.)
+#define DEC_MAXR1 33
+template <bool PX>
+__global__ __launch_bounds__(256) void decode_rows_kernel(int B, int L, int R1, const float* distri, const float* points, const float* strides, float mul_stride,
+                                                          float* boxes) {
+    __shared__ float rows[256 * DEC_MAXR1];
+    const long n = (long)B * L * 4;
+    for (long i0 = (long)blockIdx.x * 256; i0 < n; i0 += (long)gridDim.x * 256) {
+        const long cnt = (n - i0 < 256 ? n - i0 : 256) * R1;
+        const float* src = distri + i0 * R1;
+        for (long q = threadIdx.x; q < cnt; q += 256) rows[q] = src[q];
+        __syncthreads();
+        const long i = i0 + threadIdx.x;
+        if (i < n) {
+            const int k = (int)(i & 3);
+            const int l = (int)((i >> 2) % L);
+            float e;
+            softmax_expect(rows + threadIdx.x * R1, R1, e);
+            if (PX) {  // decode from PIXEL anchor points: grid point = point / stride (ppyolo_loss.py:803-804)
+                const float pc = points[2 * l + (k & 1)] / strides[l];
+                boxes[i] = k < 2 ? pc - e : pc + e;
+            } else {
+                const float pc = points[2 * l + (k & 1)];
+                const float sc = mul_stride != 0.f ? strides[l] : 1.f;
+                boxes[i] = (k < 2 ? pc - e : pc + e) * sc;
+            }
+        }
+        __syncthreads();
+    }
+}
 __global__ void decode_kernel(int B, int L, int R1, const float* distri, const float* points_grid, const float* strides, float mul_stride,
-                              float* boxes) {
+                              float* boxes) {  // (reg_max > 32: the direct form)
     long n = (long)B * L * 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int k = (int)(i & 3);
@@ -145,8 +185,12 @@ extern "C" int32_t sgx_dfl_decode(int32_t B, int32_t L, int32_t C, int32_t reg_m
                                   const float* points_grid, const float* strides, float* boxes, float* scores, void* stream) {
     SGX_CHECK_ARG(distri && points_grid && strides && boxes, "dfl_decode: null pointer");
     long n = (long)B * L, blocks = (4 * n + 255) / 256;
-    SGX_LAUNCH(decode_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, stream, B, L, reg_max + 1, distri, points_grid,
-               strides, 1.f, boxes);
+    if (reg_max + 1 <= DEC_MAXR1)
+        SGX_LAUNCH(decode_rows_kernel<false>, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, stream, B, L, reg_max + 1, distri, points_grid,
+                   strides, 1.f, boxes);
+    else
+        SGX_LAUNCH(decode_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, stream, B, L, reg_max + 1, distri, points_grid,
+                   strides, 1.f, boxes);
     SGX_CHECK_LAUNCH("dfl_decode");
     if (scores) {
         SGX_CHECK_ARG(logits, "dfl_decode: scores requested without logits");
@@ -661,8 +705,12 @@ extern "C" int32_t sgx_ppyoloe_loss_fwd(const sgx_loss_desc* d, const float* log
     SGX_MEMSET_ASYNC(w.maxi, 0, (long)d->B * (d->nmax > 0 ? d->nmax : 1) * 4, st);
     long blocks = (BL + 255) / 256;
     // 1. decode pred boxes (grid units)
-    SGX_LAUNCH(decode_px_kernel, dim3((unsigned)(4 * blocks > 16384 ? 16384 : 4 * blocks)), dim3(256), 0, stream, d->B, d->L, d->reg_max + 1, distri, points,
-               strides, w.pbox);
+    if (d->reg_max + 1 <= DEC_MAXR1)
+        SGX_LAUNCH(decode_rows_kernel<true>, dim3((unsigned)(4 * blocks > 16384 ? 16384 : 4 * blocks)), dim3(256), 0, stream, d->B, d->L, d->reg_max + 1, distri,
+                   points, strides, 0.f, w.pbox);
+    else
+        SGX_LAUNCH(decode_px_kernel, dim3((unsigned)(4 * blocks > 16384 ? 16384 : 4 * blocks)), dim3(256), 0, stream, d->B, d->L, d->reg_max + 1, distri, points,
+                   strides, w.pbox);
     SGX_CHECK_LAUNCH("decode_px");
     if (d->nmax > 0) {
         size_t smem = (size_t)d->L * sizeof(float);

@@ -208,27 +208,32 @@ __global__ __launch_bounds__(256) void maxpool_bwd_tile_kernel(int H, int W, int
 // (H x W x 64 floats: 100 KB for the 20 x 20 map) and walks the outputs in ascending order - every lane adds its gradient at its arg-max
 // pixel.  Lanes never share an address (different channels) and a lane's additions happen in output order: the sums are deterministic and in
 // the order of ATen's CPU kernel.  Eight outputs of loads in flight per lane; no atomics.
-#define MP_SCATTER_CH 64
+// Round 5: 32 channels per workgroup by default (half a wave adds; 50 KB for the 20 x 20 map).  Alone on the chip the 64-channel form is
+// as fast (the add chain is latency-bound either way), but in the train step its 100 KB workgroups waited for a CU with that much LDS
+// free while weight-gradient kernels of the side stream were resident: 200 us per call in the step's trace against 35 alone (r5m).
+#define MP_SCATTER_CH 32
 #define MP_SCATTER_THREADS 256
 #define MP_SCATTER_MAX_LDS (152 * 1024)
+template <int CH>
 __global__ __launch_bounds__(MP_SCATTER_THREADS) void maxpool_bwd_scatter_kernel(int HW, int C, int HoWo, const int* argmax, const float* dy, long dy_ld_pix,
                                                                                  long dy_ld_img, float* dx, long dx_ld_pix, long dx_ld_img, int accumulate) {
-    SGX_DYN_SMEM(float, tile);  // [HW][MP_SCATTER_CH]
-    const int groups = C / MP_SCATTER_CH, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int img = blockIdx.x / groups, c = (blockIdx.x % groups) * MP_SCATTER_CH + lane;
+    SGX_DYN_SMEM(float, tile);  // [HW][CH]
+    constexpr int PP = MP_SCATTER_THREADS / CH;  // pixels per pass of the load / store phases (thread = (pixel slot, channel))
+    const int groups = C / CH, ch = threadIdx.x % CH, ps = threadIdx.x / CH;
+    const int img = blockIdx.x / groups, c = (blockIdx.x % groups) * CH + ch;
     float* const gx = dx + (long)img * dx_ld_img + c;
-    // the slice's starting value: all four waves, eight pixels of loads in flight per lane (a lane's scatter below is a chain of ~1 us memory
+    // the slice's starting value: every thread, eight pixels of loads in flight (a lane's scatter below is a chain of ~1 us memory
     // round trips as it is: r4v measured 372 us per call with one wave doing everything, eight outputs at a time)
-    for (int p0 = wave * 8; p0 < HW; p0 += 8 * (MP_SCATTER_THREADS / 64)) {
+    for (int p0 = ps * 8; p0 < HW; p0 += 8 * PP) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = (accumulate && p0 + u < HW) ? gx[(long)(p0 + u) * dx_ld_pix] : 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (p0 + u < HW) tile[(p0 + u) * MP_SCATTER_CH + lane] = v[u];
+            if (p0 + u < HW) tile[(p0 + u) * CH + ch] = v[u];
     }
     __syncthreads();
-    if (wave == 0) {  // ONE wave adds, in output order
+    if (threadIdx.x < CH) {  // ONE (part of a) wave adds, in output order; lane = channel
         const int* const a = argmax + (long)img * HoWo * C + c;
         const float* const g = dy + (long)img * dy_ld_img + c;
         int o = 0;
@@ -242,15 +247,15 @@ __global__ __launch_bounds__(MP_SCATTER_THREADS) void maxpool_bwd_scatter_kernel
             }
 #pragma unroll
             for (int u = 0; u < 32; ++u)
-                if (ix[u] >= 0) tile[ix[u] * MP_SCATTER_CH + lane] += d[u];  // (-1: a window that lies in the padding only)
+                if (ix[u] >= 0) tile[ix[u] * CH + ch] += d[u];  // (-1: a window that lies in the padding only)
         }
         for (; o < HoWo; ++o) {
             const int ix = a[(long)o * C];
-            if (ix >= 0) tile[ix * MP_SCATTER_CH + lane] += g[(long)o * dy_ld_pix];
+            if (ix >= 0) tile[ix * CH + ch] += g[(long)o * dy_ld_pix];
         }
     }
     __syncthreads();
-    for (int p = wave; p < HW; p += MP_SCATTER_THREADS / 64) gx[(long)p * dx_ld_pix] = tile[p * MP_SCATTER_CH + lane];
+    for (int p = ps; p < HW; p += PP) gx[(long)p * dx_ld_pix] = tile[p * CH + ch];
 }
 
 extern "C" int32_t sgx_maxpool_bwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad, const int32_t* argmax,
@@ -268,12 +273,12 @@ extern "C" int32_t sgx_maxpool_bwd(int32_t N, int32_t H, int32_t W, int32_t C, i
         (void)hipGetDevice(&dev);
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(raised.load(std::memory_order_acquire) & bit)) {
-            if (hipFuncSetAttribute((const void*)maxpool_bwd_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MP_SCATTER_MAX_LDS) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)maxpool_bwd_scatter_kernel<MP_SCATTER_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, MP_SCATTER_MAX_LDS) != hipSuccess)
                 SGX_FAIL(SGX_ERR_HIP, "maxpool_bwd: cannot raise the scatter kernel's dynamic LDS limit");
             raised.fetch_or(bit, std::memory_order_release);
         }
 #endif
-        SGX_LAUNCH(maxpool_bwd_scatter_kernel, dim3((unsigned)(N * (C / MP_SCATTER_CH))), dim3(MP_SCATTER_THREADS), lds, stream, H * W, C, Ho * Wo, argmax, dy,
+        SGX_LAUNCH(maxpool_bwd_scatter_kernel<MP_SCATTER_CH>, dim3((unsigned)(N * (C / MP_SCATTER_CH))), dim3(MP_SCATTER_THREADS), lds, stream, H * W, C, Ho * Wo, argmax, dy,
                    (long)dy_ld_pix, (long)dy_ld_img, dx, (long)dx_ld_pix, (long)dx_ld_img, accumulate);
         SGX_CHECK_LAUNCH("maxpool_bwd (scatter)");
         return SGX_OK;
