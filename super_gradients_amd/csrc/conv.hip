@@ -290,8 +290,10 @@ constexpr int igemm_min_waves() {
 }
 template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0>
 __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2, NBUF>())) void igemm_kernel(IgemmParams p) {
-    static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && NBUF == 1) || (KD == 32 && !FLAT && NBUF == 2 && MATH == 1),
-                  "32-deep slabs: channel-chunked K axis; one LDS buffer, or (bf16x3) the two-buffer pipelined loop");
+    static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && NBUF == 1) || (KD == 32 && !FLAT && NBUF == 2 && MATH == 1) ||
+                      (KD == 32 && !FLAT && NBUF == 3 && MATH == 0 && PH2 == 0),
+                  "32-deep slabs: channel-chunked K axis; one LDS buffer, (bf16x3) the two-buffer pipelined loop, or (fp32, NBUF = 3) all slabs up front");
+    constexpr int LBUF = NBUF == 3 ? 1 : NBUF;  // LDS buffers
     static_assert(PH2 == 0 || !FLAT, "second K-axis source: channel-chunked K axis");
     static_assert(MATH == 0 || MATH == 1, "arithmetic: 0 = fp32 matrix pipe, 1 = bf16x3");
     // (Round 4 tried MATH = 2: the five correction products of the bf16x3 scheme added into the SAME accumulator as the leading one - it
@@ -314,10 +316,10 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
     // bf16x3 plane swizzle: 16-byte chunks of a row are permuted by row bits so that the fragment reads of 16 consecutive rows hit 16
     // distinct 4-bank groups - 32-byte rows: halves swapped on rows with bit 3 set; 64-byte rows: chunk ^= row bits 2-3
     auto swz = [](int row, int dw) { return KD == 16 ? IG_SWZ(row, dw) : (dw ^ (((row >> 2) & 3) << 2)); };
-    constexpr int SLABS = NBUF * (BM + BN) * ROWW, STAGE = WM * WN * 32 * 32;   // operand slabs; epilogue staging patches (reuse the slabs)
+    constexpr int SLABS = LBUF * (BM + BN) * ROWW, STAGE = WM * WN * 32 * 32;   // operand slabs; epilogue staging patches (reuse the slabs)
     __shared__ __attribute__((aligned(16))) float smem[SLABS > STAGE ? SLABS : STAGE];
     float* const As = smem;
-    float* const Bs = smem + NBUF * BM * ROWW;
+    float* const Bs = smem + LBUF * BM * ROWW;
     __shared__ long long rowoff[BM];
     __shared__ long long rowoff2[PH2 == 1 ? BM : 1];  // offsets into addend2 (two-source data gradient only)
     __shared__ long long rowoffT[PH2 == 2 ? 1 : SGX_MAX_BN_REQ][PH2 == 2 ? 1 : BM];  // offsets into the requests' saved conv outputs
@@ -713,6 +715,27 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                 load_tile_to(ra2, rb2, kt + 3 < nkt);
                 slab(1, ra, rb);
                 __syncthreads();
+            }
+            continue;
+        }
+        if constexpr (NBUF == 3) {
+            // ---- round 5, variant 11: reductions of at most FOUR slabs (1x1 layers with <= 128 channels - the fp32-pipe launches of the
+            // step) issue the loads of ALL their slabs before anything else.  The one-ahead loop waits for memory once per slab, and a
+            // workgroup that lives for three slabs between a prologue and an epilogue spends most of its life in those waits (r5final:
+            // these launches run at ~40 % of the HBM rate that bounds them).  64 more registers; same products in the same order.
+            float4 sa[4][AJ], sb[4][BJ];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load_tile_to(sa[q], sb[q], q < nkt);
+            compute_rowoff();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nkt) {  // (uniform)
+                    store_tile_from(0, sa[q], sb[q]);
+                    __syncthreads();
+                    compute_f32(0, 0);
+                    compute_f32(0, 16);
+                    __syncthreads();
+                }
             }
             continue;
         }
@@ -1507,7 +1530,7 @@ extern "C" int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n) {
                               (e[9] == 0) == (e[10] == 0),  // all 16 tiles of {32, 64, 96, 128}^2 are instantiated
                           "conv_tuning_load: entry %d: no weight-gradient kernel (tile %dx%d, split target %d)", i, e[9], e[10], e[11]);
         else
-            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && (e[11] == 0 || e[11] == 6 || e[11] == 7),
+            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && (e[11] == 0 || e[11] == 6 || e[11] == 7 || e[11] == 11),
                           "conv_tuning_load: entry %d: no kernel (tile %dx%d, variant %d)", i, e[9], e[10], e[11]);
         m[std::array<int, 9>{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8]}] = TuneVal{e[9], e[10], e[11]};
     }
@@ -1718,6 +1741,12 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
         else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, true>(p, stream);
         else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, true>(p, stream);
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no flat tile %dx%d", bm, bn);
+    } else if (igemm_deep_slabs(p) && conv_variant() == 11 && T * ((p.C + 31) / 32) <= 4 && bm * bn <= 128 * 64 && bn != 96 && bn != 128) {
+        // all slabs up front (reductions of <= 4 slabs: shallow 1x1 layers)
+        if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, 0, 32, 3, 0>(p, stream);
+        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 0, 32, 3, 0>(p, stream);
+        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 0, 32, 3, 0>(p, stream);
+        else launch_igemm<64, 32, 2, 1, false, 0, 32, 3, 0>(p, stream);
     } else if (igemm_deep_slabs(p)) SGX_IGEMM_TILES(0, 32, 1, 0);  // 32-deep slabs (see igemm_kernel): whole-line loads
     else SGX_IGEMM_TILES(0, 16, 2, 0);
     SGX_CHECK_LAUNCH("igemm");

@@ -1012,12 +1012,12 @@ def test_conv_deep_slabs(backend, case, math):
         for bm, bn in tiles:
             lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
             res = {}
-            for var in (7, 0, 6):  # 7 = the 16-deep loop, 0 = default (32-deep, one LDS buffer), 6 = 32-deep, two buffers
+            for var in (7, 0, 6, 11):  # 7 = the 16-deep loop, 0 = default (32-deep, one LDS buffer), 6 = the pipelined bf16x3 loop, 11 = all slabs up front (fp32, <= 4 slabs)
                 lib().sgx_debug_set_variant(var)
                 yd, parts = K.conv2d_fwd(xd, wd, bias=b.to(backend), stride=s, pad=p, stat_partials=True)
                 dx = K.conv2d_bwd_data(dyd, wd, (n, h, w, c), stride=s, pad=p)
                 res[var] = (yd.cpu().clone(), parts[0].cpu().clone(), dx.cpu().clone())
-            for var in (0, 6):
+            for var in (0, 6, 11):
                 assert_close(to_nchw_cpu(res[var][0]), y.detach(), TOL, f"variant {var} fwd tile {bm}x{bn}")
                 assert_close(to_nchw_cpu(res[var][2]), x.grad, TOL, f"variant {var} dgrad tile {bm}x{bn}")
                 for a, bb, what in zip(res[7], res[var], ("fwd", "stats", "dgrad")):

@@ -114,6 +114,15 @@ def main():
                 note(key, calls, (bm, bn, 6), t)
                 if t < best:
                     best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + " variant=6"
+            # all slabs up front (variant 11, round 5: fp32 launches whose reduction is at most four 32-deep slabs)
+            lib().sgx_debug_set_variant(11)
+            for bm, bn in ((0, 0), (64, 64), (128, 32), (64, 32), (128, 64)):
+                lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                K.clear_desc_cache()
+                t = timeit(fn)
+                note(key, calls, (bm, bn, 11), t)
+                if t < best:
+                    best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + " variant=11"
             lib().sgx_debug_set_variant(0)
         elif args.wgrad:
             note(key, calls, (0, 0, 0), base)
