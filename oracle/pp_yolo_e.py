@@ -41,15 +41,17 @@ def _conv_bn(cin, cout, k, stride, pad):
     return nn.Sequential(collections.OrderedDict([("conv", nn.Conv2d(cin, cout, k, stride, pad, bias=False)), ("bn", nn.BatchNorm2d(cout))]))
 
 
-class RepVGGBlock(nn.Module):   # PP-YOLOE configuration: no identity branch, no SE, alpha = 1
-    def __init__(self, cin, cout, act):
+class RepVGGBlock(nn.Module):   # PP-YOLOE configuration: no identity branch, no SE; alpha = 1, or (PP-YOLOE+) a learnable [1] multiplier
+    def __init__(self, cin, cout, act, use_alpha=False):
         super().__init__()
         self.branch_3x3 = _conv_bn(cin, cout, 3, 1, 1)
         self.branch_1x1 = _conv_bn(cin, cout, 1, 1, 0)
         self.nonlinearity = act()
+        # modules/repvgg_block.py:77-87: alpha = 1 + N(0, 0.01^2) as a parameter when use_alpha, else the constant 1
+        self.alpha = nn.Parameter(torch.tensor([1.0]) + torch.randn((1,)) * 0.01, requires_grad=True) if use_alpha else 1
 
-    def forward(self, x):
-        return self.nonlinearity(self.branch_3x3(x) + self.branch_1x1(x))
+    def forward(self, x):  # modules/repvgg_block.py:94-104
+        return self.nonlinearity(self.branch_3x3(x) + self.alpha * self.branch_1x1(x))
 
     def fused(self):
         """(kernel, bias) of the equivalent single 3x3 conv (repvgg_block.py:109-165)."""
@@ -59,7 +61,7 @@ class RepVGGBlock(nn.Module):   # PP-YOLOE configuration: no identity branch, no
             return branch.conv.weight * t, branch.bn.bias - branch.bn.running_mean * branch.bn.weight / std
         k3, b3 = fuse(self.branch_3x3)
         k1, b1 = fuse(self.branch_1x1)
-        return k3 + F.pad(k1, [1, 1, 1, 1]), b3 + b1
+        return k3 + self.alpha * F.pad(k1, [1, 1, 1, 1]), b3 + self.alpha * b1
 
 
 class EffectiveSEBlock(nn.Module):

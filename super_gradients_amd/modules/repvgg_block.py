@@ -2,8 +2,9 @@
 
 Reference: modules/repvgg_block.py:8-232 -
     y = act(se( bn3(conv3x3(x)) + alpha * bn1(conv1x1(x)) + [bn_id(x)] ))
-with state_dict keys branch_3x3.{conv.weight,bn.*}, branch_1x1.{conv.weight,bn.*}.  Supported subset = what PP-YOLOE builds
-(csp_resnet.py:38-40): no SE, alpha == 1, no identity-BN branch (use_residual_connection=False or in != out), groups = dilation = 1.
+with state_dict keys branch_3x3.{conv.weight,bn.*}, branch_1x1.{conv.weight,bn.*} (+ alpha when use_alpha).  Supported subset = what
+PP-YOLOE / PP-YOLOE+ build (csp_resnet.py:38-40): no SE, no identity-BN branch (use_residual_connection=False or in != out), groups =
+dilation = 1; `use_alpha=True` (PP-YOLOE+, repvgg_block.py:31,77-87): the learnable [1] multiplier of the 1x1 branch.
 
 Kernel sequence (training): the two convolutions run side by side (1x1 on the side stream), each emitting its BatchNorm partial
 statistics from the conv epilogue; two tiny finalizes; ONE sweep computes act(s3*t3 + b3 + s1*t1 + b1) [+ residual] - the reference
@@ -31,8 +32,6 @@ class RepVGGBlock(SgxBlock):
             raise NotImplementedError("RepVGGBlock on the HIP path: dilation=1, groups=1")
         if se_type not in (None, nn.Identity):
             raise NotImplementedError("RepVGGBlock on the HIP path: no SE block inside (PP-YOLOE passes nn.Identity)")
-        if use_alpha:
-            raise NotImplementedError("RepVGGBlock(use_alpha=True) (PP-YOLOE+) is not on the HIP path; alpha is the constant 1 here")
         if use_residual_connection and in_channels == out_channels and stride == 1:
             raise NotImplementedError("RepVGGBlock with the identity-BatchNorm branch (RepVGG classifiers) is not on the HIP path; PP-YOLOE builds "
                                       "its blocks with use_residual_connection=False")
@@ -40,7 +39,8 @@ class RepVGGBlock(SgxBlock):
             raise NotImplementedError("build a training-form block and call fuse_block_residual_branches() for the deployment form")
         self.in_channels, self.out_channels, self.stride, self.groups = in_channels, out_channels, stride, groups
         self.act = act_name(activation_type)
-        self.alpha = 1
+        # reference :77-87: a learnable [1] multiplier of the 1x1 branch, initialised at 1 + N(0, 0.01^2); else the constant 1
+        self.alpha = nn.Parameter(torch.tensor([1.0]) + torch.randn((1,)) * 0.01, requires_grad=True) if use_alpha else 1
         self.no_conv_branch = None
         self.branch_3x3 = _ConvBNBranch()
         self.branch_3x3.add_module("conv", ConvLayer(in_channels, out_channels, 3, stride, 1, bias=False))
@@ -70,19 +70,40 @@ class RepVGGBlock(SgxBlock):
             s3, b3, m3, i3 = bn3.scale_shift(parts3, M, True)
             self._net.join_side()
             s1, b1, m1, i1 = bn1.scale_shift(parts1, M, True)
-            y = K.dual_affine_act(t3, s3, b3, t1, s1, b1, post_add=post_add, act=self.act, out=out)
+            s1a, b1a = self._scaled(s1, b1)  # alpha * bn1(.) = (alpha s1) t1 + alpha b1: alpha rides in the sweep's per-channel constants
+            y = K.dual_affine_act(t3, s3, b3, t1, s1a, b1a, post_add=post_add, act=self.act, out=out)
             self._ctx = (x, t3, t1, s3, b3, m3, i3, s1, b1, m1, i1)
             return y
         t3, t1 = c3.conv(x), c1.conv(x)
         s3, b3, _, _ = bn3.scale_shift(None, 0, False)
         s1, b1, _, _ = bn1.scale_shift(None, 0, False)
+        s1, b1 = self._scaled(s1, b1)
         return K.dual_affine_act(t3, s3, b3, t1, s1, b1, post_add=post_add, act=self.act, out=out if out is not None else t3)
+
+    def _scaled(self, s1, b1):
+        if not isinstance(self.alpha, torch.Tensor):
+            return s1, b1
+        a = self.alpha.detach()
+        return s1 * a, b1 * a  # ([C] vectors on the device)
 
     def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
         c3, bn3, c1, bn1 = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1.conv, self.branch_1x1.bn
         (x, t3, t1, s3, b3, m3, i3, s1, b1, m1, i1), self._ctx = self._ctx, None
-        g = K.dual_affine_act_bwd(dy, t3, s3, b3, t1, s1, b1, act=self.act)
-        dt1 = bn1.backward(g, t1, s1, b1, m1, i1, None, dx_out=t1)   # in place over the saved conv outputs
+        s1a, b1a = self._scaled(s1, b1)
+        g = K.dual_affine_act_bwd(dy, t3, s3, b3, t1, s1a, b1a, act=self.act)
+        if isinstance(self.alpha, torch.Tensor):
+            # The BatchNorm backward is linear in its upstream gradient (alpha g here): run it on g with scratch parameter gradients, then
+            #   d gamma1 = alpha dg', d beta1 = alpha db', d t1 = alpha dt1'   and   d alpha = <g, bn1(t1)> = sum_c (gamma1 dg' + beta1 db')
+            # - exact for every alpha (zero included); one extra in-place pass over the 1x1 branch's gradient.
+            dg, db = torch.zeros_like(bn1.weight), torch.zeros_like(bn1.bias)
+            dt1 = K.bn_bwd(g, t1, s1, b1, bn1.weight, m1, i1, dg, db, act=None, dx_out=t1, sync=bn1._synced())
+            a = self.alpha.detach()
+            self.alpha.grad.add_((bn1.weight.detach() * dg + bn1.bias.detach() * db).sum())
+            bn1.weight.grad.add_(dg * a)
+            bn1.bias.grad.add_(db * a)
+            dt1 = K.axpy(dt1, a_dev=self.alpha, out=dt1)
+        else:
+            dt1 = bn1.backward(g, t1, s1, b1, m1, i1, None, dx_out=t1)   # in place over the saved conv outputs
         c1.wgrad(x, dt1)
         dt3 = bn3.backward(g, t3, s3, b3, m3, i3, None, dx_out=t3)
         c3.wgrad(x, dt3)
@@ -103,7 +124,8 @@ class RepVGGBlock(SgxBlock):
     def _get_equivalent_kernel_bias(self):
         k3, b3 = self._fuse_bn_tensor(self.branch_3x3)
         k1, b1 = self._fuse_bn_tensor(self.branch_1x1)
-        return k3 + self.alpha * torch.nn.functional.pad(k1, [1, 1, 1, 1]), b3 + self.alpha * b1
+        alpha = self.alpha.detach() if isinstance(self.alpha, torch.Tensor) else self.alpha
+        return k3 + alpha * torch.nn.functional.pad(k1, [1, 1, 1, 1]), b3 + alpha * b1
 
     def fuse_block_residual_branches(self):
         """Training form -> one 3x3 conv + bias (`rbr_reparam`, as in the reference).  Unlike the reference the branch modules stay

@@ -383,6 +383,54 @@ def test_repvgg_block(backend):
     _check(O(c, c, nn.SiLU), RepVGGBlock(c, c, activation_type="silu", use_residual_connection=False), x, backend)
 
 
+def test_repvgg_block_learnable_alpha(backend):
+    """RepVGGBlock(use_alpha=True) (PP-YOLOE+; reference modules/repvgg_block.py:31,77-87,94-104): y = act(bn3(conv3(x)) + alpha * bn1(conv1(x)))
+    with alpha a learnable [1] parameter - forward, input gradient, every parameter gradient INCLUDING alpha's and the 1x1 branch's
+    BatchNorm parameters (which see alpha * g), running statistics; then the deployment form, where alpha enters the fused kernel and bias."""
+    from oracle.pp_yolo_e import RepVGGBlock as O
+    from super_gradients_amd.modules.repvgg_block import RepVGGBlock
+
+    n, c, h, w = _shape(backend, (2, 64, 10, 10), (1, 8, 6, 6))
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
+    ref, blk = O(c, c, nn.SiLU, use_alpha=True), RepVGGBlock(c, c, activation_type="silu", use_residual_connection=False, use_alpha=True)
+    with torch.no_grad():
+        ref.alpha.fill_(0.7)
+    _check(ref, blk, x, backend)
+    assert abs(float(blk.alpha.detach().cpu()) - float(ref.alpha.detach())) < 1e-6 and abs(float(ref.alpha.detach()) - 1.0) > 0.05 and blk.alpha.grad is not None
+    ref.eval()
+    blk.eval()
+    blk.fuse_block_residual_branches()
+    k, b = ref.fused()
+    assert_close(blk.rbr_reparam.weight.detach().cpu(), k.detach(), 1e-6, "fused kernel")
+    assert_close(blk.rbr_reparam.bias.detach().cpu(), b.detach(), 1e-6, "fused bias")
+    with torch.no_grad():
+        assert_close(to_nchw_cpu(blk.fwd(to_nhwc(x, backend))), ref(x), 2e-5, "fused forward")
+
+
+@pytest.mark.skipif(not __import__("oracle.ref_shim", fromlist=["x"]).available(), reason="/root/reference not present (GPU box)")
+def test_oracle_repvgg_alpha_live():
+    """oracle.pp_yolo_e.RepVGGBlock(use_alpha=True) against the reference's own RepVGGBlock source executed through the import shim."""
+    from oracle import ref_shim
+    from oracle.pp_yolo_e import RepVGGBlock as O
+
+    ref_shim.install()
+    from super_gradients.modules.repvgg_block import RepVGGBlock as RefBlock
+
+    c = 8
+    r = RefBlock(c, c, activation_type=nn.SiLU, use_residual_connection=False, use_alpha=True).train()
+    o = O(c, c, nn.SiLU, use_alpha=True).train()
+    _randomize(r, 3)
+    _randomize(o, 3)  # (the same BatchNorm eps / momentum on both sides; the parameters are then copied from the reference block)
+    o.load_state_dict(r.state_dict(), strict=True)
+    x = torch.randn(2, c, 6, 6, generator=torch.Generator().manual_seed(1))
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = r(xa), o(xb)
+    assert torch.equal(ya, yb)
+    ya.sum().backward()
+    yb.sum().backward()
+    assert torch.equal(xa.grad, xb.grad) and torch.equal(r.alpha.grad, o.alpha.grad)
+
+
 def test_effective_se_block(backend):
     from oracle.pp_yolo_e import EffectiveSEBlock as O
     from super_gradients_amd.modules.se_blocks import EffectiveSEBlock
