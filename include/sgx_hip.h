@@ -404,6 +404,12 @@ int32_t sgx_dual_affine_act_fwd(const float* x1, int64_t x1_ld, const float* s1,
 int32_t sgx_dual_affine_act_bwd(const float* dy, int64_t dy_ld, const float* x1, int64_t x1_ld, const float* s1, const float* t1,
                                 const float* x2, int64_t x2_ld, const float* s2, const float* t2, float* g, int64_t g_ld, int64_t M,
                                 int32_t C, int32_t act, void* stream);
+/* the same sweep also leaving the reduce rows of BOTH BatchNorm backward passes (round 5): partials4 = [4][sgx_stats_blocks(M)][C] =
+ * sum g, sum g (x1 - mean1), sum g, sum g (x2 - mean2) - rows 0-1 are what sgx_bn_bwd_reduce(g, x1) would produce, rows 2-3 what
+ * sgx_bn_bwd_reduce(g, x2) would (act = none): two passes over g and the saved conv outputs less per RepVGG block.                   */
+int32_t sgx_dual_affine_act_bwd_reduce(const float* dy, int64_t dy_ld, const float* x1, int64_t x1_ld, const float* s1, const float* t1,
+                                       const float* mean1, const float* x2, int64_t x2_ld, const float* s2, const float* t2, const float* mean2,
+                                       float* g, int64_t g_ld, int64_t M, int32_t C, int32_t act, float* partials4, void* stream);
 /* per-channel column sum: out[c] (+)= sum_rows x[row][c]  (conv bias gradients).                     */
 /* rows_per_img/ld_img: rows are grouped in images of rows_per_img rows, image i starts at x + i*ld_img
  * (pass rows_per_img = M, ld_img = 0 for a plain [M,C] matrix).  ws: sgx_colsum_workspace(M, C) bytes.  */

@@ -168,6 +168,7 @@ PROTOTYPES = {
     "sgx_avgpool_bwd": (_i32, [_i32] * 3 + [_P, _P, _i64, _i64, _P]),
     "sgx_dual_affine_act_fwd": (_i32, [_P, _i64, _P, _P, _P, _i64, _P, _P, _P, _i64, _f, _P, _P, _i64, _i64, _i32, _i32, _P]),
     "sgx_dual_affine_act_bwd": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _i64, _P, _P, _P, _i64, _i64, _i32, _i32, _P]),
+    "sgx_dual_affine_act_bwd_reduce": (_i32, [_P, _i64, _P, _i64, _P, _P, _P, _P, _i64, _P, _P, _P, _P, _i64, _i64, _i32, _i32, _P, _P]),
     "sgx_image_colsum_workspace": (_i64, [_i32] * 3),
     "sgx_image_colsum": (_i32, [_i32] * 3 + [_P, _i64, _i64, _P, _i64, _i64, _f, _P, _i32, _P, _P, _i64, _P]),
     "sgx_channel_gate": (_i32, [_i32] * 3 + [_P, _i64, _i64, _P, _i32, _P, _f, _P, _i64, _i64, _i32, _P]),

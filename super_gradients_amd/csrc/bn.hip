@@ -972,6 +972,43 @@ extern "C" int32_t sgx_qarep_bwd_apply(const float* dout, int64_t d_ld, const fl
     return SGX_OK;
 }
 
+// RepVGG two-branch block, backward through the activation AND the reduce of both BatchNorm backward passes in one sweep (round 5):
+//   g = dy * act'(s1*x1 + t1 + s2*x2 + t2)   (written: both BatchNorm backward applies read it),
+//   partials [4][blocks][C] = sum g, sum g (x1 - mean1), sum g, sum g (x2 - mean2)   - i.e. the two [2][blocks][C] row sets sgx_bn_bwd_reduce
+// would have produced for (g, x1) and (g, x2) with two more passes over g and the saved conv outputs (modules/repvgg_block.py:94-104:
+// PP-YOLOE runs ~30 such blocks per step).  The sums are taken from the SAME g values that are stored.
+struct DualAffineBwdReduceF {
+    DualAffineF p; const float* dy; long dy_ld; float* g; long g_ld; const float* mean1; const float* mean2;
+    struct In { float4 a, b, d; };
+    struct Cst { DualAffineF::Cst k; float4 m1, m2; };
+    __device__ In load(long row, int c) const {
+        return In{sgx_ld4(p.x1 + row * p.x1_ld + c), sgx_ld4(p.x2 + row * p.x2_ld + c), sgx_ld4(dy + row * dy_ld + c)};
+    }
+    __device__ Cst consts(int c) const { return Cst{p.consts(c), sgx_ld4(mean1 + c), sgx_ld4(mean2 + c)}; }
+    __device__ void apply(long row, int c, const In& in, const Cst& k, float4 (&q)[4]) const {
+        const float4 v = p.pre(k.k, in.a, in.b);
+        const float4 o = make_float4(in.d.x * sgx_act_grad(v.x, p.act), in.d.y * sgx_act_grad(v.y, p.act), in.d.z * sgx_act_grad(v.z, p.act),
+                                     in.d.w * sgx_act_grad(v.w, p.act));
+        sgx_st4(g + row * g_ld + c, o);
+        q[0].x += o.x; q[0].y += o.y; q[0].z += o.z; q[0].w += o.w;
+        q[1].x += o.x * (in.a.x - k.m1.x); q[1].y += o.y * (in.a.y - k.m1.y); q[1].z += o.z * (in.a.z - k.m1.z); q[1].w += o.w * (in.a.w - k.m1.w);
+        q[2].x += o.x; q[2].y += o.y; q[2].z += o.z; q[2].w += o.w;
+        q[3].x += o.x * (in.b.x - k.m2.x); q[3].y += o.y * (in.b.y - k.m2.y); q[3].z += o.z * (in.b.z - k.m2.z); q[3].w += o.w * (in.b.w - k.m2.w);
+    }
+};
+extern "C" int32_t sgx_dual_affine_act_bwd_reduce(const float* dy, int64_t dy_ld, const float* x1, int64_t x1_ld, const float* s1, const float* t1,
+                                                  const float* mean1, const float* x2, int64_t x2_ld, const float* s2, const float* t2,
+                                                  const float* mean2, float* g, int64_t g_ld, int64_t M, int32_t C, int32_t act, float* partials4,
+                                                  void* stream) {
+    SGX_CHECK_ARG(dy && x1 && s1 && t1 && mean1 && x2 && s2 && t2 && mean2 && g && partials4, "dual_affine_act_bwd_reduce: null pointer");
+    SGX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "dual_affine_act_bwd_reduce: need M>0 and C%%4==0 (C=%d)", C);
+    DualAffineBwdReduceF f{DualAffineF{x1, x1_ld, s1, t1, x2, x2_ld, s2, t2, nullptr, 0, nullptr, 0, act, 1.f, nullptr}, dy, dy_ld, g, g_ld, mean1, mean2};
+    SweepGeom gm = sweep_geom(M, C);
+    SGX_LAUNCH((sweepq_kernel<DualAffineBwdReduceF, 4>), dim3(gm.nblk, gm.ctiles), dim3(SW_THREADS), 0, stream, f, gm, partials4);
+    SGX_CHECK_LAUNCH("dual_affine_act_bwd_reduce");
+    return SGX_OK;
+}
+
 struct ColsumF {
     const float* x; long ld; long rows_per_img; long ld_img;
     struct In { float4 v; };

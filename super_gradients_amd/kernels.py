@@ -780,6 +780,19 @@ def dual_affine_act_bwd(dy, x1, s1, t1, x2=None, s2=None, t2=None, act=None, out
     return out
 
 
+def dual_affine_act_bwd_reduce(dy, x1, s1, t1, mean1, x2, s2, t2, mean2, act=None, out=None):
+    """g = dy * act'(s1*x1 + t1 + s2*x2 + t2) AND the reduce rows of both BatchNorm backward passes -> (g, parts1, parts2), each parts [2, blocks, C]
+    as bn_bwd(parts=...) takes them (sum g, sum g (x - mean))."""
+    M, ld1 = rows(x1)
+    C = x1.shape[3]
+    if out is None:
+        out = torch.empty(x1.shape, device=x1.device, dtype=torch.float32)
+    parts = torch.empty(4, stats_blocks(M), C, device=x1.device, dtype=torch.float32)
+    check(lib().sgx_dual_affine_act_bwd_reduce(ptr(dy), rows(dy)[1], ptr(x1), ld1, ptr(s1), ptr(t1), ptr(mean1), ptr(x2), rows(x2)[1], ptr(s2), ptr(t2), ptr(mean2),
+                                               ptr(out), rows(out)[1], M, C, ACT[act], ptr(parts), stream()), "sgx_dual_affine_act_bwd_reduce")
+    return out, parts[0:2], parts[2:4]
+
+
 GATE = {None: 0, "none": 0, "hardsigmoid": 1, "sigmoid": 2}
 
 

@@ -9,8 +9,9 @@ dilation = 1; `use_alpha=True` (PP-YOLOE+, repvgg_block.py:31,77-87): the learna
 Kernel sequence (training): the two convolutions run side by side (1x1 on the side stream), each emitting its BatchNorm partial
 statistics from the conv epilogue; two tiny finalizes; ONE sweep computes act(s3*t3 + b3 + s1*t1 + b1) [+ residual] - the reference
 runs 2 conv + 2 BN + add + activation (+ add).  Backward: one sweep for the gradient through the activation (pre-activation
-recomputed from the saved conv outputs), then the two BatchNorm backward passes in place over t3 / t1, weight gradients on the
-side stream, and the 1x1 data gradient accumulated into the 3x3 one.
+recomputed from the saved conv outputs) that also leaves the reduce rows of both BatchNorm backward passes (round 5), then the two
+BatchNorm backward applies in place over t3 / t1, weight gradients on the side stream, and the 1x1 data gradient accumulated into the
+3x3 one.
 """
 import torch
 from torch import nn
@@ -90,22 +91,24 @@ class RepVGGBlock(SgxBlock):
         c3, bn3, c1, bn1 = self.branch_3x3.conv, self.branch_3x3.bn, self.branch_1x1.conv, self.branch_1x1.bn
         (x, t3, t1, s3, b3, m3, i3, s1, b1, m1, i1), self._ctx = self._ctx, None
         s1a, b1a = self._scaled(s1, b1)
-        g = K.dual_affine_act_bwd(dy, t3, s3, b3, t1, s1a, b1a, act=self.act)
+        # one sweep: the gradient through the activation AND the reduce rows of both BatchNorm backward passes (round 5: two passes over
+        # g and the saved conv outputs less per block)
+        g, parts3, parts1 = K.dual_affine_act_bwd_reduce(dy, t3, s3, b3, m3, t1, s1a, b1a, m1, act=self.act)
         if isinstance(self.alpha, torch.Tensor):
             # The BatchNorm backward is linear in its upstream gradient (alpha g here): run it on g with scratch parameter gradients, then
             #   d gamma1 = alpha dg', d beta1 = alpha db', d t1 = alpha dt1'   and   d alpha = <g, bn1(t1)> = sum_c (gamma1 dg' + beta1 db')
             # - exact for every alpha (zero included); one extra in-place pass over the 1x1 branch's gradient.
             dg, db = torch.zeros_like(bn1.weight), torch.zeros_like(bn1.bias)
-            dt1 = K.bn_bwd(g, t1, s1, b1, bn1.weight, m1, i1, dg, db, act=None, dx_out=t1, sync=bn1._synced())
+            dt1 = K.bn_bwd(g, t1, s1, b1, bn1.weight, m1, i1, dg, db, act=None, dx_out=t1, sync=bn1._synced(), parts=parts1)
             a = self.alpha.detach()
             self.alpha.grad.add_((bn1.weight.detach() * dg + bn1.bias.detach() * db).sum())
             bn1.weight.grad.add_(dg * a)
             bn1.bias.grad.add_(db * a)
             dt1 = K.axpy(dt1, a_dev=self.alpha, out=dt1)
         else:
-            dt1 = bn1.backward(g, t1, s1, b1, m1, i1, None, dx_out=t1)   # in place over the saved conv outputs
+            dt1 = bn1.backward(g, t1, s1, b1, m1, i1, None, dx_out=t1, parts=parts1)   # in place over the saved conv outputs
         c1.wgrad(x, dt1)
-        dt3 = bn3.backward(g, t3, s3, b3, m3, i3, None, dx_out=t3)
+        dt3 = bn3.backward(g, t3, s3, b3, m3, i3, None, dx_out=t3, parts=parts3)
         c3.wgrad(x, dt3)
         if not need_dx:
             return None
