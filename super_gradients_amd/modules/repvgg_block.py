@@ -21,6 +21,9 @@ from .engine import SgxBlock
 from .layers import BatchNorm, ConvLayer, act_name
 
 
+_FUSED_REDUCE = __import__("os").environ.get("SGX_REPVGG_FUSED_REDUCE", "1") != "0"
+
+
 class _ConvBNBranch(nn.Module):
     """Namespace so that keys read branch_*.conv.weight / branch_*.bn.* like the reference's nn.Sequential (repvgg_block.py:211-232)."""
 
@@ -93,7 +96,10 @@ class RepVGGBlock(SgxBlock):
         s1a, b1a = self._scaled(s1, b1)
         # one sweep: the gradient through the activation AND the reduce rows of both BatchNorm backward passes (round 5: two passes over
         # g and the saved conv outputs less per block)
-        g, parts3, parts1 = K.dual_affine_act_bwd_reduce(dy, t3, s3, b3, m3, t1, s1a, b1a, m1, act=self.act)
+        if _FUSED_REDUCE:
+            g, parts3, parts1 = K.dual_affine_act_bwd_reduce(dy, t3, s3, b3, m3, t1, s1a, b1a, m1, act=self.act)
+        else:  # (measurement: SGX_REPVGG_FUSED_REDUCE=0 - each BatchNorm backward runs its own reduce sweep)
+            g, parts3, parts1 = K.dual_affine_act_bwd(dy, t3, s3, b3, t1, s1a, b1a, act=self.act), None, None
         if isinstance(self.alpha, torch.Tensor):
             # The BatchNorm backward is linear in its upstream gradient (alpha g here): run it on g with scratch parameter gradients, then
             #   d gamma1 = alpha dg', d beta1 = alpha db', d t1 = alpha dt1'   and   d alpha = <g, bn1(t1)> = sum_c (gamma1 dg' + beta1 db')
