@@ -814,11 +814,17 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                     for (int r = 0; r < 16; ++r)
                         stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = o == 0 ? acc2[ACC2 ? i : 0][ACC2 ? j : 0][r] : acc[i][j][r];
                     sgx_wave_lds_sync();  // the staging patch is private to the wave
+                    long long offq[4];
+                    float4 vq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {  // (all eight LDS reads of the block ahead of its stores: see the one-output epilogue)
+                        offq[q] = rowoff[wm * TM * 32 + i * 32 + q * 8 + sr];
+                        vq[q] = sgx_ld4(stage + (q * 8 + sr) * 32 + sc4);
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int rowl = q * 8 + sr;
-                        const long long off = rowoff[wm * TM * 32 + i * 32 + rowl];
-                        float4 v = sgx_ld4(stage + rowl * 32 + sc4);
+                        const long long off = offq[q];
+                        float4 v = vq[q];
                         if (off >= 0 && colok) {
                             if (o == 1) {
                                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
@@ -878,11 +884,21 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
 #pragma unroll
             for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][r];
             sgx_wave_lds_sync();  // the staging patch is private to the wave
+            // (Round 5: the four row offsets and the four staged rows of a block come out of LDS TOGETHER, ahead of the per-row work.  The
+            // per-row form read the offset -> waited -> branched -> read the staged row -> waited -> stored, four times over: two exposed
+            // LDS round trips per row, 1000-1500 cycles per block in the stamps of tools/pconv_timing.py, r5t.)
+            long long offq[4];
+            float4 vq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                offq[q] = rowoff[wm * TM * 32 + i * 32 + q * 8 + sr];
+                vq[q] = sgx_ld4(stage + (q * 8 + sr) * 32 + sc4);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int rowl = q * 8 + sr;
-                const long long off = rowoff[wm * TM * 32 + i * 32 + rowl];
-                float4 v = sgx_ld4(stage + rowl * 32 + sc4);
+                const long long off = offq[q];
+                float4 v = vq[q];
                 if (off >= 0 && colok) {
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     float* yp = p.Y + off + col;
@@ -1307,11 +1323,17 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
                     for (int r = 0; r < 16; ++r)
                         stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = o == 0 ? acc[i][j][r] : accu[DUAL ? i : 0][DUAL ? j : 0][r];
                     sgx_wave_lds_sync();  // the staging patch is private to the wave
+                    long long offq[4];
+                    float4 vq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {  // (all eight LDS reads of the block ahead of its stores: see the one-output epilogue)
+                        offq[q] = rowoff[(wm * TM + i) * 32 + q * 8 + sr];
+                        vq[q] = sgx_ld4(stage + (q * 8 + sr) * 32 + sc4);
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int rowl = q * 8 + sr;
-                        const long long off = rowoff[(wm * TM + i) * 32 + rowl];
-                        float4 v = sgx_ld4(stage + rowl * 32 + sc4);
+                        const long long off = offq[q];
+                        float4 v = vq[q];
                         if (off >= 0 && colok) {
                             if (o == 1) {
                                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
@@ -1355,11 +1377,21 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
 #pragma unroll
             for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][r];
             sgx_wave_lds_sync();  // the staging patch is private to the wave
+            // (Round 5: the four row offsets and the four staged rows of a block come out of LDS TOGETHER, ahead of the per-row work.  The
+            // per-row form read the offset -> waited -> branched -> read the staged row -> waited -> stored, four times over: two exposed
+            // LDS round trips per row, 1000-1500 cycles per block in the stamps of tools/pconv_timing.py, r5t.)
+            long long offq[4];
+            float4 vq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                offq[q] = rowoff[(wm * TM + i) * 32 + q * 8 + sr];
+                vq[q] = sgx_ld4(stage + (q * 8 + sr) * 32 + sc4);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int rowl = q * 8 + sr;
-                const long long off = rowoff[(wm * TM + i) * 32 + rowl];
-                float4 v = sgx_ld4(stage + rowl * 32 + sc4);
+                const long long off = offq[q];
+                float4 v = vq[q];
                 if (off >= 0 && colok) {
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     float* yp = p.Y + off + col;
