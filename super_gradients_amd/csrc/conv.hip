@@ -1007,6 +1007,31 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
 // accumulators).  PH2 as in igemm_kernel: 1 = second source (1x1, its own tensor) into the same accumulator - the QARepVGG data
 // gradient; 2 = second filter on the centre tap into a second output - the QARepVGG forward pair, with the five BatchNorm moments.
 // ------------------------------------------------------------------------------------------------
+// Phase timing of the patch kernel (measurement builds only: -DSGX_PCONV_TIMING[=2], tools/pconv_timing.py, tools/visits/r5_visit12.sh): lane 0
+// of wave 0 of every workgroup stamps s_memtime at ten points (=2: a second set inside the two-output epilogue) and leaves the stamps in
+// a caller-provided buffer [workgroups][16].  The product build compiles none of it.
+#ifdef SGX_PCONV_TIMING
+__device__ unsigned long long* g_pc_timing = nullptr;
+extern "C" int32_t sgx_debug_set_pconv_timing(void* buf) {
+    unsigned long long* b = (unsigned long long*)buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pc_timing), &b, sizeof(b)) == hipSuccess ? SGX_OK : SGX_ERR_HIP;
+}
+#define PC_T(i) (pc_ts[i] = __builtin_readcyclecounter())
+#define PC_TOUT()                                                                                      \
+    do {                                                                                               \
+        PC_T(9);                                                                                       \
+        if (threadIdx.x == 0 && g_pc_timing)                                                           \
+            for (int q_ = 0; q_ < 12; ++q_) g_pc_timing[(long)blockIdx.x * 16 + q_] = pc_ts[q_];       \
+    } while (0)
+#else
+#define PC_T(i) ((void)0)
+#define PC_TOUT() ((void)0)
+#endif
+#if defined(SGX_PCONV_TIMING) && SGX_PCONV_TIMING == 2
+#define PC_E(i) (pc_ts[i] = __builtin_readcyclecounter())
+#else
+#define PC_E(i) ((void)0)
+#endif
 #define PC_TH 8
 #define PC_TW 16
 #define PC_PW (PC_TW + 2)              // patch pitch (pixels)
@@ -1039,6 +1064,10 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
     __shared__ float red[(PH2 == 2 ? 5 : 2) * WM * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SGX_PCONV_TIMING
+    unsigned long long pc_ts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    PC_T(0);
     const int wm = wave / WN, wn = wave % WN;
     const int bid = blockIdx.x;
     const int lin = (bid & 7) * p.chunk + (bid >> 3);
@@ -1233,12 +1262,17 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
             if (!p.A2) break;
             setup_src(p.A2, p.Wt2, p.Hin2, p.Win2, p.Th2, p.Tw2, p.dh02, p.dw02, p.dstep2, p.a2_ld_pix, p.a2_ld_img, p.w2_ld_n, p.a2_bytes, p.w2_bytes);
         }
+        if (src == 0) PC_T(1);
         load_chunk(0);
         if (src == 0) compute_rowoff();
+        if (src == 0) PC_T(2);
         for (int chunk = 0; chunk < cpt; ++chunk) {
             // every wave is past its last fragment read of the previous chunk (barrier below); this chunk has been travelling in registers
             store_chunk();
+            if (src == 0 && chunk == 0) PC_T(3);
+            if (src == 0 && chunk == 1) PC_T(7);
             __syncthreads();
+            if (src == 0 && chunk == 0) PC_T(4);
             if (chunk + 1 < cpt) load_chunk(chunk + 1);
             if constexpr (!FPIPE) {  // measurement variant 8: read - wait - multiply per tap (one fragment set: fewer registers)
                 Frags f;
@@ -1250,7 +1284,9 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
                     load_frags(f, NF - 1, PC_PW + 1);
                     mfma_tap(f, accu, accu2);
                 }
+                if (src == 0 && chunk == 0) PC_T(5);
                 __syncthreads();
+                if (src == 0 && chunk == 0) PC_T(6);
                 continue;
             }
             Frags fa, fb;
@@ -1270,9 +1306,12 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
             } else if constexpr (DUAL) {
                 mfma_tap(fa, accu, accu2);
             }
+            if (src == 0 && chunk == 0) PC_T(5);
             __syncthreads();
+            if (src == 0 && chunk == 0) PC_T(6);
         }
     }
+    PC_T(8);
 
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1284,6 +1323,7 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
                 if (DUAL) accu[DUAL ? i : 0][DUAL ? j : 0][r] += accu2[DUAL ? i : 0][DUAL ? j : 0][r];
             }
     // ---- epilogues: as igemm_kernel's (32x32 accumulators transposed through a per-wave LDS patch -> 16-byte stores) ------------------------
+    PC_T(11);
     float* const stage = smem + wave * (32 * 32);
     const int sr = lane >> 3, sc4 = (lane & 7) * 4;
     const bool full = oy0 + PC_TH <= p.Ha && ox0 + PC_TW <= p.Wa;
@@ -1311,6 +1351,7 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
 #pragma unroll
                 for (int t = 0; t < 5; ++t) red[(t * WM + wm) * BN + wn * TN * 32 + j * 32 + lane] = st[t];
             }
+            PC_E(1);
             const int col = n0 + wn * TN * 32 + j * 32 + sc4;
             const bool colok = col < p.Nout;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1323,6 +1364,7 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
                     for (int r = 0; r < 16; ++r)
                         stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = o == 0 ? acc[i][j][r] : accu[DUAL ? i : 0][DUAL ? j : 0][r];
                     sgx_wave_lds_sync();  // the staging patch is private to the wave
+                    if (o == 0) PC_E(2); else PC_E(4);
                     long long offq[4];
                     float4 vq[4];
 #pragma unroll
@@ -1341,10 +1383,12 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
                             sgx_st4((o == 0 ? p.Y : p.Y2) + off + col, v);
                         }
                     }
+                    if (o == 0) PC_E(3); else PC_E(5);
                     sgx_wave_lds_sync();  // the staging patch is private to the wave
                 }
             }
         }
+        PC_T(10);
         __syncthreads();
         if (tid < BN) {
             const int col = n0 + tid;
@@ -1358,6 +1402,7 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
                 }
             }
         }
+        PC_TOUT();
         return;
     }
 #pragma unroll
@@ -1455,6 +1500,7 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
             }
         }
     }
+    PC_TOUT();
 }
 
 // ------------------------------------------------------------------------------------------------
