@@ -187,6 +187,27 @@ typedef struct sgx_qarep_prep_job {
 } sgx_qarep_prep_job;
 int32_t sgx_qarep_prep_batch(const sgx_qarep_prep_job* jobs_dev, int32_t njobs, void* stream);
 
+/* Pre-split filter planes of the bf16x3 convolutions (round 5).  The reference keeps one fp32 weight tensor per convolution
+ * (modules/qarepvgg_block.py:184-204, conv_bn_act_block.py:68-93) and leaves its representation inside a launch to cuDNN; here a bf16x3
+ * launch stages its filter as three bf16 pieces per element, and a filter changes once per optimizer step while every pixel tile of every
+ * launch would split it again.  sgx_filter_planes_batch splits each job's filter src[rows][taps][ch] (dense, ch a multiple of 16) once into
+ * planes[ch / 16][hi | mid | lo][tap][row][16 bf16] (sgx_filter_planes_bytes(rows, taps, ch) bytes) and registers src -> planes; forward /
+ * data-gradient launches whose filter pointer and shape match a VALID entry, made while a scope is open, copy the planes instead of
+ * splitting - bit-identical results.  Contract of the caller (modules/engine.py): open the scope only around a training step's forward /
+ * backward, run the batch after the last weight update of the step, invalidate (NULL: everything) before weights change or the
+ * addresses are released.  jobs_host and jobs_dev hold the same records (host copy for the registry, device copy for the kernel).      */
+typedef struct sgx_fplanes_job {
+    const float* src; /* [rows][taps][ch] fp32                                         */
+    void* planes;     /* sgx_filter_planes_bytes(rows, taps, ch), 16-byte aligned      */
+    int32_t rows, taps, ch, pad_;
+} sgx_fplanes_job;
+int64_t sgx_filter_planes_bytes(int32_t rows, int32_t taps, int32_t ch);
+int32_t sgx_filter_planes_batch(const sgx_fplanes_job* jobs_host, const sgx_fplanes_job* jobs_dev, int32_t njobs, void* stream);
+int32_t sgx_filter_planes_invalidate(const sgx_fplanes_job* jobs_host, int32_t njobs);
+int32_t sgx_filter_planes_scope(int32_t open);
+int32_t sgx_debug_set_filter_planes(int32_t on); /* measurement: 0 = every launch splits its filter while staging */
+int64_t sgx_debug_filter_planes_hits(void);      /* launches that read planes so far (tests)                         */
+
 /* dw[k][r][s][c] += sum_pixels dy * x   (accumulates into dw: callers zero the gradient arena once per
  * optimizer step).  dbias[k] += sum dy if dbias != NULL.  ws: sgx_conv2d_bwd_weight_workspace(d).  */
 int64_t sgx_conv2d_bwd_weight_workspace(const sgx_conv_desc* d);

@@ -57,6 +57,10 @@ class QarepPrepJob(ctypes.Structure):  # == sgx_qarep_prep_job
                 ("identity", c_int32), ("pad_", c_int32)]
 
 
+class FplanesJob(ctypes.Structure):  # == sgx_fplanes_job
+    _fields_ = [("src", ctypes.c_void_p), ("planes", ctypes.c_void_p), ("rows", c_int32), ("taps", c_int32), ("ch", c_int32), ("pad_", c_int32)]
+
+
 class ImageJob(ctypes.Structure):  # == sgx_image_job
     _fields_ = [("src", ctypes.c_void_p), ("h0", c_int32), ("w0", c_int32), ("h", c_int32), ("w", c_int32), ("top", c_int32), ("left", c_int32)]
 
@@ -105,6 +109,12 @@ PROTOTYPES = {
     "sgx_conv2d_fwd_dual": (_i32, [_CD, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sgx_conv2d_bwd_data_dual": (_i32, [_CD, _P, _P, _P, _i64, _i64, _P, _P, _P, _i64, _i64, _f, _P, _P, _i32, _P]),
     "sgx_qarep_prep_batch": (_i32, [_P, _i32, _P]),
+    "sgx_filter_planes_bytes": (_i64, [_i32, _i32, _i32]),
+    "sgx_filter_planes_batch": (_i32, [_P, _P, _i32, _P]),
+    "sgx_filter_planes_invalidate": (_i32, [_P, _i32]),
+    "sgx_filter_planes_scope": (_i32, [_i32]),
+    "sgx_debug_set_filter_planes": (_i32, [_i32]),
+    "sgx_debug_filter_planes_hits": (_i64, []),
     "sgx_qarep_workspace": (_i64, [_i32, _i32]),
     "sgx_qarep_fwd_finalize": (_i32, [_P, _i32, _i64, _i32, _P, _P, _P, _f, _f, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P, _i64, _P]),
     "sgx_qarep_bwd_reduce": (_i32, [_P, _i64, _P, _i64, _P, _i64, _P, _P, _i64, _i32, _i32, _P, _P]),
@@ -247,6 +257,8 @@ def lib():
             _LIB.sgx_conv_set_wgrad_math(WGRAD_MATH[wgm])
         if os.environ.get("SGX_BF3_MIN_DEPTH"):  # measurement: depth (taps x channels) from which a problem runs in bf16x3 arithmetic
             _LIB.sgx_debug_set_bf3_min_depth(int(os.environ["SGX_BF3_MIN_DEPTH"]))
+        if os.environ.get("SGX_FILTER_PLANES"):  # measurement: 0 = every bf16x3 launch splits its filter while staging (round 5)
+            _LIB.sgx_debug_set_filter_planes(int(os.environ["SGX_FILTER_PLANES"]))
         if os.environ.get("SGX_PCONV_PIPE"):  # measurement: second fragment set for the patch kernel's 32-filter tiles
             _LIB.sgx_debug_set_pconv_pipe(int(os.environ["SGX_PCONV_PIPE"]))
         if os.environ.get("SGX_WGRAD_LDS_RESERVE"):  # KB of every CU's LDS the weight-gradient kernels leave to the main stream

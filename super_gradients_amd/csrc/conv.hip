@@ -23,6 +23,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------
@@ -191,6 +192,12 @@ struct IgemmParams {
     float* Y2;
     int Hin2, Win2, Th2, Tw2, dh02, dw02, dstep2;
     long a2_ld_pix, a2_ld_img, w2_ld_n, a2_bytes, w2_bytes;
+    // Pre-split filter planes (template WPL; sgx_filter_planes_batch, round 5): the bf16x3 pieces of Wt / Wt2 as the per-step producer left
+    // them - [ch / 16][hi | mid | lo][tap][row][16 bf16] - so that the filter half of a bf16x3 launch's staging is a 16-byte copy
+    // (no vector split: the filter is split by every pixel tile of a launch, the activations once per filter tile).  NULL: split while staging.
+    const unsigned char* Wp;
+    const unsigned char* Wp2;
+    long wp_bytes, wp2_bytes;
     // BatchNorm-backward REDUCE of the layer(s) whose output gradient this launch finalises (data gradients; sgx_bn_reduce_req): per request
     // a channel range of Y, that layer's saved conv output t (its own strides) and its BatchNorm scale / shift / mean.  The epilogue forms
     // g = v * act'(scale t + shift) from the value v it is about to store and leaves sum g, sum g (t - mean) per column in row block
@@ -288,8 +295,9 @@ constexpr int igemm_min_waves() {
     if (NBUF == 2 && KD == 32) return (BM + BN) * 192 * 2 > 52 * 1024 ? 2 : 3;
     return (MATH == 1 && KD == 32 && PH2 <= IG_BF3_MIN_WAVES_PH2 && BM / (WM * 32) == 1 && BN / (WN * 32) == 1) ? IG_BF3_MIN_WAVES : 1;
 }
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0>
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, bool WPL = false>
 __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2, NBUF>())) void igemm_kernel(IgemmParams p) {
+    static_assert(!WPL || (MATH == 1 && KD == 32 && NBUF == 1 && !FLAT), "pre-split filter planes: the one-buffer 32-deep bf16x3 loop");
     static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && NBUF == 1) || (KD == 32 && !FLAT && NBUF == 2 && MATH == 1) ||
                       (KD == 32 && !FLAT && NBUF == 3 && MATH == 0 && PH2 == 0),
                   "32-deep slabs: channel-chunked K axis; one LDS buffer, (bf16x3) the two-buffer pipelined loop, or (fp32, NBUF = 3) all slabs up front");
@@ -308,7 +316,12 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
     constexpr int RPP = NTH / CPR;      // slab rows staged per pass
     constexpr int LD = KD + 4;          // fp32 LDS row pitch: 20 / 36 floats -> conflict-free ds_read_b128 over 16 consecutive rows
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int AJ = (BM + RPP - 1) / RPP, BJ = (BN + RPP - 1) / RPP;
+    // WPL (IgemmParams::Wp): the filter slab arrives as 16-byte pieces of the pre-split planes - item = (plane, row, 8-channel octet) - and
+    // is copied into the LDS planes as it is: BN x 4 x 3 items per slab instead of BN x 8 float4 items with a 22-instruction split each
+    // Which (plane, 16-row block) a thread's j-th piece belongs to is the same for its whole wave: a wave copies 16 rows x 4 octets, the
+    // BN / 16 blocks of a plane follow one another, and only the place inside the block (row lane / 4, octet lane % 4) is per lane.
+    constexpr int BPI = 3 * BN * 4, WBK = BN / 16;   // pieces per slab; 16-row blocks per plane
+    constexpr int AJ = (BM + RPP - 1) / RPP, BJ = WPL ? (BPI + NTH - 1) / NTH : (BN + RPP - 1) / RPP;
     static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "bad tile");
     static_assert(NTH >= BM && NTH >= BN, "epilogue helpers need one thread per tile row/col");
     constexpr int LDPW = KD / 2;        // bf16x3: dwords per slab row and plane (KD bf16), unpadded
@@ -343,18 +356,20 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
     const int img0 = sgx_fdiv(m0, p.fd_hw);
     const int lrow = tid / CPR, chunk4 = (tid % CPR) * 4;
     sgx_buf bufA, bufB;
-    int aoff[AJ], boff[BJ];
+    int aoff[AJ], boff[WPL ? 1 : BJ];
     unsigned long long amask[AJ];
-    bool bok[BJ];
+    bool bok[WPL ? 1 : BJ];
+    int wp_lane = 0, wp_lds = 0, wp_rows = 0;  // WPL: planes byte offset / LDS dword offset of this lane's place in a 16-row block; filter rows from n0 on
     int Tw_, T_, nkt, pixstep, rowstep;
     const int cpt = (p.C + KD - 1) / KD;
     // scalar slab state of the NEXT slab to load (non-FLAT): tap row, tap column, channel chunk
     int s_ti = 0, s_tj = 0, s_ck = 0, s_kt = 0;
+    int wp_tapstep = 0, wp_ckstep = 0;  // WPL: bytes from one tap's rows to the next, from one 32-channel chunk's planes to the next
     auto setup_src = [&](const float* A, const float* Wt, int Hin, int Win, int Th, int Tw, int dh0, int dw0, int dstep, long a_ld_pix, long a_ld_img,
-                         long w_ld_n, long a_bytes, long w_bytes) {
+                         long w_ld_n, long a_bytes, long w_bytes, const unsigned char* Wp, long wp_bytes) {
         // buffer descriptors: A is re-based at the workgroup's first image so that lane offsets fit 31 bits
         bufA = sgx_make_buf(A + (long)img0 * a_ld_img, a_bytes - (long)img0 * a_ld_img * 4);
-        bufB = sgx_make_buf(Wt, w_bytes);
+        bufB = WPL ? sgx_make_buf(Wp, wp_bytes) : sgx_make_buf(Wt, w_bytes);
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int row = lrow + RPP * j;
@@ -379,12 +394,22 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                 amask[j] = mk;
             }
         }
+        if constexpr (WPL) {
+            // planes [ch / 16][plane][tap][row][32 B]: a 32-deep slab (tap, chunk ck) is the 16-channel blocks 2 ck and 2 ck + 1
+            wp_tapstep = p.Nout * 32;
+            wp_ckstep = 6 * Th * Tw * wp_tapstep;
+            const int lrow16 = lane >> 2, oct = lane & 3;
+            wp_lane = (oct >> 1) * 3 * Th * Tw * wp_tapstep + (n0 + lrow16) * 32 + (oct & 1) * 16;
+            wp_lds = lrow16 * LDPW + ((oct ^ ((lrow16 >> 2) & 3)) << 2);  // swz(row, oct * 4): a block starts at a multiple of 16 rows
+            wp_rows = p.Nout - n0 - lrow16;                               // this lane's row of block b exists if 16 b < wp_rows
+        } else {
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const int row = lrow + RPP * j;
-            const int n = n0 + row;
-            bok[j] = (row < BN) && (n < p.Nout);
-            boff[j] = (int)(((long)n * w_ld_n + (FLAT ? 0 : chunk4)) * 4);
+            for (int j = 0; j < BJ; ++j) {
+                const int row = lrow + RPP * j;
+                const int n = n0 + row;
+                bok[j] = (row < BN) && (n < p.Nout);
+                boff[j] = (int)(((long)n * w_ld_n + (FLAT ? 0 : chunk4)) * 4);
+            }
         }
         Tw_ = Tw;
         T_ = Th * Tw;
@@ -393,7 +418,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
         rowstep = pixstep * Win;               // bytes per tap step along h
         s_ti = s_tj = s_ck = s_kt = 0;
     };
-    setup_src(p.A, p.Wt, p.Hin, p.Win, p.Th, p.Tw, p.dh0, p.dw0, p.dstep, p.a_ld_pix, p.a_ld_img, p.w_ld_n, p.a_bytes, p.w_bytes);
+    setup_src(p.A, p.Wt, p.Hin, p.Win, p.Th, p.Tw, p.dh0, p.dw0, p.dstep, p.a_ld_pix, p.a_ld_img, p.w_ld_n, p.a_bytes, p.w_bytes, p.Wp, p.wp_bytes);
     // output-row offsets: needed by the epilogue only - computed AFTER the first slab's loads are in flight (64-bit divisions and
     // multiplies that used to sit between the kernel's start and its first global load); the K loop's barriers publish them
     auto compute_rowoff = [&]() {
@@ -437,15 +462,27 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
         } else {
             const int tbit = s_ti * Tw_ + s_tj;
             const int tapoff = s_ti * rowstep + s_tj * pixstep + s_ck * (KD * 4);
-            const int woff = (tbit * p.C + s_ck * KD) * 4;
+            const int woff = WPL ? s_ck * wp_ckstep + tbit * wp_tapstep : (tbit * p.C + s_ck * KD) * 4;
             const bool cok = live && s_ck * KD + chunk4 < p.C;
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 const bool ok = cok && ((amask[j] >> (tbit & 63)) & 1ull);
                 ra[j] = sgx_buf_ld4(bufA, ok ? (unsigned)(aoff[j] + tapoff) : SGX_BUF_OOB);
             }
+            // (WPL: C is a multiple of 32 - no ragged channel chunk to mask on the filter side)
+            if constexpr (WPL) {
+                const int wv = sgx_uniform_i32(tid >> 6);
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) rb[j] = sgx_buf_ld4(bufB, (cok && bok[j]) ? (unsigned)(boff[j] + woff) : SGX_BUF_OOB);
+                for (int j = 0; j < BJ; ++j) {
+                    const int blk = wv + (NTH / 64) * j;             // (plane, 16-row block) of this wave's j-th piece
+                    const int plane = blk / WBK, rb16 = (blk - plane * WBK) * 16;
+                    const bool ok = live && (BPI % NTH == 0 || blk < 3 * WBK) && rb16 < wp_rows;
+                    rb[j] = sgx_buf_ld4(bufB, ok ? (unsigned)(wp_lane + woff + plane * T_ * wp_tapstep + rb16 * 32) : SGX_BUF_OOB);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) rb[j] = sgx_buf_ld4(bufB, (cok && bok[j]) ? (unsigned)(boff[j] + woff) : SGX_BUF_OOB);
+            }
             const bool wck = ++s_ck == cpt;  // (selects, not branches: the pipelined loop wants its body in one basic block)
             s_ck = wck ? 0 : s_ck;
             s_tj += wck ? 1 : 0;
@@ -469,6 +506,15 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                     *reinterpret_cast<uint2*>(d + BM * LDPW) = m;
                     *reinterpret_cast<uint2*>(d + 2 * BM * LDPW) = l;
                 }
+            }
+            if constexpr (WPL) {
+                const int wv = sgx_uniform_i32(tid >> 6);
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) {
+                    const int blk = wv + (NTH / 64) * j;  // plane * WBK + block: the planes of a buffer follow one another (BN = 16 WBK rows each)
+                    if (BPI % NTH == 0 || blk < 3 * WBK) sgx_st4(Bs + (buf * 3 * BN + blk * 16) * LDPW + wp_lds, rb[j]);
+                }
+                return;
             }
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
@@ -601,7 +647,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
     for (int src = 0; src < (PH2 ? 2 : 1); ++src) {
         if (PH2 && src == 1) {
             if (!p.A2) break;
-            setup_src(p.A2, p.Wt2, p.Hin2, p.Win2, p.Th2, p.Tw2, p.dh02, p.dw02, p.dstep2, p.a2_ld_pix, p.a2_ld_img, p.w2_ld_n, p.a2_bytes, p.w2_bytes);
+            setup_src(p.A2, p.Wt2, p.Hin2, p.Win2, p.Th2, p.Tw2, p.dh02, p.dw02, p.dstep2, p.a2_ld_pix, p.a2_ld_img, p.w2_ld_n, p.a2_bytes, p.w2_bytes, p.Wp2, p.wp2_bytes);
             if (PH2 == 2) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -1037,7 +1083,7 @@ extern "C" int32_t sgx_debug_set_pconv_timing(void* buf) {
 #define PC_PW (PC_TW + 2)              // patch pitch (pixels)
 #define PC_NPIX ((PC_TH + 2) * PC_PW)  // 180 patch pixels
 #define PC_KC 16                       // channels per chunk
-template <int BN, int WM, int WN, int PH2, bool FPIPE = true>
+template <int BN, int WM, int WN, int PH2, bool FPIPE = true, bool WPL = false>
 __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(IgemmParams p) {
     static_assert(4 % WM == 0, "WM divides the four 32-row sub-tiles");
     constexpr int NTH = WM * WN * 64;
@@ -1047,9 +1093,16 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
     constexpr int KC = PC_KC, ROWB = KC * 2, C4 = KC / 4;   // bytes per pixel / filter row and plane; float4 items per row
     constexpr int NF = PH2 == 2 ? 10 : 9;                    // filter slabs per chunk (nine taps [+ the second filter])
     // staging items: every thread takes AR patch items and BR filter items per chunk; slots past the real data are padding (branch-free)
-    constexpr int AR = (PC_NPIX * C4 + NTH - 1) / NTH, BR = (NF * BN * C4 + NTH - 1) / NTH;
+    // WPL (pre-split filter planes, IgemmParams::Wp): the filter items are 16-byte pieces of the three planes, copied global -> register ->
+    // LDS: 3 x NF slab images of BN x 2 pieces per chunk instead of NF x BN x 4 float4 items that each cost a 22-instruction split.  A slab
+    // image (one plane of one tap: BN rows x 32 bytes) is a contiguous run in the planes and in LDS, and NTH / (2 BN) of them are copied per
+    // pass - which image a thread works on is the same for its whole wave (scalar arithmetic, no per-item offset registers).
+    constexpr int SPP = NTH / (BN * 2);                      // WPL: slab images per pass
+    constexpr int NSL = 3 * NF;                              // WPL: slab images per chunk
+    static_assert(!WPL || (NTH % (BN * 2) == 0 && (BN * 2) % 64 == 0), "a wave copies pieces of one slab image");
+    constexpr int AR = (PC_NPIX * C4 + NTH - 1) / NTH, BR = WPL ? (NSL + SPP - 1) / SPP : (NF * BN * C4 + NTH - 1) / NTH;
     constexpr int NPIXP = AR * NTH / C4;                     // patch pixel slots incl. padding (192)
-    constexpr int NROWP = BR * NTH / C4;                     // filter row slots incl. padding
+    constexpr int NROWP = WPL ? NF * BN : BR * NTH / C4;     // filter row slots incl. padding
     constexpr int A_PLANE = NPIXP * ROWB, B_PLANE = NROWP * ROWB;
     constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 3 * B_PLANE;
     constexpr int STAGE_BYTES = WM * WN * 32 * 32 * 4;
@@ -1106,13 +1159,15 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
     // ---- source state ------------------------------------------------------------------------------------------------------------
     sgx_buf bufA, bufB, bufB2;
     int aoff[AR];   // byte offset of this thread's patch items at chunk 0 (-1: outside the image / padding slot)
-    int boff[BR];   // byte offset of this thread's filter items at chunk 0 (-1: no such filter row / tap); bit 30 set: second filter (bufB2)
+    int boff[WPL ? 1 : BR];   // byte offset of this thread's filter items at chunk 0 (-1: no such filter row / tap); bit 30 set: second filter (bufB2)
+    int wp_lane = -1, wp_lds = 0;  // WPL: this thread's piece inside a slab image - planes byte offset (-1: no such filter row) and LDS byte offset
     int taps_w, dh0_, dw0_, dstep_, ntaps;
+    int bstep = 0;  // WPL: bytes from one channel chunk's planes to the next (primary filter)
     auto setup_src = [&](const float* A, const float* Wt, int Hin, int Win, int Th, int Tw, int dh0, int dw0, int dstep, long a_ld_pix, long a_ld_img,
-                         long w_ld_n, long a_bytes, long w_bytes) {
+                         long w_ld_n, long a_bytes, long w_bytes, const unsigned char* Wp, long wp_bytes) {
         bufA = sgx_make_buf(A + (long)img * a_ld_img, a_bytes - (long)img * a_ld_img * 4);
-        bufB = sgx_make_buf(Wt, w_bytes);
-        if (PH2 == 2) bufB2 = sgx_make_buf(p.Wt2, p.w2_bytes);
+        bufB = WPL ? sgx_make_buf(Wp, wp_bytes) : sgx_make_buf(Wt, w_bytes);
+        if (PH2 == 2) bufB2 = WPL ? sgx_make_buf(p.Wp2, p.wp2_bytes) : sgx_make_buf(p.Wt2, p.w2_bytes);
         ntaps = Th * Tw;
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
@@ -1123,16 +1178,25 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
             const bool ok = pp < PC_NPIX && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
             aoff[r] = ok ? (int)((((long)iy * Win + ix) * a_ld_pix + c4) * 4) : -1;
         }
+        if constexpr (WPL) {
+            // planes [chunk][plane][tap][row][32 B]: a chunk further is 3 * taps * Nout rows on.  LDS slot (n, s) of a slab image holds half
+            // s ^ (n bit 3) of row n (the fragment reads' bank swizzle): the thread that fills the slot fetches that half.
+            bstep = 3 * ntaps * p.Nout * ROWB;
+            const int w = tid & (BN * 2 - 1), n = w >> 1, s_ = w & 1;
+            wp_lane = n0 + n < p.Nout ? (n0 + n) * ROWB + (s_ ^ ((n >> 3) & 1)) * 16 : -1;
+            wp_lds = w * 16;
+        } else {
 #pragma unroll
-        for (int r = 0; r < BR; ++r) {
-            const int idx = tid + NTH * r;
-            const int row = idx / C4, c4 = (idx - row * C4) * 4;
-            const int slab = row / BN, n = row - slab * BN;
-            const bool nok = n0 + n < p.Nout;
-            int o = -1;
-            if (nok && slab < ntaps) o = (int)(((long)(n0 + n) * w_ld_n + (long)slab * p.C + c4) * 4);
-            if (PH2 == 2 && nok && slab == NF - 1) o = (int)(((long)(n0 + n) * p.w2_ld_n + c4) * 4) | (1 << 30);
-            boff[r] = o;
+            for (int r = 0; r < BR; ++r) {
+                const int idx = tid + NTH * r;
+                const int row = idx / C4, c4 = (idx - row * C4) * 4;
+                const int slab = row / BN, n = row - slab * BN;
+                const bool nok = n0 + n < p.Nout;
+                int o = -1;
+                if (nok && slab < ntaps) o = (int)(((long)(n0 + n) * w_ld_n + (long)slab * p.C + c4) * 4);
+                if (PH2 == 2 && nok && slab == NF - 1) o = (int)(((long)(n0 + n) * p.w2_ld_n + c4) * 4) | (1 << 30);
+                boff[r] = o;
+            }
         }
         taps_w = Tw; dh0_ = dh0; dw0_ = dw0; dstep_ = dstep;
     };
@@ -1141,11 +1205,28 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
     auto load_chunk = [&](int chunk) {
 #pragma unroll
         for (int r = 0; r < AR; ++r) ra[r] = sgx_buf_ld4(bufA, aoff[r] >= 0 ? (unsigned)(aoff[r] + chunk * (KC * 4)) : SGX_BUF_OOB);
+        if constexpr (WPL) {
+            const int sl0 = sgx_uniform_i32(tid / (BN * 2));
 #pragma unroll
-        for (int r = 0; r < BR; ++r) {
-            const unsigned o = boff[r] >= 0 ? (unsigned)((boff[r] & ~(1 << 30)) + chunk * (KC * 4)) : SGX_BUF_OOB;
-            if (PH2 == 2 && boff[r] >= 0 && (boff[r] & (1 << 30))) rb[r] = sgx_buf_ld4(bufB2, o);
-            else rb[r] = sgx_buf_ld4(bufB, o);
+            for (int r = 0; r < BR; ++r) {
+                const int sl = sl0 + SPP * r;              // slab image = plane * NF + slab (same for the whole wave)
+                const int plane = sl / NF, slab = sl - plane * NF;
+                const int rowstep = p.Nout * ROWB;
+                if (PH2 == 2 && slab == NF - 1) {          // the second filter (one tap): its own planes
+                    const bool ok = (NSL % SPP == 0 || sl < NSL) && wp_lane >= 0;
+                    rb[r] = sgx_buf_ld4(bufB2, ok ? (unsigned)(wp_lane + (chunk * 3 + plane) * rowstep) : SGX_BUF_OOB);
+                } else {
+                    const bool ok = (NSL % SPP == 0 || sl < NSL) && slab < ntaps && wp_lane >= 0;
+                    rb[r] = sgx_buf_ld4(bufB, ok ? (unsigned)(wp_lane + chunk * bstep + (plane * ntaps + slab) * rowstep) : SGX_BUF_OOB);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < BR; ++r) {
+                const unsigned o = boff[r] >= 0 ? (unsigned)((boff[r] & ~(1 << 30)) + chunk * (KC * 4)) : SGX_BUF_OOB;
+                if (PH2 == 2 && boff[r] >= 0 && (boff[r] & (1 << 30))) rb[r] = sgx_buf_ld4(bufB2, o);
+                else rb[r] = sgx_buf_ld4(bufB, o);
+            }
         }
     };
     auto store_chunk = [&]() {
@@ -1160,16 +1241,25 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
             *reinterpret_cast<uint2*>(d + A_PLANE) = m;
             *reinterpret_cast<uint2*>(d + 2 * A_PLANE) = l;
         }
+        if constexpr (WPL) {
+            const int sl0 = sgx_uniform_i32(tid / (BN * 2));
 #pragma unroll
-        for (int r = 0; r < BR; ++r) {
-            const int idx = tid + NTH * r;
-            const int row = idx / C4, c4 = (idx - row * C4) * 4;
-            unsigned char* const d = Bs + row * ROWB + swz(c4 >> 3, row) * 16 + ((c4 >> 2) & 1) * 8;
-            uint2 h, m, l;
-            sgx_split3(rb[r], h, m, l);
-            *reinterpret_cast<uint2*>(d) = h;
-            *reinterpret_cast<uint2*>(d + B_PLANE) = m;
-            *reinterpret_cast<uint2*>(d + 2 * B_PLANE) = l;
+            for (int r = 0; r < BR; ++r) {
+                const int sl = sl0 + SPP * r;  // (plane * NF + slab) * BN rows: B_PLANE = NF * BN rows, so slab images follow one another in LDS
+                if (NSL % SPP == 0 || sl < NSL) sgx_st4(reinterpret_cast<float*>(Bs + sl * (BN * ROWB) + wp_lds), rb[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < BR; ++r) {
+                const int idx = tid + NTH * r;
+                const int row = idx / C4, c4 = (idx - row * C4) * 4;
+                unsigned char* const d = Bs + row * ROWB + swz(c4 >> 3, row) * 16 + ((c4 >> 2) & 1) * 8;
+                uint2 h, m, l;
+                sgx_split3(rb[r], h, m, l);
+                *reinterpret_cast<uint2*>(d) = h;
+                *reinterpret_cast<uint2*>(d + B_PLANE) = m;
+                *reinterpret_cast<uint2*>(d + 2 * B_PLANE) = l;
+            }
         }
     };
 
@@ -1257,10 +1347,10 @@ __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(I
 
 #pragma unroll
     for (int src = 0; src < (PH2 == 1 ? 2 : 1); ++src) {
-        if (src == 0) setup_src(p.A, p.Wt, p.Hin, p.Win, p.Th, p.Tw, p.dh0, p.dw0, p.dstep, p.a_ld_pix, p.a_ld_img, p.w_ld_n, p.a_bytes, p.w_bytes);
+        if (src == 0) setup_src(p.A, p.Wt, p.Hin, p.Win, p.Th, p.Tw, p.dh0, p.dw0, p.dstep, p.a_ld_pix, p.a_ld_img, p.w_ld_n, p.a_bytes, p.w_bytes, p.Wp, p.wp_bytes);
         else {
             if (!p.A2) break;
-            setup_src(p.A2, p.Wt2, p.Hin2, p.Win2, p.Th2, p.Tw2, p.dh02, p.dw02, p.dstep2, p.a2_ld_pix, p.a2_ld_img, p.w2_ld_n, p.a2_bytes, p.w2_bytes);
+            setup_src(p.A2, p.Wt2, p.Hin2, p.Win2, p.Th2, p.Tw2, p.dh02, p.dw02, p.dstep2, p.a2_ld_pix, p.a2_ld_img, p.w2_ld_n, p.a2_bytes, p.w2_bytes, p.Wp2, p.wp2_bytes);
         }
         if (src == 0) PC_T(1);
         load_chunk(0);
@@ -1653,28 +1743,30 @@ static TileCfg pick_tile_heuristic(long M, int N) {
 // 16-deep loop; two LDS buffers with 32-deep slabs measured slower (lower occupancy) and were removed.
 static bool igemm_deep_slabs(const IgemmParams& p) { return conv_variant() != 7 && p.C % 32 == 0; }
 // dispatch over the eight non-flat tile shapes for one (MATH, KD, NBUF, PH2)
-#define SGX_IGEMM_TILES(MATH_, KD_, NBUF_, PH2_)                                                                  \
-    do {                                                                                                          \
-        if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, MATH_, KD_, NBUF_, PH2_>(p, stream);      \
-        else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);   \
-        else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, MATH_, KD_, NBUF_, PH2_>(p, stream);   \
-        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);   \
-        else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2, false, MATH_, KD_, NBUF_, PH2_>(p, stream);   \
-        else if (bm == 64 && bn == 96) launch_igemm<64, 96, 2, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);     \
-        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, MATH_, KD_, NBUF_, PH2_>(p, stream);     \
-        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);     \
-        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no tile %dx%d (math %d, %d-deep slabs)", bm, bn, MATH_, KD_);   \
+#define SGX_IGEMM_TILES(MATH_, KD_, NBUF_, PH2_) SGX_IGEMM_TILES_W(MATH_, KD_, NBUF_, PH2_, false)
+#define SGX_IGEMM_TILES_W(MATH_, KD_, NBUF_, PH2_, WPL_)                                                                \
+    do {                                                                                                                \
+        if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);      \
+        else if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);   \
+        else if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);   \
+        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);   \
+        else if (bm == 64 && bn == 128) launch_igemm<64, 128, 2, 2, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);   \
+        else if (bm == 64 && bn == 96) launch_igemm<64, 96, 2, 1, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);     \
+        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);     \
+        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);     \
+        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no tile %dx%d (math %d, %d-deep slabs)", bm, bn, MATH_, KD_);         \
     } while (0)
 // the two-source kernels exist for the tiles the heuristic picks (pick_tile_heuristic): overrides / table entries do not apply to them
-#define SGX_IGEMM_TILES_PH2(MATH_, KD_, NBUF_, PH2_)                                                              \
-    do {                                                                                                          \
-        if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);        \
-        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);   \
-        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, MATH_, KD_, NBUF_, PH2_>(p, stream);     \
-        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, MATH_, KD_, NBUF_, PH2_>(p, stream);     \
-        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (two sources): no tile %dx%d", bm, bn);                          \
+#define SGX_IGEMM_TILES_PH2(MATH_, KD_, NBUF_, PH2_) SGX_IGEMM_TILES_PH2_W(MATH_, KD_, NBUF_, PH2_, false)
+#define SGX_IGEMM_TILES_PH2_W(MATH_, KD_, NBUF_, PH2_, WPL_)                                                            \
+    do {                                                                                                                \
+        if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);        \
+        else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);   \
+        else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);     \
+        else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);     \
+        else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (two sources): no tile %dx%d", bm, bn);                                \
     } while (0)
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0>
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, bool WPL = false>
 static void launch_igemm(IgemmParams& p, void* stream) {
     p.mt = sgx_cdiv(p.M, BM);
     p.nt = sgx_cdiv(p.Nout, BN);
@@ -1684,7 +1776,7 @@ static void launch_igemm(IgemmParams& p, void* stream) {
     p.fd_hw = sgx_make_fastdiv(p.Ha * p.Wa);
     p.fd_wa = sgx_make_fastdiv(p.Wa);
     int grid = p.chunk * 8;
-    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF, PH2>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
+    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF, PH2, WPL>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
 }
 
 // ---- pconv dispatch ------------------------------------------------------------------------------------------------------------------
@@ -1711,6 +1803,7 @@ static bool pconv_ok(const IgemmParams& p, int ph2) {
     if ((long)p.Hin * p.Win * p.a_ld_pix * 4 > SGX_BUF_MAX) return false;
     return true;
 }
+static std::atomic<long> g_fp_hits{0};  // launches that read pre-split filter planes (see fplanes_attach)
 static std::atomic<int> g_pconv_pipe32{1};  // r5f: 716.0 -> 718.8 images/s (twice each, same box)
 extern "C" int32_t sgx_debug_set_pconv_pipe(int32_t on) {  // measurement switch, see launch_pconv
     g_pconv_pipe32 = on ? 1 : 0;
@@ -1732,7 +1825,12 @@ static void launch_pconv(IgemmParams& p, void* stream) {
     p.fd_txy = sgx_make_fastdiv(sgx_cdiv(p.Wa, PC_TW) * sgx_cdiv(p.Ha, PC_TH));
     p.fd_tx = sgx_make_fastdiv(sgx_cdiv(p.Wa, PC_TW));
     p.stat_nblk = p.mt;
-    if (fpipe) SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, true>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
+    // pre-split filter planes (fplanes_attach): every filter of the launch has them, or none is used
+    const bool wpl = p.Wp && (!(PH2 && p.A2) || p.Wp2);
+    if (wpl) g_fp_hits.fetch_add(1, std::memory_order_relaxed);
+    if (fpipe && wpl) SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, true, true>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
+    else if (wpl) SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, false, true>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
+    else if (fpipe) SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, true>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
     else SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, false>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
 }
 template <int PH2>
@@ -1748,6 +1846,107 @@ static int32_t run_pconv(IgemmParams& p, void* stream, int ph2) {
     else launch_pconv_n<2>(p, stream);
     return SGX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Pre-split filter planes (round 5, review item 1a for the weights).
+//
+// A bf16x3 launch splits its FILTER operand once per pixel tile - thousands of times per launch for a filter that changes once per
+// optimizer step - and the split is a third of the staging loop's vector work (r5v: a launch whose filter is not split runs 3-11 %
+// faster).  sgx_filter_planes_batch splits every registered filter ONCE per step into three bf16 planes laid out for 16-byte loads:
+//     planes[ch / 16][hi | mid | lo][tap][row][16 bf16]          (rows x taps x ch x 6 bytes)
+// - per (16-channel block, plane, tap) the rows of a filter tile are one contiguous run of 32-byte pieces, which is exactly what the
+// patch kernel stages per chunk and what the 32-deep GEMM loop stages per slab (two blocks); the pieces are the values sgx_split3 would
+// have produced in the kernel, so a launch that reads planes is bit-identical to one that splits.  (Round 4's r4h laid the planes out as
+// 8-byte pieces of 24 bytes per item and lost to the load instructions it added.)
+// The registry maps a filter's fp32 address to its planes.  An entry serves a launch only while (a) a training step's scope is open
+// (sgx_filter_planes_scope: the network's forward / backward - nothing else may trust a device address to still mean the same tensor),
+// (b) it is valid (produced since the weights last changed: sgx_filter_planes_batch validates, _invalidate drops), and (c) the launch's
+// filter has the entry's shape.  Anything else falls back to splitting in the kernel.
+// ------------------------------------------------------------------------------------------------
+struct FplanesEntry {
+    const unsigned char* planes;
+    int rows, taps, ch;
+    bool valid;
+};
+static std::mutex g_fp_mu;
+static std::unordered_map<const void*, FplanesEntry> g_fp_map;
+static std::atomic<int> g_fp_scope{0}, g_fp_on{1};
+__global__ void fplanes_batch_kernel(const sgx_fplanes_job* jobs) {
+    __shared__ sgx_fplanes_job job;
+    if (threadIdx.x == 0) job = jobs[blockIdx.y];
+    __syncthreads();
+    const unsigned c4n = (unsigned)job.ch / 4, T = (unsigned)job.taps, R = (unsigned)job.rows;
+    const unsigned n = R * T * c4n;
+    unsigned char* const dst = reinterpret_cast<unsigned char*>(job.planes);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned q = i % c4n, rt = i / c4n, t = rt % T, row = rt / T;
+        uint2 h, m, l;
+        sgx_split3(sgx_ld4(job.src + (size_t)i * 4), h, m, l);
+        const size_t plane = (size_t)T * R * 32;
+        unsigned char* const d = dst + (size_t)(q >> 2) * 3 * plane + ((size_t)t * R + row) * 32 + (q & 3) * 8;
+        *reinterpret_cast<uint2*>(d) = h;
+        *reinterpret_cast<uint2*>(d + plane) = m;
+        *reinterpret_cast<uint2*>(d + 2 * plane) = l;
+    }
+}
+extern "C" int64_t sgx_filter_planes_bytes(int32_t rows, int32_t taps, int32_t ch) {
+    if (rows <= 0 || taps <= 0 || ch <= 0 || ch % 16) return 0;
+    return (int64_t)rows * taps * ch * 6;
+}
+extern "C" int32_t sgx_filter_planes_batch(const sgx_fplanes_job* jobs_host, const sgx_fplanes_job* jobs_dev, int32_t njobs, void* stream) {
+    SGX_CHECK_ARG(jobs_host && jobs_dev && njobs > 0 && njobs <= 65535, "filter_planes_batch: bad args (njobs=%d)", njobs);
+    for (int i = 0; i < njobs; ++i) {
+        const sgx_fplanes_job& j = jobs_host[i];
+        SGX_CHECK_ARG(j.src && j.planes && j.rows > 0 && j.taps > 0 && j.ch > 0 && j.ch % 16 == 0, "filter_planes_batch: job %d: rows / taps / ch (a multiple of 16) / pointers", i);
+        SGX_CHECK_ARG(((uintptr_t)j.src % 16) == 0 && ((uintptr_t)j.planes % 16) == 0, "filter_planes_batch: job %d: 16-byte aligned pointers", i);
+        SGX_CHECK_ARG(sgx_filter_planes_bytes(j.rows, j.taps, j.ch) < (1 << 30), "filter_planes_batch: job %d: planes of 1 GiB or more", i);
+    }
+    SGX_LAUNCH(fplanes_batch_kernel, dim3(64, (unsigned)njobs), dim3(256), 0, stream, jobs_dev);
+    SGX_CHECK_LAUNCH("filter_planes_batch");
+    std::lock_guard<std::mutex> lk(g_fp_mu);
+    for (int i = 0; i < njobs; ++i) {
+        const sgx_fplanes_job& j = jobs_host[i];
+        g_fp_map[j.src] = FplanesEntry{reinterpret_cast<const unsigned char*>(j.planes), j.rows, j.taps, j.ch, true};
+    }
+    return SGX_OK;
+}
+// jobs_host == NULL: every entry (a new step of any network starts by dropping what earlier steps left valid)
+extern "C" int32_t sgx_filter_planes_invalidate(const sgx_fplanes_job* jobs_host, int32_t njobs) {
+    std::lock_guard<std::mutex> lk(g_fp_mu);
+    if (!jobs_host) {
+        g_fp_map.clear();
+        return SGX_OK;
+    }
+    for (int i = 0; i < njobs; ++i) g_fp_map.erase(jobs_host[i].src);
+    return SGX_OK;
+}
+extern "C" int32_t sgx_filter_planes_scope(int32_t open) {
+    g_fp_scope = open ? 1 : 0;
+    return SGX_OK;
+}
+extern "C" int32_t sgx_debug_set_filter_planes(int32_t on) {  // measurement switch: 0 = every launch splits its filter while staging
+    g_fp_on = on ? 1 : 0;
+    return SGX_OK;
+}
+static const unsigned char* fplanes_lookup(const float* w, int rows, int taps, int ch, long ld_n, long* bytes) {
+    if (!w || ld_n != (long)taps * ch) return nullptr;
+    std::lock_guard<std::mutex> lk(g_fp_mu);
+    auto it = g_fp_map.find(w);
+    if (it == g_fp_map.end()) return nullptr;
+    const FplanesEntry& e = it->second;
+    if (!e.valid || e.rows != rows || e.taps != taps || e.ch != ch) return nullptr;
+    *bytes = (long)rows * taps * ch * 6;
+    return e.planes;
+}
+static void fplanes_attach(IgemmParams& p, int ph2) {
+    p.Wp = p.Wp2 = nullptr;
+    p.wp_bytes = p.wp2_bytes = 0;
+    if (!g_fp_scope.load(std::memory_order_relaxed) || !g_fp_on.load(std::memory_order_relaxed) || p.C % 16) return;
+    p.Wp = fplanes_lookup(p.Wt, p.Nout, p.Th * p.Tw, p.C, p.w_ld_n, &p.wp_bytes);
+    if (ph2 && p.A2) p.Wp2 = fplanes_lookup(p.Wt2, p.Nout, p.Th2 * p.Tw2, p.C, p.w2_ld_n, &p.wp2_bytes);
+}
+// launches that read planes since the process started (tests: a planes-path parity check must not pass by never taking the path)
+extern "C" int64_t sgx_debug_filter_planes_hits(void) { return g_fp_hits.load(); }
 
 // ph2: 0 = one source; 1 = second source into the same accumulator; 2 = second source into a second output (see IgemmParams)
 static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 = 0) {
@@ -1765,6 +1964,7 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
                 ? 1
                 : 0;
     if (p.nreq && !p.vec) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: BatchNorm-reduce requests need 16-byte aligned outputs");
+    fplanes_attach(p, ph2);
     // algorithmic work: every input element, weight and output element once (fp32); the second source adds its taps
     const double T2 = (ph2 && p.A2) ? (double)p.Th2 * p.Tw2 : 0.0;
     // (profiling class 0 = fp32-MFMA implicit GEMM, 2 = the bf16x3 patch kernel, 3 = the implicit GEMM in bf16x3 arithmetic: same algorithmic
@@ -1786,7 +1986,11 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
         if (flat || !p.vec) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (two sources): needs C >= 16 and 16-byte aligned outputs");
         const bool bf3 = gemm_bf3;  // (mode 5: the primary source's depth decides for the launch)
         if (p.C % 32 == 0) {
-            if (bf3) {
+            if (bf3 && p.Wp && (!p.A2 || p.Wp2)) {
+                g_fp_hits.fetch_add(1, std::memory_order_relaxed);
+                if (ph2 == 1) SGX_IGEMM_TILES_PH2_W(1, 32, 1, 1, true);
+                else SGX_IGEMM_TILES_PH2_W(1, 32, 1, 2, true);
+            } else if (bf3) {
                 if (ph2 == 1) SGX_IGEMM_TILES_PH2(1, 32, 1, 1);
                 else SGX_IGEMM_TILES_PH2(1, 32, 1, 2);
             } else if (ph2 == 1) SGX_IGEMM_TILES_PH2(0, 32, 1, 1);
@@ -1810,7 +2014,11 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
             if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 1, 32, 2, 0>(p, stream);
             else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 1, 32, 2, 0>(p, stream);
             else launch_igemm<64, 32, 2, 1, false, 1, 32, 2, 0>(p, stream);
-        } else if (igemm_deep_slabs(p)) SGX_IGEMM_TILES(1, 32, 1, 0);
+        } else if (igemm_deep_slabs(p) && p.Wp) {
+            g_fp_hits.fetch_add(1, std::memory_order_relaxed);
+            SGX_IGEMM_TILES_W(1, 32, 1, 0, true);
+        }
+        else if (igemm_deep_slabs(p)) SGX_IGEMM_TILES(1, 32, 1, 0);
         else SGX_IGEMM_TILES(1, 16, 2, 0);
     } else if (flat) {
         if (bn > 64) bn = 64;  // the flat variants exist for the narrow tiles only (stem layers have few output channels)

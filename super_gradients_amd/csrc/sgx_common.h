@@ -197,7 +197,9 @@ __device__ __forceinline__ float4 sgx_ld4_dev(const float* p) {
 #ifdef SGX_EMU
 static inline unsigned long long sgx_readlane_u64(unsigned long long v, int src) { return __shfl(v, src); }
 static inline unsigned long long sgx_uniform_u64(unsigned long long v) { return v; }
+static inline int sgx_uniform_i32(int v) { return v; }
 #else
+__device__ __forceinline__ int sgx_uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // a value that IS the same in every lane, moved to scalar registers: what is computed from it afterwards runs on the scalar unit
 __device__ __forceinline__ unsigned long long sgx_uniform_u64(unsigned long long v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));

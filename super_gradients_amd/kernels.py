@@ -210,6 +210,49 @@ def wtrans_batch(jobs_dev, njobs):
     check(lib().sgx_wtrans_batch(ptr(jobs_dev), int(njobs), stream()), "sgx_wtrans_batch")
 
 
+def filter_planes_plan(filters):
+    """filters: iterable of (fp32 filter tensor viewed [rows, taps, ch] - its data_ptr is what the conv launches will see).  Returns
+    (records (src, byte offset, rows, taps, ch), total bytes) for the filters a bf16x3 launch can take planes of (ch a multiple of 16 - also the
+    shallow 1x1 filters, which ride in the QARepVGG two-output / two-source launches whatever their depth); duplicates (one filter, several launches) are planned once."""
+    seen, recs, total = set(), [], 0
+    for src, rows, taps, ch in filters:
+        if src in seen or ch % 16 or rows <= 0:
+            continue
+        n = int(lib().sgx_filter_planes_bytes(rows, taps, ch))
+        if n <= 0 or n >= (1 << 30):
+            continue
+        seen.add(src)
+        recs.append((src, total, rows, taps, ch))
+        total += (n + 255) // 256 * 256
+    return recs, total
+
+
+def filter_planes_table(recs, planes_buf):
+    """The sgx_fplanes_job records of a plan over the planes buffer (uint8 tensor): -> (host ctypes array, device uint8 tensor)."""
+    jobs = (_lib.FplanesJob * len(recs))()
+    base = planes_buf.data_ptr()
+    for j, (src, off, rows, taps, ch) in zip(jobs, recs):
+        j.src, j.planes, j.rows, j.taps, j.ch, j.pad_ = src, base + off, rows, taps, ch, 0
+    dev = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(planes_buf.device)
+    return jobs, dev
+
+
+def filter_planes_batch(jobs_host, jobs_dev):
+    """Split every planned filter into its bf16x3 planes (one launch) and mark the registry entries valid."""
+    check(lib().sgx_filter_planes_batch(ctypes.cast(jobs_host, ctypes.c_void_p), ptr(jobs_dev), len(jobs_host), stream()), "sgx_filter_planes_batch")
+
+
+def filter_planes_invalidate(jobs_host=None):
+    if jobs_host is None:
+        check(lib().sgx_filter_planes_invalidate(None, 0), "sgx_filter_planes_invalidate")
+    else:
+        check(lib().sgx_filter_planes_invalidate(ctypes.cast(jobs_host, ctypes.c_void_p), len(jobs_host)), "sgx_filter_planes_invalidate")
+
+
+def filter_planes_scope(open_: bool):
+    lib().sgx_filter_planes_scope(1 if open_ else 0)
+
+
 class BnReduceRequest:
     """A BatchNorm layer's backward reduce, handed to the data gradient that finalises the layer's output gradient (sgx_bn_reduce_req):
     the layer's saved conv output t and its scale / shift / mean, and the channel range [c_lo, c_hi) of that data gradient's dx which IS the

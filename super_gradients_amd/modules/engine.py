@@ -237,6 +237,27 @@ class SgxNetwork(nn.Module):
         if recs:
             self._qp_njobs = len(recs)
             self._qp_jobs = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(device)
+        # Pre-split filter planes (round 5; include/sgx_hip.h sgx_filter_planes_batch): every filter a bf16x3 launch of the training step reads -
+        # forward filters, their data-gradient transposes, the QARepVGG blocks' prepared 1x1 filters - is split into its three bf16 pieces
+        # ONCE per step, right behind the transposes, instead of once per pixel tile of every launch.  The library serves planes only inside
+        # the step's scope (NetFunction.forward / backward) and only for entries made since the weights last changed.  SGX_FILTER_PLANES=0: off.
+        self._fp_jobs, self._fp_dev, self._fp_buf = None, None, None
+        if self._wt_jobs is not None and os.environ.get("SGX_FILTER_PLANES", "1") != "0":
+            from .. import _lib
+            import ctypes
+
+            filters = []
+            for r in (_lib.WtransJob * self._wt_njobs).from_buffer_copy(table):
+                filters.append((r.w, r.K, r.RS, r.C))
+                filters.append((r.wt, r.C, r.T, r.K))
+            for raw in recs:
+                r = _lib.QarepPrepJob.from_buffer_copy(raw)
+                filters.append((r.w1p, r.K, 1, r.C))
+                filters.append((r.w1pt, r.C, 1, r.K))
+            plan, total = K.filter_planes_plan(filters)
+            if plan:
+                self._fp_buf = torch.empty(total, dtype=torch.uint8, device=device)
+                self._fp_jobs, self._fp_dev = K.filter_planes_table(plan, self._fp_buf)
         # Sub-modules, parameters and buffers are fixed objects from here on (arena views never move, load_state_dict copies in place, the
         # network refuses to be moved): mirror them into the instance dictionaries so that `self.bn.weight` is a plain attribute read
         # instead of nn.Module.__getattr__'s three dictionary probes (~2400 of those per YOLO-NAS-S train step).  nn.Module.__setattr__
@@ -248,7 +269,7 @@ class SgxNetwork(nn.Module):
                         if v is not None:
                             m.__dict__[name] = v
 
-    _RUNTIME_ATTRS = ("side_stream", "aux_stream", "_wt_jobs", "_qp_jobs", "_dgrad_convs", "_wg_pending")
+    _RUNTIME_ATTRS = ("side_stream", "aux_stream", "_wt_jobs", "_qp_jobs", "_dgrad_convs", "_wg_pending", "_fp_jobs", "_fp_dev", "_fp_buf")
 
     def __deepcopy__(self, memo):
         """copy.deepcopy(model) - what the reference's predict() pipeline does before fusing (pipelines.py:95-100): parameters, buffers and
@@ -291,6 +312,9 @@ class SgxNetwork(nn.Module):
             K.wtrans_batch(self._wt_jobs, self._wt_njobs)  # current stream: ordered after the optimizer step, before backward
             if getattr(self, "_qp_jobs", None) is not None:
                 K.qarep_prep_batch(self._qp_jobs, self._qp_njobs)
+            if getattr(self, "_fp_jobs", None) is not None:
+                K.filter_planes_invalidate(None)  # whatever an earlier step (of any network) left valid is not this step's
+                K.filter_planes_batch(self._fp_jobs, self._fp_dev)
             self._wt_valid = True
             return
         if aux is None:
@@ -402,6 +426,15 @@ class SgxNetwork(nn.Module):
             if getattr(m, "_folded", None) is not None:
                 m._folded = None
         self._wt_valid = False
+        self.drop_filter_planes()
+
+    def drop_filter_planes(self):
+        """The registry entries of this network's pre-split filter planes stop serving launches (the weights are about to change, or the
+        step that made them is over)."""
+        if getattr(self, "_fp_jobs", None) is not None:
+            from .. import kernels as K
+
+            K.filter_planes_invalidate(self._fp_jobs)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
@@ -485,7 +518,16 @@ class NetFunction(torch.autograd.Function):
     def forward(ctx, net, x, anchor):
         ctx.net = net
         net.prefetch_dgrad_weights()
-        flat = tuple(net._fwd(x))
+        planes = getattr(net, "_fp_jobs", None) is not None
+        if planes:
+            from .. import kernels as K
+
+            K.filter_planes_scope(True)
+        try:
+            flat = tuple(net._fwd(x))
+        finally:
+            if planes:
+                K.filter_planes_scope(False)
         ctx.mark_non_differentiable(*[t for t, d in zip(flat, net._differentiable_outputs(len(flat))) if not d])
         return flat
 
@@ -493,9 +535,17 @@ class NetFunction(torch.autograd.Function):
     def backward(ctx, *grads):
         net = ctx.net
         net.join_aux()
+        planes = getattr(net, "_fp_jobs", None) is not None
+        if planes:
+            from .. import kernels as K
+
+            K.filter_planes_scope(True)
         try:
             net._bwd(*grads)
         except BaseException:
+            if planes:
+                K.filter_planes_scope(False)
+                net.drop_filter_planes()
             # the queue holds operands of THIS backward: a later one must not launch them into the gradient arena; weight
             # gradients already forked onto the side stream are joined, and the per-step transposes count as stale
             net._wg_pending, net._wg_flops = [], 0.0
@@ -505,6 +555,9 @@ class NetFunction(torch.autograd.Function):
             except Exception:  # (the original error is the one to report)
                 pass
             raise
+        if planes:
+            K.filter_planes_scope(False)
+            net.drop_filter_planes()
         net.flush_wgrads()
         net._wt_valid = False
         net.join_side()

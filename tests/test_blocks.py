@@ -658,3 +658,84 @@ def test_deepcopy_of_a_materialised_network_trains(backend):
     assert not torch.equal(y2, y0)
     net.load_state_dict(sd)
     assert torch.equal(step(net), y2)
+
+
+def test_filter_planes_serve_a_training_step_and_nothing_else(backend):
+    """Pre-split filter planes at network level (engine.py, round 5): inside NetFunction.forward / backward the bf16x3 launches of a QARepVGG
+    chain read the planes the step's prefetch made - same bits as with SGX_FILTER_PLANES off (forward, input gradient, every parameter
+    gradient) - while an eval-mode forward after an in-place weight change, outside any step, must follow the NEW weights (no stale planes),
+    and a second step after the change must too."""
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd._lib import lib
+    from super_gradients_amd.modules import QARepVGGBlock
+    from super_gradients_amd.modules.engine import SgxNetwork
+
+    class Chain(SgxNetwork):
+        def __init__(self):
+            super().__init__()
+            self.b1 = QARepVGGBlock(32, 32, stride=1)
+            self.b2 = QARepVGGBlock(32, 64, stride=2)
+
+        def _fwd(self, x):
+            return (self.b2.fwd(self.b1.fwd(K.input_to_nhwc(x))),)
+
+        def _bwd(self, dy):
+            self.b1.bwd(self.b2.bwd(dy.contiguous()), need_dx=False)
+
+    gpu = backend.type == "cuda"
+    n, h, w = (4, 40, 40) if gpu else (1, 9, 20)
+    x = (torch.randn(n, 32, h, w, generator=torch.Generator().manual_seed(0)) + 0.5).to(backend)
+    lib().sgx_debug_set_variant(0 if gpu else 9)  # (host emulation: small maps - variant 9 lets the patch kernel take them)
+
+    def step(net):
+        net.zero_grad()
+        y = net(x)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(backend)
+        y.backward(dy)
+        net.join_side()
+        return [y.detach().cpu().clone(), net.g_arena.buf.cpu().clone()]
+
+    def build(planes):
+        import os
+
+        old = os.environ.get("SGX_FILTER_PLANES")
+        os.environ["SGX_FILTER_PLANES"] = "1" if planes else "0"
+        try:
+            torch.manual_seed(11)
+            net = Chain()
+            net.materialize(backend).train()
+        finally:
+            if old is None:
+                os.environ.pop("SGX_FILTER_PLANES", None)
+            else:
+                os.environ["SGX_FILTER_PLANES"] = old
+        return net
+
+    try:
+        plain, fast = build(False), build(True)
+        assert plain._fp_jobs is None and fast._fp_jobs is not None
+        h0 = lib().sgx_debug_filter_planes_hits()
+        ref = step(plain)
+        assert lib().sgx_debug_filter_planes_hits() == h0
+        got = step(fast)
+        assert lib().sgx_debug_filter_planes_hits() - h0 >= 3, "the step's launches did not read the planes"  # (b1 forward, b2 forward, b2 data gradient)
+        for a, b, what in zip(ref, got, ("forward", "parameter gradients")):
+            assert torch.equal(a, b), f"planes step differs in {what}: {float((a - b).abs().max()):.3e}"
+        # weights change in place outside a step: the next launches - eval forward, then a whole step - follow the new weights
+        for net in (plain, fast):
+            with torch.no_grad():
+                net.p_arena.buf.mul_(1.25)
+            net.weights_changed()
+        h1 = lib().sgx_debug_filter_planes_hits()
+        plain.eval(), fast.eval()
+        with torch.no_grad():
+            assert torch.equal(plain(x), fast(x))
+        assert lib().sgx_debug_filter_planes_hits() == h1, "a launch outside a training step read filter planes"
+        plain.train(), fast.train()
+        for a, b in zip(step(plain), step(fast)):
+            assert torch.equal(a, b)
+        assert lib().sgx_debug_filter_planes_hits() > h1
+    finally:
+        lib().sgx_debug_set_variant(0)
+        K.filter_planes_scope(False)
+        K.filter_planes_invalidate(None)

@@ -1769,3 +1769,104 @@ def test_wgrad_patch_bias_is_pinned(gpu_device):
     finally:
         lib().sgx_conv_set_wgrad_math(2)
     print("wgrad signed offsets / rms, worst per mode:", {k_: f"{v:.2e}" for k_, v in worst.items()})
+
+
+def _planes_for(filters, backend):
+    """Plan + produce the pre-split planes of `filters` ((ptr, rows, taps, ch) records) -> (host jobs, keep-alive tensors)."""
+    plan, total = K.filter_planes_plan(filters)
+    assert plan, "no filter of the case qualifies for planes"
+    buf = torch.empty(total, dtype=torch.uint8, device=backend)
+    jobs, dev = K.filter_planes_table(plan, buf)
+    K.filter_planes_batch(jobs, dev)
+    return jobs, (buf, dev)
+
+
+def _wt_filters(w, wtb, stride, pad):
+    import ctypes
+
+    from super_gradients_amd import _lib
+
+    raw = K.conv2d_transpose_jobs(w, wtb, stride=stride, pad=pad)
+    n = len(raw) // ctypes.sizeof(_lib.WtransJob)
+    return [(r.wt, r.C, r.T, r.K) for r in (_lib.WtransJob * n).from_buffer_copy(raw)]
+
+
+@pytest.mark.parametrize("case", ["patch32", "patch64", "gemm1x1", "gemm3x3s2", "qarep_s1", "qarep_s2"])
+def test_filter_planes_launches_are_bit_identical(backend, case):
+    """Pre-split filter planes (sgx_filter_planes_batch; round 5): a bf16x3 launch that copies its filter's planes must produce exactly the
+    bits of the launch that splits the fp32 filter while staging - forward, data gradient (through the transposed filters' planes) and the
+    QARepVGG two-output / two-source forms, on the patch kernel and on the 32-deep GEMM loop.  The hit counter proves the planes path ran;
+    with the scope closed, or after an invalidate, the same calls must not take it."""
+    from super_gradients_amd._lib import lib
+
+    gpu = backend.type == "cuda"
+    # (N, H, W, C, K, R, stride)
+    shape = {"patch32": (2, 40, 40, 32, 32, 3, 1) if gpu else (1, 9, 20, 16, 32, 3, 1),
+             "patch64": (2, 40, 48, 64, 128, 3, 1) if gpu else (1, 8, 16, 32, 64, 3, 1),
+             "gemm1x1": (2, 20, 20, 384, 192, 1, 1) if gpu else (1, 6, 6, 192, 192, 1, 1),
+             "gemm3x3s2": (2, 40, 40, 64, 128, 3, 2) if gpu else (1, 10, 10, 32, 64, 3, 2),
+             "qarep_s1": (2, 40, 40, 64, 64, 3, 1) if gpu else (1, 9, 20, 32, 32, 3, 1),
+             "qarep_s2": (2, 40, 40, 64, 128, 3, 2) if gpu else (1, 10, 10, 32, 64, 3, 2)}[case]
+    n, h, w_, c, k, r, st = shape
+    pad = r // 2
+    g = torch.Generator().manual_seed(500 + len(case))
+    x = to_nhwc(torch.randn(n, c, h, w_, generator=g), backend)
+    wd = K.to_ohwi((torch.randn(k, c, r, r, generator=g) / (c * r * r) ** 0.5).to(backend))
+    ho, wo = (h + 2 * pad - r) // st + 1, (w_ + 2 * pad - r) // st + 1
+    dy = to_nhwc(torch.randn(n, k, ho, wo, generator=g), backend)
+    wtb = K.conv2d_wt_buffer(wd, backend)
+    K.conv2d_transpose_weights(wd, wtb, stride=st, pad=pad)
+    qarep = case.startswith("qarep")
+    if qarep:
+        w1p = K.to_ohwi((torch.randn(k, c, 1, 1, generator=g) / c ** 0.5).to(backend))
+        w1pt = w1p.reshape(k, c).t().contiguous()
+        b1 = torch.randn(k, generator=g).to(backend)
+        ds = to_nhwc(torch.randn(n, k, ho, wo, generator=g), backend)
+
+    def run():
+        if qarep:
+            y, u, st5 = K.conv2d_fwd_dual(x, wd, w1p, b1, stride=st)
+            dx = K.conv2d_bwd_data_dual(dy, wd, wtb, ds, w1pt, (n, h, w_, c), stride=st)
+            return [y, u, st5, dx]
+        y, parts = K.conv2d_fwd(x, wd, stride=st, pad=pad, stat_partials=True)
+        dx = K.conv2d_bwd_data_wt(dy, wd, wtb, (n, h, w_, c), stride=st, pad=pad)
+        return [y, parts, dx]
+
+    K.set_conv_math("patch_bf3")
+    lib().sgx_debug_set_variant(0 if gpu else 9)  # (host emulation: small maps - variant 9 lifts the patch kernel's 40 x 40 floor)
+    jobs = None
+    try:
+        K.filter_planes_invalidate(None)
+        K.filter_planes_scope(False)
+        ref = run()
+        filters = [(wd.data_ptr(), k, r * r, c)] + _wt_filters(wd, wtb, st, pad)
+        if qarep:
+            filters += [(w1p.data_ptr(), k, 1, c), (w1pt.data_ptr(), c, 1, k)]
+        jobs, keep = _planes_for(filters, backend)
+        # scope closed: entries exist and are valid, yet no launch may use them
+        h0 = lib().sgx_debug_filter_planes_hits()
+        out = run()
+        assert lib().sgx_debug_filter_planes_hits() == h0, "a launch outside a step's scope read filter planes"
+        K.filter_planes_scope(True)
+        out = run()
+        hits = lib().sgx_debug_filter_planes_hits() - h0
+        assert hits >= 2, f"{case}: only {hits} launch(es) took the planes path"
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b), f"{case}: planes launch differs from the splitting launch (max {float((a - b).abs().max()):.3e})"
+        # the weights change: without a new batch the stale planes must not serve (the result follows the new weights)
+        K.filter_planes_invalidate(jobs)
+        wd.mul_(1.5)
+        K.conv2d_transpose_weights(wd, wtb, stride=st, pad=pad)
+        h1 = lib().sgx_debug_filter_planes_hits()
+        out2 = run()
+        assert lib().sgx_debug_filter_planes_hits() == h1, "an invalidated entry served a launch"
+        K.filter_planes_scope(False)
+        ref2 = run()
+        for a, b in zip(out2, ref2):
+            assert torch.equal(a, b)
+        assert not torch.equal(out2[0], ref[0])
+    finally:
+        K.filter_planes_scope(False)
+        K.filter_planes_invalidate(None)
+        lib().sgx_debug_set_variant(0)
+        K.set_conv_math(K.DEFAULT_CONV_MATH)

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--problems", default=",".join(DEFAULT))
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--planes", default=None, help="comma list of 0 | 1: crossed with the other axes, pre-split filter planes off / on (the problem's "
+                    "filters are split once, the step's scope is open for the whole run; data gradients then use the pre-transposed-weights entry point)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import torch
@@ -39,8 +41,9 @@ def main():
     variants = [int(v) for v in args.variants.split(",")]
     tiles = [tuple(int(a) for a in t.split("x")) for t in args.tiles.split(",")]
     maths = args.math.split(",")
-    configs = [(v, t, m) for m in maths for t in tiles for v in variants]
-    lines = [f"{'problem':<34}" + "".join(f"{f'{m[:2]}{v}/{t[0]}x{t[1]}':>14}" for v, t, m in configs) + "   (TFLOP/s, median of rounds; us below)"]
+    planes = [int(v) for v in args.planes.split(",")] if args.planes else [None]
+    configs = [(v, t, m, pl) for m in maths for t in tiles for v in variants for pl in planes]
+    lines = [f"{'problem':<34}" + "".join(f"{f'{m[:2]}{v}/{t[0]}x{t[1]}' + ('' if pl is None else f'p{pl}'):>14}" for v, t, m, pl in configs) + "   (TFLOP/s, median of rounds; us below)"]
     for spec in args.problems.split(","):
         kind, n, h, w, c, k, r, s = spec.split(":")
         n, h, w, c, k, r, s = (int(a) for a in (n, h, w, c, k, r, s))
@@ -59,12 +62,34 @@ def main():
             w1t = w1.reshape(k, c).t().contiguous()
             ds = torch.randn(n, ho, wo, k, device=dev)
             flops += 2.0 * n * ho * wo * k * c
+        keep = None
+        if args.planes:
+            import ctypes
+
+            from super_gradients_amd import _lib
+
+            wtb = K.conv2d_wt_buffer(wt, dev)
+            K.conv2d_transpose_weights(wt, wtb, stride=s, pad=pad)
+            raw = K.conv2d_transpose_jobs(wt, wtb, stride=s, pad=pad)
+            recs = (_lib.WtransJob * (len(raw) // ctypes.sizeof(_lib.WtransJob))).from_buffer_copy(raw)
+            filters = [(wt.data_ptr(), k, r * r, c)] + [(q.wt, q.C, q.T, q.K) for q in recs]
+            if kind in ("fwd2", "dgrad2"):
+                filters += [(w1.data_ptr(), k, 1, c), (w1t.data_ptr(), c, 1, k)]
+            plan, total = K.filter_planes_plan(filters)
+            if plan:
+                buf = torch.empty(total, dtype=torch.uint8, device=dev)
+                jobs, jdev = K.filter_planes_table(plan, buf)
+                K.filter_planes_batch(jobs, jdev)
+                keep = (buf, jobs, jdev)
+            K.filter_planes_scope(True)
         if kind == "fwd2":
             fn = lambda: K.conv2d_fwd_dual(x, wt, w1, b1, stride=s)
         elif kind == "dgrad2":
             fn = lambda: K.conv2d_bwd_data_dual(y, wt, wtb, ds, w1t, (n, h, w, c), stride=s, out=x)
         elif kind == "fwd":
             fn = lambda: K.conv2d_fwd(x, wt, out=y, stride=s, pad=pad, stat_partials=True)
+        elif kind == "dgrad" and args.planes:
+            fn = lambda: K.conv2d_bwd_data_wt(y, wt, wtb, (n, h, w, c), stride=s, pad=pad, out=x)
         elif kind == "dgrad":
             fn = lambda: K.conv2d_bwd_data(y, wt, (n, h, w, c), stride=s, pad=pad, out=x)
         else:
@@ -72,7 +97,9 @@ def main():
         res = {cfg: [] for cfg in configs}
         for _ in range(args.rounds):
             for cfg in configs:
-                v, (bm, bn), m = cfg
+                v, (bm, bn), m, pl = cfg
+                if pl is not None:
+                    lib().sgx_debug_set_filter_planes(pl)
                 K.set_conv_math(m)
                 lib().sgx_debug_set_variant(v)
                 lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
@@ -90,6 +117,10 @@ def main():
                     res[cfg].append(float("nan"))
         lib().sgx_debug_set_variant(0)
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
+        if args.planes:
+            lib().sgx_debug_set_filter_planes(1)
+            K.filter_planes_scope(False)
+            K.filter_planes_invalidate(None)
         K.set_conv_math(K.DEFAULT_CONV_MATH)
         K.clear_desc_cache()
         med = {cfg: statistics.median(v) for cfg, v in res.items()}
