@@ -731,10 +731,11 @@ def test_filter_planes_serve_a_training_step_and_nothing_else(backend):
         with torch.no_grad():
             assert torch.equal(plain(x), fast(x))
         assert lib().sgx_debug_filter_planes_hits() == h1, "a launch outside a training step read filter planes"
-        plain.train(), fast.train()
-        for a, b in zip(step(plain), step(fast)):
-            assert torch.equal(a, b)
-        assert lib().sgx_debug_filter_planes_hits() > h1
+        if gpu:  # (a second pair of steps costs the host emulation another minute; the kernel-level test covers re-validation there)
+            plain.train(), fast.train()
+            for a, b in zip(step(plain), step(fast)):
+                assert torch.equal(a, b)
+            assert lib().sgx_debug_filter_planes_hits() > h1
     finally:
         lib().sgx_debug_set_variant(0)
         K.filter_planes_scope(False)

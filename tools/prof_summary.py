@@ -186,8 +186,38 @@ def timeline(d, top=12, steps=0):
         print(f"  {g / 1e6:9.3f} ms  {n[:90]}")
 
 
+def neighbours(d, pattern, steps=4):
+    """Where do the dispatches of the kernels matching `pattern` sit: per queue, which kernel precedes / follows them on that queue, over the
+    last `steps` train steps - to attribute anonymous runtime kernels (copyBuffer, fillBuffer) to the host code that issued them."""
+    ev = []
+    for f in find(d, "*kernel_trace.csv"):
+        for r in csv.DictReader(open(f, newline="")):
+            q = r.get("Queue_Id") or r.get("Stream_Id") or "?"
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), str(q), short(r["Kernel_Name"])))
+    ev.sort()
+    marks = [e for s_, e, _, n in ev if n.startswith("adamw_kernel")]
+    if len(marks) > steps:
+        lo, hi = marks[-steps - 1], marks[-1]
+        ev = [e for e in ev if e[0] >= lo and e[1] <= hi]
+    byq = collections.defaultdict(list)
+    for e in ev:
+        byq[e[2]].append(e)
+    ctx = collections.Counter()
+    for q, lst in byq.items():
+        for i, e in enumerate(lst):
+            if re.search(pattern, e[3]):
+                prev = lst[i - 1][3] if i else "-"
+                nxt = lst[i + 1][3] if i + 1 < len(lst) else "-"
+                ctx[(q, prev[:60], nxt[:60])] += 1
+    print(f"# dispatches matching {pattern!r} over the last {steps} steps, by (queue, previous kernel, next kernel)")
+    for (q, a, b), n in ctx.most_common(40):
+        print(f"{n / steps:>7.1f}/step  q{q}  after {a:<60}  before {b}")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "hbm":
+    if sys.argv[1] == "neighbours":
+        neighbours(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 4)
+    elif sys.argv[1] == "hbm":
         hbm(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "timeline":
         timeline(sys.argv[2], steps=int(sys.argv[3]) if len(sys.argv) > 3 else 0)
