@@ -205,7 +205,10 @@ int64_t sgx_filter_planes_bytes(int32_t rows, int32_t taps, int32_t ch);
 int32_t sgx_filter_planes_batch(const sgx_fplanes_job* jobs_host, const sgx_fplanes_job* jobs_dev, int32_t njobs, void* stream);
 int32_t sgx_filter_planes_invalidate(const sgx_fplanes_job* jobs_host, int32_t njobs);
 int32_t sgx_filter_planes_scope(int32_t open);
-int32_t sgx_debug_set_filter_planes(int32_t on); /* measurement: 0 = every launch splits its filter while staging */
+int32_t sgx_debug_set_filter_planes(int32_t mode); /* 0 = every launch splits its filter while staging; 1 (default) = planes copied into the
+                                                    * LDS slabs; 2 = 1, and every GEMM-loop launch on a tile of one 32-filter block per wave
+                                                    * reads its filter fragments straight from the planes into registers (in mode 1: the
+                                                    * problems whose tuning-table variant is 12, and the two-output forward pair)          */
 int64_t sgx_debug_filter_planes_hits(void);      /* launches that read planes so far (tests)                         */
 
 /* dw[k][r][s][c] += sum_pixels dy * x   (accumulates into dw: callers zero the gradient arena once per

@@ -19,6 +19,7 @@
 #include "sgx_common.h"
 
 #define SGX_MAX_TAPS 64
+#include <algorithm>
 #include <array>
 #include <atomic>
 #include <map>
@@ -288,15 +289,21 @@ __device__ __forceinline__ void sgx_bnreq_publish(const IgemmParams& p, int col,
 #ifndef IG_BF3_MIN_WAVES_PH2
 #define IG_BF3_MIN_WAVES_PH2 1  // (the two-source form as well: 93 registers; the two-output form would spill - three accumulators)
 #endif
-template <int BM, int BN, int WM, int WN, int MATH, int KD, int PH2, int NBUF>
+#ifndef IG_WPR_MIN_WAVES_6464
+#define IG_WPR_MIN_WAVES_6464 5
+#endif
+template <int BM, int BN, int WM, int WN, int MATH, int KD, int PH2, int NBUF, int WPL = 0>
 constexpr int igemm_min_waves() {
+    // (register fragments of the filter, WPL = 2: 24 registers of fragments one slab ahead - under a bound of five waves only the 64x64
+    // one-source form fits them without spilling, r5ab: the spilling forms ran 1.7-2x slower)
+    if (WPL == 2) return (BM == 64 && BN == 64 && PH2 == 0) ? IG_WPR_MIN_WAVES_6464 : (BM / (WM * 32) == 1 && BN / (WN * 32) == 1 && PH2 <= 1) ? 4 : 1;
     // (the pipelined two-buffer loop: three workgroups' LDS per CU; a bound >= 2 also keeps the accumulators in ordinary registers -
     // with 512 registers on offer hipcc parks them in AGPRs and copies 32 registers in and out per slab)
     if (NBUF == 2 && KD == 32) return (BM + BN) * 192 * 2 > 52 * 1024 ? 2 : 3;
     return (MATH == 1 && KD == 32 && PH2 <= IG_BF3_MIN_WAVES_PH2 && BM / (WM * 32) == 1 && BN / (WN * 32) == 1) ? IG_BF3_MIN_WAVES : 1;
 }
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, bool WPL = false>
-__global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2, NBUF>())) void igemm_kernel(IgemmParams p) {
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, int WPL = 0>
+__global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2, NBUF, WPL>())) void igemm_kernel(IgemmParams p) {
     static_assert(!WPL || (MATH == 1 && KD == 32 && NBUF == 1 && !FLAT), "pre-split filter planes: the one-buffer 32-deep bf16x3 loop");
     static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && NBUF == 1) || (KD == 32 && !FLAT && NBUF == 2 && MATH == 1) ||
                       (KD == 32 && !FLAT && NBUF == 3 && MATH == 0 && PH2 == 0),
@@ -320,8 +327,13 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
     // is copied into the LDS planes as it is: BN x 4 x 3 items per slab instead of BN x 8 float4 items with a 22-instruction split each
     // Which (plane, 16-row block) a thread's j-th piece belongs to is the same for its whole wave: a wave copies 16 rows x 4 octets, the
     // BN / 16 blocks of a plane follow one another, and only the place inside the block (row lane / 4, octet lane % 4) is per lane.
+    // WPL = 2: the filter does not pass through LDS at all.  A 16-byte piece of the planes - row n, one half of a 16-channel block - IS
+    // the B fragment of v_mfma_f32_32x32x16_bf16 for lane (n mod 32, half): every wave loads the fragments of its own 32-filter columns
+    // straight from the planes (L2 / L1 hits: a filter is a few hundred KB, shared by every workgroup of the launch) into the registers
+    // the MFMAs read, one slab ahead - no filter stores, no filter fragment reads, half the LDS bytes per MFMA, an LDS slab of A only.
+    constexpr bool WPR = WPL == 2;
     constexpr int BPI = 3 * BN * 4, WBK = BN / 16;   // pieces per slab; 16-row blocks per plane
-    constexpr int AJ = (BM + RPP - 1) / RPP, BJ = WPL ? (BPI + NTH - 1) / NTH : (BN + RPP - 1) / RPP;
+    constexpr int AJ = (BM + RPP - 1) / RPP, BJ = WPR ? 1 : WPL ? (BPI + NTH - 1) / NTH : (BN + RPP - 1) / RPP;
     static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "bad tile");
     static_assert(NTH >= BM && NTH >= BN, "epilogue helpers need one thread per tile row/col");
     constexpr int LDPW = KD / 2;        // bf16x3: dwords per slab row and plane (KD bf16), unpadded
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
     // bf16x3 plane swizzle: 16-byte chunks of a row are permuted by row bits so that the fragment reads of 16 consecutive rows hit 16
     // distinct 4-bank groups - 32-byte rows: halves swapped on rows with bit 3 set; 64-byte rows: chunk ^= row bits 2-3
     auto swz = [](int row, int dw) { return KD == 16 ? IG_SWZ(row, dw) : (dw ^ (((row >> 2) & 3) << 2)); };
-    constexpr int SLABS = LBUF * (BM + BN) * ROWW, STAGE = WM * WN * 32 * 32;   // operand slabs; epilogue staging patches (reuse the slabs)
+    constexpr int SLABS = LBUF * (BM + (WPR ? 0 : BN)) * ROWW, STAGE = WM * WN * 32 * 32;   // operand slabs; epilogue staging patches (reuse the slabs)
     __shared__ __attribute__((aligned(16))) float smem[SLABS > STAGE ? SLABS : STAGE];
     float* const As = smem;
     float* const Bs = smem + LBUF * BM * ROWW;
@@ -365,6 +377,8 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
     // scalar slab state of the NEXT slab to load (non-FLAT): tap row, tap column, channel chunk
     int s_ti = 0, s_tj = 0, s_ck = 0, s_kt = 0;
     int wp_tapstep = 0, wp_ckstep = 0;  // WPL: bytes from one tap's rows to the next, from one 32-channel chunk's planes to the next
+    int wp_woff = 0;                    // WPR: planes offset (tap, chunk) of the slab whose A tile load_tile issued last
+    uint4 bfr[WPR ? 2 : 1][WPR ? 3 : 1][WPR ? TN : 1];  // WPR: B fragments [16-deep half][plane][column block] of the slab to compute next
     auto setup_src = [&](const float* A, const float* Wt, int Hin, int Win, int Th, int Tw, int dh0, int dw0, int dstep, long a_ld_pix, long a_ld_img,
                          long w_ld_n, long a_bytes, long w_bytes, const unsigned char* Wp, long wp_bytes) {
         // buffer descriptors: A is re-based at the workgroup's first image so that lane offsets fit 31 bits
@@ -398,10 +412,16 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
             // planes [ch / 16][plane][tap][row][32 B]: a 32-deep slab (tap, chunk ck) is the 16-channel blocks 2 ck and 2 ck + 1
             wp_tapstep = p.Nout * 32;
             wp_ckstep = 6 * Th * Tw * wp_tapstep;
-            const int lrow16 = lane >> 2, oct = lane & 3;
-            wp_lane = (oct >> 1) * 3 * Th * Tw * wp_tapstep + (n0 + lrow16) * 32 + (oct & 1) * 16;
-            wp_lds = lrow16 * LDPW + ((oct ^ ((lrow16 >> 2) & 3)) << 2);  // swz(row, oct * 4): a block starts at a multiple of 16 rows
-            wp_rows = p.Nout - n0 - lrow16;                               // this lane's row of block b exists if 16 b < wp_rows
+            if constexpr (WPR) {
+                const int nrow = n0 + wn * TN * 32 + (lane & 31);  // fragment row of column block 0; block j: 32 j rows on
+                wp_lane = nrow * 32 + (lane >> 5) * 16;
+                wp_rows = p.Nout - nrow;                           // block j exists for this lane if 32 j < wp_rows
+            } else {
+                const int lrow16 = lane >> 2, oct = lane & 3;
+                wp_lane = (oct >> 1) * 3 * Th * Tw * wp_tapstep + (n0 + lrow16) * 32 + (oct & 1) * 16;
+                wp_lds = lrow16 * LDPW + ((oct ^ ((lrow16 >> 2) & 3)) << 2);  // swz(row, oct * 4): a block starts at a multiple of 16 rows
+                wp_rows = p.Nout - n0 - lrow16;                               // this lane's row of block b exists if 16 b < wp_rows
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
@@ -470,7 +490,9 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                 ra[j] = sgx_buf_ld4(bufA, ok ? (unsigned)(aoff[j] + tapoff) : SGX_BUF_OOB);
             }
             // (WPL: C is a multiple of 32 - no ragged channel chunk to mask on the filter side)
-            if constexpr (WPL) {
+            if constexpr (WPR) {
+                wp_woff = woff;  // the fragments of this slab are fetched by load_bfrags, behind the MFMAs that read the current ones
+            } else if constexpr (WPL) {
                 const int wv = sgx_uniform_i32(tid >> 6);
 #pragma unroll
                 for (int j = 0; j < BJ; ++j) {
@@ -507,6 +529,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                     *reinterpret_cast<uint2*>(d + 2 * BM * LDPW) = l;
                 }
             }
+            if constexpr (WPR) return;
             if constexpr (WPL) {
                 const int wv = sgx_uniform_i32(tid >> 6);
 #pragma unroll
@@ -542,6 +565,17 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
         }
     };
     auto store_tile = [&](int buf) { store_tile_from(buf, ra, rb); };
+    // WPR: the B fragments of 16-deep half h of the slab load_tile addressed last: 16-channel block 2 ck + h, three planes, TN column blocks
+    auto load_bfrags = [&](int h) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const bool ok = j * 32 < wp_rows;
+                bfr[WPR ? h : 0][WPR ? pl : 0][WPR ? j : 0] =
+                    sgx_buf_ld4u(bufB, ok ? (unsigned)(wp_lane + j * (32 * 32) + wp_woff + (h * 3 + pl) * T_ * wp_tapstep) : SGX_BUF_OOB);
+            }
+    };
 
     sgx_f32x16 acc[TM][TN];
 #pragma unroll
@@ -582,10 +616,16 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const unsigned* s = reinterpret_cast<const unsigned*>(Bs) + (buf * 3 * BN + wn * TN * 32 + j * 32 + frow) * LDPW + swz(frow, half * 8 + (lane >> 5) * 4);
-            bh[j] = *reinterpret_cast<const uint4*>(s);
-            bm[j] = *reinterpret_cast<const uint4*>(s + BN * LDPW);
-            bl[j] = *reinterpret_cast<const uint4*>(s + 2 * BN * LDPW);
+            if constexpr (WPR) {
+                bh[j] = bfr[WPR ? half : 0][0][WPR ? j : 0];
+                bm[j] = bfr[WPR ? half : 0][WPR ? 1 : 0][WPR ? j : 0];
+                bl[j] = bfr[WPR ? half : 0][WPR ? 2 : 0][WPR ? j : 0];
+            } else {
+                const unsigned* s = reinterpret_cast<const unsigned*>(Bs) + (buf * 3 * BN + wn * TN * 32 + j * 32 + frow) * LDPW + swz(frow, half * 8 + (lane >> 5) * 4);
+                bh[j] = *reinterpret_cast<const uint4*>(s);
+                bm[j] = *reinterpret_cast<const uint4*>(s + BN * LDPW);
+                bl[j] = *reinterpret_cast<const uint4*>(s + 2 * BN * LDPW);
+            }
         }
         // smallest terms first; the six products of one (i, j) are interleaved across the tile's accumulators
         auto corr = [&](int i, int j) -> sgx_f32x16& { return accc[BF3 ? i : 0][BF3 ? j : 0]; };
@@ -786,6 +826,12 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
             continue;
         }
         if (nkt > 0) load_tile();
+        if constexpr (WPR) {
+            if (nkt > 0) {
+                load_bfrags(0);
+                load_bfrags(1);
+            }
+        }
         if (src == 0) compute_rowoff();
         if (nkt > 0) store_tile(0);
         __syncthreads();
@@ -793,7 +839,13 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
             if (KD == 32) {
                 // one LDS buffer: the next slab travels in registers under 16 x TM x TN MFMAs and is written after every wave has read this one
                 if (kt + 1 < nkt) load_tile();
-                if (BF3) {
+                if constexpr (WPR) {
+                    // each half's fragment registers are refilled for the next slab as soon as this slab's MFMAs have read them
+                    compute_bf3(0, 0);
+                    if (kt + 1 < nkt) load_bfrags(0);
+                    compute_bf3(0, 1);
+                    if (kt + 1 < nkt) load_bfrags(1);
+                } else if (BF3) {
                     compute_bf3(0, 0);
                     compute_bf3(0, 1);
                 } else {
@@ -1698,7 +1750,7 @@ extern "C" int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n) {
                               (e[9] == 0) == (e[10] == 0),  // all 16 tiles of {32, 64, 96, 128}^2 are instantiated
                           "conv_tuning_load: entry %d: no weight-gradient kernel (tile %dx%d, split target %d)", i, e[9], e[10], e[11]);
         else
-            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && (e[11] == 0 || e[11] == 6 || e[11] == 7 || e[11] == 11),
+            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && (e[11] == 0 || e[11] == 6 || e[11] == 7 || e[11] == 11 || e[11] == 12),
                           "conv_tuning_load: entry %d: no kernel (tile %dx%d, variant %d)", i, e[9], e[10], e[11]);
         m[std::array<int, 9>{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8]}] = TuneVal{e[9], e[10], e[11]};
     }
@@ -1743,7 +1795,7 @@ static TileCfg pick_tile_heuristic(long M, int N) {
 // 16-deep loop; two LDS buffers with 32-deep slabs measured slower (lower occupancy) and were removed.
 static bool igemm_deep_slabs(const IgemmParams& p) { return conv_variant() != 7 && p.C % 32 == 0; }
 // dispatch over the eight non-flat tile shapes for one (MATH, KD, NBUF, PH2)
-#define SGX_IGEMM_TILES(MATH_, KD_, NBUF_, PH2_) SGX_IGEMM_TILES_W(MATH_, KD_, NBUF_, PH2_, false)
+#define SGX_IGEMM_TILES(MATH_, KD_, NBUF_, PH2_) SGX_IGEMM_TILES_W(MATH_, KD_, NBUF_, PH2_, 0)
 #define SGX_IGEMM_TILES_W(MATH_, KD_, NBUF_, PH2_, WPL_)                                                                \
     do {                                                                                                                \
         if (bm == 128 && bn == 128) launch_igemm<128, 128, 2, 2, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);      \
@@ -1757,7 +1809,7 @@ static bool igemm_deep_slabs(const IgemmParams& p) { return conv_variant() != 7 
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv: no tile %dx%d (math %d, %d-deep slabs)", bm, bn, MATH_, KD_);         \
     } while (0)
 // the two-source kernels exist for the tiles the heuristic picks (pick_tile_heuristic): overrides / table entries do not apply to them
-#define SGX_IGEMM_TILES_PH2(MATH_, KD_, NBUF_, PH2_) SGX_IGEMM_TILES_PH2_W(MATH_, KD_, NBUF_, PH2_, false)
+#define SGX_IGEMM_TILES_PH2(MATH_, KD_, NBUF_, PH2_) SGX_IGEMM_TILES_PH2_W(MATH_, KD_, NBUF_, PH2_, 0)
 #define SGX_IGEMM_TILES_PH2_W(MATH_, KD_, NBUF_, PH2_, WPL_)                                                            \
     do {                                                                                                                \
         if (bm == 128 && bn == 96) launch_igemm<128, 96, 4, 1, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);        \
@@ -1766,7 +1818,7 @@ static bool igemm_deep_slabs(const IgemmParams& p) { return conv_variant() != 7 
         else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);     \
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (two sources): no tile %dx%d", bm, bn);                                \
     } while (0)
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, bool WPL = false>
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, int WPL = 0>
 static void launch_igemm(IgemmParams& p, void* stream) {
     p.mt = sgx_cdiv(p.M, BM);
     p.nt = sgx_cdiv(p.Nout, BN);
@@ -1901,7 +1953,11 @@ extern "C" int32_t sgx_filter_planes_batch(const sgx_fplanes_job* jobs_host, con
         SGX_CHECK_ARG(((uintptr_t)j.src % 16) == 0 && ((uintptr_t)j.planes % 16) == 0, "filter_planes_batch: job %d: 16-byte aligned pointers", i);
         SGX_CHECK_ARG(sgx_filter_planes_bytes(j.rows, j.taps, j.ch) < (1 << 30), "filter_planes_batch: job %d: planes of 1 GiB or more", i);
     }
-    SGX_LAUNCH(fplanes_batch_kernel, dim3(64, (unsigned)njobs), dim3(256), 0, stream, jobs_dev);
+    // grid: 64 workgroups per job for the step's largest filters (768 x 384 x 3 x 3: ~160 four-channel items per thread), fewer when every job is small
+    long items = 0;
+    for (int i = 0; i < njobs; ++i) items = std::max(items, (long)jobs_host[i].rows * jobs_host[i].taps * (jobs_host[i].ch / 4));
+    const unsigned gx = (unsigned)std::min(64L, std::max(1L, (items + 1023) / 1024));
+    SGX_LAUNCH(fplanes_batch_kernel, dim3(gx, (unsigned)njobs), dim3(256), 0, stream, jobs_dev);
     SGX_CHECK_LAUNCH("filter_planes_batch");
     std::lock_guard<std::mutex> lk(g_fp_mu);
     for (int i = 0; i < njobs; ++i) {
@@ -1924,8 +1980,11 @@ extern "C" int32_t sgx_filter_planes_scope(int32_t open) {
     g_fp_scope = open ? 1 : 0;
     return SGX_OK;
 }
-extern "C" int32_t sgx_debug_set_filter_planes(int32_t on) {  // measurement switch: 0 = every launch splits its filter while staging
-    g_fp_on = on ? 1 : 0;
+// 0 = every launch splits its filter while staging; 1 = planes copied into the LDS slabs; 2 = 1, and the GEMM loop's one-block-per-wave
+// tiles read their filter fragments straight from the planes into registers (igemm_kernel WPL = 2)
+extern "C" int32_t sgx_debug_set_filter_planes(int32_t mode) {
+    SGX_CHECK_ARG(mode >= 0 && mode <= 2, "filter planes mode %d (0 off, 1 LDS copy, 2 register fragments)", mode);
+    g_fp_on = mode;
     return SGX_OK;
 }
 static const unsigned char* fplanes_lookup(const float* w, int rows, int taps, int ch, long ld_n, long* bytes) {
@@ -1988,8 +2047,14 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
         if (p.C % 32 == 0) {
             if (bf3 && p.Wp && (!p.A2 || p.Wp2)) {
                 g_fp_hits.fetch_add(1, std::memory_order_relaxed);
-                if (ph2 == 1) SGX_IGEMM_TILES_PH2_W(1, 32, 1, 1, true);
-                else SGX_IGEMM_TILES_PH2_W(1, 32, 1, 2, true);
+                // register fragments (mode 2, or variant 12; the tiles of one 32-filter block per wave) - by default the two-output forward
+                // pair takes them (r5ac lab: -6 %) and the two-source data gradient does not (+8 %)
+                const int fpm = g_fp_on.load(std::memory_order_relaxed);
+                const bool wpr = (fpm == 2 || conv_variant() == 12 || (fpm == 1 && ph2 == 2 && conv_variant() != 13)) && bn <= 64;
+                if (wpr && ph2 == 1) SGX_IGEMM_TILES_PH2_W(1, 32, 1, 1, 2);
+                else if (wpr) SGX_IGEMM_TILES_PH2_W(1, 32, 1, 2, 2);
+                else if (ph2 == 1) SGX_IGEMM_TILES_PH2_W(1, 32, 1, 1, 1);
+                else SGX_IGEMM_TILES_PH2_W(1, 32, 1, 2, 1);
             } else if (bf3) {
                 if (ph2 == 1) SGX_IGEMM_TILES_PH2(1, 32, 1, 1);
                 else SGX_IGEMM_TILES_PH2(1, 32, 1, 2);
@@ -2016,7 +2081,14 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
             else launch_igemm<64, 32, 2, 1, false, 1, 32, 2, 0>(p, stream);
         } else if (igemm_deep_slabs(p) && p.Wp) {
             g_fp_hits.fetch_add(1, std::memory_order_relaxed);
-            SGX_IGEMM_TILES_W(1, 32, 1, 0, true);
+            // register fragments: mode 2, or the problem's tuning-table variant 12 (tools/conv_tune.py measures both forms per problem)
+            if ((g_fp_on.load(std::memory_order_relaxed) == 2 || conv_variant() == 12) && bn <= 64) {
+                if (bm == 128 && bn == 64) launch_igemm<128, 64, 2, 2, false, 1, 32, 1, 0, 2>(p, stream);
+                else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 1, 32, 1, 0, 2>(p, stream);
+                else if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 1, 32, 1, 0, 2>(p, stream);
+                else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, 1, 32, 1, 0, 2>(p, stream);
+                else SGX_IGEMM_TILES_W(1, 32, 1, 0, 1);
+            } else SGX_IGEMM_TILES_W(1, 32, 1, 0, 1);
         }
         else if (igemm_deep_slabs(p)) SGX_IGEMM_TILES(1, 32, 1, 0);
         else SGX_IGEMM_TILES(1, 16, 2, 0);

@@ -210,6 +210,9 @@ def wtrans_batch(jobs_dev, njobs):
     check(lib().sgx_wtrans_batch(ptr(jobs_dev), int(njobs), stream()), "sgx_wtrans_batch")
 
 
+DEFAULT_FILTER_PLANES = 1  # the library's default mode of sgx_debug_set_filter_planes (tests restore it)
+
+
 def filter_planes_plan(filters):
     """filters: iterable of (fp32 filter tensor viewed [rows, taps, ch] - its data_ptr is what the conv launches will see).  Returns
     (records (src, byte offset, rows, taps, ch), total bytes) for the filters a bf16x3 launch can take planes of (ch a multiple of 16 - also the

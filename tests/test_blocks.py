@@ -683,7 +683,7 @@ def test_filter_planes_serve_a_training_step_and_nothing_else(backend):
             self.b1.bwd(self.b2.bwd(dy.contiguous()), need_dx=False)
 
     gpu = backend.type == "cuda"
-    n, h, w = (4, 40, 40) if gpu else (1, 9, 20)
+    n, h, w = (4, 40, 40) if gpu else (1, 8, 16)
     x = (torch.randn(n, 32, h, w, generator=torch.Generator().manual_seed(0)) + 0.5).to(backend)
     lib().sgx_debug_set_variant(0 if gpu else 9)  # (host emulation: small maps - variant 9 lets the patch kernel take them)
 

@@ -1791,7 +1791,7 @@ def _wt_filters(w, wtb, stride, pad):
     return [(r.wt, r.C, r.T, r.K) for r in (_lib.WtransJob * n).from_buffer_copy(raw)]
 
 
-@pytest.mark.parametrize("case", ["patch32", "patch64", "gemm1x1", "gemm3x3s2", "qarep_s1", "qarep_s2"])
+@pytest.mark.parametrize("case", ["patch32", "patch64", "gemm1x1", "gemm3x3s2", "qarep_s1", "qarep_s2", "gemm1x1-regs", "gemm3x3s2-regs", "qarep_s2-regs"])
 def test_filter_planes_launches_are_bit_identical(backend, case):
     """Pre-split filter planes (sgx_filter_planes_batch; round 5): a bf16x3 launch that copies its filter's planes must produce exactly the
     bits of the launch that splits the fp32 filter while staging - forward, data gradient (through the transposed filters' planes) and the
@@ -1800,6 +1800,9 @@ def test_filter_planes_launches_are_bit_identical(backend, case):
     from super_gradients_amd._lib import lib
 
     gpu = backend.type == "cuda"
+    # "-regs": planes mode 2 - the GEMM loop's one-block-per-wave tiles read their filter fragments straight from the planes into registers
+    mode = 2 if case.endswith("-regs") else 1
+    case = case.split("-")[0]
     # (N, H, W, C, K, R, stride)
     shape = {"patch32": (2, 40, 40, 32, 32, 3, 1) if gpu else (1, 9, 20, 16, 32, 3, 1),
              "patch64": (2, 40, 48, 64, 128, 3, 1) if gpu else (1, 8, 16, 32, 64, 3, 1),
@@ -1834,6 +1837,7 @@ def test_filter_planes_launches_are_bit_identical(backend, case):
 
     K.set_conv_math("patch_bf3")
     lib().sgx_debug_set_variant(0 if gpu else 9)  # (host emulation: small maps - variant 9 lifts the patch kernel's 40 x 40 floor)
+    lib().sgx_debug_set_filter_planes(mode)
     jobs = None
     try:
         K.filter_planes_invalidate(None)
@@ -1868,5 +1872,6 @@ def test_filter_planes_launches_are_bit_identical(backend, case):
     finally:
         K.filter_planes_scope(False)
         K.filter_planes_invalidate(None)
+        lib().sgx_debug_set_filter_planes(K.DEFAULT_FILTER_PLANES)
         lib().sgx_debug_set_variant(0)
         K.set_conv_math(K.DEFAULT_CONV_MATH)

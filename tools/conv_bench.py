@@ -94,8 +94,35 @@ def record_problems(model, batch, size, dev):
     return rec
 
 
-def make_runner(k, dev):
-    """-> (callable replaying the problem once, its algorithmic FLOPs)"""
+def _with_planes(fn, filters, dev):
+    """Pre-split filter planes for the runner's filters ((ptr, rows, taps, ch) records), kept alive with the callable; the caller opens the
+    step scope (kernels.filter_planes_scope) for as long as it replays planes-aware launches."""
+    import torch
+
+    from super_gradients_amd import kernels as K
+
+    plan, total = K.filter_planes_plan(filters)
+    if plan:
+        buf = torch.empty(total, dtype=torch.uint8, device=dev)
+        jobs, jdev = K.filter_planes_table(plan, buf)
+        K.filter_planes_batch(jobs, jdev)
+        fn._planes = (buf, jobs, jdev)
+    return fn
+
+
+def _wt_filters(wt, wtt, stride, pad):
+    import ctypes
+
+    from super_gradients_amd import _lib
+    from super_gradients_amd import kernels as K
+
+    raw = K.conv2d_transpose_jobs(wt, wtt, stride=stride, pad=pad)
+    return [(q.wt, q.C, q.T, q.K) for q in (_lib.WtransJob * (len(raw) // ctypes.sizeof(_lib.WtransJob))).from_buffer_copy(raw)]
+
+
+def make_runner(k, dev, planes=False):
+    """-> (callable replaying the problem once, its algorithmic FLOPs).  planes: the problem's filters get pre-split planes (as the step's
+    prefetch makes them) and a data gradient runs from pre-transposed weights, as it does in the step."""
     import torch
 
     from super_gradients_amd import kernels as K
@@ -115,22 +142,30 @@ def make_runner(k, dev):
         w1 = K.to_ohwi(torch.randn(K_, c, 1, 1, device=dev) / c ** 0.5)
         if kind == "fwd2":
             b1 = torch.randn(K_, device=dev)
-            return (lambda: K.conv2d_fwd_dual(xin, wt, w1, b1, stride=stride)), flops
+            fn = lambda: K.conv2d_fwd_dual(xin, wt, w1, b1, stride=stride)
+            return (_with_planes(fn, [(wt.data_ptr(), K_, R * R, c), (w1.data_ptr(), K_, 1, c)], dev) if planes else fn), flops
         has_add, acc = extra
         add = buf(n, h, w, c, xl) if has_add else None
         wtt = K.conv2d_wt_buffer(wt, dev)
         K.conv2d_transpose_weights(wt, wtt, stride=stride, pad=pad)
         w1t = w1.reshape(K_, c).t().contiguous()
         ds = buf(n, ho, wo, K_, yl)
-        return (lambda: K.conv2d_bwd_data_dual(yout, wt, wtt, ds, w1t, (n, h, w, c), stride=stride, addend=add, out=xin, accumulate=acc)), flops
+        fn = lambda: K.conv2d_bwd_data_dual(yout, wt, wtt, ds, w1t, (n, h, w, c), stride=stride, addend=add, out=xin, accumulate=acc)
+        return (_with_planes(fn, _wt_filters(wt, wtt, stride, pad) + [(w1t.data_ptr(), c, 1, K_)], dev) if planes else fn), flops
     if kind == "fwd":
         has_b, has_add, act, stats = extra
         b = torch.randn(K_, device=dev) if has_b else None
         add = buf(n, ho, wo, K_, yl) if has_add else None
-        return (lambda: K.conv2d_fwd(xin, wt, bias=b, addend=add, out=yout, act=act, stride=stride, pad=pad, stat_partials=stats)), flops
+        fn = lambda: K.conv2d_fwd(xin, wt, bias=b, addend=add, out=yout, act=act, stride=stride, pad=pad, stat_partials=stats)
+        return (_with_planes(fn, [(wt.data_ptr(), K_, R * R, c)], dev) if planes else fn), flops
     if kind == "dgrad":
         has_add, acc = extra
         add = buf(n, h, w, c, xl) if has_add else None
+        if planes:
+            wtt = K.conv2d_wt_buffer(wt, dev)
+            K.conv2d_transpose_weights(wt, wtt, stride=stride, pad=pad)
+            fn = lambda: K.conv2d_bwd_data_wt(yout, wt, wtt, (n, h, w, c), stride=stride, pad=pad, addend=add, out=xin, accumulate=acc)
+            return _with_planes(fn, _wt_filters(wt, wtt, stride, pad), dev), flops
         return (lambda: K.conv2d_bwd_data(yout, wt, (n, h, w, c), stride=stride, pad=pad, addend=add, out=xin, accumulate=acc)), flops
     (has_b,) = extra
     dw = torch.zeros_like(wt)

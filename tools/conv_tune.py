@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--wgrad", action="store_true", help="also search the weight-gradient tiles")
     ap.add_argument("--emit-table", default=None, help="write the per-problem winners (forward / data gradient) as a tuning table for "
                     "sgx_conv_tuning_load (super_gradients_amd/csrc/conv_tuning_gfx950.json is loaded by default when present)")
+    ap.add_argument("--planes", action="store_true", help="replay with pre-split filter planes, as the step runs (data gradients from pre-transposed "
+                    "weights), and also search variant 12 - the GEMM loop's filter fragments straight from the planes into registers")
+    ap.add_argument("--keep-wgrad-from", default=None, help="a committed table whose weight-gradient entries are carried over (with --emit-table, without --wgrad)")
     ap.add_argument("--min-gain", type=float, default=0.02, help="a winner enters the table only if it beats the heuristic by this fraction")
     args = ap.parse_args()
     import torch
@@ -76,7 +79,11 @@ def main():
     tot_base = tot_best = 0.0
     for key, calls in rec.items():
         kind = key[0]
-        fn, flops = CB.make_runner(key, dev)
+        K.filter_planes_scope(False)
+        K.filter_planes_invalidate(None)  # (the previous problem's buffers are about to be freed)
+        fn, flops = CB.make_runner(key, dev, planes=args.planes and kind != "wgrad")
+        if args.planes:
+            K.filter_planes_scope(True)
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
         K.clear_desc_cache()
         base = timeit(fn)
@@ -123,6 +130,15 @@ def main():
                 note(key, calls, (bm, bn, 11), t)
                 if t < best:
                     best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + " variant=11"
+            if args.planes:  # variant 12: filter fragments from the planes into registers (tiles of one 32-filter block per wave)
+                lib().sgx_debug_set_variant(12)
+                for bm, bn in ((0, 0), (64, 64), (128, 32), (64, 32), (128, 64)):
+                    lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                    K.clear_desc_cache()
+                    t = timeit(fn)
+                    note(key, calls, (bm, bn, 12), t)
+                    if t < best:
+                        best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + " variant=12"
             lib().sgx_debug_set_variant(0)
         elif args.wgrad:
             note(key, calls, (0, 0, 0), base)
@@ -142,6 +158,8 @@ def main():
         lines.append((calls * (base - best), f"{kind:<6}{key[1:11]} x{calls:<3} heuristic {base:8.1f} us  best {best:8.1f} us ({flops / best / 1e6:6.1f} TF)  {best_cfg}"))
     lines.sort(key=lambda t: -t[0])
     text = "\n".join([f"# conv tile search: heuristic {tot_base / 1e3:.2f} ms/step -> best-per-problem {tot_best / 1e3:.2f} ms/step"] + [l for _, l in lines])
+    K.filter_planes_scope(False)
+    K.filter_planes_invalidate(None)
     print(text)
     if args.out:
         open(args.out, "w").write(text + "\n")
@@ -149,6 +167,11 @@ def main():
         import json
 
         entries, meta = build_table(agg, args.min_gain)
+        if args.keep_wgrad_from and not args.wgrad:
+            old = json.load(open(args.keep_wgrad_from))
+            entries += [e for e in old.get("entries", []) if e.get("kind") == "wgrad"]
+            meta["wgrad_entries_from"] = os.path.basename(args.keep_wgrad_from)
+        meta["filter_planes"] = bool(args.planes)
         meta.update(model=f"yolo_nas_{args.model}", batch=args.batch, size=args.size, conv_math=K.get_conv_math())
         json.dump(dict(meta=meta, entries=entries), open(args.emit_table, "w"), indent=1)
         print(f"# tuning table: {len(entries)} of {len(agg)} problems, {meta['ms_per_step_heuristic']} -> {meta['ms_per_step_table']} ms/step -> {args.emit_table}")
