@@ -1802,6 +1802,8 @@ def test_filter_planes_launches_are_bit_identical(backend, case):
     gpu = backend.type == "cuda"
     # "-regs": planes mode 2 - the GEMM loop's one-block-per-wave tiles read their filter fragments straight from the planes into registers
     mode = 2 if case.endswith("-regs") else 1
+    if not gpu and case == "gemm1x1-regs":
+        pytest.skip("host emulation: the register-fragment form is covered by the 3x3 stride-2 and two-source cases (CPU suite time)")
     case = case.split("-")[0]
     # (N, H, W, C, K, R, stride)
     shape = {"patch32": (2, 40, 40, 32, 32, 3, 1) if gpu else (1, 9, 20, 16, 32, 3, 1),
