@@ -187,10 +187,26 @@ __device__ __forceinline__ double colsrc_sum(const ColSrc& s, int plane, int C, 
     }
     return acc;
 }
-// this lane's rows of P planes, ascending (a fixed order), FOUR rows x P planes of loads in flight
+// this lane's rows of P planes, ascending (a fixed order).  Round 5: SIXTEEN rows x P planes of loads in flight (eight for the five-plane
+// form) before the first add, then four, then one - the adds stay in ascending row order, so every sum keeps its bits.  During the
+// backward pass these kernels run beside the weight-gradient patch kernels of the side stream, which keep the memory system busy: a load
+// then takes several microseconds, and with four rows in flight a lane's 64-100 rows were 16-25 dependent rounds - the launches that the
+// trace shows at 100-300 us instead of 8 (profiles/r5aa: every one of them overlaps a wpatch_kernel; ~0.5 ms per step on the critical path).
 template <int P, typename T>
 __device__ __forceinline__ void col_lane_sums(const T* p0, long plane_ld, int n, int C, int rl, double (&acc)[P]) {
+    constexpr int U = P <= 2 ? 16 : 8;
     int b = rl;
+    for (; b + (U - 1) * CO_RL < n; b += U * CO_RL) {
+        T v[U][P];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < P; ++q) v[u][q] = p0[q * plane_ld + (long)(b + u * CO_RL) * C];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < P; ++q) acc[q] += (double)v[u][q];
+    }
     for (; b + 3 * CO_RL < n; b += 4 * CO_RL) {
         T v[4][P];
 #pragma unroll

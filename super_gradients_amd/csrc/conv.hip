@@ -1957,7 +1957,7 @@ extern "C" int32_t sgx_filter_planes_batch(const sgx_fplanes_job* jobs_host, con
     long items = 0;
     for (int i = 0; i < njobs; ++i) items = std::max(items, (long)jobs_host[i].rows * jobs_host[i].taps * (jobs_host[i].ch / 4));
     const unsigned gx = (unsigned)std::min(64L, std::max(1L, (items + 1023) / 1024));
-    SGX_LAUNCH(fplanes_batch_kernel, dim3(gx, (unsigned)njobs), dim3(256), 0, stream, jobs_dev);
+    SGX_LAUNCH(fplanes_batch_kernel, dim3(SGX_STRIDE_GRID(gx), (unsigned)njobs), dim3(256), 0, stream, jobs_dev);
     SGX_CHECK_LAUNCH("filter_planes_batch");
     std::lock_guard<std::mutex> lk(g_fp_mu);
     for (int i = 0; i < njobs; ++i) {
@@ -2283,7 +2283,7 @@ __global__ void wtrans_batch_kernel(const sgx_wtrans_job* jobs) {
 }
 extern "C" int32_t sgx_wtrans_batch(const sgx_wtrans_job* jobs_dev, int32_t njobs, void* stream) {
     SGX_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 65535, "wtrans_batch: bad args (njobs=%d)", njobs);
-    SGX_LAUNCH(wtrans_batch_kernel, dim3(256, (unsigned)njobs), dim3(256), 0, stream, jobs_dev);
+    SGX_LAUNCH(wtrans_batch_kernel, dim3(SGX_STRIDE_GRID(256), (unsigned)njobs), dim3(256), 0, stream, jobs_dev);
     SGX_CHECK_LAUNCH("wtrans_batch");
     return SGX_OK;
 }
@@ -2305,7 +2305,7 @@ __global__ void qarep_prep_kernel(const sgx_qarep_prep_job* jobs) {
 }
 extern "C" int32_t sgx_qarep_prep_batch(const sgx_qarep_prep_job* jobs_dev, int32_t njobs, void* stream) {
     SGX_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 65535, "qarep_prep_batch: bad args (njobs=%d)", njobs);
-    SGX_LAUNCH(qarep_prep_kernel, dim3(8, (unsigned)njobs), dim3(256), 0, stream, jobs_dev);
+    SGX_LAUNCH(qarep_prep_kernel, dim3(SGX_STRIDE_GRID(8), (unsigned)njobs), dim3(256), 0, stream, jobs_dev);
     SGX_CHECK_LAUNCH("qarep_prep_batch");
     return SGX_OK;
 }

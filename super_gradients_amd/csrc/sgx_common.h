@@ -12,7 +12,12 @@
 #define SGX_LAUNCH(kernel, grid, block, smem, stream, ...) \
     sgx_emu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })
 #define SGX_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(sgx_emu_dyn_smem())
+// Workgroup count of a GRID-STRIDE kernel (every workgroup loops `for (i = global id; i < n; i += grid size)`): what the kernel computes does
+// not depend on it.  The host emulation pays two 256-thread barriers per emulated workgroup, and the per-step batch kernels (weight
+// transposes, QARepVGG filter preparation, filter planes) launch hundreds of workgroups per job - most of a small test network's step.
+#define SGX_STRIDE_GRID(n) ((n) < 2 ? (n) : 2)
 #else
+#define SGX_STRIDE_GRID(n) (n)
 #include <hip/hip_runtime.h>
 #define SGX_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
