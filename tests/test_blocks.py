@@ -662,7 +662,7 @@ def test_deepcopy_of_a_materialised_network_trains(backend):
 
 def test_filter_planes_serve_a_training_step_and_nothing_else(backend):
     """Pre-split filter planes at network level (engine.py, round 5): inside NetFunction.forward / backward the bf16x3 launches of a QARepVGG
-    chain read the planes the step's prefetch made - same bits as with SGX_FILTER_PLANES off (forward, input gradient, every parameter
+    chain read the planes the step's prefetch made - same bits as a network without planes (forward, every parameter
     gradient) - while an eval-mode forward after an in-place weight change, outside any step, must follow the NEW weights (no stale planes),
     and a second step after the change must too."""
     from super_gradients_amd import kernels as K
@@ -696,19 +696,12 @@ def test_filter_planes_serve_a_training_step_and_nothing_else(backend):
         return [y.detach().cpu().clone(), net.g_arena.buf.cpu().clone()]
 
     def build(planes):
-        import os
-
-        old = os.environ.get("SGX_FILTER_PLANES")
-        os.environ["SGX_FILTER_PLANES"] = "1" if planes else "0"
-        try:
-            torch.manual_seed(11)
-            net = Chain()
-            net.materialize(backend).train()
-        finally:
-            if old is None:
-                os.environ.pop("SGX_FILTER_PLANES", None)
-            else:
-                os.environ["SGX_FILTER_PLANES"] = old
+        torch.manual_seed(11)
+        net = Chain()
+        net.materialize(backend).train()
+        if not planes:  # (not through SGX_FILTER_PLANES: the library reads that variable once, when it is loaded, as its process-wide mode)
+            net.drop_filter_planes()
+            net._fp_jobs = net._fp_dev = net._fp_buf = None
         return net
 
     try:

@@ -573,3 +573,48 @@ def test_yolo_nas_s_headline_config_parity(gpu_device):
         assert torch.equal(a.cpu(), b), "NMS rows differ at bs32/640"
         nrows += int(b.shape[0])
     assert nrows > 0
+
+
+@pytest.mark.gpu
+def test_yolo_nas_s_step_is_bit_identical_with_filter_planes(gpu_device):
+    """Pre-split filter planes (round 5) over a whole YOLO-NAS-S train step: with the planes served (default) and on a network without them
+    the step must produce the same bits - loss and the whole gradient arena - because a launch that copies planes stages exactly the
+    pieces the splitting launch computes.  (The premise that one build repeats itself bit for bit is checked first: without it the
+    comparison would say nothing.)  The hit counter shows that the planes step really took the planes path in most of its launches."""
+    from super_gradients_amd._lib import lib
+    from super_gradients_amd.training import models
+    from super_gradients_amd.training.losses import PPYoloELoss
+    from util import synthetic_targets
+
+    def build(planes):
+        torch.manual_seed(3)
+        net = models.get("yolo_nas_s", num_classes=80).materialize(gpu_device).train()
+        if not planes:  # (not through SGX_FILTER_PLANES: the library reads that variable once, when it is loaded, as its process-wide mode)
+            net.drop_filter_planes()
+            net._fp_jobs = net._fp_dev = net._fp_buf = None
+        return net
+
+    x = torch.rand(4, 3, 320, 320, generator=torch.Generator().manual_seed(1)).to(gpu_device)
+    t = synthetic_targets(4, seed=2, kmax=6, size=320).to(gpu_device)
+    crit = PPYoloELoss(num_classes=80, use_static_assigner=False)
+
+    def step(net):
+        net.zero_grad()
+        loss, _ = crit(net(x), t)
+        loss.backward()
+        net.join_side()
+        torch.cuda.synchronize()
+        return loss.detach().cpu().clone(), net.g_arena.buf.cpu().clone()
+
+    plain, fast = build(False), build(True)
+    assert plain._fp_jobs is None and fast._fp_jobs is not None
+    fast.load_state_dict(plain.state_dict())
+    l0, g0 = step(plain)
+    l1, g1 = step(plain)
+    assert torch.equal(l0, l1) and torch.equal(g0, g1), "one build does not repeat its own step bit for bit"
+    h0 = lib().sgx_debug_filter_planes_hits()
+    l2, g2 = step(fast)
+    hits = lib().sgx_debug_filter_planes_hits() - h0
+    assert hits >= 100, f"only {hits} launches of the step read filter planes"
+    assert torch.equal(l0, l2), f"loss differs with filter planes: {float(l0)} vs {float(l2)}"
+    assert torch.equal(g0, g2), f"gradients differ with filter planes: max {float((g0 - g2).abs().max()):.3e}"
