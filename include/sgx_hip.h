@@ -195,7 +195,10 @@ int32_t sgx_qarep_prep_batch(const sgx_qarep_prep_job* jobs_dev, int32_t njobs, 
  * data-gradient launches whose filter pointer and shape match a VALID entry, made while a scope is open, copy the planes instead of
  * splitting - bit-identical results.  Contract of the caller (modules/engine.py): open the scope only around a training step's forward /
  * backward, run the batch after the last weight update of the step, invalidate (NULL: everything) before weights change or the
- * addresses are released.  jobs_host and jobs_dev hold the same records (host copy for the registry, device copy for the kernel).      */
+ * addresses are released.  jobs_host and jobs_dev hold the same records (host copy for the registry, device copy for the kernel).
+ * Ordering: the registry entries become valid when the batch is ENQUEUED; the launches that read the planes must be ordered behind it on
+ * the device (the same stream, or an event) - as every consumer of `stream`'s earlier work must.  The scope and the registry are
+ * process-wide (one training step at a time per process: the one-process-per-GPU model of the data-parallel path).                    */
 typedef struct sgx_fplanes_job {
     const float* src; /* [rows][taps][ch] fp32                                         */
     void* planes;     /* sgx_filter_planes_bytes(rows, taps, ch), 16-byte aligned      */
