@@ -13,8 +13,8 @@
 //      16x16x4 f32 : A[l&15][k=l>>4], B[k=l>>4][l&15], D reg r -> row=(l>>4)*4+r, col=l&15
 #pragma once
 #include <atomic>
+#include <climits>
 #include <cmath>
-#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +23,10 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #define __global__
 #define __device__
@@ -81,6 +85,9 @@ static inline int2 make_int2(int a, int b) { return int2{a, b}; }
 
 namespace sgx_emu {
 
+// Generation barrier.  Arrivals count under a mutex; the WAIT is on the generation word through the futex (no condition variable: its
+// waiters must re-take the mutex one after another when they wake, and with 256 threads per emulated workgroup on a few cores that
+// serial hand-over was most of the emulation's run time - the woken threads here resume in parallel).
 class Barrier {
   public:
     void reset(int n) {
@@ -89,31 +96,38 @@ class Barrier {
         waiting_ = 0;
     }
     void wait() {
-        std::unique_lock<std::mutex> g(m_);
+        m_.lock();
+        const uint32_t my = gen_.load(std::memory_order_relaxed);
         if (++waiting_ >= count_) {
             waiting_ = 0;
-            ++gen_;
-            cv_.notify_all();
+            gen_.store(my + 1, std::memory_order_release);
+            m_.unlock();
+            wake_all();
             return;
         }
-        unsigned long my = gen_;
-        cv_.wait(g, [&] { return gen_ != my; });
+        m_.unlock();
+        while (gen_.load(std::memory_order_acquire) == my) futex_wait(my);
     }
     void drop() {
-        std::lock_guard<std::mutex> g(m_);
+        m_.lock();
         --count_;
         if (count_ > 0 && waiting_ >= count_) {
             waiting_ = 0;
-            ++gen_;
-            cv_.notify_all();
+            gen_.store(gen_.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+            m_.unlock();
+            wake_all();
+            return;
         }
+        m_.unlock();
     }
 
   private:
+    void futex_wait(uint32_t expect) { syscall(SYS_futex, reinterpret_cast<uint32_t*>(&gen_), FUTEX_WAIT_PRIVATE, expect, nullptr, nullptr, 0); }
+    void wake_all() { syscall(SYS_futex, reinterpret_cast<uint32_t*>(&gen_), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
     std::mutex m_;
-    std::condition_variable cv_;
     int count_ = 0, waiting_ = 0;
-    unsigned long gen_ = 0;
+    std::atomic<uint32_t> gen_{0};
+    static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "the futex word is the atomic itself");
 };
 
 struct WaveState {
