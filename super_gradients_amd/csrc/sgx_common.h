@@ -157,7 +157,7 @@ static inline float4 sgx_ld4_dev(const float* p) { return *reinterpret_cast<cons
 #define sgx_sched_fence() ((void)0)
 #define SGX_SCHED_GROUP(mask, n) ((void)0)
 #define SGX_PIN2(a, b) ((void)0)
-#define sgx_wave_lds_sync() __syncthreads()  // (the emulation's lanes are OS threads: a workgroup barrier, reached by every thread alike)
+#define sgx_wave_lds_sync() __syncthreads()  // (the emulation's lanes are separate fibers: a workgroup barrier, reached by every thread alike)
 #else
 // LDS hand-over between the lanes of ONE wave (a patch only this wave touches): a wave's LDS instructions execute in order, so the
 // stores of all its lanes precede its later loads - only the compiler must keep them in program order and wait for the store counter.

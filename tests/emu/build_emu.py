@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE ONLY.  Builds tests/emu/_build/libsgx_emu.so: the SAME kernel sources as libsgx_hip.so,
-compiled for the host against the HIP emulation in hip_emu.h (one OS thread per HIP thread), so that
+compiled for the host against the HIP emulation in hip_emu.h (one fiber per HIP thread, workgroup by workgroup), so that
 kernel logic can be checked against the oracle in a container without a GPU.  Never used by the product."""
 import os
 import subprocess

@@ -4,7 +4,9 @@
 // (libsgx_hip.so, built by hipcc for gfx950) never contains or loads this; bench.py, smoke() and the
 // `-m gpu` tests never load libsgx_emu.so.
 //
-// Model: one OS thread per HIP thread of ONE workgroup; workgroups run one after another.
+// Model: one FIBER (a user-space context on its own stack) per HIP thread of ONE workgroup, all run by the launching OS thread;
+// workgroups run one after another.  A fiber runs until it reaches a barrier that is not complete yet, then the scheduler resumes the
+// next one - a barrier of 256 lanes is 256 register swaps, not 256 futex round trips (the OS-thread form spent 4/5 of the CPU suite in the kernel).
 //  * __syncthreads()          -> workgroup barrier (participants that already returned are dropped)
 //  * __shfl*/__ballot/MFMA    -> wave(64)-collective exchange through a per-wave buffer + wave barrier
 //  * MFMA fragment layouts follow /opt/skills/guides/cdna_hip_programming.md section 3:
@@ -23,10 +25,6 @@
 #include <mutex>
 #include <thread>
 #include <vector>
-
-#include <linux/futex.h>
-#include <sys/syscall.h>
-#include <unistd.h>
 
 #define __global__
 #define __device__
@@ -85,49 +83,35 @@ static inline int2 make_int2(int a, int b) { return int2{a, b}; }
 
 namespace sgx_emu {
 
-// Generation barrier.  Arrivals count under a mutex; the WAIT is on the generation word through the futex (no condition variable: its
-// waiters must re-take the mutex one after another when they wake, and with 256 threads per emulated workgroup on a few cores that
-// serial hand-over was most of the emulation's run time - the woken threads here resume in parallel).
+// Generation barrier of cooperative fibers (one OS thread: no locks).  The last arrival bumps the generation; the others hand the
+// processor back to the scheduler, which resumes a waiting fiber only once its barrier's generation has moved.
+void fiber_wait(const unsigned long* gen, unsigned long seen);  // hip_emu.cpp
 class Barrier {
   public:
     void reset(int n) {
-        std::lock_guard<std::mutex> g(m_);
         count_ = n;
         waiting_ = 0;
     }
     void wait() {
-        m_.lock();
-        const uint32_t my = gen_.load(std::memory_order_relaxed);
+        const unsigned long my = gen_;
         if (++waiting_ >= count_) {
             waiting_ = 0;
-            gen_.store(my + 1, std::memory_order_release);
-            m_.unlock();
-            wake_all();
+            ++gen_;
             return;
         }
-        m_.unlock();
-        while (gen_.load(std::memory_order_acquire) == my) futex_wait(my);
+        fiber_wait(&gen_, my);
     }
-    void drop() {
-        m_.lock();
+    void drop() {  // a participant that returned from the kernel no longer counts
         --count_;
         if (count_ > 0 && waiting_ >= count_) {
             waiting_ = 0;
-            gen_.store(gen_.load(std::memory_order_relaxed) + 1, std::memory_order_release);
-            m_.unlock();
-            wake_all();
-            return;
+            ++gen_;
         }
-        m_.unlock();
     }
 
   private:
-    void futex_wait(uint32_t expect) { syscall(SYS_futex, reinterpret_cast<uint32_t*>(&gen_), FUTEX_WAIT_PRIVATE, expect, nullptr, nullptr, 0); }
-    void wake_all() { syscall(SYS_futex, reinterpret_cast<uint32_t*>(&gen_), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
-    std::mutex m_;
     int count_ = 0, waiting_ = 0;
-    std::atomic<uint32_t> gen_{0};
-    static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "the futex word is the atomic itself");
+    unsigned long gen_ = 0;
 };
 
 struct WaveState {
@@ -264,7 +248,7 @@ static inline sgx_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, s
     return d;
 }
 
-// atomics (single process, OS threads)
+// atomics (plain atomics: other processes / Python threads never touch a launch's memory, but keep the device semantics)
 static inline float atomicAdd(float* p, float v) {
     auto* a = reinterpret_cast<std::atomic<float>*>(p);
     float old = a->load();

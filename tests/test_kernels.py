@@ -3,7 +3,7 @@
 
 Each test runs twice through the `backend` fixture:
   gpu  (marked gpu)  the product library libsgx_hip.so on cuda:0;
-  emu                the same kernel sources compiled against tests/emu (host threads) - logic check, small shapes.
+  emu                the same kernel sources compiled against tests/emu (one host fiber per HIP thread) - logic check, small shapes.
 Tolerances: fp32 with a different summation order -> 2e-5 of the tensor's max-abs (north star: 1e-4 rel);
 integer/index outputs bit-exact.
 """
