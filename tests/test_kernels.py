@@ -1877,3 +1877,50 @@ def test_filter_planes_launches_are_bit_identical(backend, case):
         lib().sgx_debug_set_filter_planes(K.DEFAULT_FILTER_PLANES)
         lib().sgx_debug_set_variant(0)
         K.set_conv_math(K.DEFAULT_CONV_MATH)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_filter_planes_every_tile_shape(backend, mode):
+    """The planes forms of the 32-deep GEMM loop on EVERY instantiated tile (sgx_debug_set_tiles) - the heuristics pick a few of them - on a
+    problem with ragged edges in both tile dimensions (20 output pixels, 96 filter rows: partial tiles, filter rows past the last one, a
+    wave whose plane pieces run past the tile): forward and data gradient, planes copied into LDS (mode 1) and read straight into the
+    fragment registers (mode 2, the tiles of one 32-filter block per wave; the others fall back to mode 1) - bit-identical to the
+    splitting launches."""
+    from super_gradients_amd._lib import lib
+
+    # (96 channels both ways: 32-deep slabs need multiples of 32 on the reduction axis - the filters of the forward, the transposed filters
+    # of the data gradient - and 96 rows leave the 64- and 128-wide tiles ragged)
+    n, h, w_, c, k, r, st, pad = (1, 9, 8, 96, 96, 3, 2, 1) if backend.type != "cuda" else (2, 19, 17, 96, 96, 3, 2, 1)
+    g = torch.Generator().manual_seed(900 + mode)
+    x = to_nhwc(torch.randn(n, c, h, w_, generator=g), backend)
+    wd = K.to_ohwi((torch.randn(k, c, r, r, generator=g) / (c * r * r) ** 0.5).to(backend))
+    ho, wo = (h + 2 * pad - r) // st + 1, (w_ + 2 * pad - r) // st + 1
+    dy = to_nhwc(torch.randn(n, k, ho, wo, generator=g), backend)
+    wtb = K.conv2d_wt_buffer(wd, backend)
+    K.conv2d_transpose_weights(wd, wtb, stride=st, pad=pad)
+    K.set_conv_math("bf16x3")
+    lib().sgx_debug_set_filter_planes(mode)
+    try:
+        K.filter_planes_invalidate(None)
+        jobs, keep = _planes_for([(wd.data_ptr(), k, r * r, c)] + _wt_filters(wd, wtb, st, pad), backend)
+        for bm in (64, 128):
+            for bn in (32, 64, 96, 128):
+                lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                K.clear_desc_cache()
+                K.filter_planes_scope(False)
+                y0 = K.conv2d_fwd(x, wd, stride=st, pad=pad)
+                dx0 = K.conv2d_bwd_data_wt(dy, wd, wtb, (n, h, w_, c), stride=st, pad=pad)
+                K.filter_planes_scope(True)
+                h0 = lib().sgx_debug_filter_planes_hits()
+                y1 = K.conv2d_fwd(x, wd, stride=st, pad=pad)
+                dx1 = K.conv2d_bwd_data_wt(dy, wd, wtb, (n, h, w_, c), stride=st, pad=pad)
+                assert lib().sgx_debug_filter_planes_hits() - h0 >= 2, f"tile {bm}x{bn}: the planes path did not run"
+                assert torch.equal(y0, y1), f"mode {mode} forward differs on tile {bm}x{bn}: {float((y0 - y1).abs().max()):.3e}"
+                assert torch.equal(dx0, dx1), f"mode {mode} data gradient differs on tile {bm}x{bn}: {float((dx0 - dx1).abs().max()):.3e}"
+    finally:
+        K.filter_planes_scope(False)
+        K.filter_planes_invalidate(None)
+        lib().sgx_debug_set_filter_planes(K.DEFAULT_FILTER_PLANES)
+        lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
+        K.clear_desc_cache()
+        K.set_conv_math(K.DEFAULT_CONV_MATH)
