@@ -500,6 +500,8 @@ def main():
                        "conv_math": K.get_conv_math(), "conv_variant": int(os.environ.get("SGX_CONV_VARIANT") or 0),
                        "bn_reduce_in_data_gradients": bool(getattr(net, "fuse_bn_reduce", False)),
                        "conv_tuning_entries": int(lib().sgx_conv_tuning_size()),
+                       # pre-split filter planes: the step's filters split into bf16x3 pieces once per step (SGX_FILTER_PLANES=0: off)
+                       "filter_planes": getattr(net, "_fp_jobs", None) is not None,
                        "allreduce_from_side_stream": bool(reducer.from_side) if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data gradient, "
                                                     + ("v_mfma_f32_32x32x2_f32)" if K.get_conv_math() == "fp32" else
