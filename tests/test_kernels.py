@@ -47,6 +47,11 @@ CONV_EMU = [
     (1, 6, 6, 8, 4, 1, 2, 0),
     (1, 48, 48, 4, 8, 1, 1, 0),        # 2304 pixels: weight gradient split over 9 slabs (parallel slab reduce)
     (1, 5, 5, 8, 6, 3, 1, 1),          # K % 4 != 0: scalar epilogue path (forward only)
+    # (round 5: the emulation runs a workgroup's lanes as fibers - these no longer cost minutes)
+    (1, 40, 40, 32, 32, 3, 1, 1),      # 1600 pixels: the patch kernel under the DEFAULT arithmetic (forward, data gradient), patch weight gradient
+    (1, 16, 16, 192, 96, 1, 1, 0),     # deep 1x1: the 32-deep bf16x3 GEMM loop, 96 filters (128x32 / 96-wide tiles)
+    (2, 20, 20, 64, 128, 3, 2, 1),     # 3x3 stride 2, depth 576: bf16x3 GEMM, four output-parity classes in the data gradient
+    (1, 24, 20, 32, 48, 3, 1, 1),      # 3x3 stride 1 below the patch kernel's 40 x 40 floor: GEMM loop, ragged 48 filters
 ]
 
 
