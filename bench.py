@@ -182,6 +182,7 @@ def nms_leg(device, iters=100, warmup=10):
     ms = e0.elapsed_time(e1) / iters
     ncand = int(torch.clamp(out[3], max=1000).sum())
     kept = int(out[1].sum())
+    fallbacks = K.nms_fallbacks()  # images whose stage 2 streamed the raw scores instead of stage 1's list (exact, many times slower): 0 here
     # CPU: the NMS proper on the same top-k candidates of 4 images (bounded sample)
     t0 = time.perf_counter()
     n_cpu = 0
@@ -197,7 +198,7 @@ def nms_leg(device, iters=100, warmup=10):
     # candidates' boxes and the output rows (K * 20 B per image) - whatever the implementation re-reads on top of that (its selection passes
     # over the scores) is reported as `traffic` / `passes_over_scores`, not credited
     algo_bytes = 1.0 * B * L * C * 4 + B * 1000 * 20.0
-    return {"value": round(ncand / (ms * 1e-3), 1), "unit": "boxes/s", "ms_per_batch": round(ms, 4), "candidates": ncand, "kept": kept, "batch": B,
+    return {"value": round(ncand / (ms * 1e-3), 1), "unit": "boxes/s", "ms_per_batch": round(ms, 4), "candidates": ncand, "kept": kept, "batch": B, "stage2_fallbacks": fallbacks,
             "roofline": {"bound": "hbm", "achieved": round(algo_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(algo_bytes / (ms * 1e-3) / 8e12, 4), "traffic": measured_nms_traffic().get("nms_bytes_per_call"),
                          "traffic_unit": "bytes/call (HBM, PMC: FETCH_SIZE x2 + WRITE_SIZE over the kernels of one post-prediction call; from the "
@@ -245,6 +246,117 @@ def predict_leg(device, model="s", batch=32, batches=10):
                 "config": f"YOLO-NAS-{model.upper()} predict(): 480x640 uint8 -> 640x640, conf 0.01, iou 0.7, fused copy, random-init weights"}
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}
+
+
+OTHER_CONFIGS = (  # BASELINE.json configs 4, 5 and 2, plus YOLO-NAS-L at the headline shape: (key, workload, model, size, batch, oracle loss check)
+    ("yolo_nas_m_640_bs32", "yolo_nas", "m", 640, 32, True),
+    ("yolo_nas_l_640_bs32", "yolo_nas", "l", 640, 32, False),
+    ("yolo_nas_l_1280_bs8", "yolo_nas", "l", 1280, 8, True),
+    ("resnet50_224_bs64", "resnet50", None, 224, 64, True),
+)
+
+
+def other_config_leg(device, workload, model, size, batch, steps=10, warmup=3, loss_check=True):
+    """One of the other BASELINE.json configurations under the same clock as the headline line: the same step (detection: forward,
+    PPYoloELoss, backward, AdamW, EMA; ResNet-50: forward + cross-entropy + backward, as configs[1] says), `steps` timed steps between
+    device synchronisations after `warmup` untimed ones, and - outside the timed region - the loss of the benchmarked batch at the
+    initial weights against the CPU oracle at the configuration's FULL size (bar 1e-4 relative)."""
+    import torch
+
+    from super_gradients_amd.training import models
+
+    torch.manual_seed(42)
+    rec = {}
+    if workload == "resnet50":
+        from super_gradients_amd.training.losses import CrossEntropyLoss
+
+        net = models.get("resnet50", num_classes=1000).materialize(device).train()
+        x = torch.randn(batch, 3, size, size, device=device)
+        y = torch.randint(0, 1000, (batch,), device=device)
+        crit = CrossEntropyLoss()
+        if loss_check:
+            import torch.nn.functional as F
+
+            from oracle.resnet import build
+
+            t0 = time.time()
+            torch.set_num_threads(min(os.cpu_count() or 1, 64))
+            ref = build("resnet50", 1000)
+            ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+            ref.train()
+            with torch.no_grad():
+                l_ref = float(F.cross_entropy(ref(x.cpu()), y.cpu()))
+                l_hip = float(crit(net(x), y))
+            err = abs(l_hip - l_ref) / abs(l_ref)
+            rec["loss_check_vs_oracle"] = {"hip": round(l_hip, 6), "oracle": round(l_ref, 6), "max_rel_err": float(f"{err:.3e}"), "tolerance": 1e-4,
+                                           "seconds": round(time.time() - t0, 1), "what": f"cross-entropy of the benchmarked batch ({batch} x {size}x{size}) at the initial weights, training-mode BatchNorm: HIP path vs CPU oracle"}
+            if not err <= 1e-4:
+                raise RuntimeError(f"bench: HIP loss differs from the CPU oracle: {rec}")
+
+        def step():
+            loss = crit(net(x), y)
+            loss.backward()
+            net.zero_grad()
+            return loss
+
+        gflop, label = 24.54, f"ResNet-50 synthetic ImageNet-shape {size}x{size}, bs={batch}, forward+backward only, random-init weights"
+    else:
+        from super_gradients_amd.training.losses import PPYoloELoss
+        from super_gradients_amd.training.utils.ema import ModelEMA
+        from super_gradients_amd.training.utils.optimizers import ArenaAdamW
+
+        net = models.get(f"yolo_nas_{model}", num_classes=80).materialize(device).train()
+        crit = PPYoloELoss(num_classes=80, use_static_assigner=False)
+        opt = ArenaAdamW(net, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, zero_weight_decay_on_bias_and_bn=True)
+        ema = ModelEMA.from_params(net, decay=0.9997, decay_type="threshold")
+        x, targets = synthetic_batch(batch, size, 42, device)
+        if loss_check:
+            rec["loss_check_vs_oracle"] = oracle_loss_check(net, crit, x, targets, model, "yolo_nas")
+        state = {"step": 0}
+
+        def step():
+            loss, _ = crit(net(x), targets)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            ema.update(net, state["step"], 100000)
+            state["step"] += 1
+            return loss
+
+        gflop = TRAIN_GFLOP_PER_IMG[model] * (size / 640.0) ** 2
+        label = f"YOLO-NAS-{model.upper()} synthetic COCO {size}x{size}, bs={batch}/GPU, PPYoloELoss(TAL)+AdamW+EMA, random-init weights"
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    value = batch * steps / dt
+    out = {"workload": label, "value": round(value, 2), "unit": "images/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+           "step_mfma_frac": round(value * gflop / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4), "gflop_per_image": round(gflop, 3), "final_loss": round(float(loss), 5)}
+    out.update(rec)
+    return out
+
+
+def other_configs_leg(device, steps=10, warmup=3, loss_check=True):
+    """-> list of other_config_leg objects; a failing configuration is reported in its object and does not take the bench line down."""
+    import gc
+
+    import torch
+
+    res = []
+    for key, workload, model, size, batch, check in OTHER_CONFIGS:
+        try:
+            o = other_config_leg(device, workload, model, size, batch, steps, warmup, loss_check and check)
+        except Exception as e:  # noqa: BLE001
+            o = {"error": repr(e)}
+        o["config"] = key
+        res.append(o)
+        gc.collect()
+        torch.cuda.empty_cache()
+    return res
 
 
 def measured_traffic():
@@ -349,6 +461,10 @@ def main():
     ap.add_argument("--no-predict", action="store_true", help="skip the predict() leg (YOLO-NAS only)")
     ap.add_argument("--only-nms", type=int, default=0, metavar="CALLS", help="run ONLY the NMS leg with that many timed calls and print its object "
                     "(what the rocprofv3 passes of the post-prediction kernels trace: tools/gpu_round.sh nms stage)")
+    ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"], help="the `other_configs` array: the other BASELINE.json configurations "
+                    "(YOLO-NAS-M bs32, L bs32, L@1280 bs8, ResNet-50 bs64), 10 timed steps each + the oracle loss check at the configuration's full size; "
+                    "auto = with the full default line (i.e. unless --no-cpu-baseline), so that the quick A/B and profiling invocations stay what they were")
+    ap.add_argument("--loss-check-only", action="store_true", help="run the oracle loss check of the benchmarked batch but not the timed CPU baseline")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the 3 extra untimed steps that time the conv kernels without the side stream")
     ap.add_argument("--sync-bn", action="store_true", help="synchronised BatchNorm across ranks (recipe setting; off in the reference's own benchmark)")
     ap.add_argument("--workload", default="yolo_nas", choices=["yolo_nas", "resnet50", "ppyoloe"],
@@ -400,7 +516,7 @@ def main():
 
     # parity of the benchmarked workload itself (rank 0 of a single-GPU run; skipped together with the CPU baseline)
     loss_check = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and (args.loss_check_only or not args.no_cpu_baseline):
         loss_check = oracle_loss_check(net, crit, x, targets, args.model, "ppyoloe" if args.workload == "ppyoloe" else "yolo_nas")
 
     state = {"step": 0}
@@ -573,6 +689,10 @@ def main():
             rec["nms"] = nms_leg(device)
         if not args.no_predict and world == 1 and args.workload == "yolo_nas":
             rec["predict"] = predict_leg(device, args.model, min(args.batch, 32))
+        # the other BASELINE.json configurations under the same clock (headline invocation only: S at the default shape on one GPU)
+        headline = world == 1 and args.workload == "yolo_nas" and args.model == "s" and args.size == 640 and args.batch == 32
+        if args.other_configs == "on" or (args.other_configs == "auto" and headline and not args.no_cpu_baseline):
+            rec["other_configs"] = other_configs_leg(device, loss_check=not args.no_cpu_baseline or args.loss_check_only)
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist_barrier()

@@ -197,8 +197,9 @@ int32_t sgx_qarep_prep_batch(const sgx_qarep_prep_job* jobs_dev, int32_t njobs, 
  * backward, run the batch after the last weight update of the step, invalidate (NULL: everything) before weights change or the
  * addresses are released.  jobs_host and jobs_dev hold the same records (host copy for the registry, device copy for the kernel).
  * Ordering: the registry entries become valid when the batch is ENQUEUED; the launches that read the planes must be ordered behind it on
- * the device (the same stream, or an event) - as every consumer of `stream`'s earlier work must.  The scope and the registry are
- * process-wide (one training step at a time per process: the one-process-per-GPU model of the data-parallel path).                    */
+ * the device (the same stream, or an event) - as every consumer of `stream`'s earlier work must.  The scope is a DEPTH COUNTER OF THE
+ * CALLING THREAD (open / close nest; a launch issued by another thread, or outside every scope, never looks planes up); the registry is
+ * process-wide and keyed by the filter's device address (one-process-per-GPU model of the data-parallel path).                        */
 typedef struct sgx_fplanes_job {
     const float* src; /* [rows][taps][ch] fp32                                         */
     void* planes;     /* sgx_filter_planes_bytes(rows, taps, ch), 16-byte aligned      */
@@ -554,6 +555,10 @@ int32_t sgx_debug_set_nms_split(int32_t on);
 /* Candidate selection of the multi-label path: 1 (default) = one pass over the scores behind a threshold estimated from a 1/32 sample (exact:
  * stage 2 falls back to streaming an image whose list came out short or overflowed), 0 = the exact three-pass histogram selection. */
 int32_t sgx_debug_set_nms_selection(int32_t sampled);
+/* Where a multi-label sgx_nms call with a workspace records, per image, that stage 2 fell back from stage 1's candidate list to streaming
+ * the image's raw scores (exact rows either way, many times slower): int32 index offset_ints + b * stride_ints of the call's workspace
+ * holds 1 / 0 for image b once the call's stream work is complete.  Benches and tests assert it stays 0 on their inputs.     */
+int32_t sgx_debug_nms_fallback_slot(const sgx_nms_desc* d, int64_t* offset_ints, int32_t* stride_ints);
 int64_t sgx_nms_workspace(const sgx_nms_desc* d);
 int32_t sgx_nms(const sgx_nms_desc* d, const float* boxes, const float* scores, float* out, int32_t* out_count,
                 int32_t* out_index, int32_t* num_candidates, void* ws, int64_t ws_bytes, void* stream);

@@ -1922,7 +1922,11 @@ struct FplanesEntry {
 };
 static std::mutex g_fp_mu;
 static std::unordered_map<const void*, FplanesEntry> g_fp_map;
-static std::atomic<int> g_fp_scope{0}, g_fp_on{1};
+static std::atomic<int> g_fp_on{1};
+// Scope depth of the CALLING thread (a process-global boolean let an inner close - nested autograd, a second network on another
+// thread - switch the outer step's planes off, or a launch outside the owning step see them on): a launch looks planes up only while the
+// thread that issues it is inside a training step's forward / backward.
+static thread_local int t_fp_scope = 0;
 __global__ void fplanes_batch_kernel(const sgx_fplanes_job* jobs) {
     __shared__ sgx_fplanes_job job;
     if (threadIdx.x == 0) job = jobs[blockIdx.y];
@@ -1977,7 +1981,8 @@ extern "C" int32_t sgx_filter_planes_invalidate(const sgx_fplanes_job* jobs_host
     return SGX_OK;
 }
 extern "C" int32_t sgx_filter_planes_scope(int32_t open) {
-    g_fp_scope = open ? 1 : 0;
+    if (open) ++t_fp_scope;
+    else if (t_fp_scope > 0) --t_fp_scope;
     return SGX_OK;
 }
 // 0 = every launch splits its filter while staging; 1 = planes copied into the LDS slabs; 2 = 1, and the GEMM loop's one-block-per-wave
@@ -2000,7 +2005,7 @@ static const unsigned char* fplanes_lookup(const float* w, int rows, int taps, i
 static void fplanes_attach(IgemmParams& p, int ph2) {
     p.Wp = p.Wp2 = nullptr;
     p.wp_bytes = p.wp2_bytes = 0;
-    if (!g_fp_scope.load(std::memory_order_relaxed) || !g_fp_on.load(std::memory_order_relaxed) || p.C % 16) return;
+    if (t_fp_scope <= 0 || !g_fp_on.load(std::memory_order_relaxed) || p.C % 16) return;
     p.Wp = fplanes_lookup(p.Wt, p.Nout, p.Th * p.Tw, p.C, p.w_ld_n, &p.wp_bytes);
     if (ph2 && p.A2) p.Wp2 = fplanes_lookup(p.Wt2, p.Nout, p.Th2 * p.Tw2, p.C, p.w2_ld_n, &p.wp2_bytes);
 }

@@ -207,6 +207,14 @@ extern "C" int32_t sgx_debug_set_nms_selection(int32_t sampled) {  // measuremen
     g_nms_sampled = sampled ? 1 : 0;
     return SGX_OK;
 }
+// where sgx_nms leaves "image b's stage 2 streamed the raw scores instead of stage 1's list" (1 / 0): int index offset + b * stride of the
+// workspace the call was given (multi-label calls with a workspace; read it after the call's stream work is done)
+extern "C" int32_t sgx_debug_nms_fallback_slot(const sgx_nms_desc* d, int64_t* offset_ints, int32_t* stride_ints) {
+    SGX_CHECK_ARG(d && offset_ints && stride_ints, "nms fallback slot: null pointer");
+    *offset_ints = 2L * d->B * NMS_HBINS + 2;
+    *stride_ints = NMS_CTR_INTS;
+    return SGX_OK;
+}
 __global__ __launch_bounds__(NMS_THREADS) void nms_sample_kernel(sgx_nms_desc d, const float* scores, int* ws) {
     __shared__ int hist[NMS_HBINS];
     __shared__ int sh[NMS_THREADS / 64 + 3];
@@ -382,6 +390,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(sgx_nms_desc d, const 
     // could miss part of the top K; the exact selection's list always does)
     const int m_cand = ws ? ws[2L * d.B * NMS_HBINS + (long)b * NMS_CTR_INTS + 1] : 0;
     const bool use_list = ws != nullptr && m_list <= NMS_LIST_CAP && m_list >= (m_cand < K ? m_cand : K);
+    //  the streaming fallback is exact but many times slower than the list: every call leaves, per image, whether stage 2 took it
+    // (int 2 of the image's counter line; sgx_debug_nms_fallback_slot) so that benches and tests can assert the sampled selection held
+    if (ws != nullptr && d.multi_label && tid == 0) const_cast<int*>(ws)[2L * d.B * NMS_HBINS + (long)b * NMS_CTR_INTS + 2] = use_list ? 0 : 1;
     const u64* list = ws ? reinterpret_cast<const u64*>(reinterpret_cast<const char*>(ws) + (((long)d.B * (2 * NMS_HBINS + NMS_CTR_INTS) * 4 + 255) & ~255L)) + (long)b * NMS_LIST_CAP
                          : nullptr;
     // visits every candidate's composite key: the list, or (single-label / overflowing list) the raw scores of the image

@@ -331,22 +331,31 @@ def conv2d_bwd_data_wt(dy, w, wt, x_shape, stride=1, pad=0, addend=None, out=Non
 # ---- half-precision inference (csrc/half.hip): bf16 activations, one bf16 MFMA product, fp32 accumulation ---------------------------------
 HALF = torch.bfloat16
 _HALF_W = {}
+_WEIGHTS_GEN = [0]
+
+
+def weights_written():
+    """Every writer that changes parameters THROUGH RAW POINTERS (sgx_adamw_step / sgx_sgd_step / sgx_ema_update on the arenas, and
+    SgxNetwork.weights_changed() for load_state_dict / EMA swaps / broadcasts) calls this: tensor `_version` counters do not see those writes,
+    so the bf16 operands cached below are tied to this generation instead (a model that ran half-precision inference and was then
+    trained further served the old bf16 prediction / transposed-conv filters)."""
+    _WEIGHTS_GEN[0] += 1
 
 
 def _half_cached(src, tag, build):
-    """A bf16 operand derived from the fp32 tensor `src` (a folded filter, a transposed-conv weight): built once per tensor object and
-    in-place version - the deployment form's filters never change, and a refreshed fold is a new tensor."""
-    key = (id(src), tag)
-    hit = _HALF_W.get(key)
-    if hit is not None and hit[0]() is src and hit[1] == src._version:
-        return hit[2]
-    if len(_HALF_W) > 4096:  # dead entries of models that are gone
-        for k in [k for k, v in _HALF_W.items() if v[0]() is None]:
-            del _HALF_W[k]
+    """A bf16 operand derived from the fp32 tensor `src` (a folded filter, a transposed-conv weight, a LIVE arena view): valid for this
+    tensor object, its in-place version AND the current weights generation; an entry dies with its source tensor (weakref.finalize), so
+    the bf16 filters of a discarded fused copy leave HBM with it."""
     import weakref
 
+    key = (id(src), tag)
+    hit = _HALF_W.get(key)
+    if hit is not None and hit[0]() is src and hit[1] == (src._version, _WEIGHTS_GEN[0]):
+        return hit[2]
     h = build()
-    _HALF_W[key] = (weakref.ref(src), src._version, h)
+    if hit is None or hit[0]() is not src:
+        weakref.finalize(src, _HALF_W.pop, key, None)
+    _HALF_W[key] = (weakref.ref(src), (src._version, _WEIGHTS_GEN[0]), h)
     return h
 
 
@@ -1030,7 +1039,23 @@ def nms(boxes, scores, score_threshold, iou_threshold, nms_top_k, max_prediction
     boxes, scores = boxes.contiguous().float(), scores.contiguous().float()  # bound to names: alive until the launch is enqueued
     ws = WORKSPACE.get(lib().sgx_nms_workspace(ctypes.byref(d)), dev)
     check(lib().sgx_nms(ctypes.byref(d), ptr(boxes), ptr(scores), ptr(out), ptr(cnt), ptr(idx), ptr(ncand), ptr(ws), ws.numel(), stream()), "sgx_nms")
+    _NMS_LAST[:] = [d, ws]
     return out, cnt, idx, ncand
+
+
+_NMS_LAST = [None, None]
+
+
+def nms_fallbacks() -> int:
+    """Images of the LAST `nms` call (multi-label) whose stage 2 streamed the raw scores instead of stage 1's candidate list - exact rows,
+    many times slower (csrc/nms.hip).  Synchronises; benches and tests assert 0 on their inputs."""
+    d, ws = _NMS_LAST
+    if d is None or not d.multi_label:
+        return 0
+    off, stride = ctypes.c_int64(0), ctypes.c_int32(0)
+    check(lib().sgx_debug_nms_fallback_slot(ctypes.byref(d), ctypes.byref(off), ctypes.byref(stride)), "sgx_debug_nms_fallback_slot")
+    flags = ws[: ws.numel() // 4 * 4].view(torch.int32)[off.value: off.value + d.B * stride.value: stride.value]
+    return int(flags.sum())
 
 
 def decode_topk(boxes, scores, k: int):
@@ -1095,15 +1120,18 @@ def softmax_ce(logits, labels, smoothing=0.0, weight=None, ignore_index=-100, re
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, step, seg_end, seg_wd, grad_scale=None):
     check(lib().sgx_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, ptr(seg_end), ptr(seg_wd), seg_end.numel(),
                                ptr(grad_scale), stream()), "sgx_adamw_step")
+    weights_written()
 
 
 def sgd_step(p, g, mom, lr, momentum, dampening, nesterov, first_step, seg_end, seg_wd):
     check(lib().sgx_sgd_step(ptr(p), ptr(g), ptr(mom), p.numel(), lr, momentum, dampening, int(nesterov), int(first_step), ptr(seg_end), ptr(seg_wd),
                              seg_end.numel(), stream()), "sgx_sgd_step")
+    weights_written()
 
 
 def ema_update(ema, p, decay):
     check(lib().sgx_ema_update(ptr(ema), ptr(p), ema.numel(), float(decay), stream()), "sgx_ema_update")
+    weights_written()
 
 
 # --------------------------------------------------------------------------------------------- conv arithmetic

@@ -427,6 +427,9 @@ class SgxNetwork(nn.Module):
                 m._folded = None
         self._wt_valid = False
         self.drop_filter_planes()
+        from .. import kernels as K
+
+        K.weights_written()  # bf16 operands of the half-precision path cached against live weights (kernels._half_cached)
 
     def drop_filter_planes(self):
         """The registry entries of this network's pre-split filter planes stop serving launches (the weights are about to change, or the

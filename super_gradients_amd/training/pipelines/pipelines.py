@@ -62,20 +62,22 @@ def load_images(images) -> List[Union[np.ndarray, torch.Tensor]]:
     return [_load_image(images)]
 
 
-_FP16_NOTED = False
+_FP16_NOTED = set()
 
 
-def _note_fp16_once(model):
+def _note_fp16_once(model, why="has no half-precision kernels on this build"):
     """fp16=True is the reference's default (pipelines.py:76: torch.autocast around the forward).  Architectures without half-precision
     kernels here (everything but YOLO-NAS) run the forward in fp32 - results are at least as precise, throughput is the fp32 path's.
-    Said once per process."""
-    global _FP16_NOTED
-    if not _FP16_NOTED:
-        _FP16_NOTED = True
+    Said LOUDLY (a warnings.warn UserWarning and a log record) once per model class: the fallback must not pass for the requested mode."""
+    name = type(model).__name__
+    if name not in _FP16_NOTED:
+        _FP16_NOTED.add(name)
         import logging
+        import warnings
 
-        logging.getLogger(__name__).warning(f"predict(fp16=True): {type(model).__name__} has no half-precision kernels on this build - "
-                                            "the forward runs in fp32 (pass fp16=False to silence this note)")
+        msg = f"predict(fp16=True): {name} {why} - the forward runs in fp32 (pass fp16=False to silence this note)"
+        logging.getLogger(__name__).warning(msg)
+        warnings.warn(msg, UserWarning, stacklevel=3)
 
 
 class Pipeline(ABC):
@@ -116,6 +118,13 @@ class Pipeline(ABC):
         # the copy is private to this pipeline and inference-only, so it takes the deepest form every block offers (the reference's call
         # leaves QARepVGG blocks partially fused - post-BN as a separate op - because its copy stays trainable): same function, fewer passes
         self.model.prep_model_for_conversion(input_size=input_size, full_fusion=True)
+        if self.half:
+            #  a conv + BatchNorm pair that could not be folded - a channel-padded filter, C % 4 != 0 - has no half-precision form:
+            # fall back to the fp32 path for the whole model, loudly, instead of raising at the first forward
+            unfolded = [n for n, m in self.model.named_modules() if hasattr(m, "_folded") and hasattr(m, "_parts") and m._folded is None]
+            if unfolded:
+                self.half = False
+                _note_fp16_once(self.model, f"has conv + BatchNorm pairs without a folded half-precision form ({unfolded[0]}, {len(unfolded)} in all)")
         if self.half:
             self.model.half_inference(True)  # the private fused copy only: the caller's model keeps training in fp32
         self.fuse_model = False

@@ -623,8 +623,15 @@ def test_nms_sampled_selection(backend, case):
             assert lib().sgx_debug_set_nms_selection(sampled) == 0
             out, cnt, idx, ncand = K.nms(boxes.to(backend), scores.to(backend), 0.05, 0.6, topk, maxp, multi_label=True, class_mode=0)
             res[sampled] = (out.cpu(), cnt.cpu(), idx.cpu(), ncand.cpu())
+            if sampled:
+                fallbacks = K.nms_fallbacks()
     finally:
         lib().sgx_debug_set_nms_selection(1)
+    #  the streaming fallback of stage 2 is exact but slow, and it used to be silent: the call reports it per image
+    if case == "random":
+        assert fallbacks == 0, "the sampled selection fell back to streaming on a benign input"
+    elif case == "sample_overestimates":
+        assert fallbacks == B, f"{fallbacks} of {B} images report the fallback this case forces"
     for b in range(B):
         n = int(res[1][1][b])
         assert n == ref[b].shape[0], f"{case} image {b}: kept {n} vs oracle {ref[b].shape[0]}"

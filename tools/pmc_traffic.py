@@ -3,7 +3,9 @@
     python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <out.json> [<pass dir with GRBM_GUI_ACTIVE> [<nms calls traced>]]
 Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the bytes of wide coalesced
 streaming reads (TCC_EA0_RDREQ x 64 B for 128-B requests) -> x2; both counters are in KiB; WRITE_SIZE is taken as reported
-(uncalibrated per the guide).  Per-launch = sum over all igemm_kernel dispatches / number of dispatches."""
+(uncalibrated per the guide).  Per-launch = sum over all dispatches of the family / number of dispatches; families: forward / data gradient =
+igemm_kernel + pconv_kernel, weight gradient = wgrad_kernel + wpatch_kernel (the SAME launches bench.py's `wgrad.launches_per_step` and
+`wgrad.algorithmic_bytes_per_launch` count: round 5's file summed wgrad_kernel only - 27 of the 42 launches per step)."""
 import csv
 import glob
 import json
@@ -28,7 +30,7 @@ def clock(d):
     cyc = ns = 0.0
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f, newline="")):
-            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and any(m in r["Kernel_Name"] for m in ("igemm_kernel", "pconv_kernel", "wgrad_kernel")):
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and any(m in r["Kernel_Name"] for m in ("igemm_kernel", "pconv_kernel", "wgrad_kernel", "wpatch_kernel")):
                 cyc += float(r["Counter_Value"])
                 ns += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return (cyc / 8.0 / ns) if ns else None  # GHz
@@ -37,7 +39,7 @@ def clock(d):
 def main():
     fd, wd, out = sys.argv[1:4]
     res = {}
-    for name, matches in (("igemm", ("igemm_kernel", "pconv_kernel")), ("wgrad", ("wgrad_kernel",)), ("nms", ("nms_",))):
+    for name, matches in (("igemm", ("igemm_kernel", "pconv_kernel")), ("wgrad", ("wgrad_kernel", "wpatch_kernel")), ("nms", ("nms_",))):
         f = w = 0.0
         nf = nw = 0
         for m in matches:
