@@ -290,17 +290,20 @@ __device__ __forceinline__ void sgx_bnreq_publish(const IgemmParams& p, int col,
 #define IG_BF3_MIN_WAVES_PH2 1  // (the two-source form as well: 93 registers; the two-output form would spill - three accumulators)
 #endif
 #ifndef IG_WPR_MIN_WAVES_6464
-#define IG_WPR_MIN_WAVES_6464 5
+#define IG_WPR_MIN_WAVES_6464 4  // (5 - round 5 - spilled 4 dwords)
 #endif
 template <int BM, int BN, int WM, int WN, int MATH, int KD, int PH2, int NBUF, int WPL = 0>
 constexpr int igemm_min_waves() {
-    // (register fragments of the filter, WPL = 2: 24 registers of fragments one slab ahead - under a bound of five waves only the 64x64
-    // one-source form fits them without spilling, r5ab: the spilling forms ran 1.7-2x slower)
-    if (WPL == 2) return (BM == 64 && BN == 64 && PH2 == 0) ? IG_WPR_MIN_WAVES_6464 : (BM / (WM * 32) == 1 && BN / (WN * 32) == 1 && PH2 <= 1) ? 4 : 1;
+    // Round 6: NO instantiation that a launch can select may spill (tools/kernel_regs.py --check, tests/test_tools.py): round 5 shipped the
+    // two-source 64x64 form at 96 registers with 7 spilled dwords (6 launches per step), the register-fragment forms with 1-4.  A bound is
+    // lowered by one wave wherever the allocation under it spilled.
+    // (register fragments of the filter, WPL = 2: 24 registers of fragments one slab ahead)
+    if (WPL == 2) return (BM == 64 && BN == 64 && PH2 == 0) ? IG_WPR_MIN_WAVES_6464 : (BM / (WM * 32) == 1 && BN / (WN * 32) == 1 && PH2 == 0) ? 4 : (BM / (WM * 32) == 1 && BN / (WN * 32) == 1 && PH2 == 1) ? 3 : 1;
     // (the pipelined two-buffer loop: three workgroups' LDS per CU; a bound >= 2 also keeps the accumulators in ordinary registers -
     // with 512 registers on offer hipcc parks them in AGPRs and copies 32 registers in and out per slab)
     if (NBUF == 2 && KD == 32) return (BM + BN) * 192 * 2 > 52 * 1024 ? 2 : 3;
-    return (MATH == 1 && KD == 32 && PH2 <= IG_BF3_MIN_WAVES_PH2 && BM / (WM * 32) == 1 && BN / (WN * 32) == 1) ? IG_BF3_MIN_WAVES : 1;
+    // (the two-source form carries a second source's offsets and masks: four waves - 128 registers - is what it fits without spilling)
+    return (MATH == 1 && KD == 32 && PH2 <= IG_BF3_MIN_WAVES_PH2 && BM / (WM * 32) == 1 && BN / (WN * 32) == 1) ? (PH2 == 1 ? IG_BF3_MIN_WAVES - 1 : IG_BF3_MIN_WAVES) : 1;
 }
 template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, int WPL = 0>
 __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2, NBUF, WPL>())) void igemm_kernel(IgemmParams p) {
@@ -1880,10 +1883,27 @@ static void launch_pconv(IgemmParams& p, void* stream) {
     // pre-split filter planes (fplanes_attach): every filter of the launch has them, or none is used
     const bool wpl = p.Wp && (!(PH2 && p.A2) || p.Wp2);
     if (wpl) g_fp_hits.fetch_add(1, std::memory_order_relaxed);
-    if (fpipe && wpl) SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, true, true>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
-    else if (wpl) SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, false, true>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
-    else if (fpipe) SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, true>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
-    else SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, false>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
+    // Forms whose second fragment set spills are not instantiated at all (round 6; tools/kernel_regs.py --check): the 32-filter two-output
+    // form (50 / 29 spilled dwords under its three-wave bound - only the measurement switch "always" reached it) and the 64-filter
+    // two-source form that splits its filters in the kernel (10 spilled dwords at 256 registers - reached with the planes switched off).
+    constexpr bool PIPE_PL = !(BN == 32 && PH2 == 2), PIPE_SPLIT = PIPE_PL && !(BN == 64 && PH2 == 1);
+    if (wpl) {
+        if constexpr (PIPE_PL) {
+            if (fpipe) {
+                SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, true, true>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
+                return;
+            }
+        }
+        SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, false, true>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
+        return;
+    }
+    if constexpr (PIPE_SPLIT) {
+        if (fpipe) {
+            SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, true>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
+            return;
+        }
+    }
+    SGX_LAUNCH((pconv_kernel<BN, WM, WN, PH2, false>), dim3(p.chunk * 8), dim3(WM * WN * 64), 0, stream, p);
 }
 template <int PH2>
 static void launch_pconv_n(IgemmParams& p, void* stream) {
@@ -2560,7 +2580,8 @@ struct WgGroupParams {
 
 // waves per SIMD the register budget is held to: accumulators (16 per 32x32 block of the wave's sub-tile) + 48 for the loop
 // (one-block sub-tiles fit 64 registers unprompted: no request)
-constexpr int wg_min_waves(int acc_regs, int pf) { return acc_regs <= 16 ? 1 : 512 / (acc_regs + (pf == 2 ? 64 : 48)); }
+// (round 6: two blocks with two slabs in flight spilled one dword under the five waves the formula gives them - four there)
+constexpr int wg_min_waves(int acc_regs, int pf) { return acc_regs <= 16 ? 1 : (acc_regs == 32 && pf == 2) ? 4 : 512 / (acc_regs + (pf == 2 ? 64 : 48)); }
 // MATH = 1 (the default since round 4 - r3zj / r4a: alone 13.5 -> 12.0 -> with the patch kernel 11.0 ms per step of weight gradients; written
 // against the host emulation in round 3 after the transpose read's lane mapping had been probed): the bf16x3 arithmetic of the patch kernel for the weight gradient.  A slab is staged as three bf16 planes
 // [plane][pixel][channel] (the split happens once per element, at the LDS store); the MFMA operands - eight consecutive PIXELS of one channel

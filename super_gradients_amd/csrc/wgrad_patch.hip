@@ -36,8 +36,9 @@ constexpr int wp_pitch(int n) { return n + (n % 64 == 0 ? 32 : 0); }  // bf16 el
 // spilling.)
 // NKS: K steps (16 pixels each) per tile: a tile is 16 NKS / PC rows x PC columns (four at stride 1 - 64 pixels, half the barriers and 1.7
 // instead of 2.25 patch pixels staged per output pixel; two at stride 2, whose 9 x 33 patch of a 64-pixel tile would take 57 KB of LDS)
+// (round 6: the stride-2 four-column form spilled one dword under the three-wave bound - two there; tools/kernel_regs.py --check)
 template <int S, int PC, int KB, int NKS>
-__global__ __launch_bounds__(192 * KB, 3) void wpatch_kernel(WpGroupParams g) {
+__global__ __launch_bounds__(192 * KB, (S == 2 && PC == 4) ? 2 : 3) void wpatch_kernel(WpGroupParams g) {
     constexpr int CB = 1, WT = 3;
     constexpr int NW = KB * CB * WT, NTH = 64 * NW;
     constexpr int PIX = 16 * NKS;

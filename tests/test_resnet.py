@@ -144,3 +144,28 @@ def test_product_resnet50_imagenet_shape_fwd_bwd(gpu_device):
     l2_h, l2_c = (num_h / den) ** 0.5, (num_c / den) ** 0.5
     assert l2_h <= max(1e-3, 3.0 * l2_c), f"whole-gradient L2 error vs fp64: hip {l2_h:.2e}, cpu fp32 {l2_c:.2e}"
     print(f"resnet50@224: gradient L2 error vs fp64: hip {l2_h:.2e}, cpu fp32 {l2_c:.2e}")
+
+
+@pytest.mark.gpu
+def test_product_resnet50_imagenet_shape_bs64_loss(gpu_device):
+    """BASELINE.json configs[1] AT ITS OWN SIZE (64 x 3 x 224 x 224; the gradient test above runs batch 4 for the CPU oracle's backward):
+    training-mode forward + cross-entropy against the oracle - logits within 1e-4 (relative, max-norm), loss within 1e-4."""
+    from oracle.resnet import build
+    from super_gradients_amd.training import models
+    from super_gradients_amd.training.losses import CrossEntropyLoss
+
+    torch.manual_seed(0)
+    ref = build("resnet50", 1000).train()
+    net = models.get("resnet50", num_classes=1000)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net.materialize(gpu_device).train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(64, 3, 224, 224, generator=g)
+    y = torch.randint(0, 1000, (64,), generator=g)
+    torch.set_num_threads(min(64, torch.get_num_threads() * 4))
+    with torch.no_grad():
+        lo_r = ref(x)
+        lo = net(x.to(gpu_device)).cpu()
+    assert rel_err(lo, lo_r) <= 1e-4, f"logits @ bs64: {rel_err(lo, lo_r):.2e}"
+    lr, lh = float(F.cross_entropy(lo_r, y)), float(CrossEntropyLoss()(lo.to(gpu_device), y.to(gpu_device)))
+    assert abs(lh - lr) <= 1e-4 * abs(lr)

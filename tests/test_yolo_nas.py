@@ -618,3 +618,43 @@ def test_yolo_nas_s_step_is_bit_identical_with_filter_planes(gpu_device):
     assert hits >= 100, f"only {hits} launches of the step read filter planes"
     assert torch.equal(l0, l2), f"loss differs with filter planes: {float(l0)} vs {float(l2)}"
     assert torch.equal(g0, g2), f"gradients differ with filter planes: max {float((g0 - g2).abs().max()):.3e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,size,batch,anchors", [("m", 640, 32, 8400), ("l", 1280, 8, 33600)], ids=["m_640_bs32", "l_1280_bs8"])
+def test_yolo_nas_other_baseline_configs_parity_at_full_size(gpu_device, variant, size, batch, anchors):
+    """BASELINE.json configs[3] / [4] AT THEIR OWN SIZE (round 5 held M and L to the oracle at B = 1, 256 x 256 only): YOLO-NAS-M, 32 x
+    640 x 640, and YOLO-NAS-L, 8 x 1280 x 1280 (33 600 anchors), training-mode forward + PPYoloELoss(TAL) against the CPU oracle:
+    raw head outputs and decoded predictions within 1e-4 (relative, max-norm), the four loss items within 1e-4, and - on IDENTICAL
+    predictions - assigned labels bit-exact."""
+    from oracle.ppyolo_loss import PPYoloELossOracle
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd.training.losses import PPYoloELoss
+
+    tol, C = 1e-4, 80
+    ref, net = _build_pair(variant, C, gpu_device)
+    ref.train()
+    net.train()
+    x = torch.rand(batch, 3, size, size, generator=torch.Generator().manual_seed(42))
+    targets = synthetic_targets(batch, seed=42, kmax=20, size=size, num_classes=C)
+    torch.set_num_threads(min(64, torch.get_num_threads() * 4))
+    with torch.no_grad():
+        out_ref = ref(x)
+        orc = PPYoloELossOracle(C, use_static_assigner=False)
+        _, items_ref = orc(out_ref, targets)
+        out = net(x.to(gpu_device))
+        _, items = PPYoloELoss(num_classes=C, use_static_assigner=False)(out, targets.to(gpu_device))
+    (bx, sc), (lg, ds, an, pt, cnt, st) = out
+    (bx_r, sc_r), (lg_r, ds_r, an_r, pt_r, cnt_r, st_r) = out_ref
+    assert lg.shape[1] == anchors and list(cnt) == list(cnt_r)
+    tag = f"@ {variant} bs{batch}/{size}"
+    assert_close(lg.detach().cpu(), lg_r, tol, "cls_logits " + tag)
+    assert_close(ds.detach().cpu(), ds_r, tol, "reg_distri " + tag)
+    assert_close(bx.detach().cpu(), bx_r, tol, "pred_bboxes " + tag)
+    assert_close(sc.detach().cpu(), sc_r, tol, "pred_scores " + tag)
+    assert_close(items.cpu(), items_ref, tol, "loss items, end to end " + tag)
+    preds_cpu = (lg.detach().cpu(), ds.detach().cpu(), an_r, pt_r, cnt_r, st_r)
+    _, a_label, _, _ = orc.assign(preds_cpu, targets)
+    o = K.ppyoloe_loss_fwd(lg.detach(), ds.detach(), an, pt, st, targets.to(gpu_device), [int(c) for c in cnt], False, True, (1.0, 2.5, 0.5))
+    assert torch.equal(o["label"].cpu().long(), a_label), "assigned labels differ " + tag
+    assert int((a_label != C).sum()) > batch
