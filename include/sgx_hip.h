@@ -577,6 +577,15 @@ int32_t sgx_detection_match(const sgx_match_desc* d, const float* preds, const i
                             const int32_t* gt_count, const int32_t* gt_index, const float* crowd, const int32_t* crowd_count,
                             const int32_t* crowd_index, const float* thresholds, uint8_t* matched, uint8_t* ignore, void* stream);
 
+/* predict(): inverse box maps of the image processing + packing of a batch's detections for ONE device-to-host copy.  The reference maps
+ * each image's boxes back through its processing stages on the host (training/processing/processing.py:361-364 shift by the padding,
+ * :401-403 multiply by 1 / scale factor; training/pipelines/pipelines.py:222-247 per image).  rows [B][P][6] / counts [B]: the layout
+ * sgx_nms writes; steps [B][nsteps][3] = (kind, a_x, a_y) applied in order to (x1, x2) / (y1, y2) in fp32, one rounding per step as
+ * numpy's float32 arithmetic: kind 0 += a, kind 1 *= a, kind 2 nothing; out: B * P * 6 floats (rows beyond an image's count zeroed)
+ * followed by the B clamped counts as int32 bit patterns.                                                                          */
+int32_t sgx_detection_unmap(const float* rows, const int32_t* counts, int32_t B, int32_t P, const float* steps, int32_t nsteps, float* out,
+                            void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Half-precision INFERENCE (csrc/half.hip): what `predict(fp16=True)` runs on the fused deployment form of the model
  * (training/pipelines/pipelines.py:76,223,375 wraps the reference's forward in torch.autocast; the fused form is

@@ -194,6 +194,7 @@ PROTOTYPES = {
     "sgx_nms_workspace": (_i64, [_ND]),
     "sgx_nms": (_i32, [_ND, _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
     "sgx_detection_match": (_i32, [POINTER(MatchDesc)] + [_P] * 12),
+    "sgx_detection_unmap": (_i32, [_P, _P, _i32, _i32, _P, _i32, _P, _P]),
     "sgx_softmax_ce_fwd_bwd": (_i32, [_i32, _i32, _P, _P, _f, _P, _i32, _i32, _P, _P, _P]),
     "sgx_adamw_step": (_i32, [_P, _P, _P, _P, _i64, _f, _f, _f, _f, _i32, _P, _P, _i32, _P, _P]),
     "sgx_sgd_step": (_i32, [_P, _P, _P, _i64, _f, _f, _f, _i32, _i32, _P, _P, _i32, _P]),

@@ -1074,3 +1074,46 @@ extern "C" int32_t sgx_detection_match(const sgx_match_desc* d, const float* pre
     SGX_CHECK_LAUNCH("detection_match");
     return SGX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// predict(): the inverse box maps of the image processing and the packing of a batch's detections into ONE host-bound buffer (round 6).
+// The reference maps every image's boxes back through its processing stages on the host, one numpy pass per stage per image
+// (training/processing/processing.py:361-364 shift by the padding, :401-403 multiply by 1 / scale factor; pipelines.py:222-247 loops over the
+// images).  Here: one launch for the batch - per image a short list of (kind, a_x, a_y) steps applied IN ORDER to x1, y1, x2, y2 in fp32
+// (kind 0: += a, kind 1: *= a - one rounding each, as numpy's float32 arithmetic rounds them; this file is compiled without fma
+// contraction) - and the rows of every image, followed by the B counts (int32 bit patterns), land in one contiguous fp32 buffer: one
+// device-to-host copy per batch instead of a count copy + a concatenation + a row copy.
+// ------------------------------------------------------------------------------------------------
+__global__ void boxes_unmap_kernel(const float* rows, const int* counts, int B, int P, const float* steps, int nsteps, float* out) {
+    const int b = blockIdx.y;
+    const int n = counts[b] < P ? counts[b] : P;
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(out + (size_t)B * P * 6)[b] = n;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float* o = out + ((size_t)b * P + i) * 6;
+    if (i >= n) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = 0.f;
+        return;
+    }
+    const float* r = rows + ((size_t)b * P + i) * 6;
+    float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+    const float* st = steps + (size_t)b * nsteps * 3;
+    for (int s = 0; s < nsteps; ++s) {
+        const float kind = st[3 * s], ax = st[3 * s + 1], ay = st[3 * s + 2];
+        if (kind == 0.f) {
+            x1 += ax; x2 += ax; y1 += ay; y2 += ay;
+        } else if (kind == 1.f) {
+            x1 *= ax; x2 *= ax; y1 *= ay; y2 *= ay;
+        }  // (kind 2: no step - padding of a shorter list)
+    }
+    o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = r[4]; o[5] = r[5];
+}
+extern "C" int32_t sgx_detection_unmap(const float* rows, const int32_t* counts, int32_t B, int32_t P, const float* steps, int32_t nsteps, float* out,
+                                       void* stream) {
+    SGX_CHECK_ARG(rows && counts && out && (steps || nsteps == 0), "detection_unmap: null pointer");
+    SGX_CHECK_ARG(B > 0 && P > 0 && nsteps >= 0 && nsteps <= 64, "detection_unmap: bad dims (B=%d P=%d nsteps=%d)", B, P, nsteps);
+    SGX_LAUNCH(boxes_unmap_kernel, dim3((unsigned)((P + 127) / 128), (unsigned)B), dim3(128), 0, stream, rows, counts, B, P, steps, nsteps, out);
+    SGX_CHECK_LAUNCH("detection_unmap");
+    return SGX_OK;
+}

@@ -1088,6 +1088,21 @@ def _index_targets(t, B):
     return t, cnt, idx, T
 
 
+def detection_unmap(rows, counts, steps):
+    """rows [B,P,6] + counts [B] (the NMS output layout), steps [B,S,3] fp32 (kind 0 add / 1 multiply / 2 none, a_x, a_y; S may be 0) -> ONE
+    flat fp32 tensor of B*P*6 + B elements: every image's rows mapped back through its processing stages (one fp32 rounding per step, as
+    the reference's numpy passes round), rows beyond the count zeroed, then the B clamped counts as int32 bit patterns - what predict()
+    copies to the host in one transfer."""
+    B, P, _ = rows.shape
+    rows, counts = rows.contiguous().float(), counts.contiguous().int()
+    S = 0 if steps is None else int(steps.shape[1])
+    if S:
+        steps = steps.contiguous().float()
+    out = torch.empty(B * P * 6 + B, device=rows.device, dtype=torch.float32)
+    check(lib().sgx_detection_unmap(ptr(rows), ptr(counts), B, P, ptr(steps) if S else None, S, ptr(out), stream()), "sgx_detection_unmap")
+    return out
+
+
 def detection_match(rows, counts, targets, crowd_targets, thresholds, height, width, top_k, denormalize):
     """rows [B,P,6] + counts [B] (the NMS output layout), targets / crowd_targets flat [T,6] -> (matched, ignore) uint8 [B,P,nthr]."""
     B, P, _ = rows.shape

@@ -124,6 +124,13 @@ class Processing(ABC):
     def postprocess_predictions(self, predictions: Prediction, metadata: Union[None, ProcessingMetadata]) -> Prediction:
         pass
 
+    def inverse_box_steps(self, metadata: Union[None, ProcessingMetadata]):
+        """What `postprocess_predictions` does to detection boxes, as data: a list of (kind, a_x, a_y) steps - kind 0: x += a_x, y += a_y;
+        kind 1: x *= a_x, y *= a_y - applied in order, one float32 rounding each (exactly the numpy float32 passes of the stage), so that
+        DetectionPipeline can run the whole batch's inverse maps in one device launch (kernels.detection_unmap).  None: this stage has no
+        such description (a user-defined Processing) - the pipeline then maps boxes on the host through postprocess_predictions."""
+        return None
+
     def infer_image_input_shape(self) -> Optional[Tuple[int, int]]:
         return None
 
@@ -234,6 +241,15 @@ class ComposeProcessing(Processing):
             predictions = p.postprocess_predictions(predictions, m)
         return predictions
 
+    def inverse_box_steps(self, metadata: ComposeProcessingMetadata):
+        steps = []
+        for p, m in zip(self.processings[::-1], metadata.metadata_lst[::-1]):
+            st = p.inverse_box_steps(m)
+            if st is None:
+                return None
+            steps.extend(st)
+        return steps
+
     def infer_image_input_shape(self):
         shape = None
         for p in self.processings:
@@ -272,6 +288,9 @@ class ImagePermute(Processing):
     def postprocess_predictions(self, predictions, metadata):
         return predictions
 
+    def inverse_box_steps(self, metadata):
+        return []
+
 
 @register_processing("ReverseImageChannels")
 class ReverseImageChannels(Processing):
@@ -282,6 +301,9 @@ class ReverseImageChannels(Processing):
 
     def postprocess_predictions(self, predictions, metadata):
         return predictions
+
+    def inverse_box_steps(self, metadata):
+        return []
 
 
 @register_processing("StandardizeImage")
@@ -299,6 +321,9 @@ class StandardizeImage(Processing):
 
     def postprocess_predictions(self, predictions, metadata):
         return predictions
+
+    def inverse_box_steps(self, metadata):
+        return []
 
 
 @register_processing("NormalizeImage")
@@ -320,6 +345,9 @@ class NormalizeImage(Processing):
 
     def postprocess_predictions(self, predictions, metadata):
         return predictions
+
+    def inverse_box_steps(self, metadata):
+        return []
 
 
 def _shift_bboxes_xyxy(boxes: np.ndarray, shift_w: float, shift_h: float) -> np.ndarray:
@@ -363,6 +391,10 @@ class _DetectionPadding(Processing, ABC):
         predictions.bboxes_xyxy = _shift_bboxes_xyxy(predictions.bboxes_xyxy, shift_w=-c.left, shift_h=-c.top)
         return predictions
 
+    def inverse_box_steps(self, metadata: DetectionPadToSizeMetadata):
+        c = metadata.padding_coordinates
+        return [(0.0, float(-c.left), float(-c.top))]
+
     def infer_image_input_shape(self):
         return self.output_shape
 
@@ -397,6 +429,10 @@ class DetectionAutoPadding(AutoPadding):
         predictions.bboxes_xyxy = _shift_bboxes_xyxy(predictions.bboxes_xyxy, shift_w=-c.left, shift_h=-c.top)
         return predictions
 
+    def inverse_box_steps(self, metadata: DetectionPadToSizeMetadata):
+        c = metadata.padding_coordinates
+        return [(0.0, float(-c.left), float(-c.top))]
+
 
 class _DetectionRescaleBase(Processing, ABC):
     def __init__(self, output_shape: Tuple[int, int]):
@@ -408,6 +444,9 @@ class _DetectionRescaleBase(Processing, ABC):
     def postprocess_predictions(self, predictions: DetectionPrediction, metadata: RescaleMetadata):
         predictions.bboxes_xyxy = _rescale_bboxes(predictions.bboxes_xyxy, (1 / metadata.scale_factor_h, 1 / metadata.scale_factor_w))
         return predictions
+
+    def inverse_box_steps(self, metadata: RescaleMetadata):
+        return [(1.0, 1 / metadata.scale_factor_w, 1 / metadata.scale_factor_h)]
 
     @property
     def resizes_image(self) -> bool:

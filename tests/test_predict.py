@@ -439,3 +439,33 @@ def test_skip_image_resizing_with_reversed_channels(backend):
     skip = proc.get_equivalent_compose_without_resizing(DetectionAutoPadding(shape_multiple=(32, 32), pad_value=0))
     batch, _ = skip.preprocess_batch([img], device=backend)
     assert tuple(batch.shape)[2:] == (64, 96)
+
+
+def test_predict_device_postprocess_equals_host_postprocess(backend, monkeypatch):
+    """Round 6: predict() maps every image's boxes back through its processing stages on the DEVICE (kernels.detection_unmap, the stages'
+    `inverse_box_steps`) and copies rows + counts to the host once.  The result must equal - bit for bit - the host path the reference
+    describes (processing.py:361-364, 401-403: numpy float32 passes per stage per image), which stays the fallback for stages without a
+    step description.  Ragged images: a different scale factor and padding per image."""
+    from super_gradients_amd.training.processing import ComposeProcessing
+
+    net = _small_detector(backend)
+    proc = [{"DetectionLongestMaxSizeRescale": {"output_shape": (60, 60)}}, {"DetectionCenterPadding": {"output_shape": (64, 64), "pad_value": 114}},
+            {"StandardizeImage": {"max_value": 255.0}}, {"ImagePermute": {"permutation": (2, 0, 1)}}]
+    net.set_dataset_processing_params(class_names=["a", "b", "c"], image_processor=proc, iou=0.6, conf=0.0)
+    rng = np.random.default_rng(5)
+    images = [rng.integers(0, 256, s, dtype=np.uint8) for s in ((64, 50, 3), (40, 64, 3), (97, 31, 3), (23, 23, 3))]
+    dev = net.predict(images, max_predictions=20, nms_top_k=100, fp16=False)
+    pipe = net._get_pipeline(max_predictions=20, nms_top_k=100, fp16=False)
+    steps = [pipe.image_processor.inverse_box_steps(pipe.image_processor.preprocess_batch([im], device=pipe.device)[1][0]) for im in images]
+    assert all(len(s) == 2 and s[0][0] == 0.0 and s[1][0] == 1.0 for s in steps)  # un-pad, then un-scale
+    assert len({s[1][1] for s in steps}) > 1                                       # (the images really differ in scale)
+    monkeypatch.setattr(ComposeProcessing, "inverse_box_steps", lambda self, m: None)
+    host = net.predict(images, max_predictions=20, nms_top_k=100, fp16=False)
+    n = 0
+    for a, b in zip(dev, host):
+        pa, pb = a.prediction, b.prediction
+        assert len(pa) == len(pb) and pa.image_shape == pb.image_shape
+        assert np.array_equal(pa.bboxes_xyxy, pb.bboxes_xyxy) and pa.bboxes_xyxy.dtype == pb.bboxes_xyxy.dtype
+        assert np.array_equal(pa.confidence, pb.confidence) and np.array_equal(pa.labels, pb.labels)
+        n += len(pa)
+    assert n > 0
