@@ -204,6 +204,7 @@ struct IgemmParams {
     // g = v * act'(scale t + shift) from the value v it is about to store and leaves sum g, sum g (t - mean) per column in row block
     // (req_row0 + tile row) of the request's partials - the rows sgx_bn_bwd_reduce would have produced with a pass over dy and t.
     int nreq, req_row0;
+    int lab;  // measurement builds (-DSGX_IGEMM_LAB, tools/conv_lab.py --ablate) only: see IGL below; the product build never reads it
     struct {
         const float* t;
         const float* scale;
@@ -260,6 +261,21 @@ __device__ __forceinline__ void sgx_bnreq_publish(const IgemmParams& p, int col,
         }
 }
 
+// Ablation lab of the implicit-GEMM loop (measurement builds only: -DSGX_IGEMM_LAB; sgx_debug_set_igemm_lab; tools/conv_lab.py --ablate).
+// Bits of IgemmParams::lab - each removes ONE component of the K loop (results are garbage, timings are what the lab is for):
+//   1 no global loads behind the first slab (the first slab's registers are staged again and again)   2 no LDS stores behind the first slab
+//   4 no fragment reads / MFMAs   8 no bf16 split (raw bits are stored: same stores, no vector work)   16 no epilogue (nothing is written)
+// The product build compiles IGL(b) to `false`.
+#ifdef SGX_IGEMM_LAB
+#define IGL(b) ((p.lab & (b)) != 0)
+static std::atomic<int> g_ig_lab{0};
+extern "C" int32_t sgx_debug_set_igemm_lab(int32_t bits) {
+    g_ig_lab = bits;
+    return SGX_OK;
+}
+#else
+#define IGL(b) false
+#endif
 #define IG_BK 16
 #define IG_LD 20
 // ---- "bf16x3" arithmetic (MATH = 1): fp32 operands split into three bf16 pieces (round-to-nearest, each residual exact in fp32), products hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi on the bf16 matrix pipe
@@ -487,22 +503,27 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
             const int tapoff = s_ti * rowstep + s_tj * pixstep + s_ck * (KD * 4);
             const int woff = WPL ? s_ck * wp_ckstep + tbit * wp_tapstep : (tbit * p.C + s_ck * KD) * 4;
             const bool cok = live && s_ck * KD + chunk4 < p.C;
+            const bool lab_noload = IGL(1) && s_kt > 0;
+            if (!lab_noload) {
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 const bool ok = cok && ((amask[j] >> (tbit & 63)) & 1ull);
                 ra[j] = sgx_buf_ld4(bufA, ok ? (unsigned)(aoff[j] + tapoff) : SGX_BUF_OOB);
+            }
             }
             // (WPL: C is a multiple of 32 - no ragged channel chunk to mask on the filter side)
             if constexpr (WPR) {
                 wp_woff = woff;  // the fragments of this slab are fetched by load_bfrags, behind the MFMAs that read the current ones
             } else if constexpr (WPL) {
                 const int wv = sgx_uniform_i32(tid >> 6);
+                if (!lab_noload) {
 #pragma unroll
                 for (int j = 0; j < BJ; ++j) {
                     const int blk = wv + (NTH / 64) * j;             // (plane, 16-row block) of this wave's j-th piece
                     const int plane = blk / WBK, rb16 = (blk - plane * WBK) * 16;
                     const bool ok = live && (BPI % NTH == 0 || blk < 3 * WBK) && rb16 < wp_rows;
                     rb[j] = sgx_buf_ld4(bufB, ok ? (unsigned)(wp_lane + woff + plane * T_ * wp_tapstep + rb16 * 32) : SGX_BUF_OOB);
+                }
                 }
             } else {
 #pragma unroll
@@ -525,6 +546,11 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                 const int row = lrow + RPP * j;
                 if (BM % RPP == 0 || row < BM) {
                     uint2 h, m, l;
+                    if (IGL(8)) {
+                        h = make_uint2(sgx_f2u(ra[j].x), sgx_f2u(ra[j].y));
+                        m = make_uint2(sgx_f2u(ra[j].z), sgx_f2u(ra[j].w));
+                        l = h;
+                    } else
                     sgx_split3(ra[j], h, m, l);
                     unsigned* d = reinterpret_cast<unsigned*>(As) + (buf * 3 * BM + row) * LDPW + swz(row, chunk4 >> 1);
                     *reinterpret_cast<uint2*>(d) = h;
@@ -849,15 +875,17 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                     compute_bf3(0, 1);
                     if (kt + 1 < nkt) load_bfrags(1);
                 } else if (BF3) {
-                    compute_bf3(0, 0);
-                    compute_bf3(0, 1);
+                    if (!IGL(4)) {
+                        compute_bf3(0, 0);
+                        compute_bf3(0, 1);
+                    }
                 } else {
                     compute_f32(0, 0);
                     compute_f32(0, 16);
                 }
                 __syncthreads();
                 if (kt + 1 < nkt) {
-                    store_tile(0);
+                    if (!IGL(2)) store_tile(0);
                     __syncthreads();
                 }
                 continue;
@@ -1023,7 +1051,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                             cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
                             cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
                         }
-                        sgx_st4(yp, make_float4(sgx_act(v.x, p.act), sgx_act(v.y, p.act), sgx_act(v.z, p.act), sgx_act(v.w, p.act)));
+                        if (!IGL(16)) sgx_st4(yp, make_float4(sgx_act(v.x, p.act), sgx_act(v.y, p.act), sgx_act(v.z, p.act), sgx_act(v.w, p.act)));
                     } else {
                         float e[4] = {v.x, v.y, v.z, v.w};
                         float* se[4] = {&cs.x, &cs.y, &cs.z, &cs.w};
@@ -1831,6 +1859,9 @@ static void launch_igemm(IgemmParams& p, void* stream) {
     p.fd_hw = sgx_make_fastdiv(p.Ha * p.Wa);
     p.fd_wa = sgx_make_fastdiv(p.Wa);
     int grid = p.chunk * 8;
+#ifdef SGX_IGEMM_LAB
+    p.lab = g_ig_lab.load(std::memory_order_relaxed);
+#endif
     SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF, PH2, WPL>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
 }
 

@@ -163,14 +163,19 @@ class Pipeline(ABC):
                 raise ValueError(f"Invalid input size ({h}, {w}): the model takes sizes that are multiples of ({sh}, {sw}) and at least ({mh}, {mw})")
         if self.fuse_model:
             self._fuse_model(tuple(batch.shape[-2:]))
+        # (round 6: the mode is switched only when it has to be - eval() / train() walk the whole module tree, ~500 modules with an
+        # attribute write each, and the fused copy a pipeline owns is in eval mode for good: two walks per batch were a quarter of a bf16
+        # predict() batch's host time, tools/predict_profile.py)
         was_training = self.model.training
-        self.model.eval()
+        if was_training:
+            self.model.eval()
         try:
             with torch.no_grad():
                 out = self.model(batch)
                 return decode(out, model_input=batch)
         finally:
-            self.model.train(was_training)
+            if was_training:
+                self.model.train(True)
 
     @abstractmethod
     def _decode_model_output(self, model_output, model_input):

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--planes", default=None, help="comma list of 0 | 1: crossed with the other axes, pre-split filter planes off / on (the problem's "
                     "filters are split once, the step's scope is open for the whole run; data gradients then use the pre-transposed-weights entry point)")
+    ap.add_argument("--ablate", default=None, help="comma list of ablation bit sets of a -DSGX_IGEMM_LAB build (sgx_debug_set_igemm_lab: 1 no global "
+                    "loads, 2 no LDS stores, 4 no MFMAs, 8 no split, 16 no epilogue stores), crossed with the other axes; 0 = the whole kernel")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import torch
@@ -42,8 +44,9 @@ def main():
     tiles = [tuple(int(a) for a in t.split("x")) for t in args.tiles.split(",")]
     maths = args.math.split(",")
     planes = [int(v) for v in args.planes.split(",")] if args.planes else [None]
-    configs = [(v, t, m, pl) for m in maths for t in tiles for v in variants for pl in planes]
-    lines = [f"{'problem':<34}" + "".join(f"{f'{m[:2]}{v}/{t[0]}x{t[1]}' + ('' if pl is None else f'p{pl}'):>14}" for v, t, m, pl in configs) + "   (TFLOP/s, median of rounds; us below)"]
+    ablate = [int(v) for v in args.ablate.split(",")] if args.ablate else [None]
+    configs = [(v, t, m, (pl, ab)) for m in maths for t in tiles for v in variants for pl in planes for ab in ablate]
+    lines = [f"{'problem':<34}" + "".join(f"{f'{m[:2]}{v}/{t[0]}x{t[1]}' + ('' if pl[0] is None else f'p{pl[0]}') + ('' if pl[1] is None else f'a{pl[1]}'):>16}" for v, t, m, pl in configs) + "   (TFLOP/s, median of rounds; us below)"]
     for spec in args.problems.split(","):
         kind, n, h, w, c, k, r, s = spec.split(":")
         n, h, w, c, k, r, s = (int(a) for a in (n, h, w, c, k, r, s))
@@ -97,9 +100,11 @@ def main():
         res = {cfg: [] for cfg in configs}
         for _ in range(args.rounds):
             for cfg in configs:
-                v, (bm, bn), m, pl = cfg
+                v, (bm, bn), m, (pl, ab) = cfg
                 if pl is not None:
                     lib().sgx_debug_set_filter_planes(pl)
+                if ab is not None:
+                    lib().sgx_debug_set_igemm_lab(ab)
                 K.set_conv_math(m)
                 lib().sgx_debug_set_variant(v)
                 lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
@@ -117,6 +122,8 @@ def main():
                     res[cfg].append(float("nan"))
         lib().sgx_debug_set_variant(0)
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
+        if args.ablate:
+            lib().sgx_debug_set_igemm_lab(0)
         if args.planes:
             lib().sgx_debug_set_filter_planes(1)
             K.filter_planes_scope(False)
@@ -124,8 +131,8 @@ def main():
         K.set_conv_math(K.DEFAULT_CONV_MATH)
         K.clear_desc_cache()
         med = {cfg: statistics.median(v) for cfg, v in res.items()}
-        lines.append(f"{spec:<34}" + "".join(f"{flops / med[cfg] / 1e6:>14.1f}" for cfg in configs))
-        lines.append(f"{'':<34}" + "".join(f"{med[cfg]:>14.1f}" for cfg in configs))
+        lines.append(f"{spec:<34}" + "".join(f"{flops / med[cfg] / 1e6:>16.1f}" for cfg in configs))
+        lines.append(f"{'':<34}" + "".join(f"{med[cfg]:>16.1f}" for cfg in configs))
     text = "\n".join(lines)
     print(text)
     if args.out:
