@@ -328,12 +328,16 @@ def other_config_leg(device, workload, model, size, batch, steps=10, warmup=3, l
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
+    t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     value = batch * steps / dt
+    rec["host_enqueue_ms_per_step"] = round(t_host / steps * 1e3, 3)  # (the loop returns before the device is done when the host is ahead)
+    rec["device_allocs_in_timed_steps"] = torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0  # hipMalloc calls of the caching allocator: 0 in steady state
     out = {"workload": label, "value": round(value, 2), "unit": "images/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
            "step_mfma_frac": round(value * gflop / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4), "gflop_per_image": round(gflop, 3), "final_loss": round(float(loss), 5)}
     out.update(rec)
