@@ -329,12 +329,26 @@ def other_config_leg(device, workload, model, size, batch, steps=10, warmup=3, l
         step()
     torch.cuda.synchronize()
     allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
+    prof = None
+    if os.environ.get("SGX_BENCH_LEG_PROFILE"):  # diagnosis aid: where the host spends a leg's timed steps (stderr)
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import io
+        import pstats
+
+        prof.disable()
+        buf = io.StringIO()
+        pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(14)
+        print(f"---- {label}: {dt / steps * 1e3:.1f} ms per step, host loop {t_host / steps * 1e3:.1f} ms\n" + buf.getvalue()[:3500], file=sys.stderr, flush=True)
     value = batch * steps / dt
     rec["host_enqueue_ms_per_step"] = round(t_host / steps * 1e3, 3)  # (the loop returns before the device is done when the host is ahead)
     rec["device_allocs_in_timed_steps"] = torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0  # hipMalloc calls of the caching allocator: 0 in steady state
@@ -553,8 +567,9 @@ def main():
     # Roofline leg: the SAME K steps once more with a HIP event pair around every conv launch on its launch stream.  Recording ~900 events
     # per step costs ~3 % of the step (r2f: 577 vs 558 images/s), so it is kept out of the K steps `value` is measured on; the per-kernel
     # durations are what rocprofv3 --kernel-trace reports for the same command (profiles/).
+    skip = set((os.environ.get("SGX_BENCH_SKIP") or "").split(","))  # diagnosis aid: legs left out ("prof", "host")
     K.prof_enable(True)
-    for _ in range(args.steps):
+    for _ in range(0 if "prof" in skip else args.steps):
         step()
     fence()
     # class 0 = fp32-MFMA implicit GEMM, class 2 = the bf16x3 patch kernel, class 3 = the implicit GEMM in bf16x3 arithmetic (conv math
@@ -588,7 +603,7 @@ def main():
     # host side of one step: enqueue time of a step with the device idle at the start (no sync inside)
     fence()
     h0 = time.perf_counter()
-    for _ in range(2):
+    for _ in range(0 if "host" in skip else 2):
         step()
     host_ms = (time.perf_counter() - h0) / 2 * 1e3
     fence()
