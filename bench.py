@@ -328,7 +328,7 @@ def other_config_leg(device, workload, model, size, batch, steps=10, warmup=3, l
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
+    allocs0, retries0 = torch.cuda.memory_stats().get("num_device_alloc", 0), torch.cuda.memory_stats().get("num_alloc_retries", 0)
     prof = None
     if os.environ.get("SGX_BENCH_LEG_PROFILE"):  # diagnosis aid: where the host spends a leg's timed steps (stderr)
         import cProfile
@@ -352,6 +352,11 @@ def other_config_leg(device, workload, model, size, batch, steps=10, warmup=3, l
     value = batch * steps / dt
     rec["host_enqueue_ms_per_step"] = round(t_host / steps * 1e3, 3)  # (the loop returns before the device is done when the host is ahead)
     rec["device_allocs_in_timed_steps"] = torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0  # hipMalloc calls of the caching allocator: 0 in steady state
+    # (r6a / r6c: two boxes ran the two 86 GB configurations 2.3x slower inside this process and three boxes did not; an allocator retry -
+    # hipMalloc failed, every cached block was released, the request repeated - is what memory pressure on a shared box looks like)
+    rec["alloc_retries_in_timed_steps"] = torch.cuda.memory_stats().get("num_alloc_retries", 0) - retries0
+    free_b, total_b = torch.cuda.mem_get_info()
+    rec["hbm_gb"] = {"reserved_by_this_process": round(torch.cuda.memory_reserved() / 2**30, 1), "free_on_device": round(free_b / 2**30, 1), "total": round(total_b / 2**30, 1)}
     out = {"workload": label, "value": round(value, 2), "unit": "images/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
            "step_mfma_frac": round(value * gflop / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4), "gflop_per_image": round(gflop, 3), "final_loss": round(float(loss), 5)}
     out.update(rec)
@@ -559,11 +564,14 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    allocs_timed = torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0
+    free_b, total_b = torch.cuda.mem_get_info()
     # Roofline leg: the SAME K steps once more with a HIP event pair around every conv launch on its launch stream.  Recording ~900 events
     # per step costs ~3 % of the step (r2f: 577 vs 558 images/s), so it is kept out of the K steps `value` is measured on; the per-kernel
     # durations are what rocprofv3 --kernel-trace reports for the same command (profiles/).
@@ -637,7 +645,11 @@ def main():
                        "conv_tuning_entries": int(lib().sgx_conv_tuning_size()),
                        # pre-split filter planes: the step's filters split into bf16x3 pieces once per step (SGX_FILTER_PLANES=0: off)
                        "filter_planes": getattr(net, "_fp_jobs", None) is not None,
-                       "allreduce_from_side_stream": bool(reducer.from_side) if world > 1 else None},
+                       "allreduce_from_side_stream": bool(reducer.from_side) if world > 1 else None,
+                       # hipMalloc calls of torch's caching allocator inside the timed steps (0 once the pool has its steady shape) and the device's memory
+                       "device_allocs_in_timed_steps": allocs_timed,
+                       "hbm_gb": {"reserved_by_this_process": round(torch.cuda.memory_reserved() / 2**30, 1), "free_on_device": round(free_b / 2**30, 1),
+                                  "total": round(total_b / 2**30, 1)}},
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data gradient, "
                                                     + ("v_mfma_f32_32x32x2_f32)" if K.get_conv_math() == "fp32" else
                                                        "v_mfma_f32_32x32x2_f32) + pconv_kernel (3x3 problems from an LDS patch, v_mfma_f32_32x32x16_bf16 x6)" if K.get_conv_math() == "patch"
