@@ -723,6 +723,14 @@ def main():
         # the other BASELINE.json configurations under the same clock (headline invocation only: S at the default shape on one GPU)
         headline = world == 1 and args.workload == "yolo_nas" and args.model == "s" and args.size == 640 and args.batch == 32
         if args.other_configs == "on" or (args.other_configs == "auto" and headline and not args.no_cpu_baseline):
+            # the headline model is done: its network, optimizer state, saved activations and the allocator's cached blocks (56 GB after the S
+            # steps) are released before the larger configurations take their 50 - 90 GB each
+            import gc
+
+            step = fence = None
+            del net, reducer, crit, opt, ema, x, targets, loss, side
+            gc.collect()
+            torch.cuda.empty_cache()
             rec["other_configs"] = other_configs_leg(device, loss_check=not args.no_cpu_baseline or args.loss_check_only)
         print(json.dumps(rec), flush=True)
     if world > 1:

@@ -30,16 +30,27 @@ def record_problems(model, batch, size, dev):
     # (weight gradients one call per layer for the recording: the grouped launches of the product go through conv2d_bwd_weight_group)
     group_env = os.environ.get("SGX_WGRAD_GROUP_GFLOP")
     os.environ["SGX_WGRAD_GROUP_GFLOP"] = "0"
+    # model: s / m / l = YOLO-NAS; "resnet50" (BASELINE.json configs[1]: batch x 3 x size x size, cross-entropy); "ppyoloe_s" ...
+    name = model if model.startswith(("resnet", "ppyoloe")) else f"yolo_nas_{model}"
     try:
-        net = models.get(f"yolo_nas_{model}", num_classes=80).materialize(dev).train()
+        net = models.get(name, num_classes=1000 if name.startswith("resnet") else 80).materialize(dev).train()
     finally:
         if group_env is None:
             del os.environ["SGX_WGRAD_GROUP_GFLOP"]
         else:
             os.environ["SGX_WGRAD_GROUP_GFLOP"] = group_env
-    x = torch.rand(batch, 3, size, size, device=dev)
-    t = synthetic_targets(batch, seed=0, kmax=20, size=size).to(dev)
-    crit = PPYoloELoss(80, use_static_assigner=False)
+    if name.startswith("resnet"):
+        from super_gradients_amd.training.losses import CrossEntropyLoss
+
+        x = torch.randn(batch, 3, size, size, device=dev)
+        labels = torch.randint(0, 1000, (batch,), device=dev)
+        ce = CrossEntropyLoss()
+        t = None
+        crit = lambda out, _t: (ce(out, labels), None)
+    else:
+        x = torch.rand(batch, 3, size, size, device=dev)
+        t = synthetic_targets(batch, seed=0, kmax=20, size=size).to(dev)
+        crit = PPYoloELoss(80, use_static_assigner=False)
     rec = collections.OrderedDict()
     orig = (K.conv2d_fwd, K.conv2d_bwd_data, K.conv2d_bwd_weight, K.conv2d_fwd_dual, K.conv2d_bwd_data_dual, K.conv2d_bwd_data_wt)
 

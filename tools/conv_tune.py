@@ -33,7 +33,7 @@ def build_table(agg, min_gain):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="s")
+    ap.add_argument("--model", default="s", help="s / m / l (YOLO-NAS), resnet50 (use --batch 64 --size 224), ppyoloe_s ...")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--iters", type=int, default=5)
@@ -172,7 +172,7 @@ def main():
             entries += [e for e in old.get("entries", []) if e.get("kind") == "wgrad"]
             meta["wgrad_entries_from"] = os.path.basename(args.keep_wgrad_from)
         meta["filter_planes"] = bool(args.planes)
-        meta.update(model=f"yolo_nas_{args.model}", batch=args.batch, size=args.size, conv_math=K.get_conv_math())
+        meta.update(model=args.model if args.model.startswith(("resnet", "ppyoloe")) else f"yolo_nas_{args.model}", batch=args.batch, size=args.size, conv_math=K.get_conv_math())
         json.dump(dict(meta=meta, entries=entries), open(args.emit_table, "w"), indent=1)
         print(f"# tuning table: {len(entries)} of {len(agg)} problems, {meta['ms_per_step_heuristic']} -> {meta['ms_per_step_table']} ms/step -> {args.emit_table}")
 
