@@ -391,6 +391,12 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
     unsigned long long amask[AJ];
     bool bok[WPL ? 1 : BJ];
     int wp_lane = 0, wp_lds = 0, wp_rows = 0;  // WPL: planes byte offset / LDS dword offset of this lane's place in a 16-row block; filter rows from n0 on
+    // WPL = 1 (round 6): everything about a lane's j-th piece that does not change from slab to slab - which (plane, 16-row block) its wave
+    // copies, whether its row exists, the planes offset of that place at (tap 0, chunk 0) - is formed ONCE per source; per slab the load adds
+    // the slab's wave-uniform (tap, chunk) offset through the instruction's scalar offset.  (The loop used to recompute it for every
+    // slab: three signed divisions by the block count, the row predicates and their exec-mask juggling - 45 of the loop's 75 scalar and 6 of
+    // its 69 vector instructions per slab, in a loop that issues 12 MFMAs; ISA of igemm_kernel<64,64,2,2,false,1,32,1,0,1>.)
+    unsigned wp_voff[(WPL == 1) ? BJ : 1];
     int Tw_, T_, nkt, pixstep, rowstep;
     const int cpt = (p.C + KD - 1) / KD;
     // scalar slab state of the NEXT slab to load (non-FLAT): tap row, tap column, channel chunk
@@ -440,6 +446,14 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
                 wp_lane = (oct >> 1) * 3 * Th * Tw * wp_tapstep + (n0 + lrow16) * 32 + (oct & 1) * 16;
                 wp_lds = lrow16 * LDPW + ((oct ^ ((lrow16 >> 2) & 3)) << 2);  // swz(row, oct * 4): a block starts at a multiple of 16 rows
                 wp_rows = p.Nout - n0 - lrow16;                               // this lane's row of block b exists if 16 b < wp_rows
+                const int wv = sgx_uniform_i32(tid >> 6);
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) {
+                    const int blk = wv + (NTH / 64) * j;             // (plane, 16-row block) of this wave's j-th piece
+                    const int plane = blk / WBK, rb16 = (blk - plane * WBK) * 16;
+                    const bool ok = (BPI % NTH == 0 || blk < 3 * WBK) && rb16 < wp_rows;
+                    wp_voff[(WPL == 1) ? j : 0] = ok ? (unsigned)(wp_lane + plane * Th * Tw * wp_tapstep + rb16 * 32) : SGX_BUF_OOB;
+                }
             }
         } else {
 #pragma unroll
@@ -515,15 +529,9 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
             if constexpr (WPR) {
                 wp_woff = woff;  // the fragments of this slab are fetched by load_bfrags, behind the MFMAs that read the current ones
             } else if constexpr (WPL) {
-                const int wv = sgx_uniform_i32(tid >> 6);
                 if (!lab_noload) {
 #pragma unroll
-                for (int j = 0; j < BJ; ++j) {
-                    const int blk = wv + (NTH / 64) * j;             // (plane, 16-row block) of this wave's j-th piece
-                    const int plane = blk / WBK, rb16 = (blk - plane * WBK) * 16;
-                    const bool ok = live && (BPI % NTH == 0 || blk < 3 * WBK) && rb16 < wp_rows;
-                    rb[j] = sgx_buf_ld4(bufB, ok ? (unsigned)(wp_lane + woff + plane * T_ * wp_tapstep + rb16 * 32) : SGX_BUF_OOB);
-                }
+                for (int j = 0; j < BJ; ++j) rb[j] = sgx_buf_ld4_so(bufB, live ? wp_voff[(WPL == 1) ? j : 0] : SGX_BUF_OOB, (unsigned)woff);
                 }
             } else {
 #pragma unroll

@@ -115,6 +115,13 @@ static inline float4 sgx_buf_ld4(const sgx_buf& b, unsigned off) {
     if (off < b.bytes && off + 16u <= b.bytes) memcpy(&v, b.base + off, 16);
     return v;
 }
+// per-lane offset + a wave-uniform offset (the hardware form below: voffset VGPR + soffset SGPR, no vector add; the bounds check of a raw
+// buffer looks at the per-lane offset alone, so a lane masked with SGX_BUF_OOB stays masked whatever soff is)
+static inline float4 sgx_buf_ld4_so(const sgx_buf& b, unsigned voff, unsigned soff) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (voff < b.bytes && (unsigned long long)voff + soff + 16ull <= b.bytes) memcpy(&v, b.base + voff + soff, 16);
+    return v;
+}
 static inline uint4 sgx_buf_ld4u(const sgx_buf& b, unsigned off) {
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (off < b.bytes && off + 16u <= b.bytes) memcpy(&v, b.base + off, 16);
@@ -130,6 +137,15 @@ __device__ __forceinline__ float4 sgx_buf_ld4(sgx_buf b, unsigned off) {
     typedef unsigned int sgx_u32x4 __attribute__((ext_vector_type(4)));
     sgx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 0);
     // bit-cast the WHOLE vector: hipcc (ROCm 7.2) narrows the load to one dword when the lanes are bit-cast one by one
+    sgx_f32x4 f = __builtin_bit_cast(sgx_f32x4, v);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+// per-lane offset (VGPR) + wave-uniform offset (SGPR, the instruction's soffset): no vector add per load.  A raw buffer's range check is
+// made on the per-lane offset (+ the instruction's immediate) alone - SGX_BUF_OOB in `voff` masks the lane whatever `soff` is; callers keep
+// voff + soff inside the buffer for the lanes that are not masked.
+__device__ __forceinline__ float4 sgx_buf_ld4_so(sgx_buf b, unsigned voff, unsigned soff) {
+    typedef unsigned int sgx_u32x4 __attribute__((ext_vector_type(4)));
+    sgx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, 0);
     sgx_f32x4 f = __builtin_bit_cast(sgx_f32x4, v);
     return make_float4(f.x, f.y, f.z, f.w);
 }
