@@ -308,8 +308,10 @@ extern "C" int32_t sgx_debug_set_igemm_lab(int32_t bits) {
 #ifndef IG_WPR_MIN_WAVES_6464
 #define IG_WPR_MIN_WAVES_6464 4  // (5 - round 5 - spilled 4 dwords)
 #endif
-template <int BM, int BN, int WM, int WN, int MATH, int KD, int PH2, int NBUF, int WPL = 0>
+template <int BM, int BN, int WM, int WN, int MATH, int KD, int PH2, int NBUF, int WPL = 0, int PP = 0>
 constexpr int igemm_min_waves() {
+    // (ping-pong form: 512-thread workgroups, two per CU by their LDS - four waves per SIMD, 128 registers)
+    if (PP) return 4;
     // Round 6: NO instantiation that a launch can select may spill (tools/kernel_regs.py --check, tests/test_tools.py): round 5 shipped the
     // two-source 64x64 form at 96 registers with 7 spilled dwords (6 launches per step), the register-fragment forms with 1-4.  A bound is
     // lowered by one wave wherever the allocation under it spilled.
@@ -321,9 +323,19 @@ constexpr int igemm_min_waves() {
     // (the two-source form carries a second source's offsets and masks: four waves - 128 registers - is what it fits without spilling)
     return (MATH == 1 && KD == 32 && PH2 <= IG_BF3_MIN_WAVES_PH2 && BM / (WM * 32) == 1 && BN / (WN * 32) == 1) ? (PH2 == 1 ? IG_BF3_MIN_WAVES - 1 : IG_BF3_MIN_WAVES) : 1;
 }
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, int WPL = 0>
-__global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2, NBUF, WPL>())) void igemm_kernel(IgemmParams p) {
+// PP = 1 (round 6, "ping-pong"): a 512-thread workgroup is TWO wave groups of WM x WN waves, each with its own output tile, LDS slabs and
+// epilogue scratch, running the one-buffer loop's two phases of a slab - STAGE (wait for the slab's loads, split, LDS stores, issue the
+// next slab's loads) and COMPUTE (fragment reads + MFMAs) - half a period apart: while group 0 computes slab k, group 1 stages its slab k,
+// and vice versa, one workgroup-wide barrier per phase.  Why: the ablation lab (profiles/r6c_igemm_ablation_*.txt) has the staging-only
+// and the compute-only versions of a launch at ~0.63 of the whole launch EACH - five independent workgroups per CU do not overlap their
+// phases (they convoy: loads return together, everybody splits together, everybody queues for the matrix pipe together); here the
+// complementary pairing (matrix beside memory / vector work on every SIMD, MI355X_MICROARCH.md "Two waves per SIMD") is by construction.
+// Same products in the same order per tile as PP = 0: bit-identical results.
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, int WPL = 0, int PP = 0>
+__global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2, NBUF, WPL, PP>())) void igemm_kernel(IgemmParams p) {
     static_assert(!WPL || (MATH == 1 && KD == 32 && NBUF == 1 && !FLAT), "pre-split filter planes: the one-buffer 32-deep bf16x3 loop");
+    static_assert(!PP || (MATH == 1 && KD == 32 && NBUF == 1 && !FLAT && PH2 == 0 && WPL <= 1), "ping-pong: the one-buffer 32-deep bf16x3 loop, one source");
+    constexpr int G = PP ? 2 : 1;  // wave groups (tiles) per workgroup
     static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && NBUF == 1) || (KD == 32 && !FLAT && NBUF == 2 && MATH == 1) ||
                       (KD == 32 && !FLAT && NBUF == 3 && MATH == 0 && PH2 == 0),
                   "32-deep slabs: channel-chunked K axis; one LDS buffer, (bf16x3) the two-buffer pipelined loop, or (fp32, NBUF = 3) all slabs up front");
@@ -361,23 +373,34 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
     // distinct 4-bank groups - 32-byte rows: halves swapped on rows with bit 3 set; 64-byte rows: chunk ^= row bits 2-3
     auto swz = [](int row, int dw) { return KD == 16 ? IG_SWZ(row, dw) : (dw ^ (((row >> 2) & 3) << 2)); };
     constexpr int SLABS = LBUF * (BM + (WPR ? 0 : BN)) * ROWW, STAGE = WM * WN * 32 * 32;   // operand slabs; epilogue staging patches (reuse the slabs)
-    __shared__ __attribute__((aligned(16))) float smem[SLABS > STAGE ? SLABS : STAGE];
-    float* const As = smem;
-    float* const Bs = smem + LBUF * BM * ROWW;
-    __shared__ long long rowoff[BM];
+    constexpr int SMEM1 = SLABS > STAGE ? SLABS : STAGE;
+    __shared__ __attribute__((aligned(16))) float smem_s[G * SMEM1];
+    __shared__ long long rowoff_s[G][BM];
     __shared__ long long rowoff2[PH2 == 1 ? BM : 1];  // offsets into addend2 (two-source data gradient only)
-    __shared__ long long rowoffT[PH2 == 2 ? 1 : SGX_MAX_BN_REQ][PH2 == 2 ? 1 : BM];  // offsets into the requests' saved conv outputs
-    __shared__ float red[(PH2 == 2 ? 5 : 2) * WM * BN];
+    __shared__ long long rowoffT_s[G][PH2 == 2 ? 1 : SGX_MAX_BN_REQ][PH2 == 2 ? 1 : BM];  // offsets into the requests' saved conv outputs
+    __shared__ float red_s[G][(PH2 == 2 ? 5 : 2) * WM * BN];
 
-    const int tid = threadIdx.x;
+    // (PP: everything below is written for ONE wave group - `tid`, `wave` count inside the group, the LDS objects are the group's own)
+    const int grp = PP ? (int)threadIdx.x / NTH : 0;
+    const int tid = PP ? (int)threadIdx.x - grp * NTH : (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    float* const smem = smem_s + grp * SMEM1;
+    float* const As = smem;
+    float* const Bs = smem + LBUF * BM * ROWW;
+    long long* const rowoff = rowoff_s[grp];
+    auto rowoffT = rowoffT_s[grp];
+    float* const red = red_s[grp];
 
     // XCD-aware tile assignment (block b runs on XCD b%8; give each XCD a contiguous run of tiles)
     const int bid = blockIdx.x;
-    const int lin = (bid & 7) * p.chunk + (bid >> 3);
-    if (lin >= p.nblk) return;  // whole workgroup leaves together (before any barrier)
+    const int lin0 = ((bid & 7) * p.chunk + (bid >> 3)) * G;
+    if (lin0 >= p.nblk) return;  // whole workgroup leaves together (before any barrier)
+    // (PP: an odd tile count leaves the last workgroup's second group without a tile - it repeats the first group's and writes nothing: the
+    // barriers of both groups must match)
+    const bool active = lin0 + grp < p.nblk;
+    const int lin = active ? lin0 + grp : lin0;
     const int mtile = sgx_fdiv(lin, p.fd_nt), ntile = lin - mtile * p.nt;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int hw = p.Ha * p.Wa;
@@ -478,7 +501,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
       if (tid < BM) {
         const int m = m0 + tid;
         long long off = -1;
-        if (m < p.M) {
+        if ((!PP || active) && m < p.M) {
             const int img = sgx_fdiv(m, p.fd_hw);
             const int rem = m - img * hw;
             const int a = sgx_fdiv(rem, p.fd_wa);
@@ -862,6 +885,30 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
             }
             continue;
         }
+        if constexpr (PP != 0) {
+            // ---- round 6: the ping-pong loop.  Phase ph: group g is at q = ph - g of its own sequence STAGE(0) COMPUTE(0) STAGE(1) COMPUTE(1) ...
+            // (even q: stage slab q / 2 out of the registers and issue the loads of slab q / 2 + 1; odd q: the MFMAs of slab q / 2) - the
+            // groups are one phase apart, so every phase pairs one group's matrix work with the other's memory / vector work; one
+            // workgroup-wide barrier per phase orders a group's own LDS hand-overs (stores -> reads -> next stores).  Group 0 idles in the
+            // last phase, group 1 in the first: both then run the epilogue with matching barriers.
+            if (nkt > 0) load_tile();
+            compute_rowoff();
+            const int nph = 2 * nkt + 1;
+            for (int ph = 0; ph < nph; ++ph) {
+                const int q = ph - grp;
+                if (q >= 0 && q < 2 * nkt) {
+                    if ((q & 1) == 0) {
+                        if (!IGL(2) || q == 0) store_tile(0);
+                        if ((q >> 1) + 1 < nkt) load_tile();
+                    } else if (!IGL(4)) {
+                        compute_bf3(0, 0);
+                        compute_bf3(0, 1);
+                    }
+                }
+                __syncthreads();
+            }
+            continue;
+        }
         if (nkt > 0) load_tile();
         if constexpr (WPR) {
             if (nkt > 0) {
@@ -1100,7 +1147,7 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_min_waves<BM, BN, WM, WN, MATH
     }
     if (p.stat_partials || p.nreq > 0) {
         __syncthreads();
-        if (tid < BN) {
+        if (tid < BN && (!PP || active)) {
             int col = n0 + tid;
             if (col < p.Nout) {
                 float s = 0.f, q = 0.f;
@@ -1789,7 +1836,7 @@ extern "C" int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n) {
                               (e[9] == 0) == (e[10] == 0),  // all 16 tiles of {32, 64, 96, 128}^2 are instantiated
                           "conv_tuning_load: entry %d: no weight-gradient kernel (tile %dx%d, split target %d)", i, e[9], e[10], e[11]);
         else
-            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && (e[11] == 0 || e[11] == 6 || e[11] == 7 || e[11] == 11 || e[11] == 12),
+            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && (e[11] == 0 || e[11] == 6 || e[11] == 7 || e[11] == 11 || e[11] == 12 || e[11] == 14),
                           "conv_tuning_load: entry %d: no kernel (tile %dx%d, variant %d)", i, e[9], e[10], e[11]);
         m[std::array<int, 9>{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8]}] = TuneVal{e[9], e[10], e[11]};
     }
@@ -1857,12 +1904,12 @@ static bool igemm_deep_slabs(const IgemmParams& p) { return conv_variant() != 7 
         else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);     \
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (two sources): no tile %dx%d", bm, bn);                                \
     } while (0)
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, int WPL = 0>
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, int WPL = 0, int PP = 0>
 static void launch_igemm(IgemmParams& p, void* stream) {
     p.mt = sgx_cdiv(p.M, BM);
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
-    p.chunk = sgx_cdiv(p.nblk, 8);
+    p.chunk = sgx_cdiv(PP ? sgx_cdiv(p.nblk, 2) : p.nblk, 8);  // (PP: a workgroup owns two consecutive tiles)
     p.fd_nt = sgx_make_fastdiv(p.nt);
     p.fd_hw = sgx_make_fastdiv(p.Ha * p.Wa);
     p.fd_wa = sgx_make_fastdiv(p.Wa);
@@ -1870,7 +1917,7 @@ static void launch_igemm(IgemmParams& p, void* stream) {
 #ifdef SGX_IGEMM_LAB
     p.lab = g_ig_lab.load(std::memory_order_relaxed);
 #endif
-    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF, PH2, WPL>), dim3(grid), dim3(WM * WN * 64), 0, stream, p);
+    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF, PH2, WPL, PP>), dim3(grid), dim3(WM * WN * 64 * (PP ? 2 : 1)), 0, stream, p);
 }
 
 // ---- pconv dispatch ------------------------------------------------------------------------------------------------------------------
@@ -2143,6 +2190,12 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
             if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 1, 32, 2, 0>(p, stream);
             else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 1, 32, 2, 0>(p, stream);
             else launch_igemm<64, 32, 2, 1, false, 1, 32, 2, 0>(p, stream);
+        } else if (igemm_deep_slabs(p) && p.Wp && conv_variant() == 14 && ((bm == 64 && bn == 64) || (bm == 128 && bn == 32) || (bm == 64 && bn == 32))) {
+            // the ping-pong loop (round 6; variant 14): two tiles per 512-thread workgroup, staging and matrix phases half a period apart
+            g_fp_hits.fetch_add(1, std::memory_order_relaxed);
+            if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 1, 32, 1, 0, 1, 1>(p, stream);
+            else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 1, 32, 1, 0, 1, 1>(p, stream);
+            else launch_igemm<64, 32, 2, 1, false, 1, 32, 1, 0, 1, 1>(p, stream);
         } else if (igemm_deep_slabs(p) && p.Wp) {
             g_fp_hits.fetch_add(1, std::memory_order_relaxed);
             // register fragments: mode 2, or the problem's tuning-table variant 12 (tools/conv_tune.py measures both forms per problem)

@@ -1803,7 +1803,8 @@ def _wt_filters(w, wtb, stride, pad):
     return [(r.wt, r.C, r.T, r.K) for r in (_lib.WtransJob * n).from_buffer_copy(raw)]
 
 
-@pytest.mark.parametrize("case", ["patch32", "patch64", "gemm1x1", "gemm3x3s2", "qarep_s1", "qarep_s2", "gemm1x1-regs", "gemm3x3s2-regs", "qarep_s2-regs"])
+@pytest.mark.parametrize("case", ["patch32", "patch64", "gemm1x1", "gemm3x3s2", "qarep_s1", "qarep_s2", "gemm1x1-regs", "gemm3x3s2-regs", "qarep_s2-regs",
+                                  "gemm1x1-pp", "gemm3x3s2-pp"])
 def test_filter_planes_launches_are_bit_identical(backend, case):
     """Pre-split filter planes (sgx_filter_planes_batch; round 5): a bf16x3 launch that copies its filter's planes must produce exactly the
     bits of the launch that splits the fp32 filter while staging - forward, data gradient (through the transposed filters' planes) and the
@@ -1814,6 +1815,9 @@ def test_filter_planes_launches_are_bit_identical(backend, case):
     gpu = backend.type == "cuda"
     # "-regs": planes mode 2 - the GEMM loop's one-block-per-wave tiles read their filter fragments straight from the planes into registers
     mode = 2 if case.endswith("-regs") else 1
+    # "-pp" (round 6): conv variant 14 - the ping-pong GEMM loop (two tiles per 512-thread workgroup, staging and matrix phases half a period
+    # apart; both shapes have an ODD tile count: the last workgroup's second wave group runs without a tile of its own)
+    pp = case.endswith("-pp")
     if not gpu and case == "gemm1x1-regs":
         pytest.skip("host emulation: the register-fragment form is covered by the 3x3 stride-2 and two-source cases (CPU suite time)")
     case = case.split("-")[0]
@@ -1850,7 +1854,7 @@ def test_filter_planes_launches_are_bit_identical(backend, case):
         return [y, parts, dx]
 
     K.set_conv_math("patch_bf3")
-    lib().sgx_debug_set_variant(0 if gpu else 9)  # (host emulation: small maps - variant 9 lifts the patch kernel's 40 x 40 floor)
+    lib().sgx_debug_set_variant(14 if pp else 0 if gpu else 9)  # (host emulation: small maps - variant 9 lifts the patch kernel's 40 x 40 floor)
     lib().sgx_debug_set_filter_planes(mode)
     jobs = None
     try:

@@ -139,6 +139,15 @@ def main():
                     note(key, calls, (bm, bn, 12), t)
                     if t < best:
                         best, best_cfg = t, ("heuristic tile" if bm == 0 else f"bm={bm} bn={bn}") + " variant=12"
+                # variant 14 (round 6): the ping-pong loop - two tiles per 512-thread workgroup, staging and matrix phases half a period apart
+                lib().sgx_debug_set_variant(14)
+                for bm, bn in ((64, 64), (128, 32), (64, 32)):
+                    lib().sgx_debug_set_tiles(bm, bn, 0, 0, 0)
+                    K.clear_desc_cache()
+                    t = timeit(fn)
+                    note(key, calls, (bm, bn, 14), t)
+                    if t < best:
+                        best, best_cfg = t, f"bm={bm} bn={bn} variant=14"
             lib().sgx_debug_set_variant(0)
         elif args.wgrad:
             note(key, calls, (0, 0, 0), base)
