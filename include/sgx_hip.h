@@ -555,6 +555,8 @@ int32_t sgx_debug_set_nms_split(int32_t on);
 /* Candidate selection of the multi-label path: 1 (default) = one pass over the scores behind a threshold estimated from a 1/32 sample (exact:
  * stage 2 falls back to streaming an image whose list came out short or overflowed), 0 = the exact three-pass histogram selection. */
 int32_t sgx_debug_set_nms_selection(int32_t sampled);
+/* measurement: bytes of dynamic LDS (0 .. 32768) added to every implicit-GEMM launch - an occupancy cap without another kernel build */
+int32_t sgx_debug_set_igemm_lds_pad(int32_t bytes);
 /* Where a multi-label sgx_nms call with a workspace records, per image, that stage 2 fell back from stage 1's candidate list to streaming
  * the image's raw scores (exact rows either way, many times slower): int32 index offset_ints + b * stride_ints of the call's workspace
  * holds 1 / 0 for image b once the call's stream work is complete.  Benches and tests assert it stays 0 on their inputs.     */

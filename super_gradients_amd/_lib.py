@@ -143,6 +143,7 @@ PROTOTYPES = {
     "sgx_stream_destroy": (_i32, [ctypes.c_void_p]),
     "sgx_debug_set_nms_split": (_i32, [_i32]),
     "sgx_debug_set_nms_selection": (_i32, [_i32]),
+    "sgx_debug_set_igemm_lds_pad": (_i32, [_i32]),
     "sgx_debug_nms_fallback_slot": (_i32, [_P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)]),
     "sgx_convT2x2_workspace": (_i64, [_i32] * 5),
     "sgx_convT2x2_fwd": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _P, _i64, _i64, _P, _i64, _P]),

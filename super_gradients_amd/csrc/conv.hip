@@ -308,12 +308,10 @@ extern "C" int32_t sgx_debug_set_igemm_lab(int32_t bits) {
 #ifndef IG_WPR_MIN_WAVES_6464
 #define IG_WPR_MIN_WAVES_6464 4  // (5 - round 5 - spilled 4 dwords)
 #endif
-template <int BM, int BN, int WM, int WN, int MATH, int KD, int PH2, int NBUF, int WPL = 0, int PP = 0, int FA = 0>
+template <int BM, int BN, int WM, int WN, int MATH, int KD, int PH2, int NBUF, int WPL = 0, int PP = 0>
 constexpr int igemm_min_waves() {
     // (ping-pong form: 512-thread workgroups, two per CU by their LDS - four waves per SIMD, 128 registers)
     if (PP) return 4;
-    // (fragments ahead: all twelve fragment reads of a slab in flight before its first MFMA - 48 fragment registers, four waves per SIMD)
-    if (FA) return 4;
     // Round 6: NO instantiation that a launch can select may spill (tools/kernel_regs.py --check, tests/test_tools.py): round 5 shipped the
     // two-source 64x64 form at 96 registers with 7 spilled dwords (6 launches per step), the register-fragment forms with 1-4.  A bound is
     // lowered by one wave wherever the allocation under it spilled.
@@ -333,9 +331,8 @@ constexpr int igemm_min_waves() {
 // phases (they convoy: loads return together, everybody splits together, everybody queues for the matrix pipe together); here the
 // complementary pairing (matrix beside memory / vector work on every SIMD, MI355X_MICROARCH.md "Two waves per SIMD") is by construction.
 // Same products in the same order per tile as PP = 0: bit-identical results.
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, int WPL = 0, int PP = 0, int FA = 0>
-__global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2, NBUF, WPL, PP, FA>())) void igemm_kernel(IgemmParams p) {
-    static_assert(!FA || (MATH == 1 && KD == 32 && NBUF == 1 && !FLAT && PH2 == 0 && WPL == 1 && BM / (WM * 32) == 1 && BN / (WN * 32) == 1), "fragments ahead: the one-block-per-wave planes loop");
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, int WPL = 0, int PP = 0>
+__global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2, NBUF, WPL, PP>())) void igemm_kernel(IgemmParams p) {
     static_assert(!WPL || (MATH == 1 && KD == 32 && NBUF == 1 && !FLAT), "pre-split filter planes: the one-buffer 32-deep bf16x3 loop");
     static_assert(!PP || (MATH == 1 && KD == 32 && NBUF == 1 && !FLAT && PH2 == 0 && WPL <= 1), "ping-pong: the one-buffer 32-deep bf16x3 loop, one source");
     constexpr int G = PP ? 2 : 1;  // wave groups (tiles) per workgroup
@@ -717,33 +714,6 @@ __global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (igemm_min_waves<BM, B
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = sgx_mfma_bf16(ah[i], bh[j], acc[i][j]);
     };
-    // FA (round 6, conv variant 15): the twelve fragment reads of a slab are issued TOGETHER, ahead of its twelve MFMAs (the shipped loop's
-    // five-wave register bound leaves four fragment registers sets: its reads are issued just in time, six lgkmcnt waits per slab, each an LDS
-    // round trip in front of the matrix pipe).  Same products in the same order: bit-identical.
-    auto compute_bf3_ahead = [&](int buf) {
-        uint4 fa[2][3], fb[2][3];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const unsigned* sa = reinterpret_cast<const unsigned*>(As) + (buf * 3 * BM + wm * TM * 32 + frow) * LDPW + swz(frow, half * 8 + (lane >> 5) * 4);
-            const unsigned* sb = reinterpret_cast<const unsigned*>(Bs) + (buf * 3 * BN + wn * TN * 32 + frow) * LDPW + swz(frow, half * 8 + (lane >> 5) * 4);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                fa[half][pl] = *reinterpret_cast<const uint4*>(sa + pl * BM * LDPW);
-                fb[half][pl] = *reinterpret_cast<const uint4*>(sb + pl * BN * LDPW);
-            }
-        }
-        sgx_sched_fence();
-        sgx_f32x16& cc = accc[0][0];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            cc = sgx_mfma_bf16(fa[half][2], fb[half][0], cc);
-            cc = sgx_mfma_bf16(fa[half][0], fb[half][2], cc);
-            cc = sgx_mfma_bf16(fa[half][1], fb[half][1], cc);
-            cc = sgx_mfma_bf16(fa[half][1], fb[half][0], cc);
-            cc = sgx_mfma_bf16(fa[half][0], fb[half][1], cc);
-            acc[0][0] = sgx_mfma_bf16(fa[half][0], fb[half][0], acc[0][0]);
-        }
-    };
     // fp32 arithmetic: fragments of one 16-deep step (columns kofs .. kofs+15 of the slab) and its 8 x TM x TN MFMAs
     auto compute_f32 = [&](int buf, int kofs) {
         float af[TM][8], bf[TN][8];
@@ -961,11 +931,8 @@ __global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (igemm_min_waves<BM, B
                     if (kt + 1 < nkt) load_bfrags(1);
                 } else if (BF3) {
                     if (!IGL(4)) {
-                        if constexpr (FA != 0) compute_bf3_ahead(0);
-                        else {
-                            compute_bf3(0, 0);
-                            compute_bf3(0, 1);
-                        }
+                        compute_bf3(0, 0);
+                        compute_bf3(0, 1);
                     }
                 } else {
                     compute_f32(0, 0);
@@ -1869,7 +1836,7 @@ extern "C" int32_t sgx_conv_tuning_load(const int32_t* entries, int32_t n) {
                               (e[9] == 0) == (e[10] == 0),  // all 16 tiles of {32, 64, 96, 128}^2 are instantiated
                           "conv_tuning_load: entry %d: no weight-gradient kernel (tile %dx%d, split target %d)", i, e[9], e[10], e[11]);
         else
-            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && (e[11] == 0 || e[11] == 6 || e[11] == 7 || e[11] == 11 || e[11] == 12 || e[11] == 14 || e[11] == 15),
+            SGX_CHECK_ARG((e[9] == 0 || e[9] == 64 || e[9] == 128) && wide && (e[11] == 0 || e[11] == 6 || e[11] == 7 || e[11] == 11 || e[11] == 12 || e[11] == 14),
                           "conv_tuning_load: entry %d: no kernel (tile %dx%d, variant %d)", i, e[9], e[10], e[11]);
         m[std::array<int, 9>{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8]}] = TuneVal{e[9], e[10], e[11]};
     }
@@ -1937,7 +1904,14 @@ static bool igemm_deep_slabs(const IgemmParams& p) { return conv_variant() != 7 
         else if (bm == 64 && bn == 32) launch_igemm<64, 32, 2, 1, false, MATH_, KD_, NBUF_, PH2_, WPL_>(p, stream);     \
         else SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (two sources): no tile %dx%d", bm, bn);                                \
     } while (0)
-template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, int WPL = 0, int PP = 0, int FA = 0>
+// measurement: dynamic LDS added to every implicit-GEMM launch (bytes, <= 32 KB) - fewer workgroups per CU without touching the kernel
+static std::atomic<int> g_ig_lds_pad{0};
+extern "C" int32_t sgx_debug_set_igemm_lds_pad(int32_t bytes) {
+    SGX_CHECK_ARG(bytes >= 0 && bytes <= 32768, "igemm LDS pad %d (0 .. 32768 bytes)", bytes);
+    g_ig_lds_pad = bytes;
+    return SGX_OK;
+}
+template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, int WPL = 0, int PP = 0>
 static void launch_igemm(IgemmParams& p, void* stream) {
     p.mt = sgx_cdiv(p.M, BM);
     p.nt = sgx_cdiv(p.Nout, BN);
@@ -1950,7 +1924,7 @@ static void launch_igemm(IgemmParams& p, void* stream) {
 #ifdef SGX_IGEMM_LAB
     p.lab = g_ig_lab.load(std::memory_order_relaxed);
 #endif
-    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF, PH2, WPL, PP, FA>), dim3(grid), dim3(WM * WN * 64 * (PP ? 2 : 1)), 0, stream, p);
+    SGX_LAUNCH((igemm_kernel<BM, BN, WM, WN, FLAT, MATH, KD, NBUF, PH2, WPL, PP>), dim3(grid), dim3(WM * WN * 64 * (PP ? 2 : 1)), (size_t)g_ig_lds_pad.load(std::memory_order_relaxed), stream, p);
 }
 
 // ---- pconv dispatch ------------------------------------------------------------------------------------------------------------------
@@ -2229,11 +2203,6 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
             if (bm == 64 && bn == 64) launch_igemm<64, 64, 2, 2, false, 1, 32, 1, 0, 1, 1>(p, stream);
             else if (bm == 128 && bn == 32) launch_igemm<128, 32, 4, 1, false, 1, 32, 1, 0, 1, 1>(p, stream);
             else launch_igemm<64, 32, 2, 1, false, 1, 32, 1, 0, 1, 1>(p, stream);
-        } else if (igemm_deep_slabs(p) && p.Wp && conv_variant() == 15 && bm == 64 && bn == 64) {
-            // fragments ahead (round 6; variant 15): the slab's twelve fragment reads in flight before its first MFMA, four waves per SIMD
-            // (the 128 x 32 and 64 x 32 tiles spill under that bound: 64 x 64 only)
-            g_fp_hits.fetch_add(1, std::memory_order_relaxed);
-            launch_igemm<64, 64, 2, 2, false, 1, 32, 1, 0, 1, 0, 1>(p, stream);
         } else if (igemm_deep_slabs(p) && p.Wp) {
             g_fp_hits.fetch_add(1, std::memory_order_relaxed);
             // register fragments: mode 2, or the problem's tuning-table variant 12 (tools/conv_tune.py measures both forms per problem)

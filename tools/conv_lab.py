@@ -32,6 +32,7 @@ def main():
                     "filters are split once, the step's scope is open for the whole run; data gradients then use the pre-transposed-weights entry point)")
     ap.add_argument("--ablate", default=None, help="comma list of ablation bit sets of a -DSGX_IGEMM_LAB build (sgx_debug_set_igemm_lab: 1 no global "
                     "loads, 2 no LDS stores, 4 no MFMAs, 8 no split, 16 no epilogue stores), crossed with the other axes; 0 = the whole kernel")
+    ap.add_argument("--ldspad", default=None, help="comma list of dynamic-LDS pads in KB (sgx_debug_set_igemm_lds_pad) crossed with the other axes: an occupancy cap")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import torch
@@ -45,8 +46,10 @@ def main():
     maths = args.math.split(",")
     planes = [int(v) for v in args.planes.split(",")] if args.planes else [None]
     ablate = [int(v) for v in args.ablate.split(",")] if args.ablate else [None]
+    if args.ldspad:  # (shares the ablation axis' slot: the two are not combined)
+        ablate = [-1024 * int(v) - 1 for v in args.ldspad.split(",")]
     configs = [(v, t, m, (pl, ab)) for m in maths for t in tiles for v in variants for pl in planes for ab in ablate]
-    lines = [f"{'problem':<34}" + "".join(f"{f'{m[:2]}{v}/{t[0]}x{t[1]}' + ('' if pl[0] is None else f'p{pl[0]}') + ('' if pl[1] is None else f'a{pl[1]}'):>16}" for v, t, m, pl in configs) + "   (TFLOP/s, median of rounds; us below)"]
+    lines = [f"{'problem':<34}" + "".join(f"{f'{m[:2]}{v}/{t[0]}x{t[1]}' + ('' if pl[0] is None else f'p{pl[0]}') + ('' if pl[1] is None else (f'L{-(pl[1] + 1) // 1024}' if pl[1] < 0 else f'a{pl[1]}')):>16}" for v, t, m, pl in configs) + "   (TFLOP/s, median of rounds; us below)"]
     for spec in args.problems.split(","):
         kind, n, h, w, c, k, r, s = spec.split(":")
         n, h, w, c, k, r, s = (int(a) for a in (n, h, w, c, k, r, s))
@@ -103,7 +106,9 @@ def main():
                 v, (bm, bn), m, (pl, ab) = cfg
                 if pl is not None:
                     lib().sgx_debug_set_filter_planes(pl)
-                if ab is not None:
+                if ab is not None and ab < 0:
+                    lib().sgx_debug_set_igemm_lds_pad(-(ab + 1))
+                elif ab is not None:
                     lib().sgx_debug_set_igemm_lab(ab)
                 K.set_conv_math(m)
                 lib().sgx_debug_set_variant(v)
@@ -122,7 +127,9 @@ def main():
                     res[cfg].append(float("nan"))
         lib().sgx_debug_set_variant(0)
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
-        if args.ablate:
+        if args.ldspad:
+            lib().sgx_debug_set_igemm_lds_pad(0)
+        elif args.ablate:
             lib().sgx_debug_set_igemm_lab(0)
         if args.planes:
             lib().sgx_debug_set_filter_planes(1)
