@@ -733,7 +733,7 @@ def main():
             torch.cuda.empty_cache()
             rec["other_configs"] = other_configs_leg(device, loss_check=not args.no_cpu_baseline or args.loss_check_only)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if dist.is_initialized():  # (world > 1, or the one-rank communicator of SGX_DIST_SINGLE_RANK_COLLECTIVES=1)
         dist_barrier()
         dist.destroy_process_group()
 

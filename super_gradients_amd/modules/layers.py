@@ -112,7 +112,9 @@ class BatchNorm(SgxBlock):
         pass
 
     def _synced(self):
-        return self.sync and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        from ..training.utils.distributed_training_utils import collectives_active
+
+        return self.sync and collectives_active()
 
     def scale_shift(self, parts, M, training):
         """-> (scale, shift, save_mean, save_invstd); eval mode folds the running statistics."""

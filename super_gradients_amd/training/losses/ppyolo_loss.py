@@ -27,7 +27,9 @@ class _PPYoloELossFn(torch.autograd.Function):
         static, vfl, w, world, sequential = cfg
         out = K.ppyoloe_loss_fwd(logits, distri, anchors, points, strides, targets, counts, static, vfl, w, sequential)
         sums = out["sums"]
-        if world > 1:
+        from ..utils.distributed_training_utils import collectives_active
+
+        if collectives_active():  # (more than one rank; or the single-rank communicator of the RCCL test, where the sum is an identity)
             torch.distributed.all_reduce(sums, op=torch.distributed.ReduceOp.SUM)
         items, inv = K.ppyoloe_loss_finalize(sums, w, float(world))
         ctx.save_for_backward(out["g_logits"], out["g_distri"], inv)

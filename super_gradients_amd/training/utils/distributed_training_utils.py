@@ -19,8 +19,18 @@ import torch
 import torch.distributed as dist
 
 
+def collectives_active() -> bool:
+    """A process group exists and its collectives are to be issued: more than one rank - or ONE rank with SGX_DIST_SINGLE_RANK_COLLECTIVES=1,
+    the switch of tests/test_distributed.py::test_rccl_single_rank_communicator: the whole data-parallel choreography (RCCL communicator,
+    bucket all-reduces issued from the side stream, the loss's 16-byte all-reduce, synchronised BatchNorm, buffer broadcasts) on the ONE
+    MI355X a test box has - every collective is then an identity, so the step must equal the non-distributed one."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("SGX_DIST_SINGLE_RANK_COLLECTIVES") == "1"
+
+
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return collectives_active()
 
 
 def get_world_size() -> int:
@@ -41,7 +51,7 @@ def setup_device_from_env(backend: str = None) -> Tuple[int, int, torch.device]:
     if has_gpu:
         torch.cuda.set_device(local)
     device = torch.device(f"cuda:{local}") if has_gpu else torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("SGX_DIST_SINGLE_RANK_COLLECTIVES") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend or ("nccl" if has_gpu else "gloo"), init_method="env://", rank=rank, world_size=world)
@@ -119,7 +129,7 @@ class GradientAllReducer:
 
     def ready(self, prefix: str):
         """Called by the network's backward right after the kernels of sub-network `prefix` have been enqueued."""
-        if self.world == 1 or not self.sync or prefix not in self.ranges or prefix in self.issued:
+        if not collectives_active() or not self.sync or prefix not in self.ranges or prefix in self.issued:
             return
         a, b = self.ranges[prefix]
         self.issued.add(prefix)
@@ -153,12 +163,12 @@ class GradientAllReducer:
         """What DistributedDataParallel(broadcast_buffers=True) - the reference's wrapping (sg_trainer.py:1352-1357, torch default) - does
         at the start of every training forward: BatchNorm running statistics and step counters of every rank are overwritten with rank
         `src`'s.  Two small collectives over the buffer arenas."""
-        if self.world > 1:
+        if collectives_active():
             dist.broadcast(self.net.b_arena.buf, src)
             dist.broadcast(self.net.i_arena, src)
 
     def broadcast_parameters(self, src: int = 0):
         """DDP-constructor semantics: every rank starts from rank `src`'s parameters and buffers."""
-        if self.world > 1:
+        if collectives_active():
             dist.broadcast(self.net.p_arena.buf, src)
             dist.broadcast(self.net.b_arena.buf, src)

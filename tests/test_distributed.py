@@ -304,3 +304,108 @@ def test_world_size_2_rccl(tmp_path):
         assert torch.allclose(r[i]["items"][:3], items, rtol=2e-5)
         assert torch.allclose(r[i]["sync_y"], r[0]["full_y"][i * 4:(i + 1) * 4], rtol=1e-4, atol=1e-5)
     assert torch.allclose(r[0]["sync_grad"], r[1]["sync_grad"], rtol=1e-6, atol=1e-7)
+
+
+def _worker_rccl_single(rank, world, port, outdir):
+    """ONE rank, a real RCCL communicator (SGX_DIST_SINGLE_RANK_COLLECTIVES=1 makes a one-rank group issue its collectives): what the
+    single-GPU test box can run of the data-parallel path - communicator creation, the parameter / buffer broadcasts, the bucket all-reduces
+    issued from the side stream while backward runs on the main one, the wait at the end of backward, the loss's 16-byte all-reduce,
+    synchronised BatchNorm's statistics exchange - with every collective an identity."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      SGX_DIST_SINGLE_RANK_COLLECTIVES="1")
+    import torch.distributed as dist
+
+    from super_gradients_amd import kernels as K
+    from super_gradients_amd.training.losses import CrossEntropyLoss, PPYoloELoss
+    from super_gradients_amd.training.utils import distributed_training_utils as DU
+    from super_gradients_amd.training.utils.distributed_training_utils import GradientAllReducer, setup_device_from_env
+    from test_trainer import _tiny_models
+    from oracle import golden_util as G
+    from oracle.yolo_nas import make_anchors
+
+    r, w, dev = setup_device_from_env()
+    assert (r, w) == (0, 1) and dev.type == "cuda" and dist.is_initialized() and dist.get_backend() == "nccl" and DU.collectives_active()
+    out = {}
+    ref, net = _tiny_models(dev)
+    net.materialize(dev).train()
+    g = torch.Generator().manual_seed(10)
+    x, y = torch.randn(4, 4, 8, 8, generator=g).to(dev), torch.randint(0, 4, (4,), generator=g).to(dev)
+    crit = CrossEntropyLoss()
+    net.zero_grad()
+    crit(net(x), y).backward()
+    torch.cuda.synchronize()
+    out["local"] = net.g_arena.buf.cpu().clone()
+    reducer = GradientAllReducer(net, net.gradient_buckets())
+    assert reducer.from_side and net.side_stream is not None
+    p0 = net.p_arena.buf.cpu().clone()
+    reducer.broadcast_parameters(0)
+    reducer.broadcast_buffers(0)
+    out["params_kept"] = bool(torch.equal(net.p_arena.buf.cpu(), p0))
+    issued = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (issued.append((t.numel(), torch.cuda.current_stream().cuda_stream)), orig(t, *a, **k))[1]
+    try:
+        net.zero_grad()
+        crit(net(x), y).backward()
+    finally:
+        dist.all_reduce = orig
+    torch.cuda.synchronize()
+    out["reduced"] = net.g_arena.buf.cpu().clone()
+    out["collectives"] = len(issued)
+    out["from_side_stream"] = all(s == net.side_stream.cuda_stream for _, s in issued)
+    out["covered"] = sum(n for n, _ in issued) == net.g_arena.size
+
+    def anchors(hw, strides):
+        a, pts, _pg, counts, strd = make_anchors(hw, strides)
+        return a, pts, counts, strd
+
+    preds = G.synthetic_predictions(2, [8, 4, 3], 8, 16, seed=30, make_anchors=anchors)
+    t = G.detection_targets(2, 64, seed=40, kmax=3, num_classes=8, empty_last=False)
+    dp = [p.to(dev) if torch.is_tensor(p) else p for p in preds]
+    _, items = PPYoloELoss(8, use_static_assigner=False)((None, tuple(dp)), t.to(dev))
+    out["items"] = items.cpu().clone()
+    os.environ["SGX_DIST_SINGLE_RANK_COLLECTIVES"] = "0"
+    _, items_local = PPYoloELoss(8, use_static_assigner=False)((None, tuple(dp)), t.to(dev))
+    out["items_local"] = items_local.cpu().clone()
+    os.environ["SGX_DIST_SINGLE_RANK_COLLECTIVES"] = "1"
+    # synchronised BatchNorm over one rank == the plain BatchNorm of the whole batch
+    _, snet = _tiny_models(dev)
+    snet.materialize(dev).train()
+    snet.set_sync_bn(True)
+    GradientAllReducer(snet, snet.gradient_buckets())
+    gfull = torch.Generator().manual_seed(77)
+    xfull, wfull = torch.randn(8, 4, 8, 8, generator=gfull), torch.randn(8, 6, generator=gfull)
+    ys = snet(xfull.to(dev))
+    (ys * wfull.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    out["sync_y"], out["sync_grad"] = ys.detach().cpu().clone(), snet.g_arena.buf.cpu().clone()
+    _, pnet = _tiny_models(dev)
+    pnet.materialize(dev).train()
+    yp = pnet(xfull.to(dev))
+    (yp * wfull.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    out["plain_y"], out["plain_grad"] = yp.detach().cpu().clone(), pnet.g_arena.buf.cpu().clone()
+    torch.save(out, os.path.join(outdir, "rccl_single.pt"))
+    DU.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_communicator(tmp_path):
+    """Rows a18 / e / f4 on the hardware a one-GPU box has: the data-parallel choreography over a REAL RCCL communicator of one rank (round
+    6; rounds 1 - 5 had only the gloo world-2 tests on the host emulation, and `test_world_size_2_rccl` skips without a second GPU).  Every
+    collective is an identity, so: the reduced gradient arena equals the local one bit for bit, the bucket all-reduces cover the arena and
+    were all issued from the side stream, the parameter / buffer broadcasts leave the arenas alone, the loss items equal the
+    non-distributed ones, synchronised BatchNorm equals plain BatchNorm.  Reference: sg_trainer.py:452-459, ppyolo_loss.py:971-977,
+    sg_trainer.py:1344-1350."""
+    port = 29900 + (os.getpid() % 2000)
+    mp.spawn(_worker_rccl_single, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(os.path.join(str(tmp_path), "rccl_single.pt"))
+    assert r["params_kept"]
+    assert r["collectives"] >= 2 and r["covered"] and r["from_side_stream"], r
+    assert torch.equal(r["reduced"], r["local"])
+    assert torch.allclose(r["items"], r["items_local"], rtol=1e-6, atol=0)
+    assert torch.allclose(r["sync_y"], r["plain_y"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(r["sync_grad"], r["plain_grad"], rtol=1e-4, atol=1e-6)
