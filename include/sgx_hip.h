@@ -610,6 +610,15 @@ int32_t sgx_hmaxpool_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, 
                          int64_t x_ld_img, void* y, int64_t y_ld_pix, int64_t y_ld_img, void* stream);
 /* M rows of C bf16 elements from one row-strided view into another (a skip tensor into its concat slice)                        */
 int32_t sgx_hcopy(const void* x, int64_t x_ld, int64_t M, int32_t C, void* y, int64_t y_ld, void* stream);
+/* PP-YOLOE's deployment form on bf16 (round 6): per-image channel means (adaptive_avg_pool2d of EffectiveSEBlock modules/se_blocks.py:39-42 and
+ * of the head, pp_yolo_head.py:203) as fp32 sums of bf16 activations in a fixed order; the channel gate x * f(pre[n][c]) (f: SGX_GATE_*) with
+ * the product in fp32 and one rounding to bf16; nearest x2 up-sampling (pp_yolo_e/pan.py:170) into a (slice of a) bf16 tensor.  Channel
+ * counts, strides (elements) and addresses: multiples of 8 elements.                                                                   */
+int32_t sgx_himage_colsum(int32_t N, int32_t HW, int32_t C, const void* x, int64_t x_ld_pix, int64_t x_ld_img, float scale, float* out, void* stream);
+int32_t sgx_hchannel_gate(int32_t N, int32_t HW, int32_t C, const void* x, int64_t x_ld_pix, int64_t x_ld_img, const float* pre, int32_t gate, void* y,
+                          int64_t y_ld_pix, int64_t y_ld_img, void* stream);
+int32_t sgx_hupsample2x_fwd(int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int64_t x_ld_pix, int64_t x_ld_img, void* y, int64_t y_ld_pix,
+                            int64_t y_ld_img, void* stream);
 /* fp32 rows [M][Cs] -> bf16 rows [M][Cd], Cd >= Cs, extra channels zero, round-to-nearest-even (the image batch at the entrance)  */
 int32_t sgx_cast_f32_bf16(const float* x, int64_t x_ld, int64_t M, int32_t Cs, void* y, int64_t y_ld, int32_t Cd, void* stream);
 /* Measurement aid: force the tile / slab depth of sgx_hconv2d_fwd (0 = heuristic)                                               */

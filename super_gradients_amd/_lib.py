@@ -124,6 +124,9 @@ PROTOTYPES = {
     "sgx_hconvT2x2_fwd": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _P, _i64, _i64, _P]),
     "sgx_hmaxpool_fwd": (_i32, [_i32] * 7 + [_P, _i64, _i64, _P, _i64, _i64, _P]),
     "sgx_hcopy": (_i32, [_P, _i64, _i64, _i32, _P, _i64, _P]),
+    "sgx_himage_colsum": (_i32, [_i32, _i32, _i32, _P, _i64, _i64, _f, _P, _P]),
+    "sgx_hchannel_gate": (_i32, [_i32, _i32, _i32, _P, _i64, _i64, _P, _i32, _P, _i64, _i64, _P]),
+    "sgx_hupsample2x_fwd": (_i32, [_i32, _i32, _i32, _i32, _P, _i64, _i64, _P, _i64, _i64, _P]),
     "sgx_cast_f32_bf16": (_i32, [_P, _i64, _i64, _i32, _P, _i64, _i32, _P]),
     "sgx_hconv_debug_set_tile": (_i32, [_i32] * 3),
     "sgx_conv2d_bwd_weight_workspace": (_i64, [_CD]),

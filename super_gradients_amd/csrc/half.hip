@@ -508,3 +508,111 @@ extern "C" int32_t sgx_cast_f32_bf16(const float* x, int64_t x_ld, int64_t M, in
     SGX_CHECK_LAUNCH("cast_f32_bf16");
     return SGX_OK;
 }
+
+// ---- PP-YOLOE's deployment form on bf16 (round 6): the three ops around its convolutions that YOLO-NAS does not have ------------------------
+// Reference: EffectiveSEBlock (modules/se_blocks.py:39-42: x * hardsigmoid(conv1x1(mean_hw(x)))), ESEAttn (pp_yolo_head.py:90-92: sigmoid),
+// adaptive_avg_pool2d (pp_yolo_head.py:203), F.interpolate(scale_factor=2, mode="nearest") (pp_yolo_e/pan.py:170).  Under torch.autocast the
+// reference keeps the mean in fp32 (autocast's fp32 list) and the gate product in the activation type: here the per-image channel means
+// are fp32 sums of the bf16 activations in a fixed order, the 1x1 convolution on the [N,1,1,C] means stays on the fp32 path (N x C values),
+// and the gate multiplies in fp32 and rounds once to bf16.
+__device__ __forceinline__ float hgate_fn(float p, int gate) {
+    if (gate == SGX_GATE_HARDSIGMOID) return fminf(fmaxf(p * (1.f / 6.f) + 0.5f, 0.f), 1.f);
+    if (gate == SGX_GATE_SIGMOID) return 1.f / (1.f + expf(-p));
+    return p;
+}
+// out[n][c] = scale * sum over the image's pixels: one workgroup per (image, 64 channels) - 8 channel octets x 32 pixel lanes, a lane walks
+// every 32nd pixel, the 32 partial sums of a channel fold through LDS in lane order (deterministic)
+__global__ __launch_bounds__(256) void hcolsum_kernel(int HW, int C, const unsigned short* x, long x_ld_pix, long x_ld_img, float scale, float* out) {
+    __shared__ float part[32][64 + 1];
+    const int img = blockIdx.y, c0 = blockIdx.x * 64;
+    const int oct = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c = c0 + oct * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const unsigned short* xp = x + (long)img * x_ld_img + c;
+        for (int p = pl; p < HW; p += 32) {
+            const uint4 v = *reinterpret_cast<const uint4*>(xp + (long)p * x_ld_pix);
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += sgx_u2f(u[e] << 16);
+                acc[2 * e + 1] += sgx_u2f(u[e] & 0xffff0000u);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[pl][oct * 8 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
+        float s = 0.f;
+        for (int q = 0; q < 32; ++q) s += part[q][threadIdx.x];
+        out[(long)img * C + c0 + threadIdx.x] = s * scale;
+    }
+}
+extern "C" int32_t sgx_himage_colsum(int32_t N, int32_t HW, int32_t C, const void* x, int64_t x_ld_pix, int64_t x_ld_img, float scale, float* out, void* stream) {
+    SGX_CHECK_ARG(x && out && N > 0 && HW > 0 && C > 0, "himage_colsum: bad args");
+    SGX_CHECK_ARG(C % 8 == 0 && x_ld_pix % 8 == 0 && x_ld_img % 8 == 0 && ((uintptr_t)x % 16) == 0, "himage_colsum: channel count / strides / address must be multiples of 8 elements (16 bytes)");
+    SGX_LAUNCH(hcolsum_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)N), dim3(256), 0, stream, HW, C, (const unsigned short*)x, (long)x_ld_pix, (long)x_ld_img, scale, out);
+    SGX_CHECK_LAUNCH("himage_colsum");
+    return SGX_OK;
+}
+// y = x * f(pre[n][c]): one thread per (pixel, 8 channels); the product in fp32, one rounding to bf16
+__global__ void hgate_kernel(int N, int HW, int C, const unsigned short* x, long x_ld_pix, long x_ld_img, const float* pre, int gate, unsigned short* y,
+                             long y_ld_pix, long y_ld_img) {
+    const int C8 = C / 8;
+    const long n = (long)N * HW * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8) * 8;
+        const long t = i / C8;
+        const int p = (int)(t % HW), img = (int)(t / HW);
+        const uint4 v = *reinterpret_cast<const uint4*>(x + (long)img * x_ld_img + (long)p * x_ld_pix + c);
+        const float* pp = pre + (long)img * C + c;
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+        float r[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r[2 * e] = sgx_u2f(u[e] << 16) * hgate_fn(pp[2 * e], gate);
+            r[2 * e + 1] = sgx_u2f(u[e] & 0xffff0000u) * hgate_fn(pp[2 * e + 1], gate);
+        }
+        uint4 o;
+        o.x = sgx_pack_bf16(r[0], r[1]); o.y = sgx_pack_bf16(r[2], r[3]); o.z = sgx_pack_bf16(r[4], r[5]); o.w = sgx_pack_bf16(r[6], r[7]);
+        *reinterpret_cast<uint4*>(y + (long)img * y_ld_img + (long)p * y_ld_pix + c) = o;
+    }
+}
+extern "C" int32_t sgx_hchannel_gate(int32_t N, int32_t HW, int32_t C, const void* x, int64_t x_ld_pix, int64_t x_ld_img, const float* pre, int32_t gate, void* y,
+                                     int64_t y_ld_pix, int64_t y_ld_img, void* stream) {
+    SGX_CHECK_ARG(x && y && pre && N > 0 && HW > 0 && C > 0, "hchannel_gate: bad args");
+    SGX_CHECK_ARG(gate >= SGX_GATE_NONE && gate <= SGX_GATE_SIGMOID, "hchannel_gate: unknown gate %d", gate);
+    SGX_CHECK_ARG(C % 8 == 0 && x_ld_pix % 8 == 0 && x_ld_img % 8 == 0 && y_ld_pix % 8 == 0 && y_ld_img % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0,
+                  "hchannel_gate: channel count / strides / addresses must be multiples of 8 elements (16 bytes)");
+    const long n = (long)N * HW * (C / 8), blocks = (n + 255) / 256;
+    SGX_LAUNCH(hgate_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, stream, N, HW, C, (const unsigned short*)x, (long)x_ld_pix, (long)x_ld_img, pre, gate,
+               (unsigned short*)y, (long)y_ld_pix, (long)y_ld_img);
+    SGX_CHECK_LAUNCH("hchannel_gate");
+    return SGX_OK;
+}
+// nearest x2 up-sampling: one thread per (OUTPUT pixel, 8 channels) - a copy
+__global__ void hupsample2x_kernel(int N, int H, int W, int C, const unsigned short* x, long x_ld_pix, long x_ld_img, unsigned short* y, long y_ld_pix, long y_ld_img) {
+    const int C8 = C / 8, W2 = 2 * W, H2 = 2 * H;
+    const long n = (long)N * H2 * W2 * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8) * 8;
+        long t = i / C8;
+        const int wo = (int)(t % W2);
+        t /= W2;
+        const int ho = (int)(t % H2), img = (int)(t / H2);
+        *reinterpret_cast<uint4*>(y + (long)img * y_ld_img + ((long)ho * W2 + wo) * y_ld_pix + c) =
+            *reinterpret_cast<const uint4*>(x + (long)img * x_ld_img + ((long)(ho >> 1) * W + (wo >> 1)) * x_ld_pix + c);
+    }
+}
+extern "C" int32_t sgx_hupsample2x_fwd(int32_t N, int32_t H, int32_t W, int32_t C, const void* x, int64_t x_ld_pix, int64_t x_ld_img, void* y, int64_t y_ld_pix,
+                                       int64_t y_ld_img, void* stream) {
+    SGX_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0, "hupsample2x: bad args");
+    SGX_CHECK_ARG(C % 8 == 0 && x_ld_pix % 8 == 0 && x_ld_img % 8 == 0 && y_ld_pix % 8 == 0 && y_ld_img % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0,
+                  "hupsample2x: channel count / strides / addresses must be multiples of 8 elements (16 bytes)");
+    const long n = (long)N * 4 * H * W * (C / 8), blocks = (n + 255) / 256;
+    SGX_LAUNCH(hupsample2x_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, stream, N, H, W, C, (const unsigned short*)x, (long)x_ld_pix, (long)x_ld_img,
+               (unsigned short*)y, (long)y_ld_pix, (long)y_ld_img);
+    SGX_CHECK_LAUNCH("hupsample2x");
+    return SGX_OK;
+}

@@ -855,6 +855,12 @@ def image_colsum(u, v=None, scale=1.0, pre=None, gate=None):
     """out[n,c] = scale * f'(pre[n,c]) * sum_pixels u*v   ([N,C]; v / pre optional)."""
     n, h, w, c = u.shape
     ul, ui = nhwc_strides(u)
+    if u.dtype == HALF:  # half-precision inference: the per-image channel means of a bf16 activation, fp32 sums in a fixed order
+        if v is not None or pre is not None:
+            raise _lib.SgxError("image_colsum on bf16: inference form only (plain per-image channel sums)")
+        out = torch.empty(n, c, device=u.device, dtype=torch.float32)
+        check(lib().sgx_himage_colsum(n, h * w, c, ptr(u), ul, ui, float(scale), ptr(out), stream()), "sgx_himage_colsum")
+        return out
     vl, vi = nhwc_strides(v) if v is not None else (0, 0)
     out = torch.empty(n, c, device=u.device, dtype=torch.float32)
     ws = WORKSPACE.get(lib().sgx_image_colsum_workspace(n, h * w, c), u.device)
@@ -866,6 +872,15 @@ def image_colsum(u, v=None, scale=1.0, pre=None, gate=None):
 def channel_gate(x, pre, gate, bias=None, bias_scale=1.0, out=None, accumulate=False):
     """y (+)= x * f(pre[n,c]) + bias_scale * bias[n,c]."""
     n, h, w, c = x.shape
+    if x.dtype == HALF:  # half-precision inference: product in fp32, one rounding to bf16
+        if bias is not None or accumulate:
+            raise _lib.SgxError("channel_gate on bf16: inference form only (no bias, no accumulation)")
+        if out is None:
+            out = torch.empty(x.shape, device=x.device, dtype=HALF)
+        xl, xi = nhwc_strides(x)
+        yl, yi = nhwc_strides(out)
+        check(lib().sgx_hchannel_gate(n, h * w, c, ptr(x), xl, xi, ptr(pre), GATE[gate], ptr(out), yl, yi, stream()), "sgx_hchannel_gate")
+        return out
     if out is None:
         out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     xl, xi = nhwc_strides(x)
@@ -878,9 +893,12 @@ def channel_gate(x, pre, gate, bias=None, bias_scale=1.0, out=None, accumulate=F
 def upsample2x_fwd(x, out=None):
     n, h, w, c = x.shape
     if out is None:
-        out = torch.empty(n, 2 * h, 2 * w, c, device=x.device, dtype=torch.float32)
+        out = torch.empty(n, 2 * h, 2 * w, c, device=x.device, dtype=x.dtype)
     xl, xi = nhwc_strides(x)
     yl, yi = nhwc_strides(out)
+    if x.dtype == HALF:
+        check(lib().sgx_hupsample2x_fwd(n, h, w, c, ptr(x), xl, xi, ptr(out), yl, yi, stream()), "sgx_hupsample2x_fwd")
+        return out
     check(lib().sgx_upsample2x_fwd(n, h, w, c, ptr(x), xl, xi, ptr(out), yl, yi, stream()), "sgx_upsample2x_fwd")
     return out
 

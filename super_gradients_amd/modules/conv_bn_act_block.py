@@ -20,6 +20,7 @@ class _ConvBN(SgxBlock):
     """Shared implementation; subclasses only choose where `conv`/`bn` are registered (key names)."""
 
     _folded = None  # (filter with the BatchNorm scale folded in, shift as bias): eval form set by prep_model_for_conversion
+    _folded_half = None  # the same for a channel-padded filter (C % 4 != 0: an RGB stem) - read by the half-precision path only, which re-lays filters out itself
 
     def _parts(self):
         raise NotImplementedError
@@ -37,7 +38,13 @@ class _ConvBN(SgxBlock):
         if w is None:
             raise RuntimeError("prep_model_for_conversion needs a materialised model (the fold reads the arena views)")
         K_, C_, R_, S_ = w.shape
-        if w.stride() != (R_ * S_ * C_, 1, S_ * C_, C_):  # channel-padded filters (C % 4 != 0): keep the general eval sequence
+        if w.stride() != (R_ * S_ * C_, 1, S_ * C_, C_):
+            # channel-padded filters (C % 4 != 0): the fp32 path keeps the general eval sequence; the half-precision path converts filters to
+            # its own bf16 layout anyway (kernels.half_filter takes any strides) - fold for it alone (prep used to return silently
+            # and the bf16 forward then raised "call prep_model_for_conversion() first")
+            with torch.no_grad():
+                s = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+                self._folded_half = ((w.detach() * s.view(-1, 1, 1, 1)).contiguous(), (bn.bias.detach() - bn.running_mean * s).contiguous())
             return
         with torch.no_grad():
             s = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
@@ -47,7 +54,7 @@ class _ConvBN(SgxBlock):
 
     def train(self, mode: bool = True):
         if mode:
-            self._folded = None  # the weights are about to change
+            self._folded = self._folded_half = None  # the weights are about to change
         return super().train(mode)
 
     def fwd(self, x, out=None, post_add=None, post_scale=None):
@@ -55,14 +62,15 @@ class _ConvBN(SgxBlock):
         caller's (dy reaches it unchanged).  post_scale (half-precision inference only): a multiplier of post_add."""
         conv, bn = self._parts()
         if x.dtype == K.HALF:  # half-precision inference: the folded deployment form, everything in ONE bf16 launch
-            if self.training or self._folded is None:
+            folded = self._folded if self._folded is not None else self._folded_half
+            if self.training or folded is None:
                 raise RuntimeError("half-precision inference runs the folded deployment form: call prep_model_for_conversion() in eval mode first")
-            return K.conv2d_fwd(x, self._folded[0], bias=self._folded[1], out=out, act=self.act, stride=conv.stride, pad=conv.padding,
+            return K.conv2d_fwd(x, folded[0], bias=folded[1], out=out, act=self.act, stride=conv.stride, pad=conv.padding,
                                 post_add=post_add, post_scale=post_scale)
         if post_scale is not None:
             raise RuntimeError("post_scale: half-precision inference only")
         if self.training:
-            self._folded = None  # a training step follows: a folded eval filter would be stale afterwards
+            self._folded = self._folded_half = None  # a training step follows: a folded eval filter would be stale afterwards
             t, parts = conv.conv(x, stats=True)
             M = t.shape[0] * t.shape[1] * t.shape[2]
             scale, shift, mean, invstd = bn.scale_shift(parts, M, True)

@@ -425,6 +425,8 @@ class SgxNetwork(nn.Module):
         for m in self.modules():
             if getattr(m, "_folded", None) is not None:
                 m._folded = None
+            if getattr(m, "_folded_half", None) is not None:
+                m._folded_half = None
         self._wt_valid = False
         self.drop_filter_planes()
         from .. import kernels as K

@@ -64,6 +64,8 @@ class RepVGGBlock(SgxBlock):
         if not self.build_residual_branches:  # deployment form: one 3x3 convolution with fused bias + activation
             if self.training:
                 raise RuntimeError("a fused RepVGGBlock is inference-only on the HIP path (re-parameterised training is outside the hot path)")
+            if x.dtype == K.HALF:  # half-precision inference: bias, activation and the block's `x + y` in the bf16 convolution's epilogue
+                return K.conv2d_fwd(x, self._fused_w, bias=self._fused_b, out=out, act=self.act, stride=self.stride, pad=1, post_add=post_add)
             y = K.conv2d_fwd(x, self._fused_w, bias=self._fused_b, out=out if post_add is None else None, act=self.act, stride=self.stride, pad=1)
             return y if post_add is None else K.affine_act(y, r1=post_add, out=out if out is not None else y)
         if self.training:

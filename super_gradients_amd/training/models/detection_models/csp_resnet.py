@@ -102,7 +102,7 @@ class CSPResStage(SgxBlock):
             x = self.conv_down.fwd(x)
         n, h, w, _ = x.shape
         half = self.half
-        cat = torch.empty(n, h, w, 2 * half, device=x.device, dtype=torch.float32)
+        cat = torch.empty(n, h, w, 2 * half, device=x.device, dtype=x.dtype)  # (bf16 on the half-precision inference path)
         self.conv1.fwd(x, out=cat[..., :half])
         blocks = list(self.blocks)
         cur = self.conv2.fwd(x, out=cat[..., half:] if not blocks else None)

@@ -39,8 +39,8 @@ class PPYoloESPP(SgxBlock):
     def on_materialize(self):
         pass
 
-    def alloc(self, n, h, w, device):
-        return torch.empty(n, h, w, self.cin * (1 + len(self.pool)), device=device, dtype=torch.float32)
+    def alloc(self, n, h, w, device, dtype=torch.float32):
+        return torch.empty(n, h, w, self.cin * (1 + len(self.pool)), device=device, dtype=dtype)
 
     def fwd(self, cat, out=None):
         """cat: buffer from alloc() whose slice 0 already holds x."""
@@ -98,7 +98,7 @@ class CSPStage(SgxBlock):
     def fwd(self, x, out=None):
         n, h, w, _ = x.shape
         mid = self.ch_mid
-        cat = torch.empty(n, h, w, 2 * mid, device=x.device, dtype=torch.float32)
+        cat = torch.empty(n, h, w, 2 * mid, device=x.device, dtype=x.dtype)
         self.conv1.fwd(x, out=cat[..., :mid])
         seq = list(self.convs)
         cur = self.conv2.fwd(x, out=cat[..., mid:] if not seq else None)
@@ -107,7 +107,7 @@ class CSPStage(SgxBlock):
             if isinstance(m, PPYoloESPP):
                 cur = m.fwd(cur, out=dst)   # cur is the SPP concat buffer (its slice 0 was written by the previous block)
             elif i + 1 < len(seq) and isinstance(seq[i + 1], PPYoloESPP):
-                buf = seq[i + 1].alloc(n, h, w, x.device)
+                buf = seq[i + 1].alloc(n, h, w, x.device, x.dtype)
                 m.fwd(cur, out=buf[..., :mid])
                 cur = buf
             else:
@@ -190,7 +190,7 @@ class PPYoloECSPPAN(BaseDetectionModule):
         dev = blocks[0].device
         # PAN concat buffers [route(out[i+1]) | fpn_feat i (out[i])] at the resolution of level i: the FPN stage of level i writes its
         # output straight into its slice
-        pan_cat = [torch.empty(n, blocks[i].shape[1], blocks[i].shape[2], oc[i + 1] + oc[i], device=dev, dtype=torch.float32) for i in range(nb - 1)]
+        pan_cat = [torch.empty(n, blocks[i].shape[1], blocks[i].shape[2], oc[i + 1] + oc[i], device=dev, dtype=blocks[0].dtype) for i in range(nb - 1)]
         fpn_feats = []
         src = blocks[0]
         for i in range(nb):
@@ -201,7 +201,7 @@ class PPYoloECSPPAN(BaseDetectionModule):
                 route = self.fpn_routes[i].fwd(feat)
                 nxt = blocks[i + 1]
                 r = route.shape[3]
-                cat = torch.empty(n, nxt.shape[1], nxt.shape[2], r + nxt.shape[3], device=dev, dtype=torch.float32)
+                cat = torch.empty(n, nxt.shape[1], nxt.shape[2], r + nxt.shape[3], device=dev, dtype=nxt.dtype)
                 K.upsample2x_fwd(route, out=cat[..., :r])
                 K.axpy(nxt, out=cat[..., r:])
                 src = cat

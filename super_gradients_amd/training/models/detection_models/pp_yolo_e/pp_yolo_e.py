@@ -59,6 +59,15 @@ class PPYoloE(DetectionPredictMixin, SgxNetwork):
         return PPYoloEPostPredictionCallback(score_threshold=conf, nms_threshold=iou, nms_top_k=nms_top_k, max_predictions=max_predictions,
                                              multi_label_per_box=multi_label_per_box, class_agnostic_nms=class_agnostic_nms)
 
+    def supports_half_inference(self) -> bool:
+        """predict(fp16=True) runs the fused model on the bf16 kernels of csrc/half.hip (round 6: the squeeze-excitation means / gates and the
+        nearest up-sampling of this family have bf16 forms; RepVGG blocks run as one fused 3x3 convolution each).  The bf16 kernels move 16-byte
+        lanes - 8 channels: every convolution's input (the RGB stem's aside, which is padded 3 -> 8) must have a multiple of 8 channels.  The S
+        and L widths do; M (width 0.75: 36-channel halves) and X (1.25: 60) do not - for them predict(fp16=True) keeps the fp32 path, loudly."""
+        from .....modules.layers import ConvLayer
+
+        return all(m.in_channels % 8 == 0 or m.in_channels == self.in_channels for m in self.modules() if isinstance(m, ConvLayer))
+
     def get_decoding_module(self, num_pre_nms_predictions: int, **kwargs) -> PPYoloEDecodingModule:
         return PPYoloEDecodingModule(num_pre_nms_predictions=num_pre_nms_predictions)
 
@@ -100,6 +109,8 @@ class PPYoloE(DetectionPredictMixin, SgxNetwork):
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise ValueError(f"expected an NCHW batch with {self.in_channels} channels, got {tuple(x.shape)}")
         xh = K.input_to_nhwc(x)
+        if self._half_inference and not self.training:
+            xh = K.cast_bf16(xh, cpad=8)  # the bf16 batch the stem reads (3 -> 8 channels: one 16-byte lane load per pixel)
         boxes, scores, logits, distri, anchors, pts, counts, strides = self.head.fwd(self.neck.fwd(self.backbone.fwd(xh)))
         self._aux = (anchors, pts, list(counts), strides)
         self._out_shapes = (tuple(logits.shape), tuple(distri.shape))

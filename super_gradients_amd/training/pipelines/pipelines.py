@@ -121,7 +121,7 @@ class Pipeline(ABC):
         if self.half:
             #  a conv + BatchNorm pair that could not be folded - a channel-padded filter, C % 4 != 0 - has no half-precision form:
             # fall back to the fp32 path for the whole model, loudly, instead of raising at the first forward
-            unfolded = [n for n, m in self.model.named_modules() if hasattr(m, "_folded") and hasattr(m, "_parts") and m._folded is None]
+            unfolded = [n for n, m in self.model.named_modules() if hasattr(m, "_folded") and hasattr(m, "_parts") and m._folded is None and getattr(m, "_folded_half", None) is None]
             if unfolded:
                 self.half = False
                 _note_fp16_once(self.model, f"has conv + BatchNorm pairs without a folded half-precision form ({unfolded[0]}, {len(unfolded)} in all)")

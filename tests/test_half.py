@@ -364,3 +364,136 @@ def test_half_yolo_nas_s_80_classes_640_against_autocast_oracle(gpu_device):
         mine = set(torch.topk(s16[i].flatten(), 50).indices.tolist())
         assert len(mine & set(torch.topk(sa[i].flatten(), 100).indices.tolist())) >= 40
     print(f"YOLO-NAS-S 80 classes @640: half-vs-autocast scores {float((s16 - sa).abs().max()):.2e}, half-vs-fp32 {e_half:.2e}, autocast-vs-fp32 {e_auto:.2e}")
+
+
+# ---- PP-YOLOE on the half-precision path (round 6) ------------------------------------------------------------------------------------
+def test_half_squeeze_excitation_and_upsample_kernels(backend):
+    """The three bf16 ops PP-YOLOE's deployment form needs beside its convolutions (csrc/half.hip: sgx_himage_colsum, sgx_hchannel_gate,
+    sgx_hupsample2x_fwd) against float64 on the bf16-rounded operands: the per-image channel means are fp32 sums (2e-5 relative), the gate
+    rounds once to bf16 (1 ulp), the up-sampling is a copy (exact) - also into a channel slice of a wider tensor."""
+    from super_gradients_amd import kernels as K
+
+    g = torch.Generator().manual_seed(21)
+    x32 = torch.randn(2, 9, 7, 24, generator=g)
+    x = _bf(x32).to(backend)
+    xr = x.float().cpu().double()
+    mean = K.image_colsum(x, scale=1.0 / 63)
+    assert mean.dtype == torch.float32 and tuple(mean.shape) == (2, 24)
+    ref = xr.sum(dim=(1, 2)) / 63
+    assert float((mean.cpu().double() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
+    pre = torch.randn(2, 24, generator=g).to(backend) * 3
+    for gate, fn in (("hardsigmoid", lambda p: torch.clamp(p / 6 + 0.5, 0, 1)), ("sigmoid", torch.sigmoid)):
+        wide = torch.zeros(2, 9, 7, 40, device=backend, dtype=BF)
+        y = K.channel_gate(x, pre, gate, out=wide[..., 8:32])
+        _check(y.cpu(), xr * fn(pre.cpu().double()).view(2, 1, 1, 24), f"hchannel_gate[{gate}]")
+        assert bool((wide[..., :8].float() == 0).all()) and bool((wide[..., 32:].float() == 0).all())
+    up = torch.zeros(2, 18, 14, 32, device=backend, dtype=BF)
+    K.upsample2x_fwd(x, out=up[..., :24])
+    exp = x.cpu().repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    assert torch.equal(up[..., :24].cpu(), exp) and bool((up[..., 24:].float() == 0).all())
+    with pytest.raises(Exception):
+        K.image_colsum(x, v=x)
+
+
+def _small_ppyoloe(device, num_classes=3):
+    from super_gradients_amd.training import models
+
+    arch = None if device.type == "cuda" else {"depth_mult": 0.2}  # (host emulation: the S widths - the bf16 path wants channel counts in multiples of 8 - at the least depth)
+    net = models.get("ppyoloe_s", num_classes=num_classes, arch_params=arch)
+    g = torch.Generator().manual_seed(12)
+    for m in net.modules():
+        if hasattr(m, "running_var"):
+            m.running_mean.normal_(0, 0.1, generator=g)
+            m.running_var.uniform_(0.8, 1.2, generator=g)
+    for n_, p in net.named_parameters():  # (the prediction convs start at zero weights: give the scores something to vary with)
+        if "pred_" in n_ and n_.endswith("weight"):
+            p.data.normal_(0, 0.05, generator=g)
+        elif "pred_cls" in n_ and n_.endswith("bias"):  # a spread of class priors: confident, distinct detections instead of a flat 0.01
+            p.data.add_(torch.randn(p.shape, generator=g) * 1.5 + 2.0)
+    net.materialize(device)
+    return net
+
+
+def test_half_ppyoloe_forward_against_fp32_path(backend):
+    """PP-YOLOE's fused copy on the half path (round 6: `PPYoloE.supports_half_inference()`): RepVGG blocks as one bf16 3x3 convolution with
+    the block's `x + y` in its epilogue, squeeze-excitation means in fp32 / gates in bf16, nearest up-sampling and concats in bf16, the
+    RGB stem's channel-padded filter folded for this path - raw scores / boxes against this build's fp32 path: scores 2e-2
+    absolute, boxes 2 % of the image side; the switch is not a no-op."""
+    import copy
+
+    net = _small_ppyoloe(backend)
+    size = 64
+    x = torch.rand(2, 3, size, size, generator=torch.Generator().manual_seed(4))
+    fused32 = copy.deepcopy(net).eval()
+    fused32.prep_model_for_conversion(input_size=(size, size), full_fusion=True)
+    fused16 = copy.deepcopy(fused32).eval().half_inference(True)
+    with torch.no_grad():
+        (b32, s32), (l32, d32, *_) = fused32(x.to(backend))
+        (b16, s16), (l16, d16, *_) = fused16(x.to(backend))
+    assert l16.dtype == torch.float32 and s16.dtype == torch.float32
+    b32, s32, b16, s16 = (t.cpu() for t in (b32, s32, b16, s16))
+    assert float((s16 - s32).abs().max()) < 2e-2, f"scores: half path vs fp32 path {float((s16 - s32).abs().max()):.3e}"
+    assert float((b16 - b32).abs().max()) < 0.02 * size, "boxes: half path vs fp32 path"
+    assert float((s16 - s32).abs().max()) > 0.0
+
+
+def test_predict_fp16_runs_the_half_path_for_ppyoloe(backend):
+    """predict(fp16=True) on PP-YOLOE takes the bf16 kernels too (rounds 2 - 5: a warning and the fp32 path)."""
+    net = _small_ppyoloe(backend)
+    proc = [{"DetectionRescale": {"output_shape": (64, 64)}}, {"StandardizeImage": {"max_value": 255.0}}, {"ImagePermute": {"permutation": (2, 0, 1)}}]
+    net.set_dataset_processing_params(class_names=["a", "b", "c"], image_processor=proc, iou=0.6, conf=0.0)
+    rng = np.random.default_rng(3)
+    images = [rng.integers(0, 256, (64, 50, 3), dtype=np.uint8), rng.integers(0, 256, (40, 64, 3), dtype=np.uint8)]
+    r16 = net.predict(images, max_predictions=20, nms_top_k=100)
+    p16 = net._get_pipeline(max_predictions=20, nms_top_k=100)
+    assert p16.half and p16.model._half_inference and not net._half_inference
+    r32 = net.predict(images, max_predictions=20, nms_top_k=100, fp16=False)
+    for a, b in zip(r32, r16):
+        pa, pb = a.prediction, b.prediction
+        assert len(pa) > 0 and len(pb) > 0
+        top = np.argsort(-pa.confidence)[:5]
+        iou = _iou(pa.bboxes_xyxy[top], pb.bboxes_xyxy)
+        same = pa.labels[top][:, None] == pb.labels[None, :]
+        assert bool(((iou * same).max(axis=1) >= 0.85).all()), "a confident fp32 detection has no half-path partner"
+
+
+@pytest.mark.gpu
+def test_half_ppyoloe_s_80_classes_640_against_autocast_oracle(gpu_device):
+    """The real PP-YOLOE-S (80 classes, 640 x 640) fused onto the bf16 kernels against the oracle network under torch.autocast(cpu, bfloat16)
+    (the reference's arithmetic for predict(fp16=True)) and the fp32 oracle: scores 2e-2 absolute everywhere; the autocast oracle's top-50
+    (anchor, class) pairs per image: half-path box IoU >= 0.9 and scores 2e-2; the half path no further from the fp32 oracle than 2 x autocast."""
+    import copy
+
+    from oracle import golden_util as G
+    from oracle.pp_yolo_e import PPYoloE as Oracle
+    from super_gradients_amd.training import models
+
+    torch.manual_seed(5)
+    ref = Oracle("s", num_classes=80)
+    G.deterministic_fill(ref, seed=6)
+    ref.eval()
+    net = models.get("ppyoloe_s", num_classes=80)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net.materialize(gpu_device).eval()
+    size = 640
+    x = torch.rand(2, 3, size, size, generator=torch.Generator().manual_seed(6))
+    fused = copy.deepcopy(net).eval()
+    fused.prep_model_for_conversion(input_size=(size, size), full_fusion=True)
+    fused.half_inference(True)
+    with torch.no_grad():
+        (b16, s16), _ = fused(x.to(gpu_device))
+        (br, sr), _ = ref(x)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            (ba, sa), _ = ref(x)
+    b16, s16, sa, ba = b16.cpu(), s16.cpu(), sa.float(), ba.float()
+    assert s16.shape == (2, 8400, 80)
+    assert float((s16 - sa).abs().max()) < 2e-2, f"scores: half path vs autocast oracle {float((s16 - sa).abs().max()):.3e}"
+    e_half, e_auto = float((s16 - sr).abs().max()), float((sa - sr).abs().max())
+    assert e_half <= 2.0 * e_auto + 1e-3, f"half path is {e_half:.2e} from the fp32 oracle, autocast {e_auto:.2e}"
+    for i in range(2):
+        top = torch.topk(sa[i].flatten(), 50).indices
+        anchors, classes = top // 80, top % 80
+        assert float((s16[i, anchors, classes] - sa[i, anchors, classes]).abs().max()) < 2e-2
+        iou = np.diag(_iou(ba[i, anchors].numpy(), b16[i, anchors].numpy()))
+        assert float(iou.min()) >= 0.9, f"image {i}: min IoU {float(iou.min()):.3f}"
+    print(f"PP-YOLOE-S 80 classes @640: half-vs-autocast scores {float((s16 - sa).abs().max()):.2e}, half-vs-fp32 {e_half:.2e}, autocast-vs-fp32 {e_auto:.2e}")
