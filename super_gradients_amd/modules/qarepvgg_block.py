@@ -18,6 +18,8 @@ Blocks this form does not cover (learnable alpha, fewer than 16 channels, synchr
   statistics), y = act(scale_p*s + shift_p) (one sweep); backward: post_bn and BN3 backward in place, dx = dgrad3x3 + dgrad1x1 + ds.
 """
 from torch import nn
+import os
+
 import torch
 
 from .. import kernels as K
@@ -220,7 +222,11 @@ class QARepVGGBlock(SgxBlock):
         if t1 is not None:                                                      # learnable alpha: d alpha = <ds, conv1x1(x) + b>
             K.dot_sum(t1, ds, self.alpha.grad, accumulate=True)
             ds1 = K.axpy(ds, a_dev=self.alpha, out=t1)                          # in place over t1
-        c1.wgrad(x, ds1)
+        # d b1 = sum ds1 = alpha * sum ds = 0: ds is post_bn's input gradient, which sums to zero per channel (as on the two-branch path above).
+        # (Round 6: this path - the RGB stem's - still took the sum: a 629 MB column sum at 320 x 320 in the step's tail, where the main stream
+        # has nothing left to run beside it, for a value that is zero up to round-off.  r6p, three interleaved pairs on one box: 749.0 / 753.5 / 753.2
+        # -> 754.2 / 754.8 / 754.2 images/s; flushing the 1x1 weight gradient out ahead of the second BatchNorm backward as well: 755.4 on average, not kept.)
+        c1.wgrad(x, ds1, bias_grad=False)
         dt3 = bn3.backward(ds, t3, sc3, sh3, m3, i3, None, dx_out=t3)   # in place over t3
         c3.wgrad(x, dt3)
         if not need_dx:
