@@ -340,7 +340,9 @@ __global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (igemm_min_waves<BM, B
                       (KD == 32 && !FLAT && NBUF == 3 && MATH == 0 && PH2 == 0),
                   "32-deep slabs: channel-chunked K axis; one LDS buffer, (bf16x3) the two-buffer pipelined loop, or (fp32, NBUF = 3) all slabs up front");
     constexpr int LBUF = NBUF == 3 ? 1 : NBUF;  // LDS buffers
-    static_assert(PH2 == 0 || !FLAT, "second K-axis source: channel-chunked K axis");
+    // (round 6: the two-output form also runs on the flattened K axis - the RGB stem's QARepVGG block: its second source is the 1x1 branch,
+    // one 16-wide slab of which 4 columns are live)
+    static_assert(PH2 == 0 || PH2 == 2 || !FLAT, "second K-axis source into the same accumulator: channel-chunked K axis");
     static_assert(MATH == 0 || MATH == 1, "arithmetic: 0 = fp32 matrix pipe, 1 = bf16x3");
     // (Round 4 tried MATH = 2: the five correction products of the bf16x3 scheme added into the SAME accumulator as the leading one - it
     // frees 16 registers per block and ran the step 4 % faster, but the bf16 MFMA's accumulate floors what it shifts out: small terms added
@@ -2159,7 +2161,11 @@ static int32_t run_igemm(IgemmParams& p, int bm, int bn, void* stream, int ph2 =
         SGX_CHECK_LAUNCH("pconv");
         return SGX_OK;
     }
-    if (ph2) {
+    if (ph2 == 2 && flat && p.vec && !gemm_bf3) {
+        // the two-output forward of a block with few input channels (the RGB stem, C = 4): flattened (tap, channel) K axis, fp32 pipe
+        if (bm == 128) launch_igemm<128, 64, 2, 2, true, 0, IG_BK, 2, 2>(p, stream);
+        else launch_igemm<64, 64, 2, 2, true, 0, IG_BK, 2, 2>(p, stream);
+    } else if (ph2) {
         if (flat || !p.vec) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv (two sources): needs C >= 16 and 16-byte aligned outputs");
         const bool bf3 = gemm_bf3;  // (mode 5: the primary source's depth decides for the launch)
         if (p.C % 32 == 0) {
@@ -2302,7 +2308,8 @@ extern "C" int32_t sgx_conv2d_fwd_dual(const sgx_conv_desc* d, const float* x, c
     if (rc) return rc;
     SGX_CHECK_ARG(x && w && w1 && y && u && stat5, "conv fwd_dual: null pointer");
     SGX_CHECK_ARG(d->R == d->S && (d->R & 1) && d->pad == d->R / 2, "conv fwd_dual: odd square filter with pad = R / 2 (the 1x1 branch reads its centre tap)");
-    SGX_CHECK_ARG(d->C >= IG_BK && ((uintptr_t)u % 16) == 0, "conv fwd_dual: needs C >= 16 and a 16-byte aligned second output");
+    SGX_CHECK_ARG(((uintptr_t)u % 16) == 0, "conv fwd_dual: needs a 16-byte aligned second output");
+    SGX_CHECK_ARG(d->C >= IG_BK || d->K <= 64, "conv fwd_dual: C < 16 (the flattened K axis) has the 64-filter tiles only (K = %d)", d->K);
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = x; p.Wt = w; p.Y = y; p.stat_partials = stat5;

@@ -66,8 +66,12 @@ class QARepVGGBlock(SgxBlock):
         when the block runs the general sequence.  Allocates the persistent buffers of the two-branch-per-launch form: W1 + I and its
         transpose, refreshed once per step by the network's sgx_qarep_prep_batch launch (engine.prefetch_dgrad_weights)."""
         c1 = self.branch_1x1
-        if isinstance(self.alpha, torch.Tensor) or float(self.alpha) != 1.0 or self.in_channels < 16 or self.out_channels < 16 or not self._net.wt_batch:
+        if isinstance(self.alpha, torch.Tensor) or float(self.alpha) != 1.0 or self.out_channels < 16 or not self._net.wt_batch:
             return None
+        # (round 6: blocks with fewer than 16 input channels - the RGB stem - take the two-output launch too, on the flattened K axis, while
+        # their filters fit its 64-wide tiles; they produce no input gradient, so the two-source data gradient is never asked of them)
+        if self.in_channels < 16 and (self.out_channels > 64 or self.use_residual_connection or os.environ.get("SGX_QAREP_STEM_DUAL", "1") == "0"):
+            return None  # (SGX_QAREP_STEM_DUAL=0: measurement switch, the general sequence of rounds 1 - 5)
         K_, C_ = c1._w.shape[0], c1._w.shape[1]
         self._w1p = K.ohwi_empty(K_, C_, 1, 1, c1._w.device)
         self._w1pt = torch.empty(C_, K_, device=c1._w.device, dtype=torch.float32)

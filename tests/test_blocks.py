@@ -36,7 +36,7 @@ def _randomize(mod, seed):
             m.eps, m.momentum = 1e-3, 0.03
 
 
-def _check(ref, blk, x, device, tol=2e-5, key_prefix="b.", prefetch=False):
+def _check(ref, blk, x, device, tol=2e-5, key_prefix="b.", prefetch=False, need_dx=True):
     from super_gradients_amd.modules.layers import BatchNorm
 
     _randomize(ref, 1)
@@ -57,9 +57,10 @@ def _check(ref, blk, x, device, tol=2e-5, key_prefix="b.", prefetch=False):
         net.prefetch_dgrad_weights()
     yd = blk.fwd(to_nhwc(x, device))
     assert_close(to_nchw_cpu(yd), y, tol, "forward")
-    dx = blk.bwd(to_nhwc(dy, device))
+    dx = blk.bwd(to_nhwc(dy, device)) if need_dx else blk.bwd(to_nhwc(dy, device), need_dx=False)
     net.join_side()  # weight gradients run on the network's side stream
-    assert_close(to_nchw_cpu(dx), xr.grad, 5 * tol, "input gradient")
+    if need_dx:
+        assert_close(to_nchw_cpu(dx), xr.grad, 5 * tol, "input gradient")
     rp = dict(ref.named_parameters())
     gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
     for name, p in blk.named_parameters():
@@ -128,6 +129,20 @@ def test_qarepvgg_block_two_branch_launch(backend, stride, cout, act, wide):
         ref.forward = types.MethodType(fwd, ref)
     blk = QARepVGGBlock(c, co, stride=stride, use_residual_connection=stride == 1, **kw)
     _check(ref, blk, x, backend, prefetch=True)
+    assert blk._w1p is not None and blk._ctx is None
+
+
+def test_qarepvgg_block_two_branch_launch_rgb_stem(backend):
+    """Round 6: the RGB stem (3 input channels, padded to 4; stride 2, no residual) takes the two-output launch too - on the flattened
+    (tap, channel) K axis - instead of the general five-sweep sequence at the largest map of the network: forward, every parameter
+    gradient, running statistics against the oracle's block (the block produces no input gradient in the network, and none is asked here)."""
+    from oracle.yolo_nas import QARep
+    from super_gradients_amd.modules import QARepVGGBlock
+
+    n, c, h, w = _shape(backend, (2, 4, 46, 38), (1, 4, 12, 10))  # (4 channels: the padded RGB batch the network's stem reads)
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(0)) + 0.5
+    blk = QARepVGGBlock(c, 48, stride=2, use_residual_connection=False)
+    _check(QARep(c, 48, 2, residual=False), blk, x, backend, prefetch=True, need_dx=False)
     assert blk._w1p is not None and blk._ctx is None
 
 
