@@ -1865,6 +1865,14 @@ static TileCfg pick_tile(long M, int N, int math) {
     if (const int o = g_ovr_bn.load(std::memory_order_relaxed)) t.bn = o;
     return t;
 }
+// tile of the two-source / two-output launches: the heuristic's, unless the measurement override (sgx_debug_set_tiles) names one of the tiles
+// those kernels are instantiated for
+static TileCfg ph2_tile(long M, int N) {
+    TileCfg t = pick_tile_heuristic(M, N);
+    const int bm = g_ovr_bm.load(std::memory_order_relaxed), bn = g_ovr_bn.load(std::memory_order_relaxed);
+    if ((bm == 128 && bn == 96) || (bm == 128 && bn == 32) || (bm == 64 && bn == 64) || (bm == 64 && bn == 32)) t = TileCfg{bm, bn};
+    return t;
+}
 static TileCfg pick_tile_heuristic(long M, int N) {
     // Measured (tools/conv_tune.py, profiles/r1m_conv_tune.txt: exhaustive search over the 201 conv problems of a YOLO-NAS-S
     // step): the 64x64 tile (4 waves x one 32x32 accumulator, 36 VGPRs, 22 KB LDS -> 7 workgroups per CU) wins on 83 of 140
@@ -2300,7 +2308,7 @@ extern "C" int32_t sgx_conv2d_fwd(const sgx_conv_desc* d, const float* x, const 
 extern "C" int32_t sgx_conv2d_fwd_dual_stat_blocks(const sgx_conv_desc* d) {
     if (pconv_shape_ok(d->R, d->S, d->stride, d->pad, d->C, d->K, (long)d->Ho * d->Wo)) return pconv_tiles(d->N, d->Ho, d->Wo);
     long M = (long)d->N * d->Ho * d->Wo;
-    return sgx_cdiv(M, pick_tile_heuristic(M, d->K).bm);
+    return sgx_cdiv(M, ph2_tile(M, d->K).bm);
 }
 extern "C" int32_t sgx_conv2d_fwd_dual(const sgx_conv_desc* d, const float* x, const float* w, const float* w1, const float* bias1, float* y,
                                        float* u, float* stat5, void* stream) {
@@ -2325,7 +2333,7 @@ extern "C" int32_t sgx_conv2d_fwd_dual(const sgx_conv_desc* d, const float* x, c
     p.A2 = x; p.Wt2 = w1; p.bias2 = bias1; p.Y2 = u;
     p.Hin2 = d->H; p.Win2 = d->W; p.Th2 = 1; p.Tw2 = 1; p.dh02 = 0; p.dw02 = 0; p.dstep2 = 1;
     p.a2_ld_pix = d->x_ld_pix; p.a2_ld_img = d->x_ld_img; p.w2_ld_n = d->C; p.a2_bytes = p.a_bytes; p.w2_bytes = (long)d->K * d->C * 4;
-    TileCfg t = pick_tile_heuristic(p.M, p.Nout);
+    TileCfg t = ph2_tile(p.M, p.Nout);
     p.stat_nblk = sgx_cdiv(p.M, t.bm);
     return run_igemm(p, t.bm, t.bn, stream, 2);
 }
@@ -2573,7 +2581,7 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
                 int mt;
                 if (!q.vec || flat || (ph2 && q.C < IG_BK)) rows_ok = false, mt = 0;
                 else if (pconv_ok(q, ph2)) mt = pconv_tiles(q.M / (q.Ha * q.Wa), q.Ha, q.Wa);
-                else if (ph2) mt = sgx_cdiv(q.M, pick_tile_heuristic(q.M, q.Nout).bm);
+                else if (ph2) mt = sgx_cdiv(q.M, ph2_tile(q.M, q.Nout).bm);
                 else mt = sgx_cdiv(q.M, pick_tile(q.M, q.Nout, conv_math_for(q.Th * q.Tw, q.C)).bm);
                 if (nreq) {
                     if (!rows_ok) SGX_FAIL(SGX_ERR_UNSUPPORTED, "conv bwd_data: this problem cannot carry BatchNorm-reduce requests (sgx_conv2d_bwd_data_stat_blocks = 0)");
@@ -2610,7 +2618,7 @@ static int32_t conv_bwd_data_impl(const sgx_conv_desc* d, const float* dy, const
                 p.w2_bytes = (long)d->C * d->K * 4;
                 p.addend2 = sec->addend2; p.a2d_ld_pix = sec->a2_ld_pix; p.a2d_ld_img = sec->a2_ld_img;
                 p.addend2_scale = sec->a2_scale; p.addend2_scale_dev = sec->a2_scale_dev;
-                TileCfg t = pick_tile_heuristic(p.M, p.Nout);
+                TileCfg t = ph2_tile(p.M, p.Nout);
                 rc = run_igemm(p, t.bm, t.bn, stream, 1);
                 if (rc) return rc;
             } else if (mode != 1) {

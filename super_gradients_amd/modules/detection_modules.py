@@ -6,6 +6,8 @@ concat -> 1x1).  The SPP concat is one NHWC buffer: cv1 and the three pooling ke
 """
 from typing import List
 
+import os
+
 import torch
 
 from .. import kernels as K
@@ -14,6 +16,9 @@ from ..common.registry import register_detection_module
 from .base_modules import BaseDetectionModule
 from .conv_bn_act_block import Conv
 from .layers import MaxPool, act_name
+
+
+_FOLD_EXT = os.environ.get("SGX_BACKBONE_ADDEND", "1") != "0"  # measurement switch (r6s): 0 = the accumulate passes of rounds 1 - 5
 
 
 @register_detection_module()
@@ -100,16 +105,27 @@ class NStageBackbone(BaseDetectionModule):
     def bwd(self, grads: dict, on_layer_done=None):
         """grads: {layer_name: gradient of that layer's output coming from outside the backbone (the neck)} for the
         layers in out_layers.  Walks the chain backwards, adding each external gradient where its tensor was produced."""
-        g = None
-        for layer in reversed(self._all_layers):
+        # (Round 6: the neck's gradient of a layer's output is ADDED IN THE EPILOGUE of the data-gradient launch that produces the backbone's
+        # own gradient of that output - the next layer's `addend` - instead of an accumulate pass behind it: three passes over the 160 x 160,
+        # 80 x 80 and 40 x 40 feature-map gradients per step became one read.  An external gradient that is not a dense tensor - a slice of
+        # a concat gradient - keeps the pass.)
+        order = list(reversed(self._all_layers))
+        g, folded = None, set()
+        for i, layer in enumerate(order):
             ext = grads.get(layer)
             if g is None:
                 g = ext
-            elif ext is not None:
+            elif ext is not None and layer not in folded:
                 K.axpy(ext, out=g, accumulate=True)
             if g is None:
                 continue
-            g = getattr(self, layer).bwd(g, need_dx=layer != self._all_layers[0])
+            kw = {}
+            nxt = order[i + 1] if i + 1 < len(order) else None
+            add = grads.get(nxt) if nxt is not None else None
+            if add is not None and add.is_contiguous() and add.dtype == torch.float32 and _FOLD_EXT:
+                kw["addend"] = add
+                folded.add(nxt)
+            g = getattr(self, layer).bwd(g, need_dx=layer != self._all_layers[0], **kw)
             if on_layer_done is not None:
                 on_layer_done(layer)
         return g
