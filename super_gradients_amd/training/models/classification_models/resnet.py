@@ -93,15 +93,23 @@ class _ResBlock(SgxBlock):
         branch = self._branch()
         g = K.relu_bwd(dy, y) if self.final_relu else dy
         d = g
+        parts = None
         for i in range(len(branch) - 1, 0, -1):
             conv, bn = branch[i]
             a, t, sc, sh, mean, invstd = saved[i]
-            dt = bn.backward(d, t, sc, sh, mean, invstd, None if i == len(branch) - 1 else "relu", dx_out=t)
+            dt = bn.backward(d, t, sc, sh, mean, invstd, None if i == len(branch) - 1 else "relu", dx_out=t, parts=parts)
             conv.wgrad(a, dt)
-            d = conv.dgrad(dt, tuple(a.shape))
+            # (round 6) the BatchNorm-backward reduce of the layer below rides in this data gradient's epilogue (sgx_bn_reduce_req: the launch
+            # that writes that layer's output gradient also leaves its two per-channel sums) - as the YOLO-NAS blocks have done since round 4;
+            # the ResNet blocks still ran a reduce sweep over (gradient, saved conv output) per layer: 32 of a ResNet-50 step's 53
+            _, pt, psc, psh, pmean, _ = saved[i - 1]
+            pbn = branch[i - 1][1]
+            req = K.BnReduceRequest(pt, psc, psh, pmean, "relu") if (self._net.fuse_bn_reduce and not pbn._synced()) else None
+            d = conv.dgrad(dt, tuple(a.shape), reqs=[req] if req is not None else None)
+            parts = req.parts if req is not None else None
         conv, bn = branch[0]
         a, t, sc, sh, mean, invstd = saved[0]
-        dt = bn.backward(d, t, sc, sh, mean, invstd, None if len(branch) == 1 else "relu", dx_out=t)
+        dt = bn.backward(d, t, sc, sh, mean, invstd, None if len(branch) == 1 else "relu", dx_out=t, parts=parts)
         conv.wgrad(x, dt)
         if sc_ctx is not None:
             ts, scs, shs, ms, ivs = sc_ctx
