@@ -94,21 +94,26 @@ class NStageBackbone(BaseDetectionModule):
         self.stem.replace_input_channels(in_channels=in_channels, compute_new_weights_fn=compute_new_weights_fn)
         self.in_channels = in_channels
 
-    def fwd(self, x, out=None):
+    def fwd(self, x, out=None, on_output=None):
+        """on_output(i, tensor): called as soon as output i exists (a neck that starts work on it beside the deeper stages)"""
         outs = []
         for layer in self._all_layers:
             x = getattr(self, layer).fwd(x)
             if layer in self.out_layers:
                 outs.append(x)
+                if on_output is not None:
+                    on_output(len(outs) - 1, x)
         return outs
 
-    def bwd(self, grads: dict, on_layer_done=None):
+    def bwd(self, grads: dict, on_layer_done=None, ext_ready=None):
         """grads: {layer_name: gradient of that layer's output coming from outside the backbone (the neck)} for the
         layers in out_layers.  Walks the chain backwards, adding each external gradient where its tensor was produced."""
         # (Round 6: the neck's gradient of a layer's output is ADDED IN THE EPILOGUE of the data-gradient launch that produces the backbone's
         # own gradient of that output - the next layer's `addend` - instead of an accumulate pass behind it: three passes over the 160 x 160,
         # 80 x 80 and 40 x 40 feature-map gradients per step became one read.  An external gradient that is not a dense tensor - a slice of
         # a concat gradient - keeps the pass.)
+        # ext_ready: called once, before the first external gradient other than the deepest layer's is read (the neck may still be producing
+        # those on its branch stream while this walk starts: the deepest one is the main chain's)
         order = list(reversed(self._all_layers))
         g, folded = None, set()
         for i, layer in enumerate(order):
@@ -116,16 +121,22 @@ class NStageBackbone(BaseDetectionModule):
             if g is None:
                 g = ext
             elif ext is not None and layer not in folded:
+                if ext_ready is not None:
+                    ext_ready, _ = None, ext_ready()
                 K.axpy(ext, out=g, accumulate=True)
             if g is None:
                 continue
             kw = {}
             nxt = order[i + 1] if i + 1 < len(order) else None
             add = grads.get(nxt) if nxt is not None else None
+            if add is not None and ext_ready is not None:
+                ext_ready, _ = None, ext_ready()
             if add is not None and add.is_contiguous() and add.dtype == torch.float32 and _FOLD_EXT:
                 kw["addend"] = add
                 folded.add(nxt)
             g = getattr(self, layer).bwd(g, need_dx=layer != self._all_layers[0], **kw)
             if on_layer_done is not None:
                 on_layer_done(layer)
+        if ext_ready is not None:
+            ext_ready()
         return g

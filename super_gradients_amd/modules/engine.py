@@ -202,6 +202,21 @@ class SgxNetwork(nn.Module):
         # per call.  Measured neutral-to-negative on YOLO-NAS-S (r1p: 528.7 vs 533.3 images/s): the per-call transposes already hide
         # under the side-stream weight gradients, so it stays off by default.
         self.aux_stream = torch.cuda.Stream(device=device) if (self.side_stream is not None and os.environ.get("SGX_AUX_STREAM", "0") == "1") else None
+        # Branch stream (SGX_BRANCH_STREAM: bit 0 forward, bit 1 backward; round 6): a sub-chain of a block that nothing inside the block
+        # waits for (YoloNASCSPLayer's conv2: GEMM -> finalize -> sweep, a few dozen microseconds each and dependent on one another) is
+        # enqueued on a second in-order stream and joined where its result is consumed, so that its short kernels fill the gaps between the
+        # dependent kernels of the main chain instead of lengthening it.
+        self.branch_mode = int(os.environ.get("SGX_BRANCH_STREAM", str(BRANCH_STREAM_DEFAULT))) if self.side_stream is not None else 0
+        self.branch_stream = torch.cuda.Stream(device=device) if self.branch_mode else None
+        # (SGX_BRANCH_LANES > 1: further branch streams for call sites that fork several mutually independent chains - the head levels)
+        self.branch_lanes = [self.branch_stream] + [torch.cuda.Stream(device=device) for _ in range(int(os.environ.get("SGX_BRANCH_LANES", str(BRANCH_LANES_DEFAULT))) - 1)] \
+            if self.branch_stream is not None else []
+        # which call sites fork (SGX_BRANCH_SITES bits: 1 YoloNASCSPLayer conv2, 2 coarse head levels, 4 the up stages' skip branches, 8 the batch
+        # re-layout beside the per-step filter preparations, 16 the ResNet blocks' projection shortcuts) and up
+        # to what size (SGX_BRANCH_MAX_TILES: 64-row x 64-column tiles of the forked chain's largest GEMM - a launch of several rounds of
+        # workgroups has no gaps to fill and only contends)
+        self.branch_sites = int(os.environ.get("SGX_BRANCH_SITES", str(BRANCH_SITES_DEFAULT)))
+        self.branch_max_tiles = int(os.environ.get("SGX_BRANCH_MAX_TILES", str(BRANCH_MAX_TILES_DEFAULT)))
         self._wt_valid = False
         # Weight gradients are mutually independent: blocks queue them (ConvLayer.wgrad) and the network launches a stretch of backward's
         # worth together (kernels.conv2d_bwd_weight_group: one launch per tile shape, splits sized for the group, partials folded inside
@@ -269,7 +284,7 @@ class SgxNetwork(nn.Module):
                         if v is not None:
                             m.__dict__[name] = v
 
-    _RUNTIME_ATTRS = ("side_stream", "aux_stream", "_wt_jobs", "_qp_jobs", "_dgrad_convs", "_wg_pending", "_fp_jobs", "_fp_dev", "_fp_buf")
+    _RUNTIME_ATTRS = ("side_stream", "aux_stream", "branch_stream", "branch_lanes", "_wt_jobs", "_qp_jobs", "_dgrad_convs", "_wg_pending", "_fp_jobs", "_fp_dev", "_fp_buf")
 
     def __deepcopy__(self, memo):
         """copy.deepcopy(model) - what the reference's predict() pipeline does before fusing (pipelines.py:95-100): parameters, buffers and
@@ -351,6 +366,32 @@ class SgxNetwork(nn.Module):
             if t is not None:
                 t.record_stream(side)
         return out
+
+    def branches(self, site: int, rows: int, cols: int, backward: bool = False) -> bool:
+        """Does call site `site` fork a chain whose largest GEMM has `rows` output pixels x `cols` filters?"""
+        if getattr(self, "branch_stream", None) is None or not (self.branch_mode & (2 if backward else 1)) or not (self.branch_sites & site):
+            return False
+        return ((rows + 63) // 64) * ((cols + 63) // 64) <= self.branch_max_tiles
+
+    def fork_branch(self, fn, backward: bool = False, lane: int = 0):
+        """Run fn() on the branch stream, ordered after everything enqueued so far on the current stream; returns (result, joined) where
+        `joined` is a callable the caller invokes before the first consumer of what fn wrote (a no-op when the branch stream is off).
+        Memory rule (torch's caching allocator keeps one pool per stream): what fn allocates comes from the branch stream's pool and is
+        recycled only into later branch allocations, which are ordered behind a later fork's wait; what fn reads or writes of the caller's
+        must stay referenced until `joined` was called.  Weight gradients queued inside fn are flushed inside it: the side stream must wait
+        for THIS stream's producers."""
+        if getattr(self, "branch_stream", None) is None or not (self.branch_mode & (2 if backward else 1)):
+            return fn(), _nothing
+        br = self.branch_lanes[lane % len(self.branch_lanes)]
+        main = torch.cuda.current_stream()
+        br.wait_stream(main)
+        with torch.cuda.stream(br):
+            out = fn()
+            if backward:
+                self.flush_wgrads()
+                if self.side_stream is not None:  # whatever reads this stretch's parameter gradients from the side stream (the bucket
+                    self.side_stream.wait_stream(br)  # all-reduce) is ordered behind it even when the join comes later
+        return out, lambda: main.wait_stream(br)
 
     def queue_wgrad(self, x, dy, gw, stride, pad):
         self._wg_pending.append((x, dy, gw, stride, pad))
@@ -498,6 +539,14 @@ class SgxNetwork(nn.Module):
 
 # Share of the chip's CUs the weight gradients' side stream may use (SGX_SIDE_CUS, percent; 100 = an ordinary stream).
 SIDE_STREAM_CU_PERCENT = 100
+BRANCH_STREAM_DEFAULT = 3
+BRANCH_SITES_DEFAULT = 31
+BRANCH_LANES_DEFAULT = 2
+BRANCH_MAX_TILES_DEFAULT = 1 << 30
+
+
+def _nothing():
+    return None
 
 
 def _make_side_stream(device):
@@ -522,14 +571,19 @@ class NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, anchor):
         ctx.net = net
+        # the batch's re-layout (NCHW -> NHWC, a network's _input_layout) beside the per-step filter preparations: branch stream, site 8
+        xh, joined = None, _nothing
+        if hasattr(net, "_input_layout") and net.branches(8, 0, 0):
+            xh, joined = net.fork_branch(lambda: net._input_layout(x))
         net.prefetch_dgrad_weights()
+        joined()
         planes = getattr(net, "_fp_jobs", None) is not None
         if planes:
             from .. import kernels as K
 
             K.filter_planes_scope(True)
         try:
-            flat = tuple(net._fwd(x))
+            flat = tuple(net._fwd(x) if xh is None else net._fwd(x, xh=xh))
         finally:
             if planes:
                 K.filter_planes_scope(False)

@@ -64,10 +64,21 @@ class _ResBlock(SgxBlock):
             self.shortcut.add_module("0", ConvLayer(in_planes, out_planes, 1, stride, 0, bias=False))
             self.shortcut.add_module("1", BatchNorm(out_planes))
 
+    def _shortcut_fwd(self, x):
+        ts, scs, shs, ms, ivs = _ConvBN.fwd(getattr(self.shortcut, "0"), getattr(self.shortcut, "1"), x, self.training)
+        return K.affine_act(ts, scs, shs), (ts, scs, shs, ms, ivs)
+
     def fwd(self, x, out=None):
         branch = self._branch()
         saved = []
         a = x
+        # the projection shortcut (conv -> BatchNorm, three short dependent kernels) meets the main branch in its last sweep: branch stream
+        # (engine.fork_branch, site 16), joined there
+        net = getattr(self, "_net", None)
+        forked = None
+        self._branched = bool(len(self.shortcut)) and net is not None and self.training and net.branches(16, x.shape[0] * x.shape[1] * x.shape[2], 64)
+        if self._branched:
+            forked = net.fork_branch(lambda: self._shortcut_fwd(x))
         for i, (conv, bn) in enumerate(branch):
             t, sc, sh, mean, invstd = _ConvBN.fwd(conv, bn, a, self.training)
             last = i == len(branch) - 1
@@ -79,10 +90,11 @@ class _ResBlock(SgxBlock):
                 saved.append((a, t, sc, sh, mean, invstd))
         short = x
         sc_ctx = None
-        if len(self.shortcut):
-            ts, scs, shs, ms, ivs = _ConvBN.fwd(getattr(self.shortcut, "0"), getattr(self.shortcut, "1"), x, self.training)
-            short = K.affine_act(ts, scs, shs)
-            sc_ctx = (ts, scs, shs, ms, ivs)
+        if forked is not None:
+            (short, sc_ctx), joined = forked
+            joined()
+        elif len(self.shortcut):
+            short, sc_ctx = self._shortcut_fwd(x)
         _, t, sc, sh, _, _ = saved[-1]
         y = K.affine_act(t, sc, sh, r1=short, a1=1.0, act="relu" if self.final_relu else None, out=out)
         self._ctx = (x, saved, sc_ctx, y) if self.training else None
@@ -92,6 +104,21 @@ class _ResBlock(SgxBlock):
         (x, saved, sc_ctx, y), self._ctx = self._ctx, None
         branch = self._branch()
         g = K.relu_bwd(dy, y) if self.final_relu else dy
+        # the projection shortcut's backward needs g only: forked at the start onto the branch stream (when its forward ran there: its saved
+        # tensors are that stream's pool's), its data gradient into a tensor of its own that the main branch's last data gradient adds in its
+        # epilogue - the same two-term sum as the accumulate pass
+        net = getattr(self, "_net", None)
+        fork_sc = (sc_ctx is not None and getattr(self, "_branched", False) and net is not None and net.branches(16, 0, 0, True)
+                   and need_dx and addend is None and not accumulate)
+        if fork_sc:
+            def shortcut_bwd():
+                ts, scs, shs, ms, ivs = sc_ctx
+                cs, bs = getattr(self.shortcut, "0"), getattr(self.shortcut, "1")
+                dts = bs.backward(g, ts, scs, shs, ms, ivs, None, dx_out=ts)
+                cs.wgrad(x, dts)
+                return cs.dgrad(dts, tuple(x.shape))
+
+            dxs, joined = net.fork_branch(shortcut_bwd, backward=True)
         d = g
         parts = None
         for i in range(len(branch) - 1, 0, -1):
@@ -111,6 +138,9 @@ class _ResBlock(SgxBlock):
         a, t, sc, sh, mean, invstd = saved[0]
         dt = bn.backward(d, t, sc, sh, mean, invstd, None if len(branch) == 1 else "relu", dx_out=t, parts=parts)
         conv.wgrad(x, dt)
+        if fork_sc:
+            joined()
+            return conv.dgrad(dt, tuple(x.shape), out=dx_out, addend=dxs)
         if sc_ctx is not None:
             ts, scs, shs, ms, ivs = sc_ctx
             cs, bs = getattr(self.shortcut, "0"), getattr(self.shortcut, "1")

@@ -75,13 +75,18 @@ class CustomizableDetector(DetectionPredictMixin, SgxNetwork):
         self._initialize_weights(self.bn_eps, self.bn_momentum, self.inplace_act)
 
     # ---- SgxNetwork protocol -------------------------------------------------------------------------------------
-    def _fwd(self, x):
+    def _input_layout(self, x):
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise ValueError(f"expected an NCHW batch with {self.in_channels} channels, got {tuple(x.shape)}")
-        xh = K.input_to_nhwc(x)
+        return K.input_to_nhwc(x)
+
+    def _fwd(self, x, xh=None):
+        if xh is None:
+            xh = self._input_layout(x)
         if self._half_inference and not self.training:
             xh = K.cast_bf16(xh, cpad=8)  # the bf16 batch the first convolution reads (3 -> 8 channels: one 16-byte lane load per pixel)
-        feats = self.backbone.fwd(xh)
+        pre = getattr(self.neck, "pre", None) if self.training else None
+        feats = self.backbone.fwd(xh, on_output=pre) if pre is not None else self.backbone.fwd(xh)
         p = self.neck.fwd(feats)
         boxes, scores, logits, distri, anchors, pts, counts, strides = self.heads.fwd(p)
         self._aux = (anchors, pts, list(counts), strides)  # constants of the feature-map sizes (cached in the heads)
@@ -109,9 +114,13 @@ class CustomizableDetector(DetectionPredictMixin, SgxNetwork):
         ready = self._bucket_ready
         dps = self.heads.bwd(d_logits.contiguous(), d_distri.contiguous())
         ready("heads.")
-        dcs = self.neck.bwd(*dps)
+        # (a neck with join_bwd may leave gradients of the backbone's tensors in flight on the branch stream: the backbone's walk joins
+        # before it reads the first of them)
+        join = getattr(self.neck, "join_bwd", None)
+        dcs = self.neck.bwd(*dps, **({"late_join": True} if join is not None else {}))
         ready("neck.")
-        self.backbone.bwd(dict(zip(self.backbone.out_layers, dcs)), on_layer_done=lambda layer: ready(f"backbone.{layer}."))
+        self.backbone.bwd(dict(zip(self.backbone.out_layers, dcs)), on_layer_done=lambda layer: ready(f"backbone.{layer}."),
+                          **({"ext_ready": join} if join is not None else {}))
 
     def gradient_buckets(self):
         """Arena ranges in backward-completion order (see training/utils/distributed_training_utils.GradientAllReducer)."""

@@ -191,11 +191,20 @@ class NDFLHeads(BaseDetectionModule):
         L, C, R4 = sum(counts), self.num_classes, 4 * (self.reg_max + 1)
         logits = torch.empty(B, L, C, device=feats[0].device, dtype=torch.float32)
         distri = torch.empty(B, L, R4, device=feats[0].device, dtype=torch.float32)
-        off = 0
+        off, calls = 0, []
         for i, f in enumerate(feats):
             h, w = sizes[i]
-            getattr(self, f"head{i + 1}").fwd(f, out=(distri[:, off:off + h * w].view(B, h, w, R4), logits[:, off:off + h * w].view(B, h, w, C)))
+            calls.append((getattr(self, f"head{i + 1}"), f, (distri[:, off:off + h * w].view(B, h, w, R4), logits[:, off:off + h * w].view(B, h, w, C))))
             off += h * w
+        # the levels are independent of one another: the coarse ones (a quarter and a sixteenth of the first level's pixels - launches that do
+        # not fill the chip) run on the branch stream beside the first (engine.fork_branch), joined before the decode
+        net = getattr(self, "_net", None)
+        self._branched = net is not None and len(calls) > 1 and self.training and net.branches(2, B * counts[1], 64)
+        joins = [net.fork_branch(lambda c=c: c[0].fwd(c[1], out=c[2]), lane=i)[1] for i, c in enumerate(calls[1:])] if self._branched else []
+        for h_, f, o in (calls[:1] if self._branched else calls):
+            h_.fwd(f, out=o)
+        for j in joins:
+            j()
         boxes, scores = K.dfl_decode(logits, distri, pts_grid, strides, self.reg_max)
         self._sizes = sizes
         return boxes, scores, logits, distri, anchors, pts, counts, strides
@@ -204,8 +213,16 @@ class NDFLHeads(BaseDetectionModule):
         sizes = self._sizes
         B, _, C = d_logits.shape
         R4 = d_distri.shape[2]
-        grads, off = [], 0
+        calls, off = [], 0
         for i, (h, w) in enumerate(sizes):
-            grads.append(getattr(self, f"head{i + 1}").bwd(d_distri[:, off:off + h * w].view(B, h, w, R4), d_logits[:, off:off + h * w].view(B, h, w, C)))
+            calls.append((getattr(self, f"head{i + 1}"), d_distri[:, off:off + h * w].view(B, h, w, R4), d_logits[:, off:off + h * w].view(B, h, w, C)))
             off += h * w
-        return grads
+        # (branch stream in backward only for a forward that ran there: the coarse levels' saved tensors are that stream's pool's then)
+        net = getattr(self, "_net", None)
+        if getattr(self, "_branched", False) and net is not None and net.branches(2, 0, 0, True):
+            forks = [net.fork_branch(lambda c=c: c[0].bwd(c[1], c[2]), backward=True, lane=i) for i, c in enumerate(calls[1:])]
+            first = calls[0][0].bwd(calls[0][1], calls[0][2])
+            for _, j in forks:
+                j()
+            return [first] + [g for g, _ in forks]
+        return [h_.bwd(dr, dc) for h_, dr, dc in calls]

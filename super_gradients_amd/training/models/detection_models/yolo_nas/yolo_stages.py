@@ -8,6 +8,7 @@ MI355X-specific structure: there is no torch.cat.  Every producer of a concatena
 straight into its channel slice of one preallocated buffer (the conv / sweep kernels take explicit pixel strides), and
 in backward the consumers read their slice of the concat gradient in place.
 """
+import os
 from functools import partial
 from typing import List
 
@@ -134,6 +135,10 @@ class YoloNASCSPLayer(SgxBlock):
         cat = _empty(n, h, w, hid * self.n_cat, x)
         sl = lambda i: cat[..., i * hid:(i + 1) * hid]  # noqa: E731
         blocks = list(self.bottlenecks)
+        # conv2's chain (GEMM, finalize, sweep) is needed by conv3 only: branch stream (engine.fork_branch), joined before conv3
+        net = getattr(self, "_net", None)
+        self._branched = net is not None and bool(blocks) and self.training and net.branches(1, n * h * w, hid)
+        joined = net.fork_branch(lambda: self.conv2.fwd(x, out=sl(self.n_cat - 1)))[1] if self._branched else None
         if self.concat_intermediates:
             cur = self.conv1.fwd(x, out=sl(0))
             for i, b in enumerate(blocks):
@@ -142,7 +147,10 @@ class YoloNASCSPLayer(SgxBlock):
             cur = self.conv1.fwd(x, out=sl(0) if not blocks else None)
             for i, b in enumerate(blocks):
                 cur = b.fwd(cur, out=sl(0) if i == len(blocks) - 1 else None)
-        self.conv2.fwd(x, out=sl(self.n_cat - 1))
+        if joined is None:
+            self.conv2.fwd(x, out=sl(self.n_cat - 1))
+        else:
+            joined()
         return self.conv3.fwd(cat, out=out)
 
     def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True, dx_req=None):
@@ -157,7 +165,12 @@ class YoloNASCSPLayer(SgxBlock):
             cat_req.append(r1.at(0))
         dcat = self.conv3.bwd(dy, dx_req=cat_req or None)
         sl = lambda i: dcat[..., i * hid:(i + 1) * hid]  # noqa: E731
-        dx = self.conv2.bwd(sl(self.n_cat - 1), dx_out=dx_out, accumulate=accumulate, addend=addend)
+        # conv2's backward (finalize, apply sweep, data gradient into dx) meets the main chain at conv1's data gradient: branch stream
+        net = getattr(self, "_net", None)
+        keep = (self.conv2._ctx, getattr(self.conv2, "_req", None))  # conv2's saved tensors stay referenced until the join (they may be the main stream's pool's)
+        conv2_bwd = lambda: self.conv2.bwd(sl(self.n_cat - 1), dx_out=dx_out, accumulate=accumulate, addend=addend)  # noqa: E731
+        rows = dy.shape[0] * dy.shape[1] * dy.shape[2]
+        dx, joined = net.fork_branch(conv2_bwd, backward=True) if (net is not None and blocks and net.branches(1, rows, hid, True)) else (conv2_bwd(), None)
         first_req = [r1] if (blocks and r1 is not None) else None
         if self.concat_intermediates:
             g = sl(len(blocks))
@@ -167,6 +180,9 @@ class YoloNASCSPLayer(SgxBlock):
             g = sl(0)
             for i in range(len(blocks) - 1, -1, -1):
                 g = blocks[i].bwd(g, dx_req=first_req if i == 0 else None)
+        if joined is not None:
+            joined()
+        del keep
         return self.conv1.bwd(g, dx_out=dx, accumulate=True, dx_req=dx_req)
 
 
@@ -249,20 +265,63 @@ class YoloNASUpStage(BaseDetectionModule):
     def out_channels(self):
         return self._out_channels
 
+    def pre_skip(self, which: int, s):
+        """Start skip branch `which` (1: reduce_skip1(s), 2: downsample(reduce_skip2(s))) on the branch stream as soon as its input exists -
+        the backbone calls this while its deeper stages, whose launches do not fill the chip, are still to run; fwd() joins.  No-op (fwd()
+        runs the branch) in eval mode or with the branch stream off."""
+        net = getattr(self, "_net", None)
+        n, h, w, _ = s.shape
+        oc = self._oc
+        if net is None or not self.training or not net.branches(4, n * h * w, oc) or os.environ.get("SGX_BRANCH_EARLY_FORK", "0") == "0":
+            return
+        pre = self.__dict__.setdefault("_pre", {})
+
+        def run():
+            if "cat" not in pre:
+                pre["cat"] = _empty(n, h, w, 3 * oc, s) if which == 1 else _empty(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, 3 * oc, s)
+            cat = pre["cat"]
+            if which == 1:
+                self.reduce_skip1.fwd(s, out=cat[..., oc:2 * oc])
+            else:
+                self.downsample.fwd(self.reduce_skip2.fwd(s), out=cat[..., 2 * oc:])
+
+        pre[which] = net.fork_branch(run)[1]
+
     def fwd(self, inputs, out=None):
         x, s1, s2 = inputs
         n, h, w, _ = s1.shape
         oc = self._oc
-        cat = _empty(n, h, w, 3 * oc, x)
-        self.reduce_skip1.fwd(s1, out=cat[..., oc:2 * oc])
-        self.downsample.fwd(self.reduce_skip2.fwd(s2), out=cat[..., 2 * oc:])
+        pre, self._pre = getattr(self, "_pre", None) or {}, {}
+        cat = pre["cat"] if "cat" in pre else _empty(n, h, w, 3 * oc, x)
+        if tuple(cat.shape) != (n, h, w, 3 * oc):
+            raise RuntimeError(f"YoloNASUpStage: skip branches were started for a {tuple(cat.shape)} concat, the inputs make {(n, h, w, 3 * oc)}")
+
+        def skips():
+            if 1 not in pre:
+                self.reduce_skip1.fwd(s1, out=cat[..., oc:2 * oc])
+            if 2 not in pre:
+                self.downsample.fwd(self.reduce_skip2.fwd(s2), out=cat[..., 2 * oc:])
+
+        # the two skip branches meet the main one in the concat: branch stream (engine.fork_branch; sized by reduce_skip2's GEMM) - started
+        # by pre_skip() when the backbone produced their inputs, else here
+        net = getattr(self, "_net", None)
+        self._branched = net is not None and self.training and net.branches(4, s2.shape[0] * s2.shape[1] * s2.shape[2], oc)
+        joins = [pre[k] for k in (1, 2) if k in pre]
+        if len(joins) < 2:
+            joins.append(net.fork_branch(skips)[1] if self._branched else skips())
+        self._branched = self._branched or bool(pre)
         x_inter = self.conv.fwd(x)
         self.upsample.fwd(x_inter, out=cat[..., :oc])
+        for j in joins:
+            if j is not None:
+                j()
         return x_inter, self.blocks.fwd(self.reduce_after_concat.fwd(cat), out=out)
 
-    def bwd(self, d_inter, d_out, dx=None, ds1=None, ds2=None):
+    def bwd(self, d_inter, d_out, dx=None, ds1=None, ds2=None, late_join=False):
         """d_inter: gradient arriving at x_inter from its other consumer (a down stage), or None.
-        dx/ds1/ds2: (buffer, accumulate) destinations for the three input gradients."""
+        dx/ds1/ds2: (buffer, accumulate) destinations for the three input gradients.
+        late_join: when the skip branches' backward was forked onto the branch stream, leave the join to the caller (join_bwd) - the two skip
+        gradients are not read before the backbone's backward reaches their layers."""
         oc = self._oc
         # BatchNorm reduces that ride in data gradients: reduce_after_concat's in the CSP layer's last launch; reduce_skip1's and
         # downsample's (two slices of the concat gradient) in reduce_after_concat's; reduce_skip2's in downsample's (stride 2)
@@ -271,14 +330,34 @@ class YoloNASUpStage(BaseDetectionModule):
         r_s1, r_ds = self.reduce_skip1.bn_reduce_request(), self.downsample.bn_reduce_request()
         cat_req = [r.at(c) for r, c in ((r_s1, oc), (r_ds, 2 * oc)) if r is not None]
         dcat = self.reduce_after_concat.bwd(g_rac, dx_req=cat_req or None)
+
+        def skips():
+            g1 = self.reduce_skip1.bwd(dcat[..., oc:2 * oc], dx_out=ds1[0], accumulate=ds1[1])
+            r_s2 = self.reduce_skip2.bn_reduce_request()
+            g2 = self.reduce_skip2.bwd(self.downsample.bwd(dcat[..., 2 * oc:], dx_req=[r_s2] if r_s2 is not None else None), dx_out=ds2[0], accumulate=ds2[1])
+            return g1, g2
+
+        # (branch stream in backward only for a forward that ran there: the skip branches' saved tensors are that stream's pool's then)
+        net = getattr(self, "_net", None)
+        joined = None
+        if getattr(self, "_branched", False) and net is not None and net.branches(4, 0, 0, True):
+            (g1, g2), joined = net.fork_branch(skips, backward=True)
         g_inter = self.upsample.bwd(dcat[..., :oc])
         if d_inter is not None:
             K.axpy(d_inter, out=g_inter, accumulate=True)
         gx = self.conv.bwd(g_inter, dx_out=dx[0], accumulate=dx[1])
-        g1 = self.reduce_skip1.bwd(dcat[..., oc:2 * oc], dx_out=ds1[0], accumulate=ds1[1])
-        r_s2 = self.reduce_skip2.bn_reduce_request()
-        g2 = self.reduce_skip2.bwd(self.downsample.bwd(dcat[..., 2 * oc:], dx_req=[r_s2] if r_s2 is not None else None), dx_out=ds2[0], accumulate=ds2[1])
+        if joined is None:
+            g1, g2 = skips()
+        elif late_join:
+            self._late = (joined, dcat)  # the caller joins (join_bwd) before g1 / g2 are read; the concat gradient stays referenced until then
+        else:
+            joined()
         return gx, g1, g2
+
+    def join_bwd(self):
+        late, self._late = getattr(self, "_late", None), None
+        if late is not None:
+            late[0]()
 
 
 @register_detection_module()

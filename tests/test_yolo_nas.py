@@ -621,6 +621,52 @@ def test_yolo_nas_s_step_is_bit_identical_with_filter_planes(gpu_device):
 
 
 @pytest.mark.gpu
+def test_yolo_nas_s_step_is_bit_identical_with_branch_stream(gpu_device):
+    """Branch stream (round 6; engine.fork_branch): YoloNASCSPLayer's conv2 chain, the up stages' skip branches, the coarse head levels and the
+    batch re-layout run on a second in-order stream beside the main chain, forward and backward.  Same kernels on the same operands: the step
+    must produce the same bits as the single-chain step - loss and the whole gradient arena - and keep producing them (a missing join or a
+    buffer recycled across streams would show up as a step that does not repeat).  Weight gradients one launch per layer in both networks:
+    the grouped launches size their splits by what happens to be queued, and the branch forks flush the queue at other points."""
+    from super_gradients_amd.training import models
+    from super_gradients_amd.training.losses import PPYoloELoss
+    from util import synthetic_targets
+
+    def build(branch):
+        torch.manual_seed(3)
+        net = models.get("yolo_nas_s", num_classes=80).materialize(gpu_device).train()
+        net.wg_group_flops = 0.0
+        if branch:
+            if net.branch_stream is None:  # (switched off through the environment: build the streams the default would have)
+                net.branch_stream = torch.cuda.Stream(device=gpu_device)
+                net.branch_lanes = [net.branch_stream, torch.cuda.Stream(device=gpu_device)]
+            net.branch_mode, net.branch_sites, net.branch_max_tiles = 3, 15, 1 << 30
+        else:
+            net.branch_mode = 0
+        return net
+
+    x = torch.rand(4, 3, 320, 320, generator=torch.Generator().manual_seed(1)).to(gpu_device)
+    t = synthetic_targets(4, seed=2, kmax=6, size=320).to(gpu_device)
+    crit = PPYoloELoss(num_classes=80, use_static_assigner=False)
+
+    def step(net):
+        net.zero_grad()
+        loss, _ = crit(net(x), t)
+        loss.backward()
+        net.join_side()
+        torch.cuda.synchronize()
+        return loss.detach().cpu().clone(), net.g_arena.buf.cpu().clone()
+
+    plain, forked = build(False), build(True)
+    forked.load_state_dict(plain.state_dict())
+    l0, g0 = step(plain)
+    for rep in range(4):
+        l1, g1 = step(forked)
+        assert torch.equal(l0, l1), f"repeat {rep}: loss differs with the branch stream: {float(l0)} vs {float(l1)}"
+        assert torch.equal(g0, g1), f"repeat {rep}: gradients differ with the branch stream: max {float((g0 - g1).abs().max()):.3e}"
+    assert sum(bool(getattr(m, "_branched", False)) for m in forked.modules()) >= 8, "the forked network did not fork"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant,size,batch,anchors", [("m", 640, 32, 8400), ("l", 1280, 8, 33600)], ids=["m_640_bs32", "l_1280_bs8"])
 def test_yolo_nas_other_baseline_configs_parity_at_full_size(gpu_device, variant, size, batch, anchors):
     """BASELINE.json configs[3] / [4] AT THEIR OWN SIZE (round 5 held M and L to the oracle at B = 1, 256 x 256 only): YOLO-NAS-M, 32 x
