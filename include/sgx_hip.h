@@ -420,6 +420,11 @@ int32_t sgx_axpy(const float* x, int64_t x_ld, float a, const float* a_dev, floa
 /* g = dy where y > 0, else 0: backward of a ReLU applied after a residual add (classification_models/resnet.py:43-50,72-84). */
 int32_t sgx_relu_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, float* g, int64_t g_ld, int64_t M, int32_t C,
                      void* stream);
+/* The same g AND the BatchNorm-backward reduce of the layer under the add (out = relu(bn_n(conv_n) + shortcut), resnet.py:72-84) in one pass:
+ * partials [2][sgx_stats_blocks(M)][C] = per row block sum g, sum g * (x - save_mean) - what sgx_bn_bwd_reduce(g, x, act = none) would
+ * leave, bit for bit (same row blocks, same order), so sgx_bn_bwd_finalize takes them as they are.  x: the saved conv output of bn_n. */
+int32_t sgx_relu_bwd_bn_reduce(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, const float* x, int64_t x_ld,
+                               const float* save_mean, float* g, int64_t g_ld, int64_t M, int32_t C, float* partials, void* stream);
 /* RepVGGBlock training forward (modules/repvgg_block.py:98-107: act(bn3(conv3x3 x) + bn1(conv1x1 x))) and the post-activation
  * residuals around it (csp_resnet.py:43-49 `x + y`, pp_yolo_head.py:205 `stem_cls(feat) + feat`) as ONE sweep:
  *   y = act(s1[c]*x1 + t1[c] [+ s2[c]*x2 + t2[c]]) [+ r_scale * r_scale_dev[0] * r]        x2 / r / r_scale_dev may be NULL.

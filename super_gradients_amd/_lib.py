@@ -176,6 +176,7 @@ PROTOTYPES = {
     "sgx_dot": (_i32, [_P, _i64, _P, _i64, _i64, _i32, _f, _P, _i32, _P, _i64, _P]),
     "sgx_axpy": (_i32, [_P, _i64, _f, _P, _P, _i64, _i64, _i32, _i32, _P]),
     "sgx_relu_bwd": (_i32, [_P, _i64, _P, _i64, _P, _i64, _i64, _i32, _P]),
+    "sgx_relu_bwd_bn_reduce": (_i32, [_P, _i64, _P, _i64, _P, _i64, _P, _P, _i64, _i64, _i32, _P, _P]),
     "sgx_colsum": (_i32, [_P, _i64, _i64, _i32, _i64, _i64, _P, _i32, _P, _P]),
     "sgx_maxpool_fwd": (_i32, [_i32] * 7 + [_P, _i64, _i64, _P, _i64, _i64, _P, _P]),
     "sgx_maxpool_bwd": (_i32, [_i32] * 7 + [_P, _P, _i64, _i64, _P, _i64, _i64, _i32, _P]),

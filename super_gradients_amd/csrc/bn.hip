@@ -679,6 +679,30 @@ extern "C" int32_t sgx_relu_bwd(const float* dy, int64_t dy_ld, const float* y, 
     return run_sweep<ReluBwdF, 0>(f, M, C, nullptr, stream, "relu_bwd");
 }
 
+// The same mask AND the BatchNorm-backward reduce of the layer underneath in one sweep (round 6): out = relu(bn(conv) + shortcut) hands
+// g = dy * (y > 0) to bn's backward, whose reduce sweep would read g and the saved conv output x again - here the two per-channel sums
+// (sum g, sum g * (x - mean): the partials sgx_bn_bwd_reduce leaves for act = none) come out of the pass that writes g.
+struct ReluBwdBnReduceF {
+    const float* dy; long dy_ld; const float* y; long y_ld; const float* x; long x_ld; const float* mean; float* g; long g_ld;
+    struct In { float4 d, v, u; };
+    __device__ In load(long r, int c) const { return In{sgx_ld4(dy + r * dy_ld + c), sgx_ld4(y + r * y_ld + c), sgx_ld4(x + r * x_ld + c)}; }
+    struct Cst { float4 mu; };
+    __device__ Cst consts(int c) const { return Cst{sgx_ld4(mean + c)}; }
+    __device__ void apply(long r, int c, const In& in, const Cst& k, float4& q0, float4& q1) const {
+        const float4 d = in.d, v = in.v, u = in.u, mu = k.mu;
+        const float4 o = make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
+        sgx_st4(g + r * g_ld + c, o);
+        q0.x += o.x; q0.y += o.y; q0.z += o.z; q0.w += o.w;
+        q1.x += o.x * (u.x - mu.x); q1.y += o.y * (u.y - mu.y); q1.z += o.z * (u.z - mu.z); q1.w += o.w * (u.w - mu.w);
+    }
+};
+extern "C" int32_t sgx_relu_bwd_bn_reduce(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, const float* x, int64_t x_ld,
+                                          const float* save_mean, float* g, int64_t g_ld, int64_t M, int32_t C, float* partials, void* stream) {
+    SGX_CHECK_ARG(dy && y && x && save_mean && g && partials, "relu_bwd_bn_reduce: null pointer");
+    ReluBwdBnReduceF f{dy, dy_ld, y, y_ld, x, x_ld, save_mean, g, g_ld};
+    return run_sweep<ReluBwdBnReduceF, 2>(f, M, C, partials, stream, "relu_bwd_bn_reduce");
+}
+
 // RepVGG-style two-branch BatchNorm sum + activation (+ post-activation residual) in one sweep, and the gradient through the
 // activation (the pre-activation is recomputed from the two saved conv outputs; nothing else is stored).
 struct DualAffineF {

@@ -809,6 +809,18 @@ def relu_bwd(dy, y, out=None):
     return out
 
 
+def relu_bwd_bn_reduce(dy, y, x, save_mean):
+    """(g, parts): g = dy * (y > 0) and the BatchNorm-backward reduce partials of (g, x) - bn_bwd(g, x, ..., act=None, parts=parts) skips
+    its reduce sweep."""
+    M, ld = rows(y)
+    C = y.shape[3]
+    g = torch.empty(y.shape, device=y.device, dtype=torch.float32)
+    parts = torch.empty(2, stats_blocks(M), C, device=y.device, dtype=torch.float32)
+    check(lib().sgx_relu_bwd_bn_reduce(ptr(dy), rows(dy)[1], ptr(y), ld, ptr(x), rows(x)[1], ptr(save_mean), ptr(g), rows(g)[1], M, C, ptr(parts),
+                                       stream()), "sgx_relu_bwd_bn_reduce")
+    return g, parts
+
+
 def dual_affine_act(x1, s1, t1, x2=None, s2=None, t2=None, post_add=None, act=None, out=None, post_scale=None):
     """y = act(s1*x1 + t1 [+ s2*x2 + t2]) [+ post_scale * post_add]   (RepVGG two-branch BatchNorm sum; post-activation residual;
     post_scale: a float or a one-element device tensor, default 1)."""

@@ -207,9 +207,10 @@ class SgxNetwork(nn.Module):
         # enqueued on a second in-order stream and joined where its result is consumed, so that its short kernels fill the gaps between the
         # dependent kernels of the main chain instead of lengthening it.
         self.branch_mode = int(os.environ.get("SGX_BRANCH_STREAM", str(BRANCH_STREAM_DEFAULT))) if self.side_stream is not None else 0
-        self.branch_stream = torch.cuda.Stream(device=device) if self.branch_mode else None
+        br_prio = int(os.environ.get("SGX_BRANCH_PRIORITY", "0"))  # (measurement switch, r6z)
+        self.branch_stream = torch.cuda.Stream(device=device, priority=br_prio) if self.branch_mode else None
         # (SGX_BRANCH_LANES > 1: further branch streams for call sites that fork several mutually independent chains - the head levels)
-        self.branch_lanes = [self.branch_stream] + [torch.cuda.Stream(device=device) for _ in range(int(os.environ.get("SGX_BRANCH_LANES", str(BRANCH_LANES_DEFAULT))) - 1)] \
+        self.branch_lanes = [self.branch_stream] + [torch.cuda.Stream(device=device, priority=br_prio) for _ in range(int(os.environ.get("SGX_BRANCH_LANES", str(BRANCH_LANES_DEFAULT))) - 1)] \
             if self.branch_stream is not None else []
         # which call sites fork (SGX_BRANCH_SITES bits: 1 YoloNASCSPLayer conv2, 2 coarse head levels, 4 the up stages' skip branches, 8 the batch
         # re-layout beside the per-step filter preparations, 16 the ResNet blocks' projection shortcuts) and up
@@ -225,6 +226,7 @@ class SgxNetwork(nn.Module):
         # gradient-bucket boundary and at the end of backward.  0: one call per layer.  Memory: the queue keeps the (x, dy) of its entries
         # alive until the flush - up to ~0.4 GB of operands per 160 GFLOP on YOLO-NAS-S (both would have been freed a few launches later).
         self.wg_group_flops = float(os.environ.get("SGX_WGRAD_GROUP_GFLOP", "160")) * 1e9
+        self.wg_eager_rows = int(os.environ.get("SGX_WGRAD_EAGER_ROWS", str(WGRAD_EAGER_ROWS_DEFAULT)))
         self._wg_pending, self._wg_flops = [], 0.0
         # BatchNorm-backward reduce of a plain conv -> BatchNorm -> activation layer inside the data-gradient launch that finalises the layer's
         # output gradient (kernels.BnReduceRequest; round 4): the reduce sweep over (dy, saved conv output) disappears wherever a layer's
@@ -396,8 +398,12 @@ class SgxNetwork(nn.Module):
     def queue_wgrad(self, x, dy, gw, stride, pad):
         self._wg_pending.append((x, dy, gw, stride, pad))
         k, _, r, s_ = gw.shape
-        self._wg_flops += 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * k * r * s_ * x.shape[3]
-        if self._wg_flops >= self.wg_group_flops:
+        rows = dy.shape[0] * dy.shape[1] * dy.shape[2]
+        self._wg_flops += 2.0 * rows * k * r * s_ * x.shape[3]
+        # (large maps: a layer of the main chain takes a millisecond there, and a queue that waits for 160 GFLOP leaves the side stream idle
+        # for two or three of them - then the step ends in a backlog of weight gradients with nothing beside them; r6fin2's trace: 2.9 ms idle,
+        # then 3.9 ms of backlog of which 0.8 ms behind the main chain's last kernel)
+        if self._wg_flops >= self.wg_group_flops or rows >= self.wg_eager_rows:
             self.flush_wgrads()
 
     def flush_wgrads(self):
@@ -540,6 +546,7 @@ class SgxNetwork(nn.Module):
 # Share of the chip's CUs the weight gradients' side stream may use (SGX_SIDE_CUS, percent; 100 = an ordinary stream).
 SIDE_STREAM_CU_PERCENT = 100
 BRANCH_STREAM_DEFAULT = 3
+WGRAD_EAGER_ROWS_DEFAULT = 800000  # (r6z: 800000 +0.4 % on YOLO-NAS-S at batch 32 - its 160 x 160 and 320 x 320 maps; 200000 -0.6 %, 50000 -1.9 %; M, L within noise)
 BRANCH_SITES_DEFAULT = 31
 BRANCH_LANES_DEFAULT = 2
 BRANCH_MAX_TILES_DEFAULT = 1 << 30
@@ -558,7 +565,8 @@ def _make_side_stream(device):
 
     pct = int(os.environ.get("SGX_SIDE_CUS") or SIDE_STREAM_CU_PERCENT)
     if pct >= 100:
-        return torch.cuda.Stream(device=device)
+        # (SGX_SIDE_PRIORITY=-1: a high-priority HIP stream - measurement switch, r6z)
+        return torch.cuda.Stream(device=device, priority=int(os.environ.get("SGX_SIDE_PRIORITY", "0")))
     from .._lib import check, lib
 
     handle = ctypes.c_void_p()

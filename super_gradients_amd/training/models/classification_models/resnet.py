@@ -13,6 +13,7 @@ Backward: g = dy * [out > 0] (sgx_relu_bwd: the ReLU follows the residual add, s
 backward sweeps / weight gradients / data gradients of the branch, the shortcut gradient folded into the data-gradient
 epilogue (identity) or produced by the shortcut conv's own backward.
 """
+import os
 from typing import Dict
 
 import torch
@@ -47,6 +48,9 @@ class _ConvBN:
             return (t,) + tuple(bn.scale_shift(parts, M, True))
         t = conv.conv(x)
         return (t,) + tuple(bn.scale_shift(None, 0, False))
+
+
+_RELU_REDUCE = os.environ.get("SGX_RESNET_RELU_REDUCE", "1") != "0"  # measurement switch (r6aa): 0 = mask sweep + reduce sweep
 
 
 class _ResBlock(SgxBlock):
@@ -103,7 +107,13 @@ class _ResBlock(SgxBlock):
     def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
         (x, saved, sc_ctx, y), self._ctx = self._ctx, None
         branch = self._branch()
-        g = K.relu_bwd(dy, y) if self.final_relu else dy
+        # the final ReLU's mask and the reduce of the last BatchNorm's backward in one sweep (sgx_relu_bwd_bn_reduce, round 6: 16 reduce sweeps
+        # of a ResNet-50 step gone); SGX_FUSE_BN_REDUCE=0 or a synchronised BatchNorm: the two passes
+        parts_last = None
+        if self.final_relu and self._net.fuse_bn_reduce and not branch[-1][1]._synced() and _RELU_REDUCE:
+            g, parts_last = K.relu_bwd_bn_reduce(dy, y, saved[-1][1], saved[-1][4])
+        else:
+            g = K.relu_bwd(dy, y) if self.final_relu else dy
         # the projection shortcut's backward needs g only: forked at the start onto the branch stream (when its forward ran there: its saved
         # tensors are that stream's pool's), its data gradient into a tensor of its own that the main branch's last data gradient adds in its
         # epilogue - the same two-term sum as the accumulate pass
@@ -120,7 +130,7 @@ class _ResBlock(SgxBlock):
 
             dxs, joined = net.fork_branch(shortcut_bwd, backward=True)
         d = g
-        parts = None
+        parts = parts_last
         for i in range(len(branch) - 1, 0, -1):
             conv, bn = branch[i]
             a, t, sc, sh, mean, invstd = saved[i]

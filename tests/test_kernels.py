@@ -249,6 +249,34 @@ def test_batchnorm_train(backend, act):
     assert_close(to_nchw_cpu(ye), F.batch_norm(x.detach(), rm_ref, rv_ref, gamma.detach(), beta.detach(), False, mom, eps), TOL, "bn eval")
 
 
+def test_relu_bwd_bn_reduce_is_the_two_passes(backend):
+    """sgx_relu_bwd_bn_reduce (round 6; the ResNet blocks' out = relu(bn(conv) + shortcut)): g and the reduce partials out of ONE sweep are, bit
+    for bit, what sgx_relu_bwd followed by sgx_bn_bwd_reduce(act = none) leave - so the BatchNorm backward that takes the partials is the
+    unfused one; strided views (a channel slice of a wider buffer) included."""
+    from super_gradients_amd._lib import check, lib
+    from super_gradients_amd.kernels import ptr, rows, stats_blocks, stream
+
+    for (n, h, w, c), pad in ((_sizes(backend, (4, 28, 28, 256), (2, 5, 6, 8)), 0), (_sizes(backend, (8, 56, 56, 64), (1, 40, 40, 4)), 4)):
+        g0 = torch.Generator().manual_seed(5)
+        dy, y, x = [torch.randn(n, c, h, w, generator=g0) for _ in range(3)]
+        y = F.relu(y)
+        mean = torch.randn(c, generator=g0).to(backend)
+        dyd, yd, xd = [to_nhwc(t, backend, ld_pix=c + pad) for t in (dy, y, x)]
+        g, parts = K.relu_bwd_bn_reduce(dyd, yd, xd, mean)
+        g_ref = K.relu_bwd(dyd, yd)
+        M = n * h * w
+        parts_ref = torch.empty(2, stats_blocks(M), c, device=backend, dtype=torch.float32)
+        one, zero = torch.ones(c, device=backend), torch.zeros(c, device=backend)
+        check(lib().sgx_bn_bwd_reduce(ptr(g_ref), rows(g_ref)[1], ptr(xd), rows(xd)[1], ptr(one), ptr(zero), ptr(mean), M, c, K.ACT[None], ptr(parts_ref),
+                                      stream()), "sgx_bn_bwd_reduce")
+        assert torch.equal(g.cpu(), g_ref.cpu()), "g differs from sgx_relu_bwd's"
+        assert torch.equal(parts.cpu(), parts_ref.cpu()), "reduce partials differ from sgx_bn_bwd_reduce's"
+        assert_close(to_nchw_cpu(g), dy * (y > 0), 0.0, "relu mask")
+        gx = (dy * (y > 0)).double()
+        assert_close(parts[0].sum(0).cpu(), gx.sum((0, 2, 3)).float(), 1e-4, "sum g")
+        assert_close(parts[1].sum(0).cpu(), (gx * (x.double() - mean.cpu().double().view(1, c, 1, 1))).sum((0, 2, 3)).float(), 1e-4, "sum g (x - mean)")
+
+
 def test_affine_residuals_and_sweeps(backend):
     n, h, w, c = _sizes(backend, (2, 20, 20, 192), (1, 4, 5, 8))
     g = torch.Generator().manual_seed(0)
