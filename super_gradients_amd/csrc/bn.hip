@@ -9,14 +9,25 @@
 // Reference call sites: include/sgx_hip.h (BatchNorm section).
 #include "sgx_common.h"
 #include <atomic>
+#include <cstdlib>
 
 #define SW_THREADS 256
+#define SGX_WAVE_PRIO_DEFAULT 0
 #define SW_MAXCG 64  // float4 channel groups per workgroup strip (256 channels)
 
 struct SweepGeom {
     long M;
     int C, C4, CG, RL, nblk, rows_per_blk, ctiles;
+    int prio;  // raise the waves' issue priority (SGX_WAVE_PRIO bit 1; sgx_common.h)
 };
+// SGX_WAVE_PRIO (environment, read once): bit 0 the finalize kernels, bit 1 the sweeps
+static int wave_prio_mode() {
+    static const int mode = [] {
+        const char* e = getenv("SGX_WAVE_PRIO");
+        return e ? atoi(e) : SGX_WAVE_PRIO_DEFAULT;
+    }();
+    return mode;
+}
 
 // Row blocks of a sweep: 64 rows per workgroup until the grid reaches 1024 workgroups.  (Round 1 used 256 rows: the 40x40 and 20x20
 // levels of the network then ran their sweeps on 200 / 50 workgroups - fewer than the chip has CUs; 64 rows: +4 % on the whole train
@@ -38,6 +49,7 @@ static SweepGeom sweep_geom(long M, int C) {
     g.nblk = sgx_stats_blocks(M);
     g.rows_per_blk = (int)((M + g.nblk - 1) / g.nblk);
     g.ctiles = (g.C4 + g.CG - 1) / g.CG;
+    g.prio = (wave_prio_mode() >> 1) & 1;
     return g;
 }
 
@@ -53,6 +65,7 @@ static SweepGeom sweep_geom(long M, int C) {
 template <typename F, int NQ>
 __global__ __launch_bounds__(SW_THREADS) void sweep_kernel(F f, SweepGeom g, float* partials) {
     __shared__ float4 red[NQ > 0 ? NQ : 1][SW_THREADS];
+    if (g.prio) SGX_WAVE_PRIO(2);
     const int tid = threadIdx.x;
     const int cg = tid % g.CG, rl = tid / g.CG;
     const int c4 = blockIdx.y * g.CG + cg;
@@ -145,6 +158,7 @@ struct ColSrc {  // what a finalize kernel sums over: either the fp32 partials o
     const double* d;
     int n;     // rows per plane
     int coop;  // 1: the finalize kernel is launched with CO_CH x CO_RL threads per workgroup and folds the fp32 partial rows itself
+    int prio;  // raise the waves' issue priority (SGX_WAVE_PRIO bit 0)
 };
 // ---- one-launch finalize (default; sgx_bn_set_fused_finalize(0) restores the two-launch form): instead of a pre-reduction
 // launch + a finalize launch, the finalize kernel runs with CO_CH channels x CO_RL row lanes per workgroup; every lane folds its rows
@@ -171,6 +185,7 @@ static dim3 fin_grid(const ColSrc& s, int C) { return dim3(sgx_cdiv(C, s.coop ? 
 static dim3 fin_block(const ColSrc& s) { return dim3(s.coop ? CO_CH * CO_RL : 64); }
 // channel of this thread, whether it exists, whether this thread writes the channel's results
 #define SGX_FIN_THREAD(src, C)                                                                                            \
+    if ((src).prio) SGX_WAVE_PRIO(3);                                                                                      \
     const int c = (src).coop ? blockIdx.x * CO_CH + (threadIdx.x % CO_CH) : blockIdx.x * blockDim.x + threadIdx.x;        \
     const bool cok = c < (C);                                                                                            \
     const bool writer = cok && (!(src).coop || threadIdx.x < CO_CH)
@@ -298,18 +313,18 @@ template <int PLANES>
 static int32_t col_prereduce(const float* partials, int nblk, int C, void* ws, int64_t ws_bytes, void* stream, ColSrc* src) {
     const int S = cr_slices(nblk);
     if (S == 0) {
-        *src = ColSrc{partials, nullptr, nblk, 0};
+        *src = ColSrc{partials, nullptr, nblk, 0, wave_prio_mode() & 1};
         return SGX_OK;
     }
     if (g_fused_finalize && nblk <= CR_COOP_MAX) {
-        *src = ColSrc{partials, nullptr, nblk, 1};
+        *src = ColSrc{partials, nullptr, nblk, 1, wave_prio_mode() & 1};
         return SGX_OK;
     }
     if (!ws || ws_bytes < (int64_t)PLANES * S * C * (int64_t)sizeof(double)) SGX_FAIL(SGX_ERR_WORKSPACE, "column reduce: workspace too small (sgx_reduce_workspace)");
     const int chunk = (nblk + S - 1) / S;
     SGX_LAUNCH((colreduce_kernel<PLANES>), dim3(sgx_cdiv(C, 64), S), dim3(256), 0, stream, partials, nblk, C, S, chunk, (double*)ws);
     SGX_CHECK_LAUNCH("colreduce");
-    *src = ColSrc{nullptr, (const double*)ws, S, g_fused_finalize ? 1 : 0};  // the fp64 slices are folded by row lanes as well
+    *src = ColSrc{nullptr, (const double*)ws, S, g_fused_finalize ? 1 : 0, wave_prio_mode() & 1};  // the fp64 slices are folded by row lanes as well
     return SGX_OK;
 }
 
@@ -512,7 +527,7 @@ extern "C" int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int6
     ColSrc src;
     int32_t rc = col_prereduce<2>(partials, nblk, C, ws, ws_bytes, stream, &src);
     if (rc) return rc;
-    SGX_LAUNCH(bn_bwd_finalize_kernel, fin_grid(src, C), fin_block(src), 0, stream, src, ColSrc{nullptr, nullptr, 0, 0}, (long)M, C, gamma, save_mean,
+    SGX_LAUNCH(bn_bwd_finalize_kernel, fin_grid(src, C), fin_block(src), 0, stream, src, ColSrc{nullptr, nullptr, 0, 0, 0}, (long)M, C, gamma, save_mean,
                save_invstd, dgamma, dbeta, coef);
     SGX_CHECK_LAUNCH("bn_bwd_finalize");
     return SGX_OK;
@@ -520,7 +535,7 @@ extern "C" int32_t sgx_bn_bwd_finalize(const float* partials, int32_t nblk, int6
 extern "C" int32_t sgx_bn_bwd_finalize_sums(const double* local_sums, const double* global_sums, int64_t M_total, int32_t C, const float* gamma,
                                             const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
     SGX_CHECK_ARG(local_sums && global_sums && save_mean && save_invstd && coef && M_total > 0, "bn_bwd_finalize_sums: bad args");
-    SGX_LAUNCH(bn_bwd_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, ColSrc{nullptr, global_sums, 1, 0}, ColSrc{nullptr, local_sums, 1, 0},
+    SGX_LAUNCH(bn_bwd_finalize_kernel, dim3(sgx_cdiv(C, 64)), dim3(64), 0, stream, ColSrc{nullptr, global_sums, 1, 0, 0}, ColSrc{nullptr, local_sums, 1, 0, 0},
                (long)M_total, C, gamma, save_mean, save_invstd, dgamma, dbeta, coef);
     SGX_CHECK_LAUNCH("bn_bwd_finalize_sums");
     return SGX_OK;
@@ -795,6 +810,7 @@ extern "C" int32_t sgx_dual_affine_act_bwd(const float* dy, int64_t dy_ld, const
 template <typename F, int NQ>
 __global__ __launch_bounds__(SW_THREADS) void sweepq_kernel(F f, SweepGeom g, float* partials) {
     __shared__ float4 red[NQ][SW_THREADS];
+    if (g.prio) SGX_WAVE_PRIO(2);
     const int tid = threadIdx.x;
     const int cg = tid % g.CG, rl = tid / g.CG;
     const int c4 = blockIdx.y * g.CG + cg;

@@ -26,6 +26,8 @@
 #include <mutex>
 #include <unordered_map>
 #include <vector>
+#include <cstdlib>
+#define SGX_CONV_WAVE_PRIO_DEFAULT 0
 
 // ------------------------------------------------------------------------------------------------
 // Optional per-launch timing of the two MFMA kernel classes (bench.py's roofline leg): HIP events recorded on the
@@ -154,6 +156,14 @@ extern "C" int32_t sgx_prof_summary(int32_t, double* ms, double* flops, int64_t*
 //   per load         : one v_add + one v_cndmask (masked lanes get SGX_BUF_OOB and the buffer bounds check returns 0).
 // FLAT (C < 16, the RGB stem): the GEMM-K axis is the flattened (tap, channel) axis, a 16-wide slab spans 16/C taps.
 // ------------------------------------------------------------------------------------------------
+// SGX_WAVE_PRIO (environment, read once) bit 2: the forward / data-gradient kernels run their waves at issue priority 1
+static int conv_wave_prio() {
+    static const int mode = [] {
+        const char* e = getenv("SGX_WAVE_PRIO");
+        return ((e ? atoi(e) : SGX_CONV_WAVE_PRIO_DEFAULT) >> 2) & 1;
+    }();
+    return mode;
+}
 struct IgemmParams {
     const float* A;
     const float* Wt;
@@ -205,6 +215,7 @@ struct IgemmParams {
     // (req_row0 + tile row) of the request's partials - the rows sgx_bn_bwd_reduce would have produced with a pass over dy and t.
     int nreq, req_row0;
     int lab;  // measurement builds (-DSGX_IGEMM_LAB, tools/conv_lab.py --ablate) only: see IGL below; the product build never reads it
+    int prio;  // raise the waves' issue priority over the side stream's weight-gradient waves (SGX_WAVE_PRIO bit 2; sgx_common.h)
     struct {
         const float* t;
         const float* scale;
@@ -335,6 +346,7 @@ template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_B
 __global__ __launch_bounds__(WM * WN * 64 * (PP ? 2 : 1), (igemm_min_waves<BM, BN, WM, WN, MATH, KD, PH2, NBUF, WPL, PP>())) void igemm_kernel(IgemmParams p) {
     static_assert(!WPL || (MATH == 1 && KD == 32 && NBUF == 1 && !FLAT), "pre-split filter planes: the one-buffer 32-deep bf16x3 loop");
     static_assert(!PP || (MATH == 1 && KD == 32 && NBUF == 1 && !FLAT && PH2 == 0 && WPL <= 1), "ping-pong: the one-buffer 32-deep bf16x3 loop, one source");
+    if (p.prio) SGX_WAVE_PRIO(1);
     constexpr int G = PP ? 2 : 1;  // wave groups (tiles) per workgroup
     static_assert((KD == 16 && NBUF == 2) || (KD == 32 && !FLAT && NBUF == 1) || (KD == 32 && !FLAT && NBUF == 2 && MATH == 1) ||
                       (KD == 32 && !FLAT && NBUF == 3 && MATH == 0 && PH2 == 0),
@@ -1226,6 +1238,7 @@ extern "C" int32_t sgx_debug_set_pconv_timing(void* buf) {
 template <int BN, int WM, int WN, int PH2, bool FPIPE = true, bool WPL = false>
 __global__ __launch_bounds__(WM * WN * 64, BN == 32 ? 3 : 2) void pconv_kernel(IgemmParams p) {
     static_assert(4 % WM == 0, "WM divides the four 32-row sub-tiles");
+    if (p.prio) SGX_WAVE_PRIO(1);
     constexpr int NTH = WM * WN * 64;
     constexpr int BM = PC_TH * PC_TW;           // 128 output pixels = 4 sub-tiles of 32 MFMA rows
     constexpr int TM = 4 / WM, TN = BN / (32 * WN);
@@ -1923,6 +1936,7 @@ extern "C" int32_t sgx_debug_set_igemm_lds_pad(int32_t bytes) {
 }
 template <int BM, int BN, int WM, int WN, bool FLAT, int MATH = 0, int KD = IG_BK, int NBUF = 2, int PH2 = 0, int WPL = 0, int PP = 0>
 static void launch_igemm(IgemmParams& p, void* stream) {
+    p.prio = conv_wave_prio();
     p.mt = sgx_cdiv(p.M, BM);
     p.nt = sgx_cdiv(p.Nout, BN);
     p.nblk = p.mt * p.nt;
@@ -1983,6 +1997,7 @@ static void launch_pconv(IgemmParams& p, void* stream) {
     p.fd_txy = sgx_make_fastdiv(sgx_cdiv(p.Wa, PC_TW) * sgx_cdiv(p.Ha, PC_TH));
     p.fd_tx = sgx_make_fastdiv(sgx_cdiv(p.Wa, PC_TW));
     p.stat_nblk = p.mt;
+    p.prio = conv_wave_prio();
     // pre-split filter planes (fplanes_attach): every filter of the launch has them, or none is used
     const bool wpl = p.Wp && (!(PH2 && p.A2) || p.Wp2);
     if (wpl) g_fp_hits.fetch_add(1, std::memory_order_relaxed);

@@ -233,5 +233,14 @@ __device__ __forceinline__ unsigned long long sgx_readlane_u64(unsigned long lon
 }
 #endif
 
+// Issue priority of the calling wave among the waves of its SIMD (s_setprio, 0 - 3; the default is 0).  The short dependent kernels of the
+// main chain (finalize kernels, sweeps) share their SIMDs with long-running weight-gradient waves of the side stream, which the oldest-first
+// arbiter otherwise prefers (r6fin2's trace: a 7 us finalize kernel takes 180 - 310 us when a wpatch_kernel launch started just before it).
+#ifdef SGX_EMU
+#define SGX_WAVE_PRIO(n) ((void)0)
+#else
+#define SGX_WAVE_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+
 __device__ __forceinline__ float4 sgx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void sgx_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -213,7 +213,8 @@ class SgxNetwork(nn.Module):
         self.branch_lanes = [self.branch_stream] + [torch.cuda.Stream(device=device, priority=br_prio) for _ in range(int(os.environ.get("SGX_BRANCH_LANES", str(BRANCH_LANES_DEFAULT))) - 1)] \
             if self.branch_stream is not None else []
         # which call sites fork (SGX_BRANCH_SITES bits: 1 YoloNASCSPLayer conv2, 2 coarse head levels, 4 the up stages' skip branches, 8 the batch
-        # re-layout beside the per-step filter preparations, 16 the ResNet blocks' projection shortcuts) and up
+        # re-layout beside the per-step filter preparations, 16 the ResNet blocks' projection shortcuts, 32 the bottlenecks'
+        # d alpha = <x, dz> reductions) and up
         # to what size (SGX_BRANCH_MAX_TILES: 64-row x 64-column tiles of the forked chain's largest GEMM - a launch of several rounds of
         # workgroups has no gaps to fill and only contends)
         self.branch_sites = int(os.environ.get("SGX_BRANCH_SITES", str(BRANCH_SITES_DEFAULT)))
@@ -375,13 +376,13 @@ class SgxNetwork(nn.Module):
             return False
         return ((rows + 63) // 64) * ((cols + 63) // 64) <= self.branch_max_tiles
 
-    def fork_branch(self, fn, backward: bool = False, lane: int = 0):
+    def fork_branch(self, fn, backward: bool = False, lane: int = 0, queues_wgrads: bool = True):
         """Run fn() on the branch stream, ordered after everything enqueued so far on the current stream; returns (result, joined) where
         `joined` is a callable the caller invokes before the first consumer of what fn wrote (a no-op when the branch stream is off).
         Memory rule (torch's caching allocator keeps one pool per stream): what fn allocates comes from the branch stream's pool and is
         recycled only into later branch allocations, which are ordered behind a later fork's wait; what fn reads or writes of the caller's
         must stay referenced until `joined` was called.  Weight gradients queued inside fn are flushed inside it: the side stream must wait
-        for THIS stream's producers."""
+        for THIS stream's producers (queues_wgrads=False: fn queues none and is joined before the next gradient-bucket boundary)."""
         if getattr(self, "branch_stream", None) is None or not (self.branch_mode & (2 if backward else 1)):
             return fn(), _nothing
         br = self.branch_lanes[lane % len(self.branch_lanes)]
@@ -389,7 +390,7 @@ class SgxNetwork(nn.Module):
         br.wait_stream(main)
         with torch.cuda.stream(br):
             out = fn()
-            if backward:
+            if backward and queues_wgrads:
                 self.flush_wgrads()
                 if self.side_stream is not None:  # whatever reads this stretch's parameter gradients from the side stream (the bucket
                     self.side_stream.wait_stream(br)  # all-reduce) is ordered behind it even when the join comes later
@@ -547,7 +548,7 @@ class SgxNetwork(nn.Module):
 SIDE_STREAM_CU_PERCENT = 100
 BRANCH_STREAM_DEFAULT = 3
 WGRAD_EAGER_ROWS_DEFAULT = 800000  # (r6z: 800000 +0.4 % on YOLO-NAS-S at batch 32 - its 160 x 160 and 320 x 320 maps; 200000 -0.6 %, 50000 -1.9 %; M, L within noise)
-BRANCH_SITES_DEFAULT = 31
+BRANCH_SITES_DEFAULT = 63
 BRANCH_LANES_DEFAULT = 2
 BRANCH_MAX_TILES_DEFAULT = 1 << 30
 

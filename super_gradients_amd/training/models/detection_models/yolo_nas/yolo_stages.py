@@ -72,18 +72,30 @@ class YoloNASBottleneck(SgxBlock):
             return self.cv1.bwd(self.cv2.bwd(dz, dx_req=self._mid_req()), dx_out=dx_out, accumulate=accumulate, addend=addend, need_dx=need_dx, dx_req=dx_req)
         x, self._x = self._x, None
         a, a_dev = self._alpha()
+        joined = None
         if a_dev is not None:
-            K.dot_sum(x, dz, self.alpha.grad, accumulate=True)
+            # d alpha = <x, dz>: two launches that read both tensors and that nothing waits for before the optimizer - second lane of the
+            # branch stream (the first carries the CSP layer's conv2 chain at this point), joined when this block's backward is enqueued
+            net = getattr(self, "_net", None)
+            d_alpha = lambda: K.dot_sum(x, dz, self.alpha.grad, accumulate=True)  # noqa: E731
+            if net is not None and net.branches(32, 0, 0, True):
+                joined = net.fork_branch(d_alpha, backward=True, lane=1, queues_wgrads=False)[1]
+            else:
+                d_alpha()
         dmid = self.cv2.bwd(dz, dx_req=self._mid_req())
         if isinstance(self.cv1, QARepVGGBlock):  # d(alpha * x) = alpha * dz rides in cv1's data-gradient launch
-            return self.cv1.bwd(dmid, dx_out=dx_out, accumulate=accumulate, addend=addend, addend2=dz, addend2_scale=a_dev if a_dev is not None else a,
-                                dx_req=dx_req)
-        if dx_out is not None:
-            K.axpy(dz, a=a, a_dev=a_dev, out=dx_out, accumulate=accumulate)
-            pre = dx_out
+            dx = self.cv1.bwd(dmid, dx_out=dx_out, accumulate=accumulate, addend=addend, addend2=dz, addend2_scale=a_dev if a_dev is not None else a,
+                              dx_req=dx_req)
         else:
-            pre = K.axpy(dz, a=a, a_dev=a_dev)
-        return self.cv1.bwd(dmid, dx_out=pre, accumulate=True, addend=addend, dx_req=dx_req)
+            if dx_out is not None:
+                K.axpy(dz, a=a, a_dev=a_dev, out=dx_out, accumulate=accumulate)
+                pre = dx_out
+            else:
+                pre = K.axpy(dz, a=a, a_dev=a_dev)
+            dx = self.cv1.bwd(dmid, dx_out=pre, accumulate=True, addend=addend, dx_req=dx_req)
+        if joined is not None:
+            joined()
+        return dx
 
 
 class _BottleneckList(nn.Module):
