@@ -470,8 +470,10 @@ def qarep_fwd_finalize(stat5, M, bias1, bn3, pbn):
     return cf, sv
 
 
-def qarep_bwd(dout, y, u, cf, sv, bn3, pbn, act):
-    """BatchNorm x2 + activation backward of the block in two sweeps: -> (ds written over u, dy written over y); d gamma / d beta accumulate."""
+def qarep_bwd(dout, y, u, cf, sv, bn3, pbn, act, chunks=1, after_chunk=None):
+    """BatchNorm x2 + activation backward of the block in two sweeps: -> (ds written over u, dy written over y); d gamma / d beta accumulate.
+    chunks > 1: the apply sweep runs as that many launches over consecutive runs of images and after_chunk(i, n0, n1) is called behind
+    each - a caller that needs no data gradient (the stem) sends the weight gradients of images n0:n1 out while the next run is swept."""
     M, yl = rows(y)
     C = y.shape[3]
     dl, ul = rows(dout)[1], rows(u)[1]
@@ -483,8 +485,20 @@ def qarep_bwd(dout, y, u, cf, sv, bn3, pbn, act):
     ws = WORKSPACE.get(_qarep_workspace(nblk, C), y.device)
     check(lib().sgx_qarep_bwd_finalize(ptr(parts), nblk, M, C, ptr(bn3.weight), ptr(pbn.weight), ptr(sv), ptr(bn3.weight.grad), ptr(pbn.weight.grad),
                                        ptr(pbn.bias.grad), ptr(cb), ptr(ws), ws.numel(), stream()), "sgx_qarep_bwd_finalize")
+    N = y.shape[0]
+    if chunks > 1 and N % chunks == 0 and M % N == 0:
+        per = N // chunks
+        for i in range(chunks):
+            d_, y_, u_ = dout[i * per:(i + 1) * per], y[i * per:(i + 1) * per], u[i * per:(i + 1) * per]
+            check(lib().sgx_qarep_bwd_apply(ptr(d_), dl, ptr(y_), yl, ptr(u_), ul, ptr(cf), ptr(sv), ptr(cb), ptr(u_), ul, ptr(y_), yl, M // chunks, C, a,
+                                            stream()), "sgx_qarep_bwd_apply")
+            if after_chunk is not None:
+                after_chunk(i, i * per, (i + 1) * per)
+        return u, y
     check(lib().sgx_qarep_bwd_apply(ptr(dout), dl, ptr(y), yl, ptr(u), ul, ptr(cf), ptr(sv), ptr(cb), ptr(u), ul, ptr(y), yl, M, C, a, stream()),
           "sgx_qarep_bwd_apply")
+    if after_chunk is not None:
+        after_chunk(0, 0, N)
     return u, y
 
 

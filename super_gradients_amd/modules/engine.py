@@ -214,7 +214,7 @@ class SgxNetwork(nn.Module):
             if self.branch_stream is not None else []
         # which call sites fork (SGX_BRANCH_SITES bits: 1 YoloNASCSPLayer conv2, 2 coarse head levels, 4 the up stages' skip branches, 8 the batch
         # re-layout beside the per-step filter preparations, 16 the ResNet blocks' projection shortcuts, 32 the bottlenecks'
-        # d alpha = <x, dz> reductions) and up
+        # d alpha = <x, dz> reductions, 64 the SPP block's larger pools) and up
         # to what size (SGX_BRANCH_MAX_TILES: 64-row x 64-column tiles of the forked chain's largest GEMM - a launch of several rounds of
         # workgroups has no gaps to fill and only contends)
         self.branch_sites = int(os.environ.get("SGX_BRANCH_SITES", str(BRANCH_SITES_DEFAULT)))
@@ -548,8 +548,8 @@ class SgxNetwork(nn.Module):
 SIDE_STREAM_CU_PERCENT = 100
 BRANCH_STREAM_DEFAULT = 3
 WGRAD_EAGER_ROWS_DEFAULT = 800000  # (r6z: 800000 +0.4 % on YOLO-NAS-S at batch 32 - its 160 x 160 and 320 x 320 maps; 200000 -0.6 %, 50000 -1.9 %; M, L within noise)
-BRANCH_SITES_DEFAULT = 63
-BRANCH_LANES_DEFAULT = 2
+BRANCH_SITES_DEFAULT = 127
+BRANCH_LANES_DEFAULT = 4
 BRANCH_MAX_TILES_DEFAULT = 1 << 30
 
 

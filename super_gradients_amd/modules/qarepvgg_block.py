@@ -31,6 +31,9 @@ class _Branch(nn.Module):
     pass
 
 
+_TAIL_CHUNKS = int(os.environ.get("SGX_STEM_BWD_CHUNKS", "1"))  # measurement switch (r6ad: 2 runs 794.0 against 793.4 images/s, 4 and 8 slower - the backlog behind the last sweep is stage 1's, not the stem's)
+
+
 class QARepVGGBlock(SgxBlock):
     def __init__(self, in_channels, out_channels, stride=1, dilation=1, groups=1, activation_type="relu", activation_kwargs=None,
                  se_type=None, se_kwargs=None, build_residual_branches=True, use_residual_connection=True, use_alpha=False,
@@ -212,6 +215,17 @@ class QARepVGGBlock(SgxBlock):
             accumulate, addend2 = True, None
         if self._ctx[0] == "dual":
             (_, x, y3, u, cf, sv), self._ctx = self._ctx, None
+            if not need_dx and _TAIL_CHUNKS > 1 and x.shape[0] % _TAIL_CHUNKS == 0:
+                # The first block of a network (no data gradient): its two weight gradients are the last work of the step, and the main chain has
+                # nothing left to run beside them - the apply sweep goes out in runs of images, each run's weight gradients behind it, so that
+                # only the last run's are left when the sweep ends (r6fin2's trace: 0.43 ms of stem weight gradients behind the last sweep).
+                def run_done(i, n0, n1):
+                    c1.wgrad(x[n0:n1], u[n0:n1], bias_grad=False)
+                    c3.wgrad(x[n0:n1], y3[n0:n1])
+                    self._net.flush_wgrads()
+
+                K.qarep_bwd(dy, y3, u, cf, sv, bn3, pbn, self.act, chunks=_TAIL_CHUNKS, after_chunk=run_done)
+                return None
             ds, dy3 = K.qarep_bwd(dy, y3, u, cf, sv, bn3, pbn, self.act)   # in place over u / y3
             c1.wgrad(x, ds, bias_grad=False)  # d b1 = sum ds = 0: post_bn's input gradient sums to zero per channel
             c3.wgrad(x, dy3)
