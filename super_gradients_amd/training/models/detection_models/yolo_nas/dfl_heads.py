@@ -191,7 +191,7 @@ class NDFLHeads(BaseDetectionModule):
         net = getattr(self, "_net", None)
         self._early = None
         if not self.training or net is None or len(sizes) != self.num_heads or self.num_heads < 2 or not net.branches(2, B * sizes[1][0] * sizes[1][1], 64) \
-                or os.environ.get("SGX_HEADS_EARLY", "1") == "0":
+                or os.environ.get("SGX_HEADS_EARLY", "0") == "0":
             return False
         C, R4 = self.num_classes, 4 * (self.reg_max + 1)
         L = sum(h * w for h, w in sizes)
