@@ -46,20 +46,12 @@ class SPP(BaseDetectionModule):
         # inference: stride-1 max pools with -inf padding compose exactly (pool_a o pool_b = pool_{a+b-1}: every point between an output
         # and a source inside the image is inside the image), so 5 / 9 / 13 are three 5-wide passes - 75 window reads instead of 275
         chain = not self.training and all(m.s == 1 and 2 * m.p + 1 == m.k for m in self.m) and all(b == a + ks[0] - 1 for a, b in zip(ks, ks[1:]))
-        # training: the pools read cv1's output independently of one another - the larger windows on the branch stream's lanes (site 64)
-        net = getattr(self, "_net", None)
-        fork = self.training and net is not None and net.branches(64, n * h * w, hid)
-        joins = []
         for i, m in enumerate(self.m):
             dst = cat[..., (i + 1) * hid:(i + 2) * hid]
             if chain and i > 0:
                 self.m[0].fwd(cat[..., i * hid:(i + 1) * hid], out=dst)
-            elif fork and i > 0:
-                joins.append(net.fork_branch(lambda m=m, dst=dst: m.fwd(y, out=dst), lane=i - 1)[1])
             else:
                 m.fwd(y, out=dst)
-        for j in joins:
-            j()
         return self.cv2.fwd(cat, out=out)
 
     def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):

@@ -209,13 +209,14 @@ class SgxNetwork(nn.Module):
         self.branch_mode = int(os.environ.get("SGX_BRANCH_STREAM", str(BRANCH_STREAM_DEFAULT))) if self.side_stream is not None else 0
         br_prio = int(os.environ.get("SGX_BRANCH_PRIORITY", "0"))  # (measurement switch, r6z)
         self.branch_stream = torch.cuda.Stream(device=device, priority=br_prio) if self.branch_mode else None
-        # (SGX_BRANCH_LANES > 1: further branch streams for call sites that fork several mutually independent chains - the head levels)
+        # (SGX_BRANCH_LANES: further branch streams for call sites that fork several mutually independent chains - the head levels, the
+        # d alpha reductions.  Two by default and no more: main + side + two lanes are four HIP streams on the runtime's four hardware queues;
+        # r6ae / r6af: four lanes 2 % slower, and with GPU_MAX_HW_QUEUES=8 30 % slower)
         self.branch_lanes = [self.branch_stream] + [torch.cuda.Stream(device=device, priority=br_prio) for _ in range(int(os.environ.get("SGX_BRANCH_LANES", str(BRANCH_LANES_DEFAULT))) - 1)] \
             if self.branch_stream is not None else []
         # which call sites fork (SGX_BRANCH_SITES bits: 1 YoloNASCSPLayer conv2, 2 coarse head levels, 4 the up stages' skip branches, 8 the batch
         # re-layout beside the per-step filter preparations, 16 the ResNet blocks' projection shortcuts, 32 the bottlenecks'
-        # d alpha = <x, dz> reductions, 64 the SPP block's larger pools, 128 the
-        # data-gradient filter preparations at the start of the step) and up
+        # d alpha = <x, dz> reductions) and up
         # to what size (SGX_BRANCH_MAX_TILES: 64-row x 64-column tiles of the forked chain's largest GEMM - a launch of several rounds of
         # workgroups has no gaps to fill and only contends)
         self.branch_sites = int(os.environ.get("SGX_BRANCH_SITES", str(BRANCH_SITES_DEFAULT)))
@@ -260,7 +261,7 @@ class SgxNetwork(nn.Module):
         # forward filters, their data-gradient transposes, the QARepVGG blocks' prepared 1x1 filters - is split into its three bf16 pieces
         # ONCE per step, right behind the transposes, instead of once per pixel tile of every launch.  The library serves planes only inside
         # the step's scope (NetFunction.forward / backward) and only for entries made since the weights last changed.  SGX_FILTER_PLANES=0: off.
-        self._fp_jobs, self._fp_dev, self._fp_buf, self._fp_split, self._prefetch_joined = None, None, None, None, None
+        self._fp_jobs, self._fp_dev, self._fp_buf = None, None, None
         if self._wt_jobs is not None and os.environ.get("SGX_FILTER_PLANES", "1") != "0":
             from .. import _lib
             import ctypes
@@ -277,12 +278,6 @@ class SgxNetwork(nn.Module):
             if plan:
                 self._fp_buf = torch.empty(total, dtype=torch.uint8, device=device)
                 self._fp_jobs, self._fp_dev = K.filter_planes_table(plan, self._fp_buf)
-                # the same plan as two tables: what the forward pass reads (filters, prepared 1x1 filters) and what only backward reads (their
-                # transposes) - the second one's launch, and the transposes themselves, leave the main chain (prefetch_dgrad_weights, site 128)
-                bwd_src = set(f[0] for f in filters[1::2])
-                fwd = [r for r in plan if r[0] not in bwd_src]
-                bwd = [r for r in plan if r[0] in bwd_src]
-                self._fp_split = (K.filter_planes_table(fwd, self._fp_buf), K.filter_planes_table(bwd, self._fp_buf)) if (fwd and bwd) else None
         # Sub-modules, parameters and buffers are fixed objects from here on (arena views never move, load_state_dict copies in place, the
         # network refuses to be moved): mirror them into the instance dictionaries so that `self.bn.weight` is a plain attribute read
         # instead of nn.Module.__getattr__'s three dictionary probes (~2400 of those per YOLO-NAS-S train step).  nn.Module.__setattr__
@@ -294,7 +289,7 @@ class SgxNetwork(nn.Module):
                         if v is not None:
                             m.__dict__[name] = v
 
-    _RUNTIME_ATTRS = ("side_stream", "aux_stream", "branch_stream", "branch_lanes", "_wt_jobs", "_qp_jobs", "_dgrad_convs", "_wg_pending", "_fp_jobs", "_fp_dev", "_fp_buf", "_fp_split", "_prefetch_joined")
+    _RUNTIME_ATTRS = ("side_stream", "aux_stream", "branch_stream", "branch_lanes", "_wt_jobs", "_qp_jobs", "_dgrad_convs", "_wg_pending", "_fp_jobs", "_fp_dev", "_fp_buf")
 
     def __deepcopy__(self, memo):
         """copy.deepcopy(model) - what the reference's predict() pipeline does before fusing (pipelines.py:95-100): parameters, buffers and
@@ -334,22 +329,6 @@ class SgxNetwork(nn.Module):
         if getattr(self, "_wt_jobs", None) is not None:
             from .. import kernels as K
 
-            split = getattr(self, "_fp_split", None)
-            if split is not None and getattr(self, "_fp_jobs", None) is not None and self.branches(128, 0, 0):
-                # (round 6) what only backward reads - the data-gradient transposes and their planes - on a lane of the branch stream, joined
-                # by NetFunction.backward; the forward pass waits for the prepared 1x1 filters and its own planes only
-                if getattr(self, "_qp_jobs", None) is not None:
-                    K.qarep_prep_batch(self._qp_jobs, self._qp_njobs)
-                K.filter_planes_invalidate(None)
-
-                def backward_filters():
-                    K.wtrans_batch(self._wt_jobs, self._wt_njobs)
-                    K.filter_planes_batch(*split[1])
-
-                self._prefetch_joined = self.fork_branch(backward_filters, lane=1)[1]
-                K.filter_planes_batch(*split[0])
-                self._wt_valid = True
-                return
             K.wtrans_batch(self._wt_jobs, self._wt_njobs)  # current stream: ordered after the optimizer step, before backward
             if getattr(self, "_qp_jobs", None) is not None:
                 K.qarep_prep_batch(self._qp_jobs, self._qp_njobs)
@@ -367,9 +346,6 @@ class SgxNetwork(nn.Module):
         self._wt_valid = True
 
     def join_aux(self):
-        joined, self._prefetch_joined = getattr(self, "_prefetch_joined", None), None
-        if joined is not None:
-            joined()
         aux = getattr(self, "aux_stream", None)
         if aux is not None and self._wt_valid:
             torch.cuda.current_stream().wait_stream(aux)

@@ -87,13 +87,7 @@ class CustomizableDetector(DetectionPredictMixin, SgxNetwork):
             xh = K.cast_bf16(xh, cpad=8)  # the bf16 batch the first convolution reads (3 -> 8 channels: one 16-byte lane load per pixel)
         pre = getattr(self.neck, "pre", None) if self.training else None
         feats = self.backbone.fwd(xh, on_output=pre) if pre is not None else self.backbone.fwd(xh)
-        # heads that can start a level as soon as the neck has produced it (NDFLHeads.begin / start_level: the finest level's head runs beside the
-        # neck's two down stages instead of behind them); the neck's outputs have the spatial sizes of the backbone's last three
-        begin = getattr(self.heads, "begin", None)
-        if begin is not None and self.training and len(feats) >= 3 and begin([(f.shape[1], f.shape[2]) for f in feats[-3:]], xh.shape[0], xh.device):
-            p = self.neck.fwd(feats, on_output=self.heads.start_level)
-        else:
-            p = self.neck.fwd(feats)
+        p = self.neck.fwd(feats)
         boxes, scores, logits, distri, anchors, pts, counts, strides = self.heads.fwd(p)
         self._aux = (anchors, pts, list(counts), strides)  # constants of the feature-map sizes (cached in the heads)
         self._out_shapes = (tuple(logits.shape), tuple(distri.shape))
@@ -123,12 +117,7 @@ class CustomizableDetector(DetectionPredictMixin, SgxNetwork):
         # (a neck with join_bwd may leave gradients of the backbone's tensors in flight on the branch stream: the backbone's walk joins
         # before it reads the first of them)
         join = getattr(self.neck, "join_bwd", None)
-        dp_ready = getattr(self.heads, "_dp_ready", None)  # (levels whose backward is still on the branch stream: the neck joins where it accumulates)
-        if dp_ready is not None and (join is None or len(dp_ready) != 2):
-            for j in dp_ready:
-                j()
-            dp_ready = None
-        dcs = self.neck.bwd(*dps, **({"late_join": True} if join is not None else {}), **({"dp_ready": dp_ready} if dp_ready is not None else {}))
+        dcs = self.neck.bwd(*dps, **({"late_join": True} if join is not None else {}))
         ready("neck.")
         self.backbone.bwd(dict(zip(self.backbone.out_layers, dcs)), on_layer_done=lambda layer: ready(f"backbone.{layer}."),
                           **({"ext_ready": join} if join is not None else {}))

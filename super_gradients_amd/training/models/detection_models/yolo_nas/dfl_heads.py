@@ -9,7 +9,6 @@ MI355X structure: the prediction convs write NHWC rows straight into their level
 [B,L,68] buffers (no permute / flatten / cat), decode + sigmoid is one kernel, anchors are cached per feature size.
 """
 import math
-import os
 from typing import List, Tuple
 
 import torch
@@ -184,57 +183,12 @@ class NDFLHeads(BaseDetectionModule):
         self._anchor_cache[key] = hit
         return hit
 
-    def begin(self, sizes, B, device):
-        """Allocate the level-concatenated prediction buffers for feature maps of `sizes` ahead of the features themselves: a neck that
-        reports its outputs one by one (start_level) gets each level's head started beside its remaining stages; fwd() then joins.  Returns
-        False (nothing prepared: fwd() runs the levels itself) in eval mode or with the branch stream's site 2 off."""
-        net = getattr(self, "_net", None)
-        self._early = None
-        if not self.training or net is None or len(sizes) != self.num_heads or self.num_heads < 2 or not net.branches(2, B * sizes[1][0] * sizes[1][1], 64) \
-                or os.environ.get("SGX_HEADS_EARLY", "0") == "0":
-            return False
-        C, R4 = self.num_classes, 4 * (self.reg_max + 1)
-        L = sum(h * w for h, w in sizes)
-        logits = torch.empty(B, L, C, device=device, dtype=torch.float32)
-        distri = torch.empty(B, L, R4, device=device, dtype=torch.float32)
-        self._early = {"sizes": [tuple(s) for s in sizes], "logits": logits, "distri": distri, "joins": [], "done": set()}
-        return True
-
-    def start_level(self, i, f):
-        """Feature map i exists: run its head - every level but the last on a lane of the branch stream (the last one is what the main
-        chain has left to do anyway).  Lanes 2 and up: lanes 0 and 1 carry the forks INSIDE the neck's stages (CSP layers, d alpha), and a
-        lane is in order - a head queued there would stand between a stage's fork and its join."""
-        e = getattr(self, "_early", None)
-        if e is None or i >= self.num_heads or i in e["done"]:
-            return
-        B, (h, w) = f.shape[0], e["sizes"][i]
-        if (f.shape[1], f.shape[2]) != (h, w):
-            raise RuntimeError(f"NDFLHeads: level {i} was announced as {h} x {w}, the feature map is {f.shape[1]} x {f.shape[2]}")
-        off = sum(a * b for a, b in e["sizes"][:i])
-        C, R4 = self.num_classes, 4 * (self.reg_max + 1)
-        out = (e["distri"][:, off:off + h * w].view(B, h, w, R4), e["logits"][:, off:off + h * w].view(B, h, w, C))
-        head = getattr(self, f"head{i + 1}")
-        if i < self.num_heads - 1:
-            e["joins"].append(self._net.fork_branch(lambda: head.fwd(f, out=out), lane=2 + i)[1])
-        else:
-            head.fwd(f, out=out)
-        e["done"].add(i)
-
     def fwd(self, feats, out=None):
         feats = feats[: self.num_heads]
         B = feats[0].shape[0]
         sizes = [(f.shape[1], f.shape[2]) for f in feats]
         anchors, pts, pts_grid, counts, strides = self.anchors_for(sizes, feats[0].device)
         L, C, R4 = sum(counts), self.num_classes, 4 * (self.reg_max + 1)
-        early, self._early = getattr(self, "_early", None), None
-        if early is not None and early["sizes"] == sizes and len(early["done"]) == self.num_heads:
-            for j in early["joins"]:
-                j()
-            logits, distri = early["logits"], early["distri"]
-            boxes, scores = K.dfl_decode(logits, distri, pts_grid, strides, self.reg_max)
-            self._sizes, self._branched, self._early_bwd = sizes, True, True
-            return boxes, scores, logits, distri, anchors, pts, counts, strides
-        self._early_bwd = False
         logits = torch.empty(B, L, C, device=feats[0].device, dtype=torch.float32)
         distri = torch.empty(B, L, R4, device=feats[0].device, dtype=torch.float32)
         off, calls = 0, []
@@ -246,7 +200,7 @@ class NDFLHeads(BaseDetectionModule):
         # not fill the chip) run on the branch stream beside the first (engine.fork_branch), joined before the decode
         net = getattr(self, "_net", None)
         self._branched = net is not None and len(calls) > 1 and self.training and net.branches(2, B * counts[1], 64)
-        joins = [net.fork_branch(lambda c=c: c[0].fwd(c[1], out=c[2]), lane=2 + i)[1] for i, c in enumerate(calls[1:])] if self._branched else []
+        joins = [net.fork_branch(lambda c=c: c[0].fwd(c[1], out=c[2]), lane=i)[1] for i, c in enumerate(calls[1:])] if self._branched else []
         for h_, f, o in (calls[:1] if self._branched else calls):
             h_.fwd(f, out=o)
         for j in joins:
@@ -265,16 +219,8 @@ class NDFLHeads(BaseDetectionModule):
             off += h * w
         # (branch stream in backward only for a forward that ran there: the coarse levels' saved tensors are that stream's pool's then)
         net = getattr(self, "_net", None)
-        if getattr(self, "_early_bwd", False) and net is not None and net.branches(2, 0, 0, True):
-            # the forward ran every level but the last on its lane: so does the backward, and the joins are the neck's to call (dp_ready) -
-            # right before its down stages accumulate into the two finer levels' gradients; the last level's is what the neck starts from
-            forks = [net.fork_branch(lambda c=c: c[0].bwd(c[1], c[2]), backward=True, lane=2 + i) for i, c in enumerate(calls[:-1])]
-            last = calls[-1][0].bwd(calls[-1][1], calls[-1][2])
-            self._dp_ready = tuple(j for _, j in forks)
-            return [g for g, _ in forks] + [last]
-        self._dp_ready = None
-        if getattr(self, "_branched", False) and not getattr(self, "_early_bwd", False) and net is not None and net.branches(2, 0, 0, True):
-            forks = [net.fork_branch(lambda c=c: c[0].bwd(c[1], c[2]), backward=True, lane=2 + i) for i, c in enumerate(calls[1:])]
+        if getattr(self, "_branched", False) and net is not None and net.branches(2, 0, 0, True):
+            forks = [net.fork_branch(lambda c=c: c[0].bwd(c[1], c[2]), backward=True, lane=i) for i, c in enumerate(calls[1:])]
             first = calls[0][0].bwd(calls[0][1], calls[0][2])
             for _, j in forks:
                 j()

@@ -35,28 +35,18 @@ class YoloNASPANNeckWithC2(BaseDetectionModule):
             if hasattr(stage, "pre_skip"):
                 stage.pre_skip(which, t)
 
-    def fwd(self, inputs, out=None, on_output=None):
-        """on_output(i, p): called as soon as output i exists (heads that start a level's work beside the remaining, coarser stages)"""
+    def fwd(self, inputs, out=None):
         c2, c3, c4, c5 = inputs
         i1, x = self.neck1.fwd([c5, c4, c3])
         i2, p3 = self.neck2.fwd([x, c3, c2])
-        if on_output is not None:
-            on_output(0, p3)
         p4 = self.neck3.fwd([p3, i2])
-        if on_output is not None:
-            on_output(1, p4)
         p5 = self.neck4.fwd([p4, i1])
-        if on_output is not None:
-            on_output(2, p5)
         return p3, p4, p5
 
-    def bwd(self, dp3, dp4, dp5, late_join=False, dp_ready=None):
-        """dp3/dp4/dp5: gradients from the heads (owned buffers: accumulated into).  -> (dc2, dc3, dc4, dc5)
-        dp_ready: (ready3, ready4) - callables that make the current stream wait for dp3 / dp4 when the heads produced them on the branch
-        stream; each is called right before the launch that accumulates into the buffer."""
-        r3, r4 = dp_ready if dp_ready is not None else (None, None)
-        g_p4, d_i1 = self.neck4.bwd(dp5, dx=(dp4, True), **({"dx_ready": r4} if r4 is not None else {}))    # p4 feeds head2 and neck4
-        g_p3, d_i2 = self.neck3.bwd(g_p4, dx=(dp3, True), **({"dx_ready": r3} if r3 is not None else {}))    # p3 feeds head1 and neck3
+    def bwd(self, dp3, dp4, dp5, late_join=False):
+        """dp3/dp4/dp5: gradients from the heads (owned buffers: accumulated into).  -> (dc2, dc3, dc4, dc5)"""
+        g_p4, d_i1 = self.neck4.bwd(dp5, dx=(dp4, True))          # p4 feeds head2 and neck4
+        g_p3, d_i2 = self.neck3.bwd(g_p4, dx=(dp3, True))          # p3 feeds head1 and neck3
         # (the up stages' skip-branch gradients dc2 / dc3 / dc4 may still be in flight on the branch stream: join_bwd() before they are read -
         # both stages fork onto the same in-order stream, so neck1's accumulation into dc3 is ordered behind neck2's write of it)
         late = late_join and os.environ.get("SGX_BRANCH_LATE_JOIN", "1") != "0"

@@ -402,13 +402,9 @@ class YoloNASDownStage(BaseDetectionModule):
         K.axpy(skip, out=cat[..., self._half:])
         return self.blocks.fwd(cat, out=out)
 
-    def bwd(self, d_out, dx=None, dx_ready=None):
-        """-> (gx, d_skip view); d_skip is a channel slice of the concat gradient (read in place by the up stage).
-        dx_ready: called before the launch that accumulates into dx[0] (a buffer another stream may still be writing: a head level's
-        input gradient produced on the branch stream)."""
+    def bwd(self, d_out, dx=None):
+        """-> (gx, d_skip view); d_skip is a channel slice of the concat gradient (read in place by the up stage)."""
         r = self.conv.bn_reduce_request()  # its output gradient = the first half of the CSP layer's input gradient
         dcat = self.blocks.bwd(d_out, dx_req=[r.at(0)] if r is not None else None)
-        if dx_ready is not None:
-            dx_ready()
         gx = self.conv.bwd(dcat[..., : self._half], dx_out=dx[0], accumulate=dx[1])
         return gx, dcat[..., self._half:]

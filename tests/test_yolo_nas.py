@@ -638,8 +638,8 @@ def test_yolo_nas_s_step_is_bit_identical_with_branch_stream(gpu_device):
         if branch:
             if net.branch_stream is None:  # (switched off through the environment: build the streams the default would have)
                 net.branch_stream = torch.cuda.Stream(device=gpu_device)
-                net.branch_lanes = [net.branch_stream] + [torch.cuda.Stream(device=gpu_device) for _ in range(3)]
-            net.branch_mode, net.branch_sites, net.branch_max_tiles = 3, 255, 1 << 30
+                net.branch_lanes = [net.branch_stream, torch.cuda.Stream(device=gpu_device)]
+            net.branch_mode, net.branch_sites, net.branch_max_tiles = 3, 63, 1 << 30
         else:
             net.branch_mode = 0
         return net
