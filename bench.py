@@ -596,6 +596,20 @@ def main():
     # CUs, which is what makes the step faster but stretches every launch).  For the kernel's own efficiency: 3 extra, untimed steps
     # with the side stream off (every kernel has the GPU to itself), same HIP-event timing.
     fence()
+    # (round 6: the branch stream - sub-chains of the model on lanes beside the main chain, modules/engine.py fork_branch - stretches the
+    # launches the same way; `single_chain` = 3 extra steps with the lanes off and the side stream on, the concurrency rounds 1 - 5's `frac`
+    # was measured under, for the trend across rounds; `exclusive` has lanes AND side stream off)
+    branch_mode = getattr(net, "branch_mode", 0)
+    sc_ms = sc_fl = scw_ms = scw_fl = 0.0
+    if branch_mode:
+        net.branch_mode = 0
+        K.prof_enable(True)
+        for _ in range(0 if args.no_exclusive else 3):
+            step()
+        fence()
+        sc_ms, sc_fl = (sum(K.prof_summary(c)[i] for c in (0, 2, 3)) for i in (0, 1))
+        scw_ms, scw_fl, _ = K.prof_summary(1)
+        K.prof_enable(False)
     side, net.side_stream = getattr(net, "side_stream", None), None
     K.prof_enable(True)
     for _ in range(0 if args.no_exclusive else 3):
@@ -608,6 +622,8 @@ def main():
     ex_bound_ms = conv_bound_ms(K)
     K.prof_enable(False)
     net.side_stream = side
+    if branch_mode:
+        net.branch_mode = branch_mode
     # host side of one step: enqueue time of a step with the device idle at the start (no sync inside)
     fence()
     h0 = time.perf_counter()
@@ -660,7 +676,10 @@ def main():
                          # the same launches priced on the pipe most of them EXECUTE on: bf16 MFMA FLOPs issued (6 x algorithmic) / the dense bf16 peak
                          "frac_of_executed_pipe": None if bf_n == 0 else round(6.0 * bf_fl / (bf_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                          "frac_note": "frac = algorithmic fp32 FLOPs / the fp32-MFMA peak BASELINE.md prices the target against; "
-                                      "frac_of_executed_pipe = the bf16x3 launches (most of the step) against the bf16 pipe they run on",
+                                      "frac_of_executed_pipe = the bf16x3 launches (most of the step) against the bf16 pipe they run on.  Launch durations are "
+                                      "taken in the benchmarked configuration, i.e. with the weight-gradient stream and (round 6) the branch-stream lanes sharing the "
+                                      "chip - see single_chain (lanes off: the conditions of earlier rounds' frac) and exclusive (nothing concurrent); the step-level "
+                                      "figure that follows the wall clock is step_mfma_frac",
                          "timed_over": f"{args.steps} further steps of the same loop with a HIP event pair around every launch of the kernel on its launch stream",
                          "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_src, "traffic_measured_in_this_run": False,
                          # the two matrix pipes apart (round 4): launches on the fp32 pipe against the fp32 peak, launches of the bf16x3 patch kernel
@@ -689,8 +708,15 @@ def main():
                          "exclusive": {"achieved": round(ex_fl / (ex_ms * 1e-3) / 1e12, 2) if ex_ms > 0 else None,
                                        "frac": round(ex_fl / (ex_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ex_ms > 0 else None,
                                        "wgrad_achieved": round(exw_fl / (exw_ms * 1e-3) / 1e12, 2) if exw_ms > 0 else None,
-                                       "note": "same kernels and launches with the side HIP stream disabled (no concurrent weight-gradient kernels): "
-                                               "3 extra untimed steps after the timed region"},
+                                       "note": "same kernels and launches with the side HIP stream and the branch-stream lanes disabled (every kernel has the "
+                                               "chip to itself): 3 extra untimed steps after the timed region"},
+                         "single_chain": None if sc_ms <= 0 else {
+                             "achieved": round(sc_fl / (sc_ms * 1e-3) / 1e12, 2), "frac": round(sc_fl / (sc_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                             "wgrad_achieved": round(scw_fl / (scw_ms * 1e-3) / 1e12, 2) if scw_ms > 0 else None,
+                             "note": "same kernels and launches with the branch-stream lanes off and the side stream on - the concurrency `frac` was measured under "
+                                     "in rounds 1 - 5 (3 extra untimed steps).  `frac` itself is taken in the benchmarked configuration: since round 6 sub-chains of "
+                                     "the model run on two more HIP streams beside the main chain, which shortens the step and stretches every launch that shares "
+                                     "the chip with them (sum of kernel durations per step up, wall clock per step down)"},
                          "wgrad": {"achieved": round(wg_tf, 2), "frac": round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4), "launches_per_step": wg_n // max(args.steps, 1),
                                    "kernel_ms_per_step": round(wg_ms / args.steps, 3),
                                    # arithmetic of the weight gradient (sgx_conv_get_wgrad_math: 0 fp32 pipe, 1 bf16x3 slab loop, 2 + patch kernel): in

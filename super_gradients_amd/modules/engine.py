@@ -378,6 +378,20 @@ class SgxNetwork(nn.Module):
             return False
         return ((rows + 63) // 64) * ((cols + 63) // 64) <= self.branch_max_tiles
 
+    def data_parallel_streams(self):
+        """Stream budget of a data-parallel run (called by GradientAllReducer): the collectives' stream takes the hardware queue of the second
+        branch lane.  Measured on the one-rank RCCL communicator (bucket all-reduces really issued; `profiles/r6ah_collectives_lanes.txt`):
+        two lanes 743 against 790 images/s without collectives (-6 %), one lane and no d alpha site 783 against 784 (-0.2 %).  Explicit
+        SGX_BRANCH_LANES / SGX_BRANCH_SITES settings are left alone."""
+        import os
+
+        if getattr(self, "branch_stream", None) is None:
+            return
+        if "SGX_BRANCH_LANES" not in os.environ:
+            self.branch_lanes = self.branch_lanes[:1]
+        if "SGX_BRANCH_SITES" not in os.environ:
+            self.branch_sites &= ~32
+
     def fork_branch(self, fn, backward: bool = False, lane: int = 0, queues_wgrads: bool = True):
         """Run fn() on the branch stream, ordered after everything enqueued so far on the current stream; returns (result, joined) where
         `joined` is a callable the caller invokes before the first consumer of what fn wrote (a no-op when the branch stream is off).

@@ -748,3 +748,45 @@ def test_filter_planes_serve_a_training_step_and_nothing_else(backend):
         lib().sgx_debug_set_variant(0)
         K.filter_planes_scope(False)
         K.filter_planes_invalidate(None)
+
+
+def test_branch_stream_policy_and_host_behaviour():
+    """engine.SgxNetwork.branches / fork_branch (round 6): which call sites fork is a pure function of the mode bits, the site bits and the size
+    limit; without HIP streams (host emulation, SGX_SIDE_STREAM=0) nothing forks - fork_branch runs the chain in place and its join is a no-op."""
+    from types import SimpleNamespace
+
+    from super_gradients_amd.modules.engine import SgxNetwork, _nothing
+
+    net = SimpleNamespace(branch_stream=object(), branch_mode=3, branch_sites=1 | 4, branch_max_tiles=100)
+    assert SgxNetwork.branches(net, 1, 64 * 10, 64 * 10) and SgxNetwork.branches(net, 4, 64 * 10, 64 * 10, backward=True)
+    assert not SgxNetwork.branches(net, 2, 64, 64), "site bit off"
+    assert not SgxNetwork.branches(net, 1, 64 * 11, 64 * 10), "110 tiles > the limit of 100"
+    net.branch_mode = 1
+    assert SgxNetwork.branches(net, 1, 64, 64) and not SgxNetwork.branches(net, 1, 64, 64, backward=True), "forward bit only"
+    net.branch_stream = None
+    assert not SgxNetwork.branches(net, 1, 64, 64)
+    ran = []
+    out, joined = SgxNetwork.fork_branch(net, lambda: ran.append(1) or "result", backward=True)
+    assert out == "result" and ran == [1] and joined is _nothing and joined() is None
+
+
+def test_data_parallel_run_gives_a_branch_lane_to_the_collectives(monkeypatch):
+    """engine.SgxNetwork.data_parallel_streams (r6ah): with collectives on, one branch lane and no d alpha site - unless set explicitly."""
+    from types import SimpleNamespace
+
+    from super_gradients_amd.modules.engine import SgxNetwork
+
+    monkeypatch.delenv("SGX_BRANCH_LANES", raising=False)
+    monkeypatch.delenv("SGX_BRANCH_SITES", raising=False)
+    a, b = object(), object()
+    net = SimpleNamespace(branch_stream=a, branch_lanes=[a, b], branch_sites=63)
+    SgxNetwork.data_parallel_streams(net)
+    assert net.branch_lanes == [a] and net.branch_sites == 31
+    monkeypatch.setenv("SGX_BRANCH_LANES", "2")
+    monkeypatch.setenv("SGX_BRANCH_SITES", "63")
+    net = SimpleNamespace(branch_stream=a, branch_lanes=[a, b], branch_sites=63)
+    SgxNetwork.data_parallel_streams(net)
+    assert net.branch_lanes == [a, b] and net.branch_sites == 63
+    net = SimpleNamespace(branch_stream=None, branch_lanes=[], branch_sites=63)
+    SgxNetwork.data_parallel_streams(net)
+    assert net.branch_lanes == []
