@@ -281,6 +281,11 @@ int64_t sgx_convT2x2_workspace(int32_t N, int32_t H, int32_t W, int32_t C, int32
 int32_t sgx_convT2x2_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const float* x, int64_t x_ld_pix,
                          int64_t x_ld_img, const float* wt, const float* bias, float* y, int64_t y_ld_pix,
                          int64_t y_ld_img, void* ws, int64_t ws_bytes, void* stream);
+/* the same with the filter already in the data-gradient order of the adjoint convolution (sgx_conv2d_transpose_weights / _jobs on a
+ * descriptor with K = C filters of K channels, R = S = 2, stride 2, pad 0): no transpose launches inside the call */
+int32_t sgx_convT2x2_fwd_wt(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const float* x, int64_t x_ld_pix,
+                            int64_t x_ld_img, const float* wtt, const float* bias, float* y, int64_t y_ld_pix,
+                            int64_t y_ld_img, void* stream);
 int32_t sgx_convT2x2_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const float* dy, int64_t dy_ld_pix,
                               int64_t dy_ld_img, const float* wt, float* dx, int64_t dx_ld_pix, int64_t dx_ld_img,
                               void* stream);

@@ -150,6 +150,7 @@ PROTOTYPES = {
     "sgx_debug_nms_fallback_slot": (_i32, [_P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)]),
     "sgx_convT2x2_workspace": (_i64, [_i32] * 5),
     "sgx_convT2x2_fwd": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _P, _i64, _i64, _P, _i64, _P]),
+    "sgx_convT2x2_fwd_wt": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _P, _i64, _i64, _P]),
     "sgx_convT2x2_bwd_data": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _P, _i64, _i64, _P]),
     "sgx_convT2x2_bwd_weight": (_i32, [_i32] * 5 + [_P, _i64, _i64, _P, _i64, _i64, _P, _P, _P, _i64, _P]),
     "sgx_nchw_to_nhwc": (_i32, [_i32] * 5 + [_P, _P, _P]),

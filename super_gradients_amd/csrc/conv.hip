@@ -3459,6 +3459,14 @@ extern "C" int32_t sgx_convT2x2_fwd(int32_t N, int32_t H, int32_t W, int32_t C, 
     sgx_conv_desc d = convT_adjoint_desc(N, H, W, C, K, x_ld_pix, x_ld_img, y_ld_pix, y_ld_img);
     return conv_bwd_data_impl(&d, x, wt, bias, nullptr, y, 0, ws, ws_bytes, stream, 0);
 }
+// wtt: the filter as sgx_conv2d_transpose_weights leaves it for the adjoint convolution (K = C filters of K channels, 2x2, stride 2, no padding) -
+// the host mirror keeps it in the network's per-step transpose batch, so the four parity launches go out without a transpose launch each
+extern "C" int32_t sgx_convT2x2_fwd_wt(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const float* x, int64_t x_ld_pix, int64_t x_ld_img,
+                                       const float* wtt, const float* bias, float* y, int64_t y_ld_pix, int64_t y_ld_img, void* stream) {
+    SGX_CHECK_ARG(wtt, "convT2x2_fwd_wt: null pointer");
+    sgx_conv_desc d = convT_adjoint_desc(N, H, W, C, K, x_ld_pix, x_ld_img, y_ld_pix, y_ld_img);
+    return conv_bwd_data_impl(&d, x, nullptr, bias, nullptr, y, 0, const_cast<float*>(wtt), sgx_conv2d_bwd_data_workspace(&d), stream, 2);
+}
 extern "C" int32_t sgx_convT2x2_bwd_data(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, const float* dy, int64_t dy_ld_pix,
                                          int64_t dy_ld_img, const float* wt, float* dx, int64_t dx_ld_pix, int64_t dx_ld_img, void* stream) {
     sgx_conv_desc d = convT_adjoint_desc(N, H, W, C, K, dx_ld_pix, dx_ld_img, dy_ld_pix, dy_ld_img);

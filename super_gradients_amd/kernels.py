@@ -556,7 +556,9 @@ def convT_empty(C, K, device):
     return torch.empty(C, 2, 2, K, device=device, dtype=torch.float32).permute(0, 3, 1, 2)
 
 
-def convT2x2_fwd(x, wt, bias=None, out=None):
+def convT2x2_fwd(x, wt, bias=None, out=None, wtt=None):
+    """wtt: the filter in data-gradient order (conv2d_transpose_weights of the adjoint 2x2 stride-2 convolution - the network's per-step
+    transpose batch keeps it current): the call then launches no transposes."""
     n, h, w, c = x.shape
     K = wt.shape[1]
     _chk_wt(wt, c, K)
@@ -572,6 +574,9 @@ def convT2x2_fwd(x, wt, bias=None, out=None):
         out = torch.empty(n, 2 * h, 2 * w, K, device=x.device, dtype=torch.float32)
     xl, xi = nhwc_strides(x)
     yl, yi = nhwc_strides(out)
+    if wtt is not None:
+        check(lib().sgx_convT2x2_fwd_wt(n, h, w, c, K, ptr(x), xl, xi, ptr(wtt), ptr(bias), ptr(out), yl, yi, stream()), "sgx_convT2x2_fwd_wt")
+        return out
     nbytes = lib().sgx_convT2x2_workspace(n, h, w, c, K)
     ws = WORKSPACE.get(nbytes, x.device)
     check(lib().sgx_convT2x2_fwd(n, h, w, c, K, ptr(x), xl, xi, ptr(wt), ptr(bias), ptr(out), yl, yi, ptr(ws), ws.numel(), stream()), "sgx_convT2x2_fwd")

@@ -222,6 +222,7 @@ class SgxNetwork(nn.Module):
         self.branch_sites = int(os.environ.get("SGX_BRANCH_SITES", str(BRANCH_SITES_DEFAULT)))
         self.branch_max_tiles = int(os.environ.get("SGX_BRANCH_MAX_TILES", str(BRANCH_MAX_TILES_DEFAULT)))
         self._wt_valid = False
+        self._step_forward = False  # True while NetFunction.forward runs the network behind prefetch_dgrad_weights
         # Weight gradients are mutually independent: blocks queue them (ConvLayer.wgrad) and the network launches a stretch of backward's
         # worth together (kernels.conv2d_bwd_weight_group: one launch per tile shape, splits sized for the group, partials folded inside
         # the launch) - whenever the queued work passes SGX_WGRAD_GROUP_GFLOP (default 160, ~2 ms of chip time; measured r3i/r3j on
@@ -607,9 +608,11 @@ class NetFunction(torch.autograd.Function):
             from .. import kernels as K
 
             K.filter_planes_scope(True)
+        net._step_forward = True  # (the per-step filter preparations above are current for exactly this forward: ConvTranspose2x2.fwd)
         try:
             flat = tuple(net._fwd(x) if xh is None else net._fwd(x, xh=xh))
         finally:
+            net._step_forward = False
             if planes:
                 K.filter_planes_scope(False)
         ctx.mark_non_differentiable(*[t for t, d in zip(flat, net._differentiable_outputs(len(flat))) if not d])

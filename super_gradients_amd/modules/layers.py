@@ -10,6 +10,7 @@ The fused sequences (conv -> BN statistics in the conv epilogue -> one affine+ac
 blocks in conv_bn_act_block.py / qarepvgg_block.py.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -148,10 +149,18 @@ class ConvTranspose2x2(SgxBlock):
         slots = {s.param: s for s in self._net.slots}
         s = slots[self.weight]
         self._w, self._gw = s.kernel_view, s.grad_kernel_view
+        # the forward IS the data gradient of the adjoint 2x2 stride-2 convolution: its transposed filter rides in the network's per-step
+        # transpose batch like every data gradient's (engine.prefetch_dgrad_weights) - four transpose launches per call off the forward chain
+        self.stride, self.padding = 2, 0
+        self._wt = K.conv2d_wt_buffer(self._w, self._w.device) if (self._net.wt_batch and os.environ.get("SGX_CONVT_PRETRANSPOSED", "1") != "0") else None  # (0: measurement switch)
+
+    def transpose_weights(self):
+        K.conv2d_transpose_weights(self._w, self._wt, stride=2, pad=0)
 
     def fwd(self, x, out=None):
         self._x = x if self.training else None
-        return K.convT2x2_fwd(x, self._w, self.bias, out=out)
+        pre = self._wt is not None and self._net._wt_valid and self._net._step_forward and x.dtype == torch.float32
+        return K.convT2x2_fwd(x, self._w, self.bias, out=out, wtt=self._wt if pre else None)
 
     def bwd(self, dy, dx_out=None, accumulate=False, addend=None, need_dx=True):
         x, self._x = self._x, None

@@ -7,6 +7,7 @@ Each test runs twice through the `backend` fixture:
 Tolerances: fp32 with a different summation order -> 2e-5 of the tensor's max-abs (north star: 1e-4 rel);
 integer/index outputs bit-exact.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -16,6 +17,7 @@ import torch.nn.functional as F
 
 from util import assert_close, empty_nhwc, rel_err, to_nchw_cpu, to_nhwc
 
+from super_gradients_amd import _lib
 from super_gradients_amd import kernels as K
 
 TOL = 2e-5
@@ -190,6 +192,16 @@ def test_conv_transpose(backend):
     wd.copy_(wt.detach().to(backend))
     yd = K.convT2x2_fwd(xd, wd, b.detach().to(backend))
     assert_close(to_nchw_cpu(yd), y, TOL, "convT fwd")
+    # the pre-transposed form (round 6: the filter rides in the network's per-step transpose batch) launches the same four parity GEMMs
+    wtt = K.conv2d_wt_buffer(wd, wd.device)
+    K.conv2d_transpose_weights(wd, wtt, stride=2, pad=0)
+    assert torch.equal(K.convT2x2_fwd(xd, wd, b.detach().to(backend), wtt=wtt), yd), "convT fwd from the pre-transposed filter"
+    if backend == "cuda":  # the batched job table writes the buffer conv2d_transpose_weights writes
+        wtt2 = torch.zeros_like(wtt)
+        table = K.conv2d_transpose_jobs(wd, wtt2, stride=2, pad=0)
+        K.wtrans_batch(torch.frombuffer(bytearray(table), dtype=torch.uint8).to(backend), len(table) // ctypes.sizeof(_lib.WtransJob))
+        n_w = wd.numel()
+        assert torch.equal(wtt2[:n_w], wtt[:n_w])
     dyd = to_nhwc(dy, backend)
     assert_close(to_nchw_cpu(K.convT2x2_bwd_data(dyd, wd)), x.grad, TOL, "convT dgrad")
     dw = K.convT_empty(c, k, backend)
