@@ -23,6 +23,8 @@ from .....modules.engine import SgxBlock
 from .....modules.layers import ConvTranspose2x2, act_name
 from .....modules.qarepvgg_block import QARepVGGBlock
 
+_DALPHA_SYNC = os.environ.get("SGX_DALPHA_SYNC", "0") == "1"  # bit-reproducible d alpha at -8 % of the step (YoloNASBottleneck.bwd)
+
 
 def _empty(n, h, w, c, like):
     return torch.empty(n, h, w, c, device=like.device, dtype=like.dtype)  # (bf16 on the half-precision inference path, fp32 otherwise)
@@ -78,6 +80,13 @@ class YoloNASBottleneck(SgxBlock):
             # branch stream (the first carries the CSP layer's conv2 chain at this point), joined when this block's backward is enqueued
             net = getattr(self, "_net", None)
             d_alpha = lambda: K.dot_sum(x, dz, self.alpha.grad, accumulate=True)  # noqa: E731
+            # (Round 6, r6an - r6ar: this dot's last bit is not reproducible while a weight-gradient kernel of the side stream is resident
+            # beside it - one ulp of one of the twelve alphas in ~0.5 % of the steps, in single-chain networks too, every other gradient
+            # element bit-identical over 10 000 probed steps; the sums cancel ~1e3 x and land within 1e-8 of a rounding boundary for two of
+            # the alphas.  SGX_DALPHA_SYNC=1 makes the main chain wait for the side stream first: reproducible to the bit (0 flips in 1 600
+            # steps) at -8 % of the step - a determinism switch, off by default)
+            if _DALPHA_SYNC and net is not None and net.side_stream is not None:
+                torch.cuda.current_stream().wait_stream(net.side_stream)
             if net is not None and net.branches(32, 0, 0, True):
                 joined = net.fork_branch(d_alpha, backward=True, lane=1, queues_wgrads=False)[1]
             else:

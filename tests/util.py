@@ -52,3 +52,25 @@ def synthetic_targets(batch, seed=0, kmax=20, size=640, num_classes=80):
             x1, y1, x2, y2 = max(cx - w / 2, 0), max(cy - h / 2, 0), min(cx + w / 2, size), min(cy + h / 2, size)
             rows.append([b, g.randint(0, num_classes), (x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1])
     return torch.tensor(rows, dtype=torch.float32).reshape(-1, 6)
+
+
+def assert_gradient_arenas_match(net, g0, g1, what):
+    """Two runs of the same step must leave the same BITS in the gradient arena - except in the YOLO-NAS bottlenecks' d alpha = <x, dz> (one scalar
+    each): that dot cancels ~1e3 x, lands within 1e-8 of a rounding boundary for some of the alphas, and its last bit is not reproducible while
+    a weight-gradient kernel of the side stream is resident beside it (round 6, tools/branch_flake_probe.py, profiles/r6an - r6ar: one ulp of
+    one alpha in ~0.5 % of the steps, single-chain networks included; SGX_DALPHA_SYNC=1 removes it at -8 % of the step).
+    Those scalars are held to 4 ulp, everything else to equality; a failure names the parameters."""
+    import torch
+
+    if torch.equal(g0, g1):
+        return
+    bad = (g0 != g1).nonzero().flatten()
+    slot_of = lambda i: next((s for s in net.slots if s.start <= int(i) < s.start + max(s.numel, 1)), None)  # noqa: E731
+    hard = []
+    for i in bad[:4096]:
+        s = slot_of(i)
+        ok = s is not None and s.name.endswith(".alpha") and s.numel == 1 and abs(float(g0[i]) - float(g1[i])) <= 4 * 2.0 ** -23 * max(abs(float(g0[i])), abs(float(g1[i])))
+        if not ok:
+            hard.append((s.name if s is not None else "?", int(i)))
+    assert not hard and bad.numel() <= 4096, (f"{what}: {bad.numel()} gradient elements differ (max {float((g0 - g1).abs().max()):.3e}); beyond the d alpha scalars: "
+                                              f"{sorted({n for n, _ in hard})[:12]}")
