@@ -1,0 +1,77 @@
+"""sgx_dot beside another kernel: does its result move?  (the bottlenecks' d alpha flips its last bit in ~0.5 % of the steps, only
+while a weight-gradient kernel of the side stream is resident.)  One fixed pair of operands with the cancellation of the real dot; the dot runs on
+the main stream while a second stream runs, in turn: nothing, 3x3 weight gradients (patch kernel), 1x1 weight gradients, forward convolutions,
+a BatchNorm sweep, a torch matmul.  Counts how many of N results differ from the dot alone, and by how much (fp64 of the two launches' output)."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from super_gradients_amd import kernels as K  # noqa: E402
+
+dev = torch.device("cuda:0")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+g = torch.Generator().manual_seed(0)
+n, h, w, c = 4, 40, 40, 64
+x = torch.randn(n, h, w, c, generator=g).to(dev)
+dz = (torch.randn(n, h, w, c, generator=g) * 1e-3).to(dev)
+out = torch.zeros(1, device=dev)
+side = torch.cuda.Stream(device=dev)
+
+# the co-runners' operands
+bx = torch.randn(8, 80, 80, 96, generator=g).to(dev)
+bdy3 = torch.randn(8, 80, 80, 96, generator=g).to(dev)
+dw3 = K.ohwi_empty(96, 96, 3, 3, dev)
+dw1 = K.ohwi_empty(96, 96, 1, 1, dev)
+w3 = K.to_ohwi(torch.randn(96, 96, 3, 3, generator=g).to(dev) * 0.05)
+a = torch.randn(4096, 4096, device=dev)
+
+
+def co_wgrad3():
+    dw3.zero_()
+    K.conv2d_bwd_weight(bx, bdy3, dw3, stride=1, pad=1)
+
+
+def co_wgrad1():
+    dw1.zero_()
+    K.conv2d_bwd_weight(bx, bdy3, dw1, stride=1, pad=0)
+
+
+def co_fwd():
+    K.conv2d_fwd(bx, w3, stride=1, pad=1)
+
+
+def co_sweep():
+    K.axpy(bx, a=1.0001)
+
+
+def co_matmul():
+    torch.mm(a, a)
+
+
+def dot():
+    K.dot_sum(x, dz, out, accumulate=False)
+    return out.clone()
+
+
+torch.cuda.synchronize()
+ref = float(dot())
+print(f"reference {ref!r}", flush=True)
+for name, co in (("nothing", None), ("3x3 weight gradient", co_wgrad3), ("1x1 weight gradient", co_wgrad1), ("forward convolution", co_fwd), ("axpy sweep", co_sweep),
+                 ("torch.mm", co_matmul), ("3x3 weight gradient", co_wgrad3)):
+    vals, t0 = [], time.time()
+    for i in range(N):
+        if co is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                co()
+                co()
+        vals.append(dot())
+        if co is not None and i % 16 == 15:
+            torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    v = torch.cat(vals).cpu()
+    bad = v != ref
+    print(f"beside {name}: {int(bad.sum())} of {N} results differ from the dot alone" + (f" (values {sorted(set(v[bad].tolist()))[:4]})" if bool(bad.any()) else "")
+          + f"  [{time.time() - t0:.0f} s]", flush=True)
