@@ -80,11 +80,10 @@ class YoloNASBottleneck(SgxBlock):
             # branch stream (the first carries the CSP layer's conv2 chain at this point), joined when this block's backward is enqueued
             net = getattr(self, "_net", None)
             d_alpha = lambda: K.dot_sum(x, dz, self.alpha.grad, accumulate=True)  # noqa: E731
-            # (Round 6, r6an - r6ar: this dot's last bit is not reproducible while a weight-gradient kernel of the side stream is resident
-            # beside it - one ulp of one of the twelve alphas in ~0.5 % of the steps, in single-chain networks too, every other gradient
-            # element bit-identical over 10 000 probed steps; the sums cancel ~1e3 x and land within 1e-8 of a rounding boundary for two of
-            # the alphas.  SGX_DALPHA_SYNC=1 makes the main chain wait for the side stream first: reproducible to the bit (0 flips in 1 600
-            # steps) at -8 % of the step - a determinism switch, off by default)
+            # (Round 6, DESIGN.md 11.12: this dot's last bit did not repeat while a weight-gradient kernel of the side stream was resident beside
+            # it - the compiler had packed its TwoSum lanes into v_pk_*_f32 instructions, whose results move beside those kernels; the library is
+            # built without such instructions now.  SGX_DALPHA_SYNC=1 - the main chain waits for the side stream first, -8 % of the step - is
+            # the switch the cause was bracketed with; off.)
             if _DALPHA_SYNC and net is not None and net.side_stream is not None:
                 torch.cuda.current_stream().wait_stream(net.side_stream)
             if net is not None and net.branches(32, 0, 0, True):

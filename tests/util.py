@@ -55,11 +55,12 @@ def synthetic_targets(batch, seed=0, kmax=20, size=640, num_classes=80):
 
 
 def assert_gradient_arenas_match(net, g0, g1, what):
-    """Two runs of the same step must leave the same BITS in the gradient arena - except in the YOLO-NAS bottlenecks' d alpha = <x, dz> (one scalar
-    each): that dot cancels ~1e3 x, lands within 1e-8 of a rounding boundary for some of the alphas, and its last bit is not reproducible while
-    a weight-gradient kernel of the side stream is resident beside it (round 6, tools/branch_flake_probe.py, profiles/r6an - r6ar: one ulp of
-    one alpha in ~0.5 % of the steps, single-chain networks included; SGX_DALPHA_SYNC=1 removes it at -8 % of the step).
-    Those scalars are held to 4 ulp, everything else to equality; a failure names the parameters."""
+    """Two runs of the same step must leave the same BITS in the gradient arena.  One documented allowance: the YOLO-NAS bottlenecks' d alpha =
+    <x, dz> (one scalar each), 4 ulp.  That dot cancels ~1e3 x and lands within 1e-8 of a rounding boundary for some of the alphas; while its
+    TwoSum lanes were compiled into packed fp32 instructions its last bit did not repeat beside a weight-gradient kernel of the side stream
+    (round 6, DESIGN.md 11.12: one ulp of one alpha in ~0.5 % of the steps, single-chain networks included).  The library is built without
+    packed fp32 instructions since (tests/test_tools.py checks the code objects); the allowance stays as the bound that was measured.
+    Everything else is held to equality, and a failure names the parameters."""
     import torch
 
     if torch.equal(g0, g1):

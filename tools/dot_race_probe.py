@@ -50,14 +50,19 @@ def co_matmul():
     torch.mm(a, a)
 
 
+NPART = K.stats_blocks(n * h * w) * ((c // 4 + 15) // 16)  # workgroups of the first stage = fp64 partial rows in the stream's workspace
+
+
 def dot():
+    """-> (fp32 result, the first stage's fp64 partials as raw bits: any change of a single addend shows, not only a flipped last bit)"""
     K.dot_sum(x, dz, out, accumulate=False)
-    return out.clone()
+    ws = K.WORKSPACE.get(1, dev)
+    return torch.cat([out.view(torch.int32).to(torch.int64), ws[: NPART * 8].view(torch.int64)])
 
 
 torch.cuda.synchronize()
-ref = float(dot())
-print(f"reference {ref!r}", flush=True)
+ref = dot().cpu()
+print(f"reference {float(out)!r}, {NPART} partial rows", flush=True)
 for name, co in (("nothing", None), ("3x3 weight gradient", co_wgrad3), ("1x1 weight gradient", co_wgrad1), ("forward convolution", co_fwd), ("axpy sweep", co_sweep),
                  ("torch.mm", co_matmul), ("3x3 weight gradient", co_wgrad3)):
     vals, t0 = [], time.time()
@@ -71,7 +76,15 @@ for name, co in (("nothing", None), ("3x3 weight gradient", co_wgrad3), ("1x1 we
         if co is not None and i % 16 == 15:
             torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    v = torch.cat(vals).cpu()
-    bad = v != ref
-    print(f"beside {name}: {int(bad.sum())} of {N} results differ from the dot alone" + (f" (values {sorted(set(v[bad].tolist()))[:4]})" if bool(bad.any()) else "")
+    v = torch.stack(vals).cpu()
+    bad_out = v[:, 0] != ref[0]
+    bad_part = (v[:, 1:] != ref[1:]).any(dim=1)
+    rows = sorted({int(j) for j in (v[:, 1:] != ref[1:]).nonzero()[:, 1].tolist()})[:8]
+    if rows:  # how far: relative distance of the fp64 rows, rows per call
+        d64, r64 = v[:, 1:].contiguous().view(torch.float64), ref[1:].contiguous().view(torch.float64)
+        rel = ((d64 - r64).abs() / r64.abs().clamp_min(1e-300))
+        per_call = (v[:, 1:] != ref[1:]).sum(dim=1)
+        print(f"    rows per differing call: min {int(per_call[bad_part].min())} max {int(per_call[bad_part].max())}; relative distance of a row: max {float(rel.max()):.3e}, "
+              f"median of the differing ones {float(rel[rel > 0].median()):.3e}; total (sum of rows) moves by at most {float((d64.sum(dim=1) - r64.sum()).abs().max() / r64.sum().abs()):.3e}", flush=True)
+    print(f"beside {name}: fp32 result differs in {int(bad_out.sum())} of {N} calls, fp64 partial rows in {int(bad_part.sum())}" + (f" (rows {rows})" if rows else "")
           + f"  [{time.time() - t0:.0f} s]", flush=True)

@@ -46,6 +46,31 @@ def code_object_kernels(obj):
     return [k for k in kernels if "name" in k]
 
 
+def packed_fp32_instructions(obj):
+    """-> number of packed fp32 VALU instructions (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32, ...) in the gfx950 code object of a hipcc host
+    object.  Round 6: their results are not reproducible while a weight-gradient kernel of another stream is resident, and
+    beside MFMAs they are slow - the build passes -fno-slp-vectorize (and -fno-vectorize where the loop vectoriser made them) and nothing of
+    the product may contain one."""
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "k.co")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
+        if not os.path.exists(fat) or os.path.getsize(fat) == 0:
+            return 0
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--unbundle", f"--input={fat}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+    return len(re.findall(r"\bv_pk_\w+_f32\b", dis))
+
+
+def check_packed_fp32(objdir=None, verbose=True):
+    """-> [(object, count)] for every built object whose device code contains packed fp32 instructions"""
+    objdir = objdir or DEFAULT_OBJDIR
+    bad = [(o, n) for o in sorted(os.listdir(objdir)) if o.endswith(".o") for n in [packed_fp32_instructions(os.path.join(objdir, o))] if n]
+    if verbose:
+        print(f"kernel_spills: packed fp32 instructions in {objdir}: {bad or 'none'}")
+    return bad
+
+
 def demangle(names):
     out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
     return [re.sub(r"\(.*$", "", re.sub(r"^void ", "", n)) for n in out]
@@ -74,4 +99,5 @@ def check_built_objects(objdir=None, verbose=True):
 
 if __name__ == "__main__":
     bad, total = check_built_objects(sys.argv[1] if len(sys.argv) > 1 else None)
-    sys.exit(1 if bad or total == 0 else 0)
+    packed = check_packed_fp32(sys.argv[1] if len(sys.argv) > 1 else None)
+    sys.exit(1 if bad or packed or total == 0 else 0)
