@@ -75,3 +75,7 @@ def assert_gradient_arenas_match(net, g0, g1, what):
             hard.append((s.name if s is not None else "?", int(i)))
     assert not hard and bad.numel() <= 4096, (f"{what}: {bad.numel()} gradient elements differ (max {float((g0 - g1).abs().max()):.3e}); beyond the d alpha scalars: "
                                               f"{sorted({n for n, _ in hard})[:12]}")
+    import warnings
+
+    warnings.warn(f"{what}: {bad.numel()} d alpha scalar(s) differ within 4 ulp ({sorted({slot_of(i).name for i in bad})[:4]}) - the allowance was used; "
+                  "with the library built without packed fp32 instructions this is not expected (DESIGN.md 11.12)")
