@@ -1980,3 +1980,43 @@ def test_filter_planes_every_tile_shape(backend, mode):
         lib().sgx_debug_set_tiles(0, 0, 0, 0, 0)
         K.clear_desc_cache()
         K.set_conv_math(K.DEFAULT_CONV_MATH)
+
+
+@pytest.mark.gpu
+def test_dot_repeats_its_bits_beside_weight_gradients(gpu_device):
+    """Round 6 (tools/dot_race_probe.py): while sgx_dot's TwoSum lanes were compiled into packed fp32 instructions, its fp64 partial
+    rows moved in 8 - 14 % of the calls made while a weight-gradient kernel of another stream was resident (one ulp of a YOLO-NAS bottleneck's
+    d alpha in ~0.5 % of the train steps).  The library is built without such instructions; the dot must leave the same bits - result AND
+    first-stage partial rows - alone and beside 3x3 / 1x1 weight gradients."""
+    dev = gpu_device
+    g = torch.Generator().manual_seed(0)
+    n, h, w, c = 4, 40, 40, 64
+    x = torch.randn(n, h, w, c, generator=g).to(dev)
+    dz = (torch.randn(n, h, w, c, generator=g) * 1e-3).to(dev)
+    out = torch.zeros(1, device=dev)
+    bx, bdy = torch.randn(8, 80, 80, 96, generator=g).to(dev), torch.randn(8, 80, 80, 96, generator=g).to(dev)
+    dw3, dw1 = K.ohwi_empty(96, 96, 3, 3, dev), K.ohwi_empty(96, 96, 1, 1, dev)
+    side = torch.cuda.Stream(device=dev)
+    npart = K.stats_blocks(n * h * w) * ((c // 4 + 15) // 16)
+
+    def dot():
+        K.dot_sum(x, dz, out, accumulate=False)
+        return torch.cat([out.view(torch.int32).to(torch.int64), K.WORKSPACE.get(1, dev)[: npart * 8].view(torch.int64)])
+
+    torch.cuda.synchronize()
+    ref = dot().clone()
+    for pad, dw in ((1, dw3), (0, dw1)):
+        vals = []
+        for i in range(400):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    dw.zero_()
+                    K.conv2d_bwd_weight(bx, bdy, dw, stride=1, pad=pad)
+            vals.append(dot())
+            if i % 16 == 15:
+                torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        v = torch.stack(vals)
+        moved = int((v != ref).any(dim=1).sum())
+        assert moved == 0, f"sgx_dot beside {'3x3' if pad else '1x1'} weight gradients: {moved} of 400 calls left other bits than the dot alone"
